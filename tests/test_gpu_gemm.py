@@ -1,0 +1,122 @@
+"""GPU parity of the bf16 MFMA GEMM kernels (through the C ABI) against fp32 torch matmul on the
+same bf16-rounded inputs.  Tolerance: fp32 accumulation of bf16 products -> 2e-3 relative to the
+row scale for fp32 outputs, bf16 rounding (2^-8) for bf16 outputs."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, gen, scale=1.0):
+    return (torch.randn(shape, generator=gen, device="cuda") * scale).to(torch.bfloat16)
+
+
+def _gelu(x):
+    return x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (300, 200, 192), (37 * 5, 1601, 256),
+                                   (1000, 1000, 768), (61, 30522, 128), (4096, 2304, 768)])
+def test_gemm_nt_bias_f32_and_bf16(M, N, K):
+    from unimm_amd import lib
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + N)
+    x, w = _rand((M, K), g), _rand((N, K), g, 0.05)
+    bias = torch.randn(N, generator=g, device="cuda")
+    ref = x.float() @ w.float().t() + bias
+    ldo = (N + 7) // 8 * 8
+    out32 = torch.full((M, ldo), float("nan"), device="cuda")
+    lib.gemm_nt(x, w, out32, bias=bias, N=N)
+    torch.cuda.synchronize()
+    err = (out32[:, :N] - ref).abs().max().item()
+    assert err <= 2e-3 * max(1.0, ref.abs().max().item()), err
+    if ldo > N:
+        assert torch.isnan(out32[:, N:]).all()          # pad columns untouched
+    out16 = torch.zeros((M, ldo), device="cuda", dtype=torch.bfloat16)
+    lib.gemm_nt(x, w, out16, bias=bias, N=N)
+    torch.cuda.synchronize()
+    assert (out16[:, :N].float() - ref).abs().max().item() <= 2 ** -7 * max(1.0, ref.abs().max().item())
+
+
+def test_gemm_nt_asymmetric_identity():
+    """A = I against an asymmetric B catches a transposed C layout (cdna guide 3)."""
+    from unimm_amd import lib
+    n = 128
+    x = torch.eye(n, device="cuda", dtype=torch.bfloat16)
+    w = (torch.arange(n * n, device="cuda").reshape(n, n) % 251).to(torch.bfloat16)
+    out = torch.empty((n, n), device="cuda")
+    lib.gemm_nt(x, w, out)
+    torch.cuda.synchronize()
+    assert torch.equal(out, w.float().t())
+
+
+def test_gemm_nt_strided_views_and_epilogues():
+    from unimm_amd import lib
+    g = torch.Generator(device="cuda").manual_seed(5)
+    M, N, K = 384, 256, 128
+    big = _rand((M, 3 * K), g)
+    x = big[:, K:2 * K]                     # row stride 3K
+    w = _rand((N, K), g, 0.1)
+    bias = torch.randn(N, generator=g, device="cuda")
+    aux = _rand((M, N), g)
+    base = x.float() @ w.float().t()
+    # GELU with both outputs
+    h = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+    u = torch.empty_like(h)
+    lib.gemm_nt(x, w, h, bias=bias, epilogue=lib.EPI_BIAS_GELU, out2=u)
+    torch.cuda.synchronize()
+    assert (u.float() - (base + bias)).abs().max() <= 2 ** -7 * (base + bias).abs().max()
+    assert (h.float() - _gelu(base + bias)).abs().max() <= 2 ** -7 * (base + bias).abs().max()
+    # residual (no dropout)
+    o = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+    lib.gemm_nt(x, w, o, bias=bias, epilogue=lib.EPI_BIAS_DROP_RESID, aux=aux)
+    ref = base + bias + aux.float()
+    torch.cuda.synchronize()
+    assert (o.float() - ref).abs().max() <= 2 ** -7 * ref.abs().max()
+    # relu
+    lib.gemm_nt(x, w, o, bias=bias, epilogue=lib.EPI_BIAS_RELU)
+    torch.cuda.synchronize()
+    assert (o.float() - torch.relu(base + bias)).abs().max() <= 2 ** -7 * ref.abs().max()
+    # dgelu: out = acc * gelu'(aux)
+    a32 = aux.float().requires_grad_(True)
+    _gelu(a32).sum().backward()
+    lib.gemm_nt(x, w, o, epilogue=lib.EPI_DGELU, aux=aux)
+    torch.cuda.synchronize()
+    ref = base * a32.grad
+    assert (o.float() - ref).abs().max() <= 2 ** -7 * max(1.0, ref.abs().max().item())
+    # add
+    lib.gemm_nt(x, w, o, epilogue=lib.EPI_ADD, aux=aux)
+    torch.cuda.synchronize()
+    ref = base + aux.float()
+    assert (o.float() - ref).abs().max() <= 2 ** -7 * ref.abs().max()
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 128, 128), (640, 256, 384), (1000, 200, 72), (37 * 30, 1024, 1024),
+                                   (5000, 768, 768), (333, 1601, 256), (700, 1000, 128)])
+def test_gemm_tn(M, N, K):
+    from unimm_amd import lib
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    ldy, ldx = (N + 7) // 8 * 8, (K + 7) // 8 * 8
+    dy = torch.zeros((M, ldy), device="cuda", dtype=torch.bfloat16)
+    x = torch.zeros((M, ldx), device="cuda", dtype=torch.bfloat16)
+    dy[:, :N] = _rand((M, N), g)
+    x[:, :K] = _rand((M, K), g)
+    init = torch.randn((N, K), generator=g, device="cuda")
+    dw = init.clone()
+    lib.gemm_tn(dy, x, dw, N=N, K=K)
+    torch.cuda.synchronize()
+    ref = init + dy[:, :N].float().t() @ x[:, :K].float()
+    err = (dw - ref).abs().max().item()
+    assert err <= 2e-3 * max(1.0, ref.abs().max().item()), err
+
+
+def test_gemm_rejects_bad_arguments():
+    from unimm_amd import lib
+    x = torch.zeros((128, 100), device="cuda", dtype=torch.bfloat16)      # K % 64 != 0
+    w = torch.zeros((128, 100), device="cuda", dtype=torch.bfloat16)
+    out = torch.zeros((128, 128), device="cuda")
+    with pytest.raises(lib.UnimmHipError):
+        lib.gemm_nt(x, w, out)
+    with pytest.raises(lib.UnimmHipError):
+        lib.gemm_nt(x.cpu(), w, out)

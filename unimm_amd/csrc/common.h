@@ -1,0 +1,81 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the UniMM-UL hot path.
+// Wave = 64 lanes everywhere; bf16 storage is uint16_t bit patterns.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/unimm_hip.h"
+
+typedef uint16_t bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+#define UNIMM_CHECK_LAUNCH()                                         \
+  do {                                                               \
+    hipError_t e__ = hipGetLastError();                              \
+    if (e__ != hipSuccess) return UNIMM_E_HIP;                       \
+  } while (0)
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even through the hardware convert (keeps NaN a NaN)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;
+  return *reinterpret_cast<bf16_t*>(&b);
+}
+
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+// exact erf GELU (reference: models/vilbert_dialog.py:115-121)
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// d/dx gelu(x) = Phi(x) + x*phi(x)
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// Counter-based dropout: keep(idx) = mix32(idx ^ key) >= thr, key = per-(step, site) word built on
+// the host (unimm_amd/dropout.py mirrors this bit for bit so the oracle can replay the masks).
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU;
+  x ^= x >> 15; x *= 0x846ca68bU;
+  x ^= x >> 16;
+  return x;
+}
+struct DropoutArg {
+  uint32_t key;    // 0 with thr == 0 => disabled
+  uint32_t thr;    // p * 2^32
+  float scale;     // 1 / (1 - p)
+};
+__device__ __forceinline__ float drop_apply(const DropoutArg& d, uint32_t idx, float v) {
+  return (mix32(idx ^ d.key) >= d.thr) ? v * d.scale : 0.0f;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// XCD-aware bijective remap of a 1-D grid: blocks b and b+8 share an XCD (round-robin dispatch), so
+// give every XCD a contiguous chunk of the logical tile order (cdna guide T1, bijective form).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
