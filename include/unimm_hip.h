@@ -77,6 +77,144 @@ typedef struct {
 
 int unimm_gemm_tn(const unimm_gemm_tn_args* args, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Fused attention core: out = dropout(softmax(Q K^T * scale + additive(mask))) V per (sequence,
+ * head); additive(mask) = (1 - bit) * -10000 exactly as models/vilbert_dialog.py:1415-1431.
+ * Replaces :390-410 (text, Tq=Tk=256, D=64, dense mask), :519-539 (image, 37x37, D=128, key mask)
+ * and both directions of :681-721 (256x37 with the image key mask; 37x256 with the co-attention
+ * mask).  Q/K/V are strided views into the fused projection output: row (b*T + t), columns
+ * head*D .. head*D+D-1 from the given base pointer.  Tq, Tk <= 256; D in {64, 128}.
+ * mask: bit-packed words [B][rows][ceil(Tk/32)] (unimm_mask_pack); mask_q_stride = 0 broadcasts
+ * one row over all queries (key-padding mask).  lse (fp32 [B,H,Tq], log-sum-exp of the masked,
+ * scaled scores) is what the backward kernels need; may be NULL for inference.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  const void* q; const void* k; const void* v; /* bf16 */
+  void* out;                                   /* bf16 [B*Tq, ldo] */
+  float* lse;
+  const uint32_t* mask;
+  int32_t B, H, Tq, Tk, D;
+  int32_t ldq, ldk, ldv, ldo;
+  int32_t mask_q_stride, mask_b_stride; /* in 32-bit words */
+  float scale;
+  uint32_t drop_key, drop_thr; float drop_scale; /* element index = ((b*H+h)*Tq+q)*Tk+k */
+} unimm_attn_args;
+
+int unimm_attn_fwd(const unimm_attn_args* args, void* stream);
+
+/* Backward of unimm_attn_fwd (autograd of models/vilbert_dialog.py:390-410 / 519-539 / 681-721):
+ * two launches on `stream` -- dQ (+ delta = rowsum(dO o O), fp32 [B,H,Tq] scratch) then dK/dV.
+ * P is recomputed from Q, K and lse; the dropout mask is re-generated from (key, thr).
+ * dq/dk/dv are bf16 strided views like q/k/v (typically into one [rows, 3*H*D] buffer). */
+typedef struct {
+  const void* q; const void* k; const void* v; const void* out; const void* dout; /* bf16 */
+  const float* lse; float* delta;
+  void* dq; void* dk; void* dv; /* bf16 */
+  const uint32_t* mask;
+  int32_t B, H, Tq, Tk, D;
+  int32_t ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
+  int32_t mask_q_stride, mask_b_stride;
+  float scale;
+  uint32_t drop_key, drop_thr; float drop_scale;
+} unimm_attn_bwd_args;
+
+int unimm_attn_bwd(const unimm_attn_bwd_args* args, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Row kernels (HBM-bound).
+ * ------------------------------------------------------------------------------------------- */
+enum { UNIMM_DT_U8 = 0, UNIMM_DT_I32 = 1, UNIMM_DT_I64 = 2, UNIMM_DT_F32 = 3 };
+
+/* Bit-pack a 0/1 mask [rows, t] (bool/uint8, int32, int64 or fp32; nonzero = attend) into
+ * ceil(t/32) words per row.  Replaces the fp32 (1-m)*-10000 mask tensors of
+ * models/vilbert_dialog.py:1415-1431 (the -10000 is applied inside the attention kernels). */
+int unimm_mask_pack(const void* mask, int dtype, uint32_t* out, int64_t rows, int32_t t, void* stream);
+
+/* y = LayerNorm(x) (eps inside sqrt, torch.nn.LayerNorm; models/vilbert_dialog.py:279) with optional
+ * dropout on y; x, y bf16 [M, H] contiguous; mean/rstd fp32 [M] saved for backward (may be NULL). */
+int unimm_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                        int32_t M, int32_t H, float eps, uint32_t drop_key, uint32_t drop_thr, float drop_scale,
+                        void* stream);
+
+/* bytes of the `partials` scratch the two backward row kernels need for hidden size H */
+int64_t unimm_colpartials_bytes(int32_t H);
+
+/* LayerNorm backward.  dx (bf16) is the gradient w.r.t. the pre-LayerNorm sum (= the residual
+ * branch gradient); dx_drop (optional) = dropout-masked dx for the dense branch (drop_*: the mask the
+ * forward GEMM epilogue applied); odrop_*: dropout applied to y in the forward (embeddings), 0 = none.
+ * dgamma/dbeta/dbias (fp32 [H], any may be NULL) are ACCUMULATED (+=); dbias = colsum(dx_drop). */
+int unimm_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                        void* dx, void* dx_drop, float* dgamma, float* dbeta, float* dbias, float* partials,
+                        int32_t M, int32_t H, uint32_t drop_key, uint32_t drop_thr, float drop_scale,
+                        uint32_t odrop_key, uint32_t odrop_thr, float odrop_scale, void* stream);
+
+/* Text embeddings: y = dropout(LN(word[ids] + pos[position] + type)) with token-type ids >= type_vocab
+ * routed to the 10-row extension table (BertEmbeddingsDialog.forward, models/vilbert_dialog.py:326-356).
+ * Tables are the bf16 weight copies; ids int32 [M]. */
+typedef struct {
+  const int32_t* ids; const int32_t* pos; const int32_t* typ;
+  const void* word; const void* post; const void* type; const void* ext; /* bf16 tables, row length H */
+  const float* gamma; const float* beta;
+  int32_t M, H, type_vocab;
+  float eps;
+  uint32_t drop_key, drop_thr; float drop_scale;
+} unimm_embed_args;
+
+int unimm_embed_fwd(const unimm_embed_args* args, void* y, void* stream);
+/* backward: re-gathers the rows, LayerNorm backward, scatter-add (fp32 atomics) into the word /
+ * position / extension-type gradient tables; dtype [2, H], dgamma, dbeta accumulated via partials. */
+int unimm_embed_bwd(const unimm_embed_args* args, const void* dy, float* dword, float* dpos, float* dtype,
+                    float* dext, float* dgamma, float* dbeta, float* partials, void* stream);
+
+/* db[N] += column sums of dy (bf16 [M, N], row stride ld): bias gradients. */
+int unimm_colsum(const void* dy, float* db, int32_t M, int32_t N, int32_t ld, void* stream);
+
+/* fp32 -> bf16 weight copies: flat cast, and dst[c][r] = src[r][c] (dst row stride ldd >= R, columns
+ * R..ldd-1 zero-filled) for the transposed copies the input-gradient GEMMs read. */
+int unimm_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
+int unimm_transpose_cast(const float* src, void* dst, int32_t R, int32_t C, int32_t ldd, void* stream);
+
+/* Region features fp32 [rows, F] + box geometry fp32 [rows, 5] -> bf16 [rows, ld] = [feat | loc | 0]:
+ * the operand of the single image-embedding GEMM (models/vilbert_dialog.py:1488-1489). */
+int unimm_pack_image(const float* feat, const float* loc, void* out, int32_t rows, int32_t F, int32_t ld, void* stream);
+
+/* out = dropout(a * b) (pooled_t * pooled_v, models/vilbert_dialog.py:1065) and its backward, which also
+ * folds in the pooler ReLU gradient (:951, :966): da = [a>0] drop(dout) b, db = [b>0] drop(dout) a. */
+int unimm_mul_dropout(const void* a, const void* b, void* out, int64_t n, uint32_t drop_key, uint32_t drop_thr,
+                      float drop_scale, void* stream);
+int unimm_mul_dropout_bwd(const void* a, const void* b, const void* dout, void* da, void* db, int64_t n,
+                          uint32_t drop_key, uint32_t drop_thr, float drop_scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Losses.  Row kernels (one workgroup per row) keep logits, log-sum-exp and 1-p in fp32.
+ * `g` is a DEVICE pointer to the upstream gradient of the (shape-[1]) loss; inv_denom a host float.
+ * ------------------------------------------------------------------------------------------- */
+/* Token-level likelihood / unlikelihood (models/vilbert_dialog.py:1577-1595): per decoded row with
+ * label y (-1 = ignore) and integer weight w: w>0 -> -w*log p_y; w==-1 -> -log(clamp(1-p_y, 1e-6)).
+ * rowloss is the un-normalised contribution, rownll = -log p_y (generative scoring, val_lm.py:131-136),
+ * lse the row's log-sum-exp.  The :1600-1604 CrossEntropy fallback is this with w = [y != -1]. */
+int unimm_lm_loss_fwd(const float* logits, const int32_t* labels, const int32_t* weights, float* rowloss,
+                      float* rownll, float* lse, int32_t n, int32_t V, int32_t ld, void* stream);
+/* dlogits (bf16 [n, ldd], columns >= V zero-filled) = g * inv_denom * d(rowloss)/d(logits) */
+int unimm_lm_loss_bwd(const float* logits, const int32_t* labels, const int32_t* weights, const float* lse,
+                      const float* g, float inv_denom, void* dlogits, int32_t n, int32_t V, int32_t ld,
+                      int32_t ldd, void* stream);
+/* Masked-region KL (models/vilbert_dialog.py:1569-1574): rowloss = [label==1] * sum_j t_j (log t_j - logp_j) */
+int unimm_kl_loss_fwd(const float* pred, const float* target, const int32_t* label, float* rowloss, float* lse,
+                      int32_t rows, int32_t C, int32_t ld, void* stream);
+int unimm_kl_loss_bwd(const float* pred, const float* target, const int32_t* label, const float* lse,
+                      const float* g, float inv_denom, void* dpred, int32_t rows, int32_t C, int32_t ld,
+                      int32_t ldd, void* stream);
+/* Weighted 2-way cross-entropy, reduction 'mean' = sum w_y l / sum w_y (models/vilbert_dialog.py:1617-1621);
+ * w0, w1 already divided by w0 (:1608). */
+int unimm_nsp_loss_fwd(const float* logits, const int32_t* labels, float w0, float w1, float* loss, int32_t B,
+                       int32_t ld, void* stream);
+int unimm_nsp_loss_bwd(const float* logits, const int32_t* labels, float w0, float w1, const float* g,
+                       void* dlogits, int32_t B, int32_t ld, int32_t ldd, void* stream);
+/* dst[0] = scale * sum(src) (fixed order, deterministic); dst[seg[i]] += sign * src[i] */
+int unimm_reduce_sum(const float* src, int64_t n, float* dst, float scale, void* stream);
+int unimm_segment_sum(const float* src, const int32_t* seg, float* dst, int64_t n, float sign, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,290 @@
+"""GPU parity of the attention / row / loss kernels (through the C ABI) against fp32 PyTorch
+references of the same op on the same bf16-rounded inputs, and against the oracle's loss functions.
+Tolerances: bf16 outputs 2^-7 relative to the tensor scale; fp32 loss scalars 1e-4."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def relerr(a, b):
+    return ((a.float() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-6)).item()
+
+
+# ----------------------------------------------------------------------------------------------
+# attention
+# ----------------------------------------------------------------------------------------------
+def _attn_case(B, H, Tq, Tk, D, dense_mask, seed, p_drop=0.0):
+    from unimm_amd import dropout as DR
+    from unimm_amd import lib
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    HD = H * D
+    qkv_q = bf(torch.randn((B * Tq, 3 * HD), generator=g, device=DEV))
+    qkv_k = qkv_q if Tq == Tk else bf(torch.randn((B * Tk, 3 * HD), generator=g, device=DEV))
+    q, k, v = qkv_q[:, :HD], qkv_k[:, HD:2 * HD], qkv_k[:, 2 * HD:]
+    if dense_mask:
+        m = (torch.rand((B, Tq, Tk), generator=g, device=DEV) < 0.6)
+        m[:, :, 0] = True
+        m[0, Tq // 2:] = False                  # fully masked rows (pad rows of the generative mask)
+        mq, mb = (Tk + 31) // 32, Tq * ((Tk + 31) // 32)
+    else:
+        m = (torch.rand((B, 1, Tk), generator=g, device=DEV) < 0.8)
+        m[:, :, 0] = True
+        mq, mb = 0, (Tk + 31) // 32
+    packed = lib.mask_pack(m.to(torch.int64) if seed % 2 else m)
+    scale = 1.0 / math.sqrt(D)
+    drop = DR.drop_arg(p_drop, DR.make_key(7, 1, seed))
+    out = torch.zeros((B * Tq, HD), device=DEV, dtype=torch.bfloat16)
+    lse = torch.zeros((B, H, Tq), device=DEV)
+    lib.attn_fwd(q, k, v, out, lse, packed, B, H, Tq, Tk, D, scale, mq, mb, drop)
+
+    # fp32 reference with autograd
+    qf = q.float().reshape(B, Tq, H, D).permute(0, 2, 1, 3).detach().requires_grad_(True)
+    kf = k.float().reshape(B, Tk, H, D).permute(0, 2, 1, 3).detach().requires_grad_(True)
+    vf = v.float().reshape(B, Tk, H, D).permute(0, 2, 1, 3).detach().requires_grad_(True)
+    s = qf @ kf.transpose(-1, -2) * scale + ((1.0 - m.float()) * -10000.0)[:, None]
+    pr = torch.softmax(s, -1)
+    if p_drop > 0:
+        keep = DR.keep_mask(drop[0], drop[1], B * H * Tq * Tk).reshape(B, H, Tq, Tk)
+        pr = pr * torch.from_numpy(keep).to(DEV) * drop[2]
+    ref = (pr @ vf).permute(0, 2, 1, 3).reshape(B * Tq, HD)
+    torch.cuda.synchronize()
+    assert relerr(out, ref) < 2 ** -6, relerr(out, ref)
+    ref_lse = torch.logsumexp(s, -1)
+    assert (lse - ref_lse).abs().max().item() < 2e-2
+
+    # backward
+    dout = bf(torch.randn((B * Tq, HD), generator=g, device=DEV))
+    ref.backward(dout.float())
+    dq_buf = torch.zeros_like(qkv_q)
+    dk_buf = dq_buf if Tq == Tk else torch.zeros_like(qkv_k)
+    delta = torch.zeros((B, H, Tq), device=DEV)
+    lib.attn_bwd(q, k, v, out, dout, lse, delta, dq_buf[:, :HD], dk_buf[:, HD:2 * HD], dk_buf[:, 2 * HD:], packed,
+                 B, H, Tq, Tk, D, scale, mq, mb, drop)
+    torch.cuda.synchronize()
+    rq = qf.grad.permute(0, 2, 1, 3).reshape(B * Tq, HD)
+    rk = kf.grad.permute(0, 2, 1, 3).reshape(B * Tk, HD)
+    rv = vf.grad.permute(0, 2, 1, 3).reshape(B * Tk, HD)
+    assert relerr(dq_buf[:, :HD], rq) < 2 ** -5, ("dq", relerr(dq_buf[:, :HD], rq))
+    assert relerr(dk_buf[:, HD:2 * HD], rk) < 2 ** -5, ("dk", relerr(dk_buf[:, HD:2 * HD], rk))
+    assert relerr(dk_buf[:, 2 * HD:], rv) < 2 ** -5, ("dv", relerr(dk_buf[:, 2 * HD:], rv))
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk,D,dense", [
+    (2, 2, 256, 256, 64, True),      # text self-attention, dense per-sequence mask
+    (3, 2, 64, 64, 64, True),        # small-config text (tests/golden/small_config.json)
+    (2, 2, 37, 37, 128, False),      # visual self-attention, key-padding mask
+    (2, 2, 256, 37, 128, False),     # co-attention: text queries, image keys
+    (2, 2, 37, 256, 128, True),      # co-attention: image queries, text keys (co-mask)
+    (2, 2, 64, 37, 128, False), (2, 2, 37, 64, 128, True), (1, 1, 100, 200, 64, True),
+])
+def test_attention_fwd_bwd(B, H, Tq, Tk, D, dense):
+    _attn_case(B, H, Tq, Tk, D, dense, seed=Tq + Tk + D)
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk,D,dense", [(2, 2, 256, 256, 64, True), (2, 2, 37, 256, 128, True),
+                                               (2, 2, 256, 37, 128, False)])
+def test_attention_dropout_replays_in_backward(B, H, Tq, Tk, D, dense):
+    _attn_case(B, H, Tq, Tk, D, dense, seed=3 + Tq, p_drop=0.1)
+
+
+# ----------------------------------------------------------------------------------------------
+# row kernels
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape,dtype", [((3, 256, 256), torch.int64), ((3, 256, 256), torch.bool),
+                                          ((5, 37), torch.float32), ((2, 37, 256), torch.int32), ((4, 100), torch.bool)])
+def test_mask_pack(shape, dtype):
+    from unimm_amd import lib
+    g = torch.Generator(device=DEV).manual_seed(1)
+    m = (torch.rand(shape, generator=g, device=DEV) < 0.5)
+    words = lib.mask_pack(m.to(dtype)).cpu().numpy().view(np.uint32)
+    t = shape[-1]
+    bits = np.zeros(shape[:-1] + (((t + 31) // 32) * 32,), dtype=np.uint8)
+    bits[..., :t] = m.cpu().numpy()
+    want = np.packbits(bits.reshape(shape[:-1] + (-1, 32)), axis=-1, bitorder="little").view(np.uint32)[..., 0]
+    assert np.array_equal(words, want)
+
+
+@pytest.mark.parametrize("M,H", [(1000, 768), (333, 1024), (64, 128), (77, 256)])
+def test_layernorm_fwd_bwd(M, H):
+    from unimm_amd import dropout as DR
+    from unimm_amd import lib
+    g = torch.Generator(device=DEV).manual_seed(M)
+    x = bf(torch.randn((M, H), generator=g, device=DEV) * 2 + 0.5)
+    gamma = torch.randn(H, generator=g, device=DEV) * 0.2 + 1
+    beta = torch.randn(H, generator=g, device=DEV) * 0.1
+    y = torch.empty_like(x)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    lib.layernorm_fwd(x, gamma, beta, y, mean, rstd, M, H)
+    xr = x.float().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (H,), gr, br, 1e-12)
+    torch.cuda.synchronize()
+    assert relerr(y, ref) < 2 ** -7
+    dy = bf(torch.randn((M, H), generator=g, device=DEV))
+    drop = DR.drop_arg(0.1, DR.make_key(1, 2, 3))
+    ref.backward(dy.float())
+    dx, dxd = torch.empty_like(x), torch.empty_like(x)
+    dg, db, dbias = torch.ones(H, device=DEV), torch.ones(H, device=DEV), torch.ones(H, device=DEV)
+    part = torch.empty(lib.colpartials_bytes(H) // 4, device=DEV)
+    lib.layernorm_bwd(dy, x, mean, rstd, gamma, dx, dxd, dg, db, dbias, part, M, H, drop=drop)
+    torch.cuda.synchronize()
+    assert relerr(dx, xr.grad) < 2 ** -6
+    keep = torch.from_numpy(DR.keep_mask(drop[0], drop[1], M * H).reshape(M, H)).to(DEV)
+    want_dxd = xr.grad * keep * drop[2]
+    assert relerr(dxd, want_dxd) < 2 ** -6
+    assert relerr(dg - 1, gr.grad) < 5e-3 and relerr(db - 1, br.grad) < 5e-3      # accumulate (+=) semantics
+    assert relerr(dbias - 1, want_dxd.sum(0)) < 5e-3
+
+
+def test_embeddings_fwd_bwd():
+    from unimm_amd import lib
+    g = torch.Generator(device=DEV).manual_seed(4)
+    M, H, V = 700, 768, 2000
+    tabs = [bf(torch.randn((n, H), generator=g, device=DEV) * 0.05) for n in (V, 512, 2, 10)]
+    ids = torch.randint(0, V, (M,), generator=g, device=DEV, dtype=torch.int32)
+    ids[::7] = 103
+    pos = torch.randint(0, 512, (M,), generator=g, device=DEV, dtype=torch.int32)
+    typ = torch.randint(0, 12, (M,), generator=g, device=DEV, dtype=torch.int32)
+    typ[::3] = 0
+    typ[1::3] = 1
+    gamma = torch.randn(H, generator=g, device=DEV) * 0.2 + 1
+    beta = torch.randn(H, generator=g, device=DEV) * 0.1
+    y = torch.empty((M, H), device=DEV, dtype=torch.bfloat16)
+    lib.embed_fwd(ids, pos, typ, *tabs, gamma, beta, y, M, H)
+    leaves = [t.float().requires_grad_(True) for t in tabs]
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    il, pl, tl = ids.long(), pos.long(), typ.long()
+    tvec = torch.where((tl >= 2)[:, None], leaves[3][(tl - 2).clamp_min(0)], leaves[2][tl.clamp_max(1)])
+    ref = torch.nn.functional.layer_norm(leaves[0][il] + leaves[1][pl] + tvec, (H,), gr, br, 1e-12)
+    torch.cuda.synchronize()
+    assert relerr(y, ref) < 2 ** -7
+    dy = bf(torch.randn((M, H), generator=g, device=DEV))
+    ref.backward(dy.float())
+    grads = [torch.zeros((n, H), device=DEV) for n in (V, 512, 2, 10)]
+    dg, db = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+    part = torch.empty(lib.colpartials_bytes(H) // 4, device=DEV)
+    lib.embed_bwd(ids, pos, typ, *tabs, gamma, beta, dy, grads[0], grads[1], grads[2], grads[3], dg, db, part, M, H)
+    torch.cuda.synchronize()
+    for got, leaf in zip(grads, leaves):
+        assert relerr(got, leaf.grad) < 2e-3
+    assert relerr(dg, gr.grad) < 2e-3 and relerr(db, br.grad) < 2e-3
+
+
+def test_colsum_casts_pack():
+    from unimm_amd import lib
+    g = torch.Generator(device=DEV).manual_seed(9)
+    dy = bf(torch.randn((1234, 1608), generator=g, device=DEV))
+    db = torch.ones(1601, device=DEV)
+    lib.colsum(dy, db, 1234, 1601)
+    torch.cuda.synchronize()
+    assert relerr(db - 1, dy[:, :1601].float().sum(0)) < 1e-3
+    w = torch.randn((300, 200), generator=g, device=DEV)
+    flat = torch.empty(300 * 200, device=DEV, dtype=torch.bfloat16)
+    lib.cast_f32_bf16(w, flat)
+    wt = torch.full((200, 320), 7.0, device=DEV, dtype=torch.bfloat16)
+    lib.transpose_cast(w, wt, 300, 200, 320)
+    torch.cuda.synchronize()
+    assert torch.equal(flat.view(300, 200), bf(w))
+    assert torch.equal(wt[:, :300], bf(w).t()) and (wt[:, 300:] == 0).all()
+    feat = torch.randn((74, 2048), generator=g, device=DEV)
+    loc = torch.rand((74, 5), generator=g, device=DEV)
+    packed = torch.full((74, 2112), 3.0, device=DEV, dtype=torch.bfloat16)
+    lib.pack_image(feat, loc, packed, 74, 2048, 2112)
+    torch.cuda.synchronize()
+    assert torch.equal(packed[:, :2048], bf(feat)) and torch.equal(packed[:, 2048:2053], bf(loc))
+    assert (packed[:, 2053:] == 0).all()
+
+
+# ----------------------------------------------------------------------------------------------
+# losses (reference: the oracle's functions, which are pinned to the reference's goldens)
+# ----------------------------------------------------------------------------------------------
+def test_lm_ul_loss_fwd_bwd_against_oracle():
+    from oracle import vilbert_ref as R
+    from oracle.cases import loss_inputs
+    from unimm_amd import lib
+    li = loss_inputs()
+    V = li["pred_t"].shape[-1]
+    ld = (V + 7) // 8 * 8
+    z = torch.from_numpy(li["pred_t"]).reshape(-1, V)
+    labels, weights = torch.from_numpy(li["labels"]).reshape(-1), torch.from_numpy(li["weights"]).reshape(-1)
+    sel = torch.nonzero(weights != 0)[:, 0]
+    n = sel.numel()
+    logits = torch.zeros((n, ld), device=DEV)
+    logits[:, :V] = z[sel].to(DEV)
+    lab, wgt = labels[sel].int().to(DEV), weights[sel].int().to(DEV)
+    rowloss, rownll, lse = (torch.empty(n, device=DEV) for _ in range(3))
+    lib.lm_loss_fwd(logits, lab, wgt, rowloss, rownll, lse, n, V)
+    loss = torch.empty(1, device=DEV)
+    lib.reduce_sum(rowloss, n, loss, 1.0 / n)
+    zt = torch.from_numpy(li["pred_t"]).requires_grad_(True)
+    want = R.mlm_ul_loss(zt, torch.from_numpy(li["labels"]), torch.from_numpy(li["weights"]))
+    want.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - want.item()) < 1e-4 * max(1.0, abs(want.item()))
+    gdev = torch.ones(1, device=DEV)
+    dl = torch.full((n, ld), 9.0, device=DEV, dtype=torch.bfloat16)
+    lib.lm_loss_bwd(logits, lab, wgt, lse, gdev, 1.0 / n, dl, n, V)
+    torch.cuda.synchronize()
+    ref = zt.grad.reshape(-1, V)[sel]
+    assert (dl[:, :V].float().cpu() - ref).abs().max() < 2 ** -7 * ref.abs().max() + 1e-6
+    assert (dl[:, V:] == 0).all()
+    # per-row nll = generative scoring term (val_lm.py:131-136)
+    ref_nll = torch.nn.functional.cross_entropy(z[sel], labels[sel], reduction="none")
+    assert (rownll.cpu() - ref_nll).abs().max() < 1e-3
+
+
+def test_kl_and_nsp_losses_against_oracle():
+    from oracle import vilbert_ref as R
+    from oracle.cases import loss_inputs
+    from unimm_amd import lib
+    li = loss_inputs()
+    pv = torch.from_numpy(li["pred_v"])
+    B, Rg, C = pv.shape
+    rows = B * Rg
+    pred = torch.zeros((rows, 1604), device=DEV)
+    pred[:, :C] = pv.reshape(rows, C).to(DEV)
+    tgt = torch.from_numpy(li["image_target"]).reshape(rows, C).contiguous().to(DEV)
+    lab = torch.from_numpy(li["image_label"]).reshape(rows).int().to(DEV)
+    rowloss, lse, loss = torch.empty(rows, device=DEV), torch.empty(rows, device=DEV), torch.empty(1, device=DEV)
+    lib.kl_loss_fwd(pred, tgt, lab, rowloss, lse, rows, C)
+    nsel = int((li["image_label"] == 1).sum())
+    lib.reduce_sum(rowloss, rows, loss, 1.0 / nsel)
+    pvt = pv.clone().requires_grad_(True)
+    want = R.image_kl_loss(pvt, torch.from_numpy(li["image_target"]), torch.from_numpy(li["image_label"]))
+    want.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - want.item()) < 1e-4 * max(1.0, abs(want.item()))
+    dp = torch.full((rows, 1664), 5.0, device=DEV, dtype=torch.bfloat16)
+    lib.kl_loss_bwd(pred, tgt, lab, lse, torch.ones(1, device=DEV), 1.0 / nsel, dp, rows, C)
+    torch.cuda.synchronize()
+    ref = pvt.grad.reshape(rows, C)
+    assert (dp[:, :C].float().cpu() - ref).abs().max() < 2 ** -7 * ref.abs().max() + 1e-7
+    assert (dp[:, C:] == 0).all()
+    # NSP
+    g = torch.Generator().manual_seed(0)
+    nb = 37
+    z = torch.randn((nb, 2), generator=g)
+    y = (torch.rand(nb, generator=g) < 0.8).long()
+    zt = z.clone().requires_grad_(True)
+    want = R.nsp_loss(zt, y, torch.tensor([[5.0, 1.0]]))
+    want.backward()
+    zd = torch.zeros((nb, 4), device=DEV)
+    zd[:, :2] = z.to(DEV)
+    loss = torch.empty(1, device=DEV)
+    lib.nsp_loss_fwd(zd, y.int().to(DEV), 1.0, 0.2, loss, nb)
+    dz = torch.full((nb, 64), 3.0, device=DEV, dtype=torch.bfloat16)
+    lib.nsp_loss_bwd(zd, y.int().to(DEV), 1.0, 0.2, torch.ones(1, device=DEV), dz, nb)
+    torch.cuda.synchronize()
+    assert abs(loss.item() - want.item()) < 1e-5
+    assert (dz[:, :2].float().cpu() - zt.grad).abs().max() < 2 ** -7 * zt.grad.abs().max()
+    assert (dz[:, 2:] == 0).all()

@@ -1,0 +1,527 @@
+// Fused masked attention cores for the UniMM-UL hot path (gfx950): forward, dQ and dK/dV kernels.
+//
+// Replaces softmax(Q K^T / sqrt(d) + mask) . V with attention-prob dropout, in the four shapes of
+// the reference: text self-attention (T=256, d=64, dense per-sequence mask;
+// models/vilbert_dialog.py:390-410), visual self-attention (R=37, d=128, key-padding mask; :519-539)
+// and both directions of the co-attention (:681-721).  No score matrix ever reaches HBM.
+//
+// Structure (one workgroup = one (sequence, head); one wave = one 32-query tile):
+//   * K and V of the head are staged once into LDS (<= 256 keys x d fits: 64 KiB at d=64).
+//   * S^T = K . Q^T with v_mfma_f32_32x32x16_bf16 ("swapped" product): the query sits on the lane,
+//     keys in the 16 accumulator registers, so row max / row sum are register reductions plus one
+//     cross-half exchange, and the whole 256-key row stays in registers (exact softmax, no online
+//     rescaling needed at T <= 256).
+//   * masks are bit-packed (1 bit per (query,key), 8 KiB per sequence instead of 512 KiB int64);
+//     masked scores get the reference's additive -10000 (not -inf), so fully masked rows reproduce
+//     softmax(raw scores) exactly as models/vilbert_dialog.py:1418 does.
+//   * P (bf16) feeds O^T = V^T . P^T directly from the accumulator registers (its key index is the
+//     MFMA's reduction index); V^T fragments come from ds_read_b64_tr_b16.
+#include "common.h"
+
+namespace {
+
+struct AttnParams {
+  const bf16_t* q; const bf16_t* k; const bf16_t* v;
+  bf16_t* o; float* lse;
+  const uint32_t* mask;  // [B][mask rows][nw] words, bit j of word t = key 32t+j may be attended
+  int B, H, Tq, Tk, ldq, ldk, ldv, ldo;
+  int mask_q_stride, mask_b_stride;  // in words; q stride 0 = one row per sequence (key padding)
+  float scale;
+  DropoutArg drop;
+};
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+// ---- LDS images -------------------------------------------------------------------------------
+// Rows of D bf16 (2D bytes = D/8 chunks of 16 B), 16-B chunk index XOR-swizzled per row with ONE
+// function that keeps both kinds of read conflict-free: ds_read_b128 row fragments (a 16-lane group
+// reads 16 rows at one chunk) and ds_read_b64_tr_b16 transposed fragments (a 32-lane half reads
+// 4 rows x 64 B).  D=128 is the guide's image (b); D=64 is its 128-B-row analogue.
+template <int D> __device__ __forceinline__ int swz(int row) {
+  if constexpr (D == 64) { const int t = row >> 1; return (t & 7) ^ ((t & 1) << 2); }
+  else return ((row & 3) << 2) | ((row >> 2) & 3);
+}
+
+// cooperative stage of `nrows_pad` rows of one head (rows >= nrows are zero-filled)
+template <int D>
+__device__ __forceinline__ void stage_head(const bf16_t* __restrict__ g, int ld, int nrows, int nrows_pad,
+                                           char* img, int tid, int nthreads) {
+  constexpr int CPR = D / 8;  // chunks per row
+  for (int c = tid; c < nrows_pad * CPR; c += nthreads) {
+    const int row = c / CPR, ch = c % CPR;
+    u32x4 val = {0u, 0u, 0u, 0u};
+    if (row < nrows) val = *reinterpret_cast<const u32x4*>(g + (size_t)row * ld + ch * 8);
+    *reinterpret_cast<u32x4*>(img + row * (2 * D) + ((ch ^ swz<D>(row)) << 4)) = val;
+  }
+}
+
+template <int D> __device__ __forceinline__ bf16x8 read_row_frag(const char* img, int row, int chunk) {
+  return *reinterpret_cast<const bf16x8*>(img + row * (2 * D) + ((chunk ^ swz<D>(row)) << 4));
+}
+
+// transposed 32x32x16 operand (permuted reduction order, cdna guide 3 "accumulator tile as operand"):
+// element j of lane (r = lane&31, h = lane>>5) = img[rowbase + 8*(j>>2) + 4h + (j&3)][col0 + r]
+template <int D>
+__device__ __forceinline__ bf16x8 read_tr_frag(const char* img, int rowbase, int col0, int lane) {
+  const int h = lane >> 5, i = lane & 15, qq = i >> 2, pp = i & 3;
+  const int col = col0 + 16 * ((lane >> 4) & 1) + 4 * pp;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x4 part[2];
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) {
+    const int row = rowbase + 8 * jj + 4 * h + qq;
+    const int pch = (col >> 3) ^ swz<D>(row);
+    part[jj] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)LDS_PTR(img + row * (2 * D) + pch * 16 + (col & 7) * 2));
+  }
+  s16x8 v = {part[0][0], part[0][1], part[0][2], part[0][3], part[1][0], part[1][1], part[1][2], part[1][3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__device__ __forceinline__ bf16x8 pack8(const float* p) {
+  typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+  u4 w = {pack2bf(p[0], p[1]), pack2bf(p[2], p[3]), pack2bf(p[4], p[5]), pack2bf(p[6], p[7])};
+  return __builtin_bit_cast(bf16x8, w);
+}
+
+__device__ __forceinline__ int key_of_reg(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <int D, int NKT>
+__global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KPAD = NKT * 32;
+  char* kimg = smem;
+  char* vimg = smem + KPAD * 2 * D;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int b = blockIdx.x / p.H, head = blockIdx.x % p.H;
+  const int r = lane & 31, h = lane >> 5;
+
+  const bf16_t* kg = p.k + (size_t)b * p.Tk * p.ldk + head * D;
+  const bf16_t* vg = p.v + (size_t)b * p.Tk * p.ldv + head * D;
+  stage_head<D>(kg, p.ldk, p.Tk, KPAD, kimg, tid, blockDim.x);
+  stage_head<D>(vg, p.ldv, p.Tk, KPAD, vimg, tid, blockDim.x);
+
+  // Q fragments straight from HBM (each element is used once per key tile, by this wave only)
+  const int q0 = wave * 32;
+  int qrow = q0 + r;
+  const bool qvalid = qrow < p.Tq;
+  if (!qvalid) qrow = p.Tq - 1;
+  const bf16_t* qg = p.q + ((size_t)b * p.Tq + qrow) * p.ldq + head * D;
+  bf16x8 qf[D / 16];
+#pragma unroll
+  for (int ks = 0; ks < D / 16; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qg + 16 * ks + 8 * h);
+
+  // mask words of this query row
+  uint32_t mw[NKT];
+  {
+    const uint32_t* mp = p.mask + (size_t)b * p.mask_b_stride + (size_t)qrow * p.mask_q_stride;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) mw[t] = mp[t];
+  }
+  __syncthreads();
+
+  // ---- S^T = K . Q^T, all key tiles kept in registers
+  f32x16 s[NKT];
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+    f32x16 acc = {};
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks) {
+      const bf16x8 kf = read_row_frag<D>(kimg, 32 * t + r, 2 * ks + h);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], acc, 0, 0, 0);
+    }
+    s[t] = acc;
+  }
+
+  // ---- mask + softmax over the lane's 16*NKT keys and its partner's (lane ^ 32)
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+    const uint32_t w = mw[t] >> (4 * h);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int kk = (e & 3) + 8 * (e >> 2);              // + 4h folded into w
+      const int key = 32 * t + kk + 4 * h;
+      float v = s[t][e] * p.scale;
+      v += ((w >> kk) & 1u) ? 0.0f : -10000.0f;            // additive mask, fp32 (reference :1418)
+      v = key < p.Tk ? v : -INFINITY;                      // padded keys do not exist
+      s[t][e] = v;
+      mx = fmaxf(mx, v);
+    }
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  const float mxl = mx * LOG2E;
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < NKT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float pe = exp2f(s[t][e] * LOG2E - mxl);
+      s[t][e] = pe;
+      sum += pe;
+    }
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.0f / sum;
+
+  if (p.drop.thr != 0u) {
+    const uint32_t base = (((uint32_t)b * p.H + head) * p.Tq + (uint32_t)qrow) * (uint32_t)p.Tk;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[t][e] = drop_apply(p.drop, base + 32 * t + key_of_reg(e, h), s[t][e]);
+  }
+
+  // ---- O^T = V^T . P^T
+  f32x16 o[D / 32];
+#pragma unroll
+  for (int dt = 0; dt < D / 32; ++dt) o[dt] = f32x16{};
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) {
+      float pv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pv[j] = s[t][8 * ss + j];
+      const bf16x8 pf = pack8(pv);
+#pragma unroll
+      for (int dt = 0; dt < D / 32; ++dt) {
+        const bf16x8 vf = read_tr_frag<D>(vimg, 32 * t + 16 * ss, 32 * dt, lane);
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+      }
+    }
+  }
+
+  if (qvalid) {
+    bf16_t* og = p.o + ((size_t)b * p.Tq + qrow) * p.ldo + head * D;
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int d = 32 * dt + 8 * qd + 4 * h;
+        *reinterpret_cast<u32x2*>(og + d) = u32x2{pack2bf(o[dt][4 * qd] * inv, o[dt][4 * qd + 1] * inv),
+                                                  pack2bf(o[dt][4 * qd + 2] * inv, o[dt][4 * qd + 3] * inv)};
+      }
+    if (p.lse != nullptr && h == 0) p.lse[((size_t)b * p.H + head) * p.Tq + qrow] = mx + logf(sum);
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// backward, part 1: dQ (query on the lane, same walk as the forward) + delta = rowsum(dO o O)
+//   P = exp(S' - lse);  dP = dO . V^T (dropout mask re-generated);  dS = scale * P o (dP - delta)
+//   dQ^T += K^T . dS^T    (K^T fragments: transposed reads of the same K image)
+// ------------------------------------------------------------------------------------------------
+struct AttnBwdParams {
+  const bf16_t* q; const bf16_t* k; const bf16_t* v; const bf16_t* o; const bf16_t* dout;
+  const float* lse; float* delta;
+  bf16_t* dq; bf16_t* dk; bf16_t* dv;
+  const uint32_t* mask;
+  int B, H, Tq, Tk, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
+  int mask_q_stride, mask_b_stride;
+  float scale;
+  DropoutArg drop;
+};
+
+template <int D, int NKT>
+__global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KPAD = NKT * 32;
+  char* kimg = smem;
+  char* vimg = smem + KPAD * 2 * D;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int b = blockIdx.x / p.H, head = blockIdx.x % p.H;
+  const int r = lane & 31, h = lane >> 5;
+
+  stage_head<D>(p.k + (size_t)b * p.Tk * p.ldk + head * D, p.ldk, p.Tk, KPAD, kimg, tid, blockDim.x);
+  stage_head<D>(p.v + (size_t)b * p.Tk * p.ldv + head * D, p.ldv, p.Tk, KPAD, vimg, tid, blockDim.x);
+
+  int qrow = wave * 32 + r;
+  const bool qvalid = qrow < p.Tq;
+  if (!qvalid) qrow = p.Tq - 1;
+  const size_t grow = (size_t)b * p.Tq + qrow;
+  const bf16_t* qg = p.q + grow * p.ldq + head * D;
+  const bf16_t* dog = p.dout + grow * p.lddo + head * D;
+  const bf16_t* og = p.o + grow * p.ldo + head * D;
+  bf16x8 qf[D / 16], dof[D / 16];
+  float delta = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < D / 16; ++ks) {
+    qf[ks] = *reinterpret_cast<const bf16x8*>(qg + 16 * ks + 8 * h);
+    dof[ks] = *reinterpret_cast<const bf16x8*>(dog + 16 * ks + 8 * h);
+    const bf16x8 of = *reinterpret_cast<const bf16x8*>(og + 16 * ks + 8 * h);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) delta += (float)dof[ks][j] * (float)of[j];
+  }
+  delta += __shfl_xor(delta, 32, 64);
+  const size_t stat = ((size_t)b * p.H + head) * p.Tq + qrow;
+  const float lse_l = p.lse[stat] * LOG2E;
+  if (qvalid && h == 0) p.delta[stat] = delta;
+
+  uint32_t mw[NKT];
+  {
+    const uint32_t* mp = p.mask + (size_t)b * p.mask_b_stride + (size_t)qrow * p.mask_q_stride;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) mw[t] = mp[t];
+  }
+  __syncthreads();
+
+  f32x16 dq[D / 32];
+#pragma unroll
+  for (int dt = 0; dt < D / 32; ++dt) dq[dt] = f32x16{};
+  const uint32_t dbase = (((uint32_t)b * p.H + head) * p.Tq + (uint32_t)qrow) * (uint32_t)p.Tk;
+
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+    if (32 * t >= p.Tk) break;
+    f32x16 sacc = {}, dpacc = {};
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks) {
+      const bf16x8 kf = read_row_frag<D>(kimg, 32 * t + r, 2 * ks + h);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc, 0, 0, 0);
+      const bf16x8 vf = read_row_frag<D>(vimg, 32 * t + r, 2 * ks + h);
+      dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dpacc, 0, 0, 0);
+    }
+    const uint32_t w = mw[t] >> (4 * h);
+    float ds[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int kk = (e & 3) + 8 * (e >> 2);
+      const int key = 32 * t + kk + 4 * h;
+      float v = sacc[e] * p.scale;
+      v += ((w >> kk) & 1u) ? 0.0f : -10000.0f;
+      const float pe = key < p.Tk ? exp2f(v * LOG2E - lse_l) : 0.f;
+      float dp = dpacc[e];
+      if (p.drop.thr != 0u) dp = drop_apply(p.drop, dbase + key, dp);
+      ds[e] = pe * (dp - delta) * p.scale;
+    }
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) {
+      const bf16x8 dsf = pack8(ds + 8 * ss);
+#pragma unroll
+      for (int dt = 0; dt < D / 32; ++dt) {
+        const bf16x8 ktf = read_tr_frag<D>(kimg, 32 * t + 16 * ss, 32 * dt, lane);
+        dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf, dq[dt], 0, 0, 0);
+      }
+    }
+  }
+
+  if (qvalid) {
+    bf16_t* dqg = p.dq + grow * p.lddq + head * D;
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd)
+        *reinterpret_cast<u32x2*>(dqg + 32 * dt + 8 * qd + 4 * h) =
+            u32x2{pack2bf(dq[dt][4 * qd], dq[dt][4 * qd + 1]), pack2bf(dq[dt][4 * qd + 2], dq[dt][4 * qd + 3])};
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, part 2: dK, dV (key on the lane; one wave = one 32-key tile, walks all query tiles)
+//   S = Q . K^T and dP = dO . V^T land as [query regs][key lane]; P / dS feed
+//   dV^T += dO^T . P_drop  and  dK^T += Q^T . dS  straight from the accumulators, with the
+//   transposed operands read from the Q / dO images.  No atomics, no cross-wave reduction.
+// ------------------------------------------------------------------------------------------------
+template <int D, int NQT>
+__global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int QPAD = NQT * 32;
+  char* qimg = smem;
+  char* doimg = smem + QPAD * 2 * D;
+  float* lse_s = reinterpret_cast<float*>(smem + 2 * QPAD * 2 * D);
+  float* del_s = lse_s + QPAD;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int b = blockIdx.x / p.H, head = blockIdx.x % p.H;
+  const int r = lane & 31, h = lane >> 5;
+
+  stage_head<D>(p.q + (size_t)b * p.Tq * p.ldq + head * D, p.ldq, p.Tq, QPAD, qimg, tid, blockDim.x);
+  stage_head<D>(p.dout + (size_t)b * p.Tq * p.lddo + head * D, p.lddo, p.Tq, QPAD, doimg, tid, blockDim.x);
+  for (int i = tid; i < QPAD; i += blockDim.x) {
+    const size_t stat = ((size_t)b * p.H + head) * p.Tq + i;
+    lse_s[i] = i < p.Tq ? p.lse[stat] * LOG2E : INFINITY;   // +inf => P = 0 for padded queries
+    del_s[i] = i < p.Tq ? p.delta[stat] : 0.f;
+  }
+
+  int krow = wave * 32 + r;
+  const bool kvalid = krow < p.Tk;
+  if (!kvalid) krow = p.Tk - 1;
+  const size_t grow = (size_t)b * p.Tk + krow;
+  const bf16_t* kg = p.k + grow * p.ldk + head * D;
+  const bf16_t* vg = p.v + grow * p.ldv + head * D;
+  bf16x8 kf[D / 16], vf[D / 16];
+#pragma unroll
+  for (int ks = 0; ks < D / 16; ++ks) {
+    kf[ks] = *reinterpret_cast<const bf16x8*>(kg + 16 * ks + 8 * h);
+    vf[ks] = *reinterpret_cast<const bf16x8*>(vg + 16 * ks + 8 * h);
+  }
+  __syncthreads();
+
+  f32x16 dk[D / 32], dv[D / 32];
+#pragma unroll
+  for (int dt = 0; dt < D / 32; ++dt) { dk[dt] = f32x16{}; dv[dt] = f32x16{}; }
+  const uint32_t* mbase = p.mask + (size_t)b * p.mask_b_stride + wave;
+  const uint32_t hbase = ((uint32_t)b * p.H + head) * (uint32_t)p.Tq;
+
+#pragma unroll 1
+  for (int qt = 0; qt < NQT; ++qt) {
+    if (32 * qt >= p.Tq) break;
+    f32x16 sacc = {}, dpacc = {};
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks) {
+      const bf16x8 qf = read_row_frag<D>(qimg, 32 * qt + r, 2 * ks + h);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[ks], sacc, 0, 0, 0);
+      const bf16x8 df = read_row_frag<D>(doimg, 32 * qt + r, 2 * ks + h);
+      dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, vf[ks], dpacc, 0, 0, 0);
+    }
+    float pd[16], ds[16];
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int qb = 32 * qt + 8 * g4 + 4 * h;   // 4 consecutive queries for registers 4*g4 .. 4*g4+3
+      const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qb);
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + qb);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int e = 4 * g4 + i;
+        int qi = qb + i;
+        qi = qi < p.Tq ? qi : p.Tq - 1;
+        const uint32_t w = mbase[(size_t)qi * p.mask_q_stride];
+        float v = sacc[e] * p.scale;
+        v += ((w >> r) & 1u) ? 0.0f : -10000.0f;
+        const float pe = kvalid ? exp2f(v * LOG2E - l4[i]) : 0.f;
+        float dp = dpacc[e];
+        float pdrop = pe;
+        if (p.drop.thr != 0u) {
+          const uint32_t idx = (hbase + (uint32_t)qi) * (uint32_t)p.Tk + (uint32_t)krow;
+          const bool keep = mix32(idx ^ p.drop.key) >= p.drop.thr;
+          dp = keep ? dp * p.drop.scale : 0.f;
+          pdrop = keep ? pe * p.drop.scale : 0.f;
+        }
+        pd[e] = pdrop;
+        ds[e] = pe * (dp - d4[i]) * p.scale;
+      }
+    }
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) {
+      const bf16x8 pf = pack8(pd + 8 * ss);
+      const bf16x8 dsf = pack8(ds + 8 * ss);
+#pragma unroll
+      for (int dt = 0; dt < D / 32; ++dt) {
+        const bf16x8 dotf = read_tr_frag<D>(doimg, 32 * qt + 16 * ss, 32 * dt, lane);
+        dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf, pf, dv[dt], 0, 0, 0);
+        const bf16x8 qtf = read_tr_frag<D>(qimg, 32 * qt + 16 * ss, 32 * dt, lane);
+        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, dsf, dk[dt], 0, 0, 0);
+      }
+    }
+  }
+
+  if (kvalid) {
+    bf16_t* dkg = p.dk + grow * p.lddk + head * D;
+    bf16_t* dvg = p.dv + grow * p.lddv + head * D;
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int d = 32 * dt + 8 * qd + 4 * h;
+        *reinterpret_cast<u32x2*>(dkg + d) =
+            u32x2{pack2bf(dk[dt][4 * qd], dk[dt][4 * qd + 1]), pack2bf(dk[dt][4 * qd + 2], dk[dt][4 * qd + 3])};
+        *reinterpret_cast<u32x2*>(dvg + d) =
+            u32x2{pack2bf(dv[dt][4 * qd], dv[dt][4 * qd + 1]), pack2bf(dv[dt][4 * qd + 2], dv[dt][4 * qd + 3])};
+      }
+  }
+}
+
+template <typename K>
+int set_lds(K kern, size_t lds) {
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return UNIMM_E_HIP;
+  return UNIMM_OK;
+}
+
+template <int D, int NKT>
+int launch_bwd_dq(const AttnBwdParams& p, hipStream_t s) {
+  const size_t lds = (size_t)2 * NKT * 32 * 2 * D;
+  auto kern = attn_bwd_dq_kernel<D, NKT>;
+  if (set_lds(kern, lds) != UNIMM_OK) return UNIMM_E_HIP;
+  hipLaunchKernelGGL(kern, dim3(p.B * p.H), dim3(((p.Tq + 31) / 32) * 64), lds, s, p);
+  UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
+}
+
+template <int D, int NQT>
+int launch_bwd_dkv(const AttnBwdParams& p, hipStream_t s) {
+  const size_t lds = (size_t)2 * NQT * 32 * 2 * D + 2 * NQT * 32 * sizeof(float);
+  auto kern = attn_bwd_dkv_kernel<D, NQT>;
+  if (set_lds(kern, lds) != UNIMM_OK) return UNIMM_E_HIP;
+  hipLaunchKernelGGL(kern, dim3(p.B * p.H), dim3(((p.Tk + 31) / 32) * 64), lds, s, p);
+  UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
+}
+
+template <int D, int NKT>
+int launch_fwd(const AttnParams& p, hipStream_t s) {
+  const int waves = (p.Tq + 31) / 32;
+  const size_t lds = (size_t)2 * NKT * 32 * 2 * D;
+  auto kern = attn_fwd_kernel<D, NKT>;
+  if (set_lds(kern, lds) != UNIMM_OK) return UNIMM_E_HIP;
+  hipLaunchKernelGGL(kern, dim3(p.B * p.H), dim3(waves * 64), lds, s, p);
+  UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
+}
+
+}  // namespace
+
+extern "C" int unimm_attn_fwd(const unimm_attn_args* a, void* stream) {
+  if (a == nullptr || !a->q || !a->k || !a->v || !a->out || !a->mask) return UNIMM_E_ARG;
+  if (a->B <= 0 || a->H <= 0 || a->Tq <= 0 || a->Tk <= 0 || a->Tq > 256 || a->Tk > 256) return UNIMM_E_SHAPE;
+  if (a->D != 64 && a->D != 128) return UNIMM_E_SHAPE;
+  if ((a->ldq % 8) || (a->ldk % 8) || (a->ldv % 8) || (a->ldo % 4)) return UNIMM_E_ALIGN;
+  if (((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v) & 15) return UNIMM_E_ALIGN;
+  AttnParams p;
+  p.q = (const bf16_t*)a->q; p.k = (const bf16_t*)a->k; p.v = (const bf16_t*)a->v;
+  p.o = (bf16_t*)a->out; p.lse = a->lse; p.mask = a->mask;
+  p.B = a->B; p.H = a->H; p.Tq = a->Tq; p.Tk = a->Tk;
+  p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo;
+  p.mask_q_stride = a->mask_q_stride; p.mask_b_stride = a->mask_b_stride;
+  p.scale = a->scale;
+  p.drop.key = a->drop_key; p.drop.thr = a->drop_thr; p.drop.scale = a->drop_scale;
+  hipStream_t s = (hipStream_t)stream;
+  const bool small_k = a->Tk <= 64;
+  if (a->D == 64) return small_k ? launch_fwd<64, 2>(p, s) : launch_fwd<64, 8>(p, s);
+  return small_k ? launch_fwd<128, 2>(p, s) : launch_fwd<128, 8>(p, s);
+}
+
+extern "C" int unimm_attn_bwd(const unimm_attn_bwd_args* a, void* stream) {
+  if (a == nullptr || !a->q || !a->k || !a->v || !a->out || !a->dout || !a->lse || !a->delta || !a->dq || !a->dk ||
+      !a->dv || !a->mask)
+    return UNIMM_E_ARG;
+  if (a->B <= 0 || a->H <= 0 || a->Tq <= 0 || a->Tk <= 0 || a->Tq > 256 || a->Tk > 256) return UNIMM_E_SHAPE;
+  if (a->D != 64 && a->D != 128) return UNIMM_E_SHAPE;
+  if ((a->ldq % 8) || (a->ldk % 8) || (a->ldv % 8) || (a->ldo % 8) || (a->lddo % 8) || (a->lddq % 4) || (a->lddk % 4) ||
+      (a->lddv % 4))
+    return UNIMM_E_ALIGN;
+  if (((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v | (uintptr_t)a->out | (uintptr_t)a->dout) & 15)
+    return UNIMM_E_ALIGN;
+  AttnBwdParams p;
+  p.q = (const bf16_t*)a->q; p.k = (const bf16_t*)a->k; p.v = (const bf16_t*)a->v; p.o = (const bf16_t*)a->out;
+  p.dout = (const bf16_t*)a->dout; p.lse = a->lse; p.delta = a->delta;
+  p.dq = (bf16_t*)a->dq; p.dk = (bf16_t*)a->dk; p.dv = (bf16_t*)a->dv; p.mask = a->mask;
+  p.B = a->B; p.H = a->H; p.Tq = a->Tq; p.Tk = a->Tk;
+  p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo; p.lddo = a->lddo;
+  p.lddq = a->lddq; p.lddk = a->lddk; p.lddv = a->lddv;
+  p.mask_q_stride = a->mask_q_stride; p.mask_b_stride = a->mask_b_stride;
+  p.scale = a->scale;
+  p.drop.key = a->drop_key; p.drop.thr = a->drop_thr; p.drop.scale = a->drop_scale;
+  hipStream_t s = (hipStream_t)stream;
+  const bool small_k = a->Tk <= 64, small_q = a->Tq <= 64;
+  int rc;
+  if (a->D == 64) rc = small_k ? launch_bwd_dq<64, 2>(p, s) : launch_bwd_dq<64, 8>(p, s);
+  else rc = small_k ? launch_bwd_dq<128, 2>(p, s) : launch_bwd_dq<128, 8>(p, s);
+  if (rc != UNIMM_OK) return rc;
+  if (a->D == 64) return small_q ? launch_bwd_dkv<64, 2>(p, s) : launch_bwd_dkv<64, 8>(p, s);
+  return small_q ? launch_bwd_dkv<128, 2>(p, s) : launch_bwd_dkv<128, 8>(p, s);
+}

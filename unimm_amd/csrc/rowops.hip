@@ -1,0 +1,654 @@
+// HBM-bound row kernels of the UniMM-UL hot path (gfx950): mask bit-packing, LayerNorm fwd/bwd,
+// embedding gather+LayerNorm fwd/bwd, column sums (bias gradients), dtype casts / transposed weight
+// copies, region-feature packing.  All are one-wave-per-row or flat streaming kernels
+// with 16-byte vector accesses; none is MFMA work, their roofline is HBM bandwidth.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXC = 2;          // 8-element chunks per lane: hidden sizes up to 1024
+constexpr int RED_BLOCKS = 512;  // row-kernel grid for kernels that emit per-block column partials
+
+// ------------------------------------------------------------------------------------------------
+// mask pack: any 0/1 mask tensor [rows, T] -> bit words [rows, ceil(T/32)]   (SURVEY K13;
+// replaces the fp32 (1-m)*-10000 tensors of models/vilbert_dialog.py:1415-1431)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void mask_pack_ballot_kernel(const T* __restrict__ m, uint32_t* __restrict__ out, size_t ngroups) {
+  const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const size_t nwaves = (size_t)gridDim.x * (blockDim.x >> 6);
+  const int lane = threadIdx.x & 63;
+  for (size_t g = wave; g < ngroups; g += nwaves) {
+    const bool bit = m[g * 64 + lane] != (T)0;
+    const unsigned long long bal = __ballot(bit);
+    if (lane == 0) {
+      out[2 * g] = (uint32_t)bal;
+      out[2 * g + 1] = (uint32_t)(bal >> 32);
+    }
+  }
+}
+
+template <typename T>
+__global__ void mask_pack_generic_kernel(const T* __restrict__ m, uint32_t* __restrict__ out, size_t rows, int t,
+                                         int nw) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * nw) return;
+  const size_t row = i / nw;
+  const int w = (int)(i % nw);
+  uint32_t bits = 0;
+  for (int j = 0; j < 32; ++j) {
+    const int c = w * 32 + j;
+    if (c < t && m[row * t + c] != (T)0) bits |= 1u << j;
+  }
+  out[i] = bits;
+}
+
+template <typename T>
+int mask_pack_impl(const void* m, uint32_t* out, size_t rows, int t, hipStream_t s) {
+  const int nw = (t + 31) / 32;
+  if (t % 64 == 0) {
+    const size_t ngroups = rows * (size_t)(t / 64);
+    int blocks = (int)((ngroups + 3) / 4);
+    blocks = blocks > 4096 ? 4096 : blocks;
+    hipLaunchKernelGGL(mask_pack_ballot_kernel<T>, dim3(blocks), dim3(256), 0, s, (const T*)m, out, ngroups);
+  } else {
+    const size_t n = rows * nw;
+    hipLaunchKernelGGL(mask_pack_generic_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const T*)m,
+                       out, rows, t, nw);
+  }
+  UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// row helpers: a wave owns one row of H elements as 8-element (16-byte) chunks, chunk c = lane + 64*i
+// ------------------------------------------------------------------------------------------------
+struct Row8 { float v[MAXC][8]; };
+
+__device__ __forceinline__ void load_row_bf16(const bf16_t* __restrict__ p, int H, int lane, Row8& r) {
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c * 8 < H) {
+      const u32x4 raw = *reinterpret_cast<const u32x4*>(p + c * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        r.v[i][2 * j] = __uint_as_float(raw[j] << 16);
+        r.v[i][2 * j + 1] = __uint_as_float(raw[j] & 0xffff0000u);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r.v[i][j] = 0.f;
+    }
+  }
+}
+
+__device__ __forceinline__ void store_row_bf16(bf16_t* __restrict__ p, int H, int lane, const Row8& r) {
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c * 8 < H)
+      *reinterpret_cast<u32x4*>(p + c * 8) = u32x4{pack2bf(r.v[i][0], r.v[i][1]), pack2bf(r.v[i][2], r.v[i][3]),
+                                                   pack2bf(r.v[i][4], r.v[i][5]), pack2bf(r.v[i][6], r.v[i][7])};
+  }
+}
+
+__device__ __forceinline__ void load_vec_f32(const float* __restrict__ p, int H, int lane, Row8& r) {
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c * 8 < H) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(p + c * 8);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(p + c * 8 + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { r.v[i][j] = a[j]; r.v[i][4 + j] = b[j]; }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r.v[i][j] = 0.f;
+    }
+  }
+}
+
+__device__ __forceinline__ void row_stats(const Row8& x, int H, float& mean, float& rstd, float eps) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += x.v[i][j];
+  mean = wave_sum(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = (threadIdx.x & 63) + 64 * i;
+    if (c * 8 < H) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = x.v[i][j] - mean; q += d * d; }
+    }
+  }
+  rstd = rsqrtf(wave_sum(q) / (float)H + eps);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm forward (torch.nn.LayerNorm, eps 1e-12; models/vilbert_dialog.py:279,425,468,...)
+// optional dropout on the output (embedding dropouts :355, :1491)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                            float* __restrict__ mean_o, float* __restrict__ rstd_o, int M,
+                                                            int H, float eps, DropoutArg drop) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * (blockDim.x >> 6);
+  Row8 g, b;
+  load_vec_f32(gamma, H, lane, g);
+  load_vec_f32(beta, H, lane, b);
+  for (int row = wave; row < M; row += nwaves) {
+    Row8 xv;
+    load_row_bf16(x + (size_t)row * H, H, lane, xv);
+    float mean, rstd;
+    row_stats(xv, H, mean, rstd, eps);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float v = (xv.v[i][j] - mean) * rstd * g.v[i][j] + b.v[i][j];
+        if (drop.thr != 0u) v = drop_apply(drop, (uint32_t)row * (uint32_t)H + (uint32_t)((lane + 64 * i) * 8 + j), v);
+        xv.v[i][j] = v;
+      }
+    store_row_bf16(y + (size_t)row * H, H, lane, xv);
+    if (lane == 0 && mean_o != nullptr) { mean_o[row] = mean; rstd_o[row] = rstd; }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm backward.  dx = rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dy*gamma.
+// Also emits (a) dx_drop = dropout-masked dx for the dense branch when the forward applied
+// dropout before the residual add (:424, :467, ...), and (b) per-block column partials of
+// dgamma, dbeta and dbias = colsum(dx_drop) that `colpartials_finish` adds into the gradient arena
+// (two-stage, deterministic; no same-address atomics from 1000+ waves).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                            const float* __restrict__ mean_i,
+                                                            const float* __restrict__ rstd_i,
+                                                            const float* __restrict__ gamma, bf16_t* __restrict__ dx,
+                                                            bf16_t* __restrict__ dx_drop, float* __restrict__ partials,
+                                                            int M, int H, DropoutArg drop, DropoutArg out_drop) {
+  __shared__ float red[4 * 1024];  // [wave][col], reused for each of the three quantities
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wave = blockIdx.x * 4 + wv;
+  const int nwaves = gridDim.x * 4;
+  Row8 g;
+  load_vec_f32(gamma, H, lane, g);
+  Row8 dg, db, dbias;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { dg.v[i][j] = 0.f; db.v[i][j] = 0.f; dbias.v[i][j] = 0.f; }
+  const float invH = 1.0f / (float)H;
+  for (int row = wave; row < M; row += nwaves) {
+    Row8 dyv, xv;
+    load_row_bf16(dy + (size_t)row * H, H, lane, dyv);
+    load_row_bf16(x + (size_t)row * H, H, lane, xv);
+    const float mean = mean_i[row], rstd = rstd_i[row];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float d = dyv.v[i][j];
+        if (out_drop.thr != 0u)  // forward applied dropout AFTER this LayerNorm (embeddings)
+          d = drop_apply(out_drop, (uint32_t)row * (uint32_t)H + (uint32_t)((lane + 64 * i) * 8 + j), d);
+        const float xh = (xv.v[i][j] - mean) * rstd;
+        const float gg = d * g.v[i][j];
+        dg.v[i][j] += d * xh;
+        db.v[i][j] += d;
+        s1 += gg;
+        s2 += gg * xh;
+        dyv.v[i][j] = gg;
+        xv.v[i][j] = xh;
+      }
+    s1 = wave_sum(s1) * invH;
+    s2 = wave_sum(s2) * invH;
+    Row8 dd;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = rstd * (dyv.v[i][j] - s1 - xv.v[i][j] * s2);
+        dyv.v[i][j] = v;
+        float vd = v;
+        if (drop.thr != 0u) vd = drop_apply(drop, (uint32_t)row * (uint32_t)H + (uint32_t)((lane + 64 * i) * 8 + j), v);
+        dd.v[i][j] = vd;
+        dbias.v[i][j] += vd;
+      }
+    store_row_bf16(dx + (size_t)row * H, H, lane, dyv);
+    if (dx_drop != nullptr) store_row_bf16(dx_drop + (size_t)row * H, H, lane, dd);
+  }
+  // block reduce the three column partials over the 4 waves, write [block][3][H]
+  float* redf = red;
+  for (int qn = 0; qn < 3; ++qn) {
+    const Row8& src = qn == 0 ? dg : (qn == 1 ? db : dbias);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int col = (lane + 64 * i) * 8 + j;
+        if (col < H) redf[wv * 1024 + col] = src.v[i][j];
+      }
+    __syncthreads();
+    for (int col = threadIdx.x; col < H; col += 256)
+      partials[((size_t)blockIdx.x * 3 + qn) * H + col] =
+          redf[col] + redf[1024 + col] + redf[2048 + col] + redf[3072 + col];
+  }
+}
+
+// out[q][col] += sum_blocks partials[block][q][col]  (q-th quantity goes to dst[q], NULL = skip)
+__global__ void colpartials_finish_kernel(const float* __restrict__ partials, int nblocks, int nq, int H,
+                                          float* d0, float* d1, float* d2, float* d3) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  const int qn = blockIdx.y;
+  float* dst = qn == 0 ? d0 : (qn == 1 ? d1 : (qn == 2 ? d2 : d3));
+  if (col >= H || dst == nullptr) return;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += partials[((size_t)b * nq + qn) * H + col];
+  dst[col] += s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// text embeddings: LN(word[id] + pos[pid] + type) with type ids >= tv routed to the 10-row extension
+// table (models/vilbert_dialog.py:326-356), dropout after the LayerNorm.
+// ------------------------------------------------------------------------------------------------
+struct EmbArgs {
+  const int32_t* ids; const int32_t* pos; const int32_t* typ;
+  const bf16_t* word; const bf16_t* post; const bf16_t* type; const bf16_t* ext;
+  const float* gamma; const float* beta;
+  int M, H, type_vocab;
+  float eps;
+  DropoutArg drop;
+};
+
+__device__ __forceinline__ void emb_gather(const EmbArgs& a, int row, int lane, Row8& x, int& id, int& pid, int& tt) {
+  id = a.ids[row]; pid = a.pos[row]; tt = a.typ[row];
+  Row8 t1, t2;
+  load_row_bf16(a.word + (size_t)id * a.H, a.H, lane, x);
+  load_row_bf16(a.post + (size_t)pid * a.H, a.H, lane, t1);
+  if (tt < a.type_vocab) load_row_bf16(a.type + (size_t)tt * a.H, a.H, lane, t2);
+  else load_row_bf16(a.ext + (size_t)(tt - a.type_vocab) * a.H, a.H, lane, t2);
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x.v[i][j] += t1.v[i][j] + t2.v[i][j];
+}
+
+__global__ __launch_bounds__(256) void embed_fwd_kernel(EmbArgs a, bf16_t* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * 4;
+  Row8 g, b;
+  load_vec_f32(a.gamma, a.H, lane, g);
+  load_vec_f32(a.beta, a.H, lane, b);
+  for (int row = wave; row < a.M; row += nwaves) {
+    Row8 x;
+    int id, pid, tt;
+    emb_gather(a, row, lane, x, id, pid, tt);
+    float mean, rstd;
+    row_stats(x, a.H, mean, rstd, a.eps);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float v = (x.v[i][j] - mean) * rstd * g.v[i][j] + b.v[i][j];
+        if (a.drop.thr != 0u)
+          v = drop_apply(a.drop, (uint32_t)row * (uint32_t)a.H + (uint32_t)((lane + 64 * i) * 8 + j), v);
+        x.v[i][j] = v;
+      }
+    store_row_bf16(y + (size_t)row * a.H, a.H, lane, x);
+  }
+}
+
+// backward: re-gathers x (nothing was saved), LayerNorm backward, scatter-add into the fp32 tables.
+// The two regular type rows receive a colsum from every token -> per-block partials, not atomics.
+__global__ __launch_bounds__(256) void embed_bwd_kernel(EmbArgs a, const bf16_t* __restrict__ dy, float* __restrict__ dword,
+                                                        float* __restrict__ dpos, float* __restrict__ dext,
+                                                        float* __restrict__ partials) {
+  __shared__ float red[4 * 1024];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wave = blockIdx.x * 4 + wv;
+  const int nwaves = gridDim.x * 4;
+  Row8 g;
+  load_vec_f32(a.gamma, a.H, lane, g);
+  Row8 dg, db, dt0, dt1;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { dg.v[i][j] = 0.f; db.v[i][j] = 0.f; dt0.v[i][j] = 0.f; dt1.v[i][j] = 0.f; }
+  const float invH = 1.0f / (float)a.H;
+  for (int row = wave; row < a.M; row += nwaves) {
+    Row8 x, dyv;
+    int id, pid, tt;
+    emb_gather(a, row, lane, x, id, pid, tt);
+    float mean, rstd;
+    row_stats(x, a.H, mean, rstd, a.eps);
+    load_row_bf16(dy + (size_t)row * a.H, a.H, lane, dyv);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float d = dyv.v[i][j];
+        if (a.drop.thr != 0u)
+          d = drop_apply(a.drop, (uint32_t)row * (uint32_t)a.H + (uint32_t)((lane + 64 * i) * 8 + j), d);
+        const float xh = (x.v[i][j] - mean) * rstd;
+        const float gg = d * g.v[i][j];
+        dg.v[i][j] += d * xh;
+        db.v[i][j] += d;
+        s1 += gg; s2 += gg * xh;
+        dyv.v[i][j] = gg; x.v[i][j] = xh;
+      }
+    s1 = wave_sum(s1) * invH;
+    s2 = wave_sum(s2) * invH;
+    float* wrow = dword + (size_t)id * a.H;
+    float* prow = dpos + (size_t)pid * a.H;
+    float* erow = (tt >= a.type_vocab) ? dext + (size_t)(tt - a.type_vocab) * a.H : nullptr;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c * 8 >= a.H) continue;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = rstd * (dyv.v[i][j] - s1 - x.v[i][j] * s2);
+        const int col = c * 8 + j;
+        atomicAdd(wrow + col, v);
+        atomicAdd(prow + col, v);
+        if (erow != nullptr) atomicAdd(erow + col, v);
+        else if (tt == 0) dt0.v[i][j] += v;
+        else dt1.v[i][j] += v;   // type_vocab_size is 2 (config/bert_base_6layer_6conect.json:11)
+      }
+    }
+  }
+  for (int qn = 0; qn < 4; ++qn) {
+    const Row8& src = qn == 0 ? dg : (qn == 1 ? db : (qn == 2 ? dt0 : dt1));
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int col = (lane + 64 * i) * 8 + j;
+        if (col < a.H) red[wv * 1024 + col] = src.v[i][j];
+      }
+    __syncthreads();
+    for (int col = threadIdx.x; col < a.H; col += 256)
+      partials[((size_t)blockIdx.x * 4 + qn) * a.H + col] = red[col] + red[1024 + col] + red[2048 + col] + red[3072 + col];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// column sums: db[N] += sum_m dY[m, :]   (bias gradients of the projections whose dY is produced by
+// a GEMM / attention kernel rather than by layernorm_bwd)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ dy, float* __restrict__ db, int M, int N,
+                                                     int ld) {
+  __shared__ float red[4][64 * 8];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int col0 = (blockIdx.x * 64 + lane) * 8;
+  const int rows_per = (M + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * rows_per;
+  int r1 = r0 + rows_per;
+  r1 = r1 < M ? r1 : M;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (col0 < N) {
+    for (int row = r0 + wv; row < r1; row += 4) {
+      const u32x4 raw = *reinterpret_cast<const u32x4*>(dy + (size_t)row * ld + col0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[2 * j] += __uint_as_float(raw[j] << 16);
+        acc[2 * j + 1] += __uint_as_float(raw[j] & 0xffff0000u);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[wv][lane * 8 + j] = acc[j];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 512; i += 256) {
+    const int col = blockIdx.x * 512 + i;
+    if (col < N) atomicAdd(db + col, red[0][i] + red[1][i] + red[2][i] + red[3][i]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// casts
+// ------------------------------------------------------------------------------------------------
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n) {
+  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  const size_t stride = (size_t)gridDim.x * blockDim.x * 8;
+  for (; i + 8 <= n; i += stride) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(src + i);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(src + i + 4);
+    *reinterpret_cast<u32x4*>(dst + i) =
+        u32x4{pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(b[0], b[1]), pack2bf(b[2], b[3])};
+  }
+  if (i < n)
+    for (size_t j = i; j < n && j < i + 8; ++j) dst[j] = f2bf(src[j]);
+}
+
+// dst[c][r] (bf16, row stride ldd, columns >= R zero up to ldd) = src[r][c] (fp32 [R, C])
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
+                                                             int R, int C, int ldd) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + ty + 8 * k, c = c0 + tx;
+    tile[ty + 8 * k][tx] = (r < R && c < C) ? src[(size_t)r * C + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c0 + ty + 8 * k, r = r0 + tx;
+    if (c < C && r < ldd) dst[(size_t)c * ldd + r] = f2bf(tile[tx][ty + 8 * k]);
+  }
+}
+
+// region features: fp32 [rows, F] + fp32 loc [rows, 5] -> bf16 [rows, ld] = [feat | loc | 0...]
+// (operand of the single image-embedding GEMM; models/vilbert_dialog.py:1488-1489)
+__global__ void pack_image_kernel(const float* __restrict__ feat, const float* __restrict__ loc, bf16_t* __restrict__ out,
+                                  int rows, int F, int ld) {
+  const int chunks = ld / 8;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)rows * chunks;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    const int row = (int)(i / chunks), c = (int)(i % chunks) * 8;
+    float v[8];
+    if (c + 8 <= F) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(feat + (size_t)row * F + c);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(feat + (size_t)row * F + c + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int col = c + j;
+        v[j] = col < F ? feat[(size_t)row * F + col] : (col < F + 5 ? loc[(size_t)row * 5 + (col - F)] : 0.f);
+      }
+    }
+    *reinterpret_cast<u32x4*>(out + (size_t)row * ld + c) =
+        u32x4{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+  }
+}
+
+// out = dropout(a * b)  bf16 [n]   (pooled_t * pooled_v, models/vilbert_dialog.py:1065)
+__global__ void mul_dropout_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, bf16_t* __restrict__ out,
+                                   size_t n, DropoutArg drop) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v = bf2f(a[i]) * bf2f(b[i]);
+  if (drop.thr != 0u) v = drop_apply(drop, (uint32_t)i, v);
+  out[i] = f2bf(v);
+}
+
+// backward of the above given dfused: da = drop(dfused) * b, db = drop(dfused) * a
+__global__ void mul_dropout_bwd_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
+                                       const bf16_t* __restrict__ dout, bf16_t* __restrict__ da, bf16_t* __restrict__ db,
+                                       size_t n, DropoutArg drop) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float d = bf2f(dout[i]);
+  if (drop.thr != 0u) d = drop_apply(drop, (uint32_t)i, d);
+  // ReLU of the poolers (:951,:966) is folded in: a, b are post-ReLU, gradient is zero where they are
+  const float av = bf2f(a[i]), bv = bf2f(b[i]);
+  da[i] = f2bf(av > 0.f ? d * bv : 0.f);
+  db[i] = f2bf(bv > 0.f ? d * av : 0.f);
+}
+
+inline DropoutArg mk_drop(uint32_t key, uint32_t thr, float scale) { DropoutArg d; d.key = key; d.thr = thr; d.scale = scale; return d; }
+
+}  // namespace
+
+extern "C" int unimm_mask_pack(const void* mask, int dtype, uint32_t* out, int64_t rows, int32_t t, void* stream) {
+  if (!mask || !out || rows <= 0 || t <= 0) return UNIMM_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  switch (dtype) {
+    case UNIMM_DT_U8: return mask_pack_impl<uint8_t>(mask, out, (size_t)rows, t, s);
+    case UNIMM_DT_I32: return mask_pack_impl<int32_t>(mask, out, (size_t)rows, t, s);
+    case UNIMM_DT_I64: return mask_pack_impl<int64_t>(mask, out, (size_t)rows, t, s);
+    case UNIMM_DT_F32: return mask_pack_impl<float>(mask, out, (size_t)rows, t, s);
+    default: return UNIMM_E_ARG;
+  }
+}
+
+extern "C" int unimm_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                   int32_t M, int32_t H, float eps, uint32_t drop_key, uint32_t drop_thr, float drop_scale,
+                                   void* stream) {
+  if (!x || !gamma || !beta || !y) return UNIMM_E_ARG;
+  if (M <= 0 || H <= 0 || H > MAXC * 512 || (H % 8)) return UNIMM_E_SHAPE;
+  int blocks = (M + 3) / 4;
+  blocks = blocks > 2048 ? 2048 : blocks;
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, gamma, beta,
+                     (bf16_t*)y, mean, rstd, M, H, eps, mk_drop(drop_key, drop_thr, drop_scale));
+  UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
+}
+
+extern "C" int64_t unimm_colpartials_bytes(int32_t H) { return (int64_t)RED_BLOCKS * 4 * H * sizeof(float); }
+
+extern "C" int unimm_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                                   void* dx, void* dx_drop, float* dgamma, float* dbeta, float* dbias, float* partials,
+                                   int32_t M, int32_t H, uint32_t drop_key, uint32_t drop_thr, float drop_scale,
+                                   uint32_t odrop_key, uint32_t odrop_thr, float odrop_scale, void* stream) {
+  if (!dy || !x || !mean || !rstd || !gamma || !dx || !partials) return UNIMM_E_ARG;
+  if (M <= 0 || H <= 0 || H > MAXC * 512 || (H % 8)) return UNIMM_E_SHAPE;
+  int blocks = (M + 3) / 4;
+  blocks = blocks > RED_BLOCKS ? RED_BLOCKS : blocks;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd,
+                     gamma, (bf16_t*)dx, (bf16_t*)dx_drop, partials, M, H, mk_drop(drop_key, drop_thr, drop_scale),
+                     mk_drop(odrop_key, odrop_thr, odrop_scale));
+  UNIMM_CHECK_LAUNCH();
+  hipLaunchKernelGGL(colpartials_finish_kernel, dim3((H + 255) / 256, 3), dim3(256), 0, s, partials, blocks, 3, H, dgamma,
+                     dbeta, dbias, (float*)nullptr);
+  UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
+}
+
+extern "C" int unimm_embed_fwd(const unimm_embed_args* a, void* y, void* stream) {
+  if (!a || !a->ids || !a->pos || !a->typ || !a->word || !a->post || !a->type || !a->ext || !a->gamma || !a->beta || !y)
+    return UNIMM_E_ARG;
+  if (a->M <= 0 || a->H <= 0 || a->H > MAXC * 512 || (a->H % 8)) return UNIMM_E_SHAPE;
+  EmbArgs e;
+  e.ids = a->ids; e.pos = a->pos; e.typ = a->typ;
+  e.word = (const bf16_t*)a->word; e.post = (const bf16_t*)a->post; e.type = (const bf16_t*)a->type;
+  e.ext = (const bf16_t*)a->ext; e.gamma = a->gamma; e.beta = a->beta;
+  e.M = a->M; e.H = a->H; e.type_vocab = a->type_vocab; e.eps = a->eps;
+  e.drop = mk_drop(a->drop_key, a->drop_thr, a->drop_scale);
+  int blocks = (a->M + 3) / 4;
+  blocks = blocks > 2048 ? 2048 : blocks;
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, e, (bf16_t*)y);
+  UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
+}
+
+extern "C" int unimm_embed_bwd(const unimm_embed_args* a, const void* dy, float* dword, float* dpos, float* dtype,
+                               float* dext, float* dgamma, float* dbeta, float* partials, void* stream) {
+  if (!a || !dy || !dword || !dpos || !dtype || !dext || !dgamma || !dbeta || !partials) return UNIMM_E_ARG;
+  if (a->M <= 0 || a->H <= 0 || a->H > MAXC * 512 || (a->H % 8) || a->type_vocab != 2) return UNIMM_E_SHAPE;
+  EmbArgs e;
+  e.ids = a->ids; e.pos = a->pos; e.typ = a->typ;
+  e.word = (const bf16_t*)a->word; e.post = (const bf16_t*)a->post; e.type = (const bf16_t*)a->type;
+  e.ext = (const bf16_t*)a->ext; e.gamma = a->gamma; e.beta = a->beta;
+  e.M = a->M; e.H = a->H; e.type_vocab = a->type_vocab; e.eps = a->eps;
+  e.drop = mk_drop(a->drop_key, a->drop_thr, a->drop_scale);
+  int blocks = (a->M + 3) / 4;
+  blocks = blocks > RED_BLOCKS ? RED_BLOCKS : blocks;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(blocks), dim3(256), 0, s, e, (const bf16_t*)dy, dword, dpos, dext, partials);
+  UNIMM_CHECK_LAUNCH();
+  hipLaunchKernelGGL(colpartials_finish_kernel, dim3((a->H + 255) / 256, 4), dim3(256), 0, s, partials, blocks, 4, a->H,
+                     dgamma, dbeta, dtype, dtype + a->H);
+  UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
+}
+
+extern "C" int unimm_colsum(const void* dy, float* db, int32_t M, int32_t N, int32_t ld, void* stream) {
+  if (!dy || !db) return UNIMM_E_ARG;
+  if (M <= 0 || N <= 0 || (ld % 8) || ld < ((N + 7) & ~7)) return UNIMM_E_ALIGN;
+  int ysplit = (M + 255) / 256;
+  ysplit = ysplit > 64 ? 64 : ysplit;
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 511) / 512, ysplit), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, db,
+                     M, N, ld);
+  UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
+}
+
+extern "C" int unimm_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream) {
+  if (!src || !dst || n <= 0) return UNIMM_E_ARG;
+  if (((uintptr_t)src | (uintptr_t)dst) & 15) return UNIMM_E_ALIGN;
+  int64_t blocks = (n / 8 + 255) / 256;
+  blocks = blocks > 4096 ? 4096 : (blocks < 1 ? 1 : blocks);
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst,
+                     (size_t)n);
+  UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
+}
+
+extern "C" int unimm_transpose_cast(const float* src, void* dst, int32_t R, int32_t C, int32_t ldd, void* stream) {
+  if (!src || !dst || R <= 0 || C <= 0 || ldd < R) return UNIMM_E_ARG;
+  hipLaunchKernelGGL(transpose_cast_kernel, dim3((C + 31) / 32, (ldd + 31) / 32), dim3(256), 0, (hipStream_t)stream, src,
+                     (bf16_t*)dst, R, C, ldd);
+  UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
+}
+
+extern "C" int unimm_pack_image(const float* feat, const float* loc, void* out, int32_t rows, int32_t F, int32_t ld,
+                                void* stream) {
+  if (!feat || !loc || !out || rows <= 0 || F <= 0 || (F % 8) || (ld % 8) || ld < F + 5) return UNIMM_E_ARG;
+  if (((uintptr_t)feat | (uintptr_t)out) & 15) return UNIMM_E_ALIGN;
+  const size_t total = (size_t)rows * (ld / 8);
+  size_t blocks = (total + 255) / 256;
+  blocks = blocks > 8192 ? 8192 : blocks;
+  hipLaunchKernelGGL(pack_image_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, feat, loc, (bf16_t*)out,
+                     rows, F, ld);
+  UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
+}
+
+extern "C" int unimm_mul_dropout(const void* a, const void* b, void* out, int64_t n, uint32_t drop_key, uint32_t drop_thr,
+                                 float drop_scale, void* stream) {
+  if (!a || !b || !out || n <= 0) return UNIMM_E_ARG;
+  hipLaunchKernelGGL(mul_dropout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, (size_t)n, mk_drop(drop_key, drop_thr, drop_scale));
+  UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
+}
+
+extern "C" int unimm_mul_dropout_bwd(const void* a, const void* b, const void* dout, void* da, void* db, int64_t n,
+                                     uint32_t drop_key, uint32_t drop_thr, float drop_scale, void* stream) {
+  if (!a || !b || !dout || !da || !db || n <= 0) return UNIMM_E_ARG;
+  hipLaunchKernelGGL(mul_dropout_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)a, (const bf16_t*)b, (const bf16_t*)dout, (bf16_t*)da, (bf16_t*)db, (size_t)n,
+                     mk_drop(drop_key, drop_thr, drop_scale));
+  UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
+}

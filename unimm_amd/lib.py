@@ -57,14 +57,21 @@ def lib():
         raise UnimmHipError(f"libunimm_hip.so ABI {L.unimm_version()} != expected {ABI_VERSION}: rebuild")
     for name in SYMBOLS:
         fn = getattr(L, name)
-        if name not in ("unimm_arch",):
+        if name == "unimm_colpartials_bytes":
+            fn.restype = C.c_int64
+        elif name != "unimm_arch":
             fn.restype = C.c_int
     _lib = L
     return L
 
 
 # every symbol include/unimm_hip.h declares (tests check the .so exports each of them)
-SYMBOLS = ["unimm_version", "unimm_arch", "unimm_gemm_nt", "unimm_gemm_tn"]
+SYMBOLS = ["unimm_version", "unimm_arch", "unimm_gemm_nt", "unimm_gemm_tn", "unimm_attn_fwd", "unimm_attn_bwd",
+           "unimm_mask_pack", "unimm_layernorm_fwd", "unimm_colpartials_bytes", "unimm_layernorm_bwd",
+           "unimm_embed_fwd", "unimm_embed_bwd", "unimm_colsum", "unimm_cast_f32_bf16", "unimm_transpose_cast",
+           "unimm_pack_image", "unimm_mul_dropout", "unimm_mul_dropout_bwd", "unimm_lm_loss_fwd",
+           "unimm_lm_loss_bwd", "unimm_kl_loss_fwd", "unimm_kl_loss_bwd", "unimm_nsp_loss_fwd",
+           "unimm_nsp_loss_bwd", "unimm_reduce_sum", "unimm_segment_sum"]
 
 
 def _check(rc, what):
@@ -115,3 +122,222 @@ def gemm_tn(dy, x, dw, M=None, N=None, K=None):
     a.lddy, a.ldx, a.lddw = dy.stride(0), x.stride(0), dw.stride(0)
     _check(lib().unimm_gemm_tn(C.byref(a), _stream()), "unimm_gemm_tn")
     return dw
+
+
+# ---------------------------------------------------------------------------------------------
+# attention
+# ---------------------------------------------------------------------------------------------
+class AttnArgs(C.Structure):
+    _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("out", C.c_void_p),
+                ("lse", C.c_void_p), ("mask", C.c_void_p),
+                ("B", C.c_int32), ("H", C.c_int32), ("Tq", C.c_int32), ("Tk", C.c_int32), ("D", C.c_int32),
+                ("ldq", C.c_int32), ("ldk", C.c_int32), ("ldv", C.c_int32), ("ldo", C.c_int32),
+                ("mask_q_stride", C.c_int32), ("mask_b_stride", C.c_int32), ("scale", C.c_float),
+                ("drop_key", C.c_uint32), ("drop_thr", C.c_uint32), ("drop_scale", C.c_float)]
+
+
+class AttnBwdArgs(C.Structure):
+    _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("out", C.c_void_p), ("dout", C.c_void_p),
+                ("lse", C.c_void_p), ("delta", C.c_void_p),
+                ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p), ("mask", C.c_void_p),
+                ("B", C.c_int32), ("H", C.c_int32), ("Tq", C.c_int32), ("Tk", C.c_int32), ("D", C.c_int32),
+                ("ldq", C.c_int32), ("ldk", C.c_int32), ("ldv", C.c_int32), ("ldo", C.c_int32), ("lddo", C.c_int32),
+                ("lddq", C.c_int32), ("lddk", C.c_int32), ("lddv", C.c_int32),
+                ("mask_q_stride", C.c_int32), ("mask_b_stride", C.c_int32), ("scale", C.c_float),
+                ("drop_key", C.c_uint32), ("drop_thr", C.c_uint32), ("drop_scale", C.c_float)]
+
+
+NO_DROP = (0, 0, 1.0)
+
+
+def attn_fwd(q, k, v, out, lse, mask, B, H, Tq, Tk, D, scale, mask_q_stride, mask_b_stride, drop=NO_DROP):
+    """q/k/v/out: 2-D bf16 views [B*T, >=H*D] (row stride = stride(0)); mask: packed uint32 words."""
+    _dev(q, k, v, out, lse, mask)
+    a = AttnArgs()
+    a.q, a.k, a.v, a.out, a.lse, a.mask = _ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), _ptr(mask)
+    a.B, a.H, a.Tq, a.Tk, a.D = B, H, Tq, Tk, D
+    a.ldq, a.ldk, a.ldv, a.ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
+    a.mask_q_stride, a.mask_b_stride, a.scale = mask_q_stride, mask_b_stride, scale
+    a.drop_key, a.drop_thr, a.drop_scale = drop
+    _check(lib().unimm_attn_fwd(C.byref(a), _stream()), "unimm_attn_fwd")
+
+
+def attn_bwd(q, k, v, out, dout, lse, delta, dq, dk, dv, mask, B, H, Tq, Tk, D, scale, mask_q_stride,
+             mask_b_stride, drop=NO_DROP):
+    _dev(q, k, v, out, dout, lse, delta, dq, dk, dv, mask)
+    a = AttnBwdArgs()
+    a.q, a.k, a.v, a.out, a.dout = _ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(dout)
+    a.lse, a.delta, a.dq, a.dk, a.dv, a.mask = _ptr(lse), _ptr(delta), _ptr(dq), _ptr(dk), _ptr(dv), _ptr(mask)
+    a.B, a.H, a.Tq, a.Tk, a.D = B, H, Tq, Tk, D
+    a.ldq, a.ldk, a.ldv, a.ldo, a.lddo = q.stride(0), k.stride(0), v.stride(0), out.stride(0), dout.stride(0)
+    a.lddq, a.lddk, a.lddv = dq.stride(0), dk.stride(0), dv.stride(0)
+    a.mask_q_stride, a.mask_b_stride, a.scale = mask_q_stride, mask_b_stride, scale
+    a.drop_key, a.drop_thr, a.drop_scale = drop
+    _check(lib().unimm_attn_bwd(C.byref(a), _stream()), "unimm_attn_bwd")
+
+
+# ---------------------------------------------------------------------------------------------
+# row kernels
+# ---------------------------------------------------------------------------------------------
+_DT = {torch.bool: 0, torch.uint8: 0, torch.int32: 1, torch.int64: 2, torch.float32: 3}
+
+
+def mask_pack(mask, out=None):
+    """0/1 mask [..., T] -> uint32 words [..., ceil(T/32)] (stored in an int32 tensor)."""
+    _dev(mask)
+    if mask.dtype not in _DT:
+        raise UnimmHipError(f"mask dtype {mask.dtype} not supported (bool, uint8, int32, int64, float32)")
+    mask = mask.contiguous()
+    t = mask.shape[-1]
+    rows = mask.numel() // t
+    nw = (t + 31) // 32
+    if out is None:
+        out = torch.empty(mask.shape[:-1] + (nw,), dtype=torch.int32, device=mask.device)
+    _check(lib().unimm_mask_pack(_ptr(mask), _DT[mask.dtype], _ptr(out), C.c_int64(rows), C.c_int32(t), _stream()),
+           "unimm_mask_pack")
+    return out
+
+
+def colpartials_bytes(H):
+    return int(lib().unimm_colpartials_bytes(C.c_int32(H)))
+
+
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, M, H, eps=1e-12, drop=NO_DROP):
+    _dev(x, gamma, beta, y, mean, rstd)
+    _check(lib().unimm_layernorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), C.c_int32(M),
+                                     C.c_int32(H), C.c_float(eps), C.c_uint32(drop[0]), C.c_uint32(drop[1]),
+                                     C.c_float(drop[2]), _stream()), "unimm_layernorm_fwd")
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dx_drop, dgamma, dbeta, dbias, partials, M, H, drop=NO_DROP,
+                  out_drop=NO_DROP):
+    _dev(dy, x, mean, rstd, gamma, dx, dx_drop, dgamma, dbeta, dbias, partials)
+    _check(lib().unimm_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(dx), _ptr(dx_drop),
+                                     _ptr(dgamma), _ptr(dbeta), _ptr(dbias), _ptr(partials), C.c_int32(M), C.c_int32(H),
+                                     C.c_uint32(drop[0]), C.c_uint32(drop[1]), C.c_float(drop[2]),
+                                     C.c_uint32(out_drop[0]), C.c_uint32(out_drop[1]), C.c_float(out_drop[2]),
+                                     _stream()), "unimm_layernorm_bwd")
+
+
+class EmbedArgs(C.Structure):
+    _fields_ = [("ids", C.c_void_p), ("pos", C.c_void_p), ("typ", C.c_void_p),
+                ("word", C.c_void_p), ("post", C.c_void_p), ("type", C.c_void_p), ("ext", C.c_void_p),
+                ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("M", C.c_int32), ("H", C.c_int32), ("type_vocab", C.c_int32), ("eps", C.c_float),
+                ("drop_key", C.c_uint32), ("drop_thr", C.c_uint32), ("drop_scale", C.c_float)]
+
+
+def _embed_args(ids, pos, typ, word, post, type_, ext, gamma, beta, M, H, type_vocab, eps, drop):
+    _dev(ids, pos, typ, word, post, type_, ext, gamma, beta)
+    a = EmbedArgs()
+    a.ids, a.pos, a.typ = _ptr(ids), _ptr(pos), _ptr(typ)
+    a.word, a.post, a.type, a.ext = _ptr(word), _ptr(post), _ptr(type_), _ptr(ext)
+    a.gamma, a.beta = _ptr(gamma), _ptr(beta)
+    a.M, a.H, a.type_vocab, a.eps = M, H, type_vocab, eps
+    a.drop_key, a.drop_thr, a.drop_scale = drop
+    return a
+
+
+def embed_fwd(ids, pos, typ, word, post, type_, ext, gamma, beta, y, M, H, type_vocab=2, eps=1e-12, drop=NO_DROP):
+    a = _embed_args(ids, pos, typ, word, post, type_, ext, gamma, beta, M, H, type_vocab, eps, drop)
+    _dev(y)
+    _check(lib().unimm_embed_fwd(C.byref(a), _ptr(y), _stream()), "unimm_embed_fwd")
+
+
+def embed_bwd(ids, pos, typ, word, post, type_, ext, gamma, beta, dy, dword, dpos, dtype, dext, dgamma, dbeta,
+              partials, M, H, type_vocab=2, eps=1e-12, drop=NO_DROP):
+    a = _embed_args(ids, pos, typ, word, post, type_, ext, gamma, beta, M, H, type_vocab, eps, drop)
+    _dev(dy, dword, dpos, dtype, dext, dgamma, dbeta, partials)
+    _check(lib().unimm_embed_bwd(C.byref(a), _ptr(dy), _ptr(dword), _ptr(dpos), _ptr(dtype), _ptr(dext), _ptr(dgamma),
+                                 _ptr(dbeta), _ptr(partials), _stream()), "unimm_embed_bwd")
+
+
+def colsum(dy, db, M, N):
+    _dev(dy, db)
+    _check(lib().unimm_colsum(_ptr(dy), _ptr(db), C.c_int32(M), C.c_int32(N), C.c_int32(dy.stride(0)), _stream()),
+           "unimm_colsum")
+
+
+def cast_f32_bf16(src, dst, n=None):
+    _dev(src, dst)
+    _check(lib().unimm_cast_f32_bf16(_ptr(src), _ptr(dst), C.c_int64(src.numel() if n is None else n), _stream()),
+           "unimm_cast_f32_bf16")
+
+
+def transpose_cast(src, dst, R, C_, ldd):
+    _dev(src, dst)
+    _check(lib().unimm_transpose_cast(_ptr(src), _ptr(dst), C.c_int32(R), C.c_int32(C_), C.c_int32(ldd), _stream()),
+           "unimm_transpose_cast")
+
+
+def pack_image(feat, loc, out, rows, F, ld):
+    _dev(feat, loc, out)
+    _check(lib().unimm_pack_image(_ptr(feat), _ptr(loc), _ptr(out), C.c_int32(rows), C.c_int32(F), C.c_int32(ld),
+                                  _stream()), "unimm_pack_image")
+
+
+def mul_dropout(a, b, out, n, drop=NO_DROP):
+    _dev(a, b, out)
+    _check(lib().unimm_mul_dropout(_ptr(a), _ptr(b), _ptr(out), C.c_int64(n), C.c_uint32(drop[0]), C.c_uint32(drop[1]),
+                                   C.c_float(drop[2]), _stream()), "unimm_mul_dropout")
+
+
+def mul_dropout_bwd(a, b, dout, da, db, n, drop=NO_DROP):
+    _dev(a, b, dout, da, db)
+    _check(lib().unimm_mul_dropout_bwd(_ptr(a), _ptr(b), _ptr(dout), _ptr(da), _ptr(db), C.c_int64(n),
+                                       C.c_uint32(drop[0]), C.c_uint32(drop[1]), C.c_float(drop[2]), _stream()),
+           "unimm_mul_dropout_bwd")
+
+
+# ---------------------------------------------------------------------------------------------
+# losses
+# ---------------------------------------------------------------------------------------------
+def lm_loss_fwd(logits, labels, weights, rowloss, rownll, lse, n, V):
+    _dev(logits, labels, weights, rowloss, rownll, lse)
+    _check(lib().unimm_lm_loss_fwd(_ptr(logits), _ptr(labels), _ptr(weights), _ptr(rowloss), _ptr(rownll), _ptr(lse),
+                                   C.c_int32(n), C.c_int32(V), C.c_int32(logits.stride(0)), _stream()),
+           "unimm_lm_loss_fwd")
+
+
+def lm_loss_bwd(logits, labels, weights, lse, g, inv_denom, dlogits, n, V):
+    _dev(logits, labels, weights, lse, g, dlogits)
+    _check(lib().unimm_lm_loss_bwd(_ptr(logits), _ptr(labels), _ptr(weights), _ptr(lse), _ptr(g), C.c_float(inv_denom),
+                                   _ptr(dlogits), C.c_int32(n), C.c_int32(V), C.c_int32(logits.stride(0)),
+                                   C.c_int32(dlogits.stride(0)), _stream()), "unimm_lm_loss_bwd")
+
+
+def kl_loss_fwd(pred, target, label, rowloss, lse, rows, Cn):
+    _dev(pred, target, label, rowloss, lse)
+    _check(lib().unimm_kl_loss_fwd(_ptr(pred), _ptr(target), _ptr(label), _ptr(rowloss), _ptr(lse), C.c_int32(rows),
+                                   C.c_int32(Cn), C.c_int32(pred.stride(0)), _stream()), "unimm_kl_loss_fwd")
+
+
+def kl_loss_bwd(pred, target, label, lse, g, inv_denom, dpred, rows, Cn):
+    _dev(pred, target, label, lse, g, dpred)
+    _check(lib().unimm_kl_loss_bwd(_ptr(pred), _ptr(target), _ptr(label), _ptr(lse), _ptr(g), C.c_float(inv_denom),
+                                   _ptr(dpred), C.c_int32(rows), C.c_int32(Cn), C.c_int32(pred.stride(0)),
+                                   C.c_int32(dpred.stride(0)), _stream()), "unimm_kl_loss_bwd")
+
+
+def nsp_loss_fwd(logits, labels, w0, w1, loss, B):
+    _dev(logits, labels, loss)
+    _check(lib().unimm_nsp_loss_fwd(_ptr(logits), _ptr(labels), C.c_float(w0), C.c_float(w1), _ptr(loss), C.c_int32(B),
+                                    C.c_int32(logits.stride(0)), _stream()), "unimm_nsp_loss_fwd")
+
+
+def nsp_loss_bwd(logits, labels, w0, w1, g, dlogits, B):
+    _dev(logits, labels, g, dlogits)
+    _check(lib().unimm_nsp_loss_bwd(_ptr(logits), _ptr(labels), C.c_float(w0), C.c_float(w1), _ptr(g), _ptr(dlogits),
+                                    C.c_int32(B), C.c_int32(logits.stride(0)), C.c_int32(dlogits.stride(0)), _stream()),
+           "unimm_nsp_loss_bwd")
+
+
+def reduce_sum(src, n, dst, scale=1.0):
+    _dev(src, dst)
+    _check(lib().unimm_reduce_sum(_ptr(src), C.c_int64(n), _ptr(dst), C.c_float(scale), _stream()), "unimm_reduce_sum")
+
+
+def segment_sum(src, seg, dst, n, sign=1.0):
+    _dev(src, seg, dst)
+    _check(lib().unimm_segment_sum(_ptr(src), _ptr(seg), _ptr(dst), C.c_int64(n), C.c_float(sign), _stream()),
+           "unimm_segment_sum")
