@@ -40,7 +40,7 @@ const char* unimm_arch(void);     /* "gfx950" */
 enum {
   UNIMM_EPI_BIAS = 0,            /* out = acc + bias                                            */
   UNIMM_EPI_BIAS_GELU = 1,       /* u = acc + bias; out = erf-GELU(u) (:115-121); out2 = u      */
-  UNIMM_EPI_BIAS_DROP_RESID = 2, /* out = dropout(acc + bias) + aux  (:423-425, :466-468, ...)  */
+  UNIMM_EPI_BIAS_DROP_RESID = 2, /* out(fp32) = dropout(acc + bias) + aux(fp32 residual stream) (:423-425, :466-468, ...) */
   UNIMM_EPI_BIAS_RELU = 3,       /* poolers (:950-951, :965-966)                                */
   UNIMM_EPI_DGELU = 4,           /* out = acc * GELU'(aux)           (backward of :453-454)     */
   UNIMM_EPI_ADD = 5              /* out = acc + aux                  (residual gradient join)   */
@@ -50,7 +50,7 @@ typedef struct {
   const void* x;     /* [M, K] bf16 */
   const void* w;     /* [N, K] bf16 */
   const float* bias; /* [N] fp32 or NULL */
-  const void* aux;   /* [M, N] bf16, epilogue operand (residual / pre-activation) or NULL */
+  const void* aux;   /* [M, N] epilogue operand or NULL: fp32 residual (DROP_RESID), bf16 otherwise */
   void* out;         /* [M, N] bf16, or fp32 when out_f32 != 0 */
   void* out2;        /* [M, N] bf16 second output of UNIMM_EPI_BIAS_GELU (row stride ldo) or NULL */
   int32_t M, N, K;
@@ -131,36 +131,38 @@ enum { UNIMM_DT_U8 = 0, UNIMM_DT_I32 = 1, UNIMM_DT_I64 = 2, UNIMM_DT_F32 = 3 };
 int unimm_mask_pack(const void* mask, int dtype, uint32_t* out, int64_t rows, int32_t t, void* stream);
 
 /* y = LayerNorm(x) (eps inside sqrt, torch.nn.LayerNorm; models/vilbert_dialog.py:279) with optional
- * dropout on y; x, y bf16 [M, H] contiguous; mean/rstd fp32 [M] saved for backward (may be NULL). */
-int unimm_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
-                        int32_t M, int32_t H, float eps, uint32_t drop_key, uint32_t drop_thr, float drop_scale,
-                        void* stream);
+ * dropout on y.  The residual stream is fp32 (as under the reference's autocast, where layer_norm and
+ * the residual add run in fp32): x fp32 [M, H]; y32 (fp32, next residual) and / or y16 (bf16, next GEMM
+ * operand) are written; mean/rstd fp32 [M] saved for backward (may be NULL). */
+int unimm_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y32, void* y16, float* mean,
+                        float* rstd, int32_t M, int32_t H, float eps, uint32_t drop_key, uint32_t drop_thr,
+                        float drop_scale, void* stream);
 
 /* bytes of the `partials` scratch the two backward row kernels need for hidden size H */
 int64_t unimm_colpartials_bytes(int32_t H);
 
-/* LayerNorm backward.  dx (bf16) is the gradient w.r.t. the pre-LayerNorm sum (= the residual
+/* LayerNorm backward (dy bf16, x = the fp32 pre-LayerNorm sum).  dx (bf16) is the gradient w.r.t. the pre-LayerNorm sum (= the residual
  * branch gradient); dx_drop (optional) = dropout-masked dx for the dense branch (drop_*: the mask the
  * forward GEMM epilogue applied); odrop_*: dropout applied to y in the forward (embeddings), 0 = none.
  * dgamma/dbeta/dbias (fp32 [H], any may be NULL) are ACCUMULATED (+=); dbias = colsum(dx_drop). */
-int unimm_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+int unimm_layernorm_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                         void* dx, void* dx_drop, float* dgamma, float* dbeta, float* dbias, float* partials,
                         int32_t M, int32_t H, uint32_t drop_key, uint32_t drop_thr, float drop_scale,
                         uint32_t odrop_key, uint32_t odrop_thr, float odrop_scale, void* stream);
 
 /* Text embeddings: y = dropout(LN(word[ids] + pos[position] + type)) with token-type ids >= type_vocab
  * routed to the 10-row extension table (BertEmbeddingsDialog.forward, models/vilbert_dialog.py:326-356).
- * Tables are the bf16 weight copies; ids int32 [M]. */
+ * Tables are the fp32 master weights; ids int32 [M]; y32 / y16 as for unimm_layernorm_fwd. */
 typedef struct {
   const int32_t* ids; const int32_t* pos; const int32_t* typ;
-  const void* word; const void* post; const void* type; const void* ext; /* bf16 tables, row length H */
+  const float* word; const float* post; const float* type; const float* ext; /* fp32 tables, row length H */
   const float* gamma; const float* beta;
   int32_t M, H, type_vocab;
   float eps;
   uint32_t drop_key, drop_thr; float drop_scale;
 } unimm_embed_args;
 
-int unimm_embed_fwd(const unimm_embed_args* args, void* y, void* stream);
+int unimm_embed_fwd(const unimm_embed_args* args, float* y32, void* y16, void* stream);
 /* backward: re-gathers the rows, LayerNorm backward, scatter-add (fp32 atomics) into the word /
  * position / extension-type gradient tables; dtype [2, H], dgamma, dbeta accumulated via partials. */
 int unimm_embed_bwd(const unimm_embed_args* args, const void* dy, float* dword, float* dpos, float* dtype,
@@ -184,6 +186,13 @@ int unimm_mul_dropout(const void* a, const void* b, void* out, int64_t n, uint32
                       float drop_scale, void* stream);
 int unimm_mul_dropout_bwd(const void* a, const void* b, const void* dout, void* da, void* db, int64_t n,
                           uint32_t drop_key, uint32_t drop_thr, float drop_scale, void* stream);
+
+/* du = dt * GELU'(u), bf16 flat [n], n % 8 == 0 (prediction-head transforms, :983-985, :1002-1004) */
+int unimm_gelu_bwd(const void* dt, const void* u, void* du, int64_t n, void* stream);
+/* scatter == 0: dst[i,:] = src[idx[i],:]; scatter != 0: dst[idx[i],:] = src[i,:]  (bf16 rows of H, idx unique).
+ * Selects the labelled token rows the decoder runs on (the reference decodes all 256 rows and then
+ * boolean-gathers, models/vilbert_dialog.py:1583-1584). */
+int unimm_gather_rows(const void* src, const int32_t* idx, void* dst, int32_t n, int32_t H, int32_t scatter, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Losses.  Row kernels (one workgroup per row) keep logits, log-sum-exp and 1-p in fp32.

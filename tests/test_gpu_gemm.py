@@ -68,12 +68,16 @@ def test_gemm_nt_strided_views_and_epilogues():
     torch.cuda.synchronize()
     assert (u.float() - (base + bias)).abs().max() <= 2 ** -7 * (base + bias).abs().max()
     assert (h.float() - _gelu(base + bias)).abs().max() <= 2 ** -7 * (base + bias).abs().max()
-    # residual (no dropout)
+    # fp32 residual stream (no dropout)
     o = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
-    lib.gemm_nt(x, w, o, bias=bias, epilogue=lib.EPI_BIAS_DROP_RESID, aux=aux)
-    ref = base + bias + aux.float()
+    o32 = torch.empty((M, N), device="cuda")
+    res32 = torch.randn((M, N), generator=g, device="cuda")
+    lib.gemm_nt(x, w, o32, bias=bias, epilogue=lib.EPI_BIAS_DROP_RESID, aux=res32)
+    ref = base + bias + res32
     torch.cuda.synchronize()
-    assert (o.float() - ref).abs().max() <= 2 ** -7 * ref.abs().max()
+    assert (o32 - ref).abs().max() <= 2e-3 * ref.abs().max()
+    with pytest.raises(lib.UnimmHipError):      # residual epilogue only writes fp32
+        lib.gemm_nt(x, w, o, bias=bias, epilogue=lib.EPI_BIAS_DROP_RESID, aux=res32)
     # relu
     lib.gemm_nt(x, w, o, bias=bias, epilogue=lib.EPI_BIAS_RELU)
     torch.cuda.synchronize()

@@ -119,21 +119,22 @@ def test_layernorm_fwd_bwd(M, H):
     from unimm_amd import dropout as DR
     from unimm_amd import lib
     g = torch.Generator(device=DEV).manual_seed(M)
-    x = bf(torch.randn((M, H), generator=g, device=DEV) * 2 + 0.5)
+    x = torch.randn((M, H), generator=g, device=DEV) * 2 + 0.5
     gamma = torch.randn(H, generator=g, device=DEV) * 0.2 + 1
     beta = torch.randn(H, generator=g, device=DEV) * 0.1
-    y = torch.empty_like(x)
+    y = torch.empty((M, H), device=DEV, dtype=torch.bfloat16)
+    y32 = torch.empty((M, H), device=DEV)
     mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
-    lib.layernorm_fwd(x, gamma, beta, y, mean, rstd, M, H)
-    xr = x.float().requires_grad_(True)
+    lib.layernorm_fwd(x, gamma, beta, y32, y, mean, rstd, M, H)
+    xr = x.clone().requires_grad_(True)
     gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
     ref = torch.nn.functional.layer_norm(xr, (H,), gr, br, 1e-12)
     torch.cuda.synchronize()
-    assert relerr(y, ref) < 2 ** -7
+    assert relerr(y, ref) < 2 ** -7 and relerr(y32, ref) < 1e-5
     dy = bf(torch.randn((M, H), generator=g, device=DEV))
     drop = DR.drop_arg(0.1, DR.make_key(1, 2, 3))
     ref.backward(dy.float())
-    dx, dxd = torch.empty_like(x), torch.empty_like(x)
+    dx, dxd = torch.empty_like(y), torch.empty_like(y)
     dg, db, dbias = torch.ones(H, device=DEV), torch.ones(H, device=DEV), torch.ones(H, device=DEV)
     part = torch.empty(lib.colpartials_bytes(H) // 4, device=DEV)
     lib.layernorm_bwd(dy, x, mean, rstd, gamma, dx, dxd, dg, db, dbias, part, M, H, drop=drop)
@@ -150,7 +151,7 @@ def test_embeddings_fwd_bwd():
     from unimm_amd import lib
     g = torch.Generator(device=DEV).manual_seed(4)
     M, H, V = 700, 768, 2000
-    tabs = [bf(torch.randn((n, H), generator=g, device=DEV) * 0.05) for n in (V, 512, 2, 10)]
+    tabs = [torch.randn((n, H), generator=g, device=DEV) * 0.05 for n in (V, 512, 2, 10)]
     ids = torch.randint(0, V, (M,), generator=g, device=DEV, dtype=torch.int32)
     ids[::7] = 103
     pos = torch.randint(0, 512, (M,), generator=g, device=DEV, dtype=torch.int32)
@@ -160,14 +161,15 @@ def test_embeddings_fwd_bwd():
     gamma = torch.randn(H, generator=g, device=DEV) * 0.2 + 1
     beta = torch.randn(H, generator=g, device=DEV) * 0.1
     y = torch.empty((M, H), device=DEV, dtype=torch.bfloat16)
-    lib.embed_fwd(ids, pos, typ, *tabs, gamma, beta, y, M, H)
-    leaves = [t.float().requires_grad_(True) for t in tabs]
+    y32 = torch.empty((M, H), device=DEV)
+    lib.embed_fwd(ids, pos, typ, *tabs, gamma, beta, y32, y, M, H)
+    leaves = [t.clone().requires_grad_(True) for t in tabs]
     gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
     il, pl, tl = ids.long(), pos.long(), typ.long()
     tvec = torch.where((tl >= 2)[:, None], leaves[3][(tl - 2).clamp_min(0)], leaves[2][tl.clamp_max(1)])
     ref = torch.nn.functional.layer_norm(leaves[0][il] + leaves[1][pl] + tvec, (H,), gr, br, 1e-12)
     torch.cuda.synchronize()
-    assert relerr(y, ref) < 2 ** -7
+    assert relerr(y, ref) < 2 ** -7 and relerr(y32, ref) < 1e-5
     dy = bf(torch.randn((M, H), generator=g, device=DEV))
     ref.backward(dy.float())
     grads = [torch.zeros((n, H), device=DEV) for n in (V, 512, 2, 10)]

@@ -1,0 +1,91 @@
+"""Flat parameter / gradient arenas.
+
+All parameters of the model live in ONE fp32 buffer and all gradients in another (each
+nn.Parameter is a view), laid out by `params.arena_groups`.  This is what makes the MI355X path
+cheap around the kernels: one cast kernel refreshes every bf16 weight copy, gradients are zeroed
+with one memset, fused QKV GEMMs read three projections as one operand, and the data-parallel
+all-reduce walks a handful of contiguous buckets instead of 535 tensors.
+
+Device-agnostic (CPU tensors work), so the multi-process gloo tests exercise the same code."""
+from __future__ import annotations
+
+from typing import Dict, List, Tuple
+
+import torch
+
+from . import params as P
+
+ALIGN = 64  # elements: keeps every parameter 256-byte aligned (16-B vector loads, bf16 copy 128-B)
+
+
+class FlatArena:
+    def __init__(self, named_params: Dict[str, torch.nn.Parameter], groups, device=None):
+        """named_params: state_dict name -> Parameter (tied alias excluded).  groups: arena_groups(cfg)."""
+        self.offsets: Dict[str, Tuple[int, tuple]] = {}
+        self.buckets: List[Tuple[str, int, int]] = []   # (group, lo, hi) element ranges
+        off = 0
+        for gname, items in groups:
+            lo = off
+            for name, shape in items:
+                n = 1
+                for s in shape:
+                    n *= s
+                self.offsets[name] = (off, tuple(shape))
+                off += (n + ALIGN - 1) // ALIGN * ALIGN
+            self.buckets.append((gname, lo, off))
+        self.numel = off
+        first = next(iter(named_params.values()))
+        self.device = torch.device(device) if device is not None else first.device
+        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=self.device)
+        self.grad_flat = torch.zeros(self.numel, dtype=torch.float32, device=self.device)
+        self.params = named_params
+        with torch.no_grad():
+            for name, p in named_params.items():
+                o, shape = self.offsets[name]
+                view = self.flat[o:o + p.numel()].view(shape)
+                view.copy_(p.data.to(self.device))
+                p.data = view
+        self._grads_attached = False
+
+    # -- views ---------------------------------------------------------------------------------
+    def view(self, name, buf=None):
+        o, shape = self.offsets[name]
+        n = 1
+        for s in shape:
+            n *= s
+        return (self.flat if buf is None else buf)[o:o + n].view(shape)
+
+    def grad(self, name):
+        return self.view(name, self.grad_flat)
+
+    def is_current(self) -> bool:
+        """False once something (module.to(), load of new Parameters) re-pointed the parameters."""
+        for name, p in self.params.items():
+            o, _ = self.offsets[name]
+            return p.data_ptr() == self.flat.data_ptr() + 4 * o and p.device == self.flat.device
+        return True
+
+    # -- gradients -----------------------------------------------------------------------------
+    def attach_grads(self):
+        """Point every used parameter's .grad at its arena slice (zeroing the arena when a grad was
+        dropped, e.g. by optimizer.zero_grad(set_to_none=True))."""
+        probe = None
+        for name, p in self.params.items():
+            if not P.is_unused(name):
+                probe = (name, p)
+                break
+        name, p = probe
+        o, _ = self.offsets[name]
+        ok = self._grads_attached and p.grad is not None and p.grad.data_ptr() == self.grad_flat.data_ptr() + 4 * o
+        if ok:
+            return
+        self.grad_flat.zero_()
+        for name, p in self.params.items():
+            p.grad = None if P.is_unused(name) else self.grad(name)
+        self._grads_attached = True
+
+    def zero_grads(self):
+        self.grad_flat.zero_()
+
+    def used_ranges(self) -> List[Tuple[str, int, int]]:
+        return list(self.buckets)

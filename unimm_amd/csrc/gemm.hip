@@ -24,7 +24,7 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
 
 struct GemmNtParams {
-  const bf16_t* x; const bf16_t* w; const float* bias; const bf16_t* aux;
+  const bf16_t* x; const bf16_t* w; const float* bias; const void* aux;  // aux: fp32 for DROP_RESID, bf16 otherwise
   void* out; bf16_t* out2;
   int M, N, K, ldx, ldw, ldaux, ldo;
   DropoutArg drop;
@@ -119,14 +119,25 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNtParams p) {
       for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + b[e];
       if constexpr (EPI == UNIMM_EPI_BIAS_DROP_RESID || EPI == UNIMM_EPI_DGELU || EPI == UNIMM_EPI_ADD) {
         float a[4];
-        const bf16_t* ap = p.aux + (size_t)m * p.ldaux + n;
-        if (full) {
-          const u32x2 raw = *reinterpret_cast<const u32x2*>(ap);
-          a[0] = __uint_as_float(raw[0] << 16); a[1] = __uint_as_float(raw[0] & 0xffff0000u);
-          a[2] = __uint_as_float(raw[1] << 16); a[3] = __uint_as_float(raw[1] & 0xffff0000u);
-        } else {
+        if constexpr (EPI == UNIMM_EPI_BIAS_DROP_RESID) {   // fp32 residual stream
+          const float* ap = reinterpret_cast<const float*>(p.aux) + (size_t)m * p.ldaux + n;
+          if (full) {
+            const f32x4 raw = *reinterpret_cast<const f32x4*>(ap);
+            a[0] = raw[0]; a[1] = raw[1]; a[2] = raw[2]; a[3] = raw[3];
+          } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) a[e] = (n + e < p.N) ? bf2f(ap[e]) : 0.f;
+            for (int e = 0; e < 4; ++e) a[e] = (n + e < p.N) ? ap[e] : 0.f;
+          }
+        } else {
+          const bf16_t* ap = reinterpret_cast<const bf16_t*>(p.aux) + (size_t)m * p.ldaux + n;
+          if (full) {
+            const u32x2 raw = *reinterpret_cast<const u32x2*>(ap);
+            a[0] = __uint_as_float(raw[0] << 16); a[1] = __uint_as_float(raw[0] & 0xffff0000u);
+            a[2] = __uint_as_float(raw[1] << 16); a[3] = __uint_as_float(raw[1] & 0xffff0000u);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] = (n + e < p.N) ? bf2f(ap[e]) : 0.f;
+          }
         }
         if constexpr (EPI == UNIMM_EPI_BIAS_DROP_RESID) {
           if (p.drop.thr != 0u) {
@@ -338,8 +349,9 @@ extern "C" int unimm_gemm_nt(const unimm_gemm_nt_args* a, void* stream) {
   const bool needs_aux = a->epilogue == UNIMM_EPI_BIAS_DROP_RESID || a->epilogue == UNIMM_EPI_DGELU ||
                          a->epilogue == UNIMM_EPI_ADD;
   if (needs_aux && (a->aux == nullptr || (a->ldaux % 4) || a->ldaux < a->N)) return UNIMM_E_ARG;
+  if (a->epilogue == UNIMM_EPI_BIAS_DROP_RESID && !a->out_f32) return UNIMM_E_ARG;  // residual stream is fp32
   GemmNtParams p;
-  p.x = (const bf16_t*)a->x; p.w = (const bf16_t*)a->w; p.bias = a->bias; p.aux = (const bf16_t*)a->aux;
+  p.x = (const bf16_t*)a->x; p.w = (const bf16_t*)a->w; p.bias = a->bias; p.aux = a->aux;
   p.out = a->out; p.out2 = (bf16_t*)a->out2;
   p.M = a->M; p.N = a->N; p.K = a->K; p.ldx = a->ldx; p.ldw = a->ldw; p.ldaux = a->ldaux; p.ldo = a->ldo;
   p.drop.key = a->drop_key; p.drop.thr = a->drop_thr; p.drop.scale = a->drop_scale;

@@ -93,6 +93,17 @@ __device__ __forceinline__ void store_row_bf16(bf16_t* __restrict__ p, int H, in
   }
 }
 
+__device__ __forceinline__ void store_row_f32(float* __restrict__ p, int H, int lane, const Row8& r) {
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c * 8 < H) {
+      *reinterpret_cast<f32x4*>(p + c * 8) = f32x4{r.v[i][0], r.v[i][1], r.v[i][2], r.v[i][3]};
+      *reinterpret_cast<f32x4*>(p + c * 8 + 4) = f32x4{r.v[i][4], r.v[i][5], r.v[i][6], r.v[i][7]};
+    }
+  }
+}
+
 __device__ __forceinline__ void load_vec_f32(const float* __restrict__ p, int H, int lane, Row8& r) {
 #pragma unroll
   for (int i = 0; i < MAXC; ++i) {
@@ -132,8 +143,9 @@ __device__ __forceinline__ void row_stats(const Row8& x, int H, float& mean, flo
 // LayerNorm forward (torch.nn.LayerNorm, eps 1e-12; models/vilbert_dialog.py:279,425,468,...)
 // optional dropout on the output (embedding dropouts :355, :1491)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, bf16_t* __restrict__ y,
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ y32,
+                                                            bf16_t* __restrict__ y,
                                                             float* __restrict__ mean_o, float* __restrict__ rstd_o, int M,
                                                             int H, float eps, DropoutArg drop) {
   const int lane = threadIdx.x & 63;
@@ -144,7 +156,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
   load_vec_f32(beta, H, lane, b);
   for (int row = wave; row < M; row += nwaves) {
     Row8 xv;
-    load_row_bf16(x + (size_t)row * H, H, lane, xv);
+    load_vec_f32(x + (size_t)row * H, H, lane, xv);
     float mean, rstd;
     row_stats(xv, H, mean, rstd, eps);
 #pragma unroll
@@ -155,7 +167,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
         if (drop.thr != 0u) v = drop_apply(drop, (uint32_t)row * (uint32_t)H + (uint32_t)((lane + 64 * i) * 8 + j), v);
         xv.v[i][j] = v;
       }
-    store_row_bf16(y + (size_t)row * H, H, lane, xv);
+    if (y32 != nullptr) store_row_f32(y32 + (size_t)row * H, H, lane, xv);
+    if (y != nullptr) store_row_bf16(y + (size_t)row * H, H, lane, xv);
     if (lane == 0 && mean_o != nullptr) { mean_o[row] = mean; rstd_o[row] = rstd; }
   }
 }
@@ -167,7 +180,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
 // dgamma, dbeta and dbias = colsum(dx_drop) that `colpartials_finish` adds into the gradient arena
 // (two-stage, deterministic; no same-address atomics from 1000+ waves).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ mean_i,
                                                             const float* __restrict__ rstd_i,
                                                             const float* __restrict__ gamma, bf16_t* __restrict__ dx,
@@ -188,7 +201,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
   for (int row = wave; row < M; row += nwaves) {
     Row8 dyv, xv;
     load_row_bf16(dy + (size_t)row * H, H, lane, dyv);
-    load_row_bf16(x + (size_t)row * H, H, lane, xv);
+    load_vec_f32(x + (size_t)row * H, H, lane, xv);
     const float mean = mean_i[row], rstd = rstd_i[row];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -261,7 +274,7 @@ __global__ void colpartials_finish_kernel(const float* __restrict__ partials, in
 // ------------------------------------------------------------------------------------------------
 struct EmbArgs {
   const int32_t* ids; const int32_t* pos; const int32_t* typ;
-  const bf16_t* word; const bf16_t* post; const bf16_t* type; const bf16_t* ext;
+  const float* word; const float* post; const float* type; const float* ext;   // fp32 master tables
   const float* gamma; const float* beta;
   int M, H, type_vocab;
   float eps;
@@ -271,17 +284,17 @@ struct EmbArgs {
 __device__ __forceinline__ void emb_gather(const EmbArgs& a, int row, int lane, Row8& x, int& id, int& pid, int& tt) {
   id = a.ids[row]; pid = a.pos[row]; tt = a.typ[row];
   Row8 t1, t2;
-  load_row_bf16(a.word + (size_t)id * a.H, a.H, lane, x);
-  load_row_bf16(a.post + (size_t)pid * a.H, a.H, lane, t1);
-  if (tt < a.type_vocab) load_row_bf16(a.type + (size_t)tt * a.H, a.H, lane, t2);
-  else load_row_bf16(a.ext + (size_t)(tt - a.type_vocab) * a.H, a.H, lane, t2);
+  load_vec_f32(a.word + (size_t)id * a.H, a.H, lane, x);
+  load_vec_f32(a.post + (size_t)pid * a.H, a.H, lane, t1);
+  if (tt < a.type_vocab) load_vec_f32(a.type + (size_t)tt * a.H, a.H, lane, t2);
+  else load_vec_f32(a.ext + (size_t)(tt - a.type_vocab) * a.H, a.H, lane, t2);
 #pragma unroll
   for (int i = 0; i < MAXC; ++i)
 #pragma unroll
     for (int j = 0; j < 8; ++j) x.v[i][j] += t1.v[i][j] + t2.v[i][j];
 }
 
-__global__ __launch_bounds__(256) void embed_fwd_kernel(EmbArgs a, bf16_t* __restrict__ y) {
+__global__ __launch_bounds__(256) void embed_fwd_kernel(EmbArgs a, float* __restrict__ y32, bf16_t* __restrict__ y) {
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * 4;
@@ -303,6 +316,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(EmbArgs a, bf16_t* __res
           v = drop_apply(a.drop, (uint32_t)row * (uint32_t)a.H + (uint32_t)((lane + 64 * i) * 8 + j), v);
         x.v[i][j] = v;
       }
+    store_row_f32(y32 + (size_t)row * a.H, a.H, lane, x);
     store_row_bf16(y + (size_t)row * a.H, a.H, lane, x);
   }
 }
@@ -503,6 +517,41 @@ __global__ void mul_dropout_bwd_kernel(const bf16_t* __restrict__ a, const bf16_
   db[i] = f2bf(bv > 0.f ? d * av : 0.f);
 }
 
+// du = dt * GELU'(u)  (backward of the erf-GELU that sits between a dense and a LayerNorm in the two
+// prediction-head transforms, models/vilbert_dialog.py:983-985, :1002-1004)
+__global__ void gelu_bwd_kernel(const bf16_t* __restrict__ dt, const bf16_t* __restrict__ u, bf16_t* __restrict__ du,
+                                size_t n8) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n8; i += stride) {
+    const u32x4 a = *reinterpret_cast<const u32x4*>(dt + i * 8);
+    const u32x4 b = *reinterpret_cast<const u32x4*>(u + i * 8);
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float d0 = __uint_as_float(a[j] << 16), d1 = __uint_as_float(a[j] & 0xffff0000u);
+      const float u0 = __uint_as_float(b[j] << 16), u1 = __uint_as_float(b[j] & 0xffff0000u);
+      o[j] = pack2bf(d0 * gelu_erf_grad(u0), d1 * gelu_erf_grad(u1));
+    }
+    *reinterpret_cast<u32x4*>(du + i * 8) = o;
+  }
+}
+
+// dst[i, :] = src[idx[i], :]  /  dst[idx[i], :] = src[i, :]   (bf16 rows of H elements, H % 8 == 0)
+__global__ void gather_rows_kernel(const bf16_t* __restrict__ src, const int32_t* __restrict__ idx, bf16_t* __restrict__ dst,
+                                   int n, int H, int scatter) {
+  const int cpr = H / 8;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)n * cpr;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    const int r = (int)(i / cpr), c = (int)(i % cpr) * 8;
+    const int g = idx[r];
+    if (scatter) *reinterpret_cast<u32x4*>(dst + (size_t)g * H + c) = *reinterpret_cast<const u32x4*>(src + (size_t)r * H + c);
+    else *reinterpret_cast<u32x4*>(dst + (size_t)r * H + c) = *reinterpret_cast<const u32x4*>(src + (size_t)g * H + c);
+  }
+}
+
 inline DropoutArg mk_drop(uint32_t key, uint32_t thr, float scale) { DropoutArg d; d.key = key; d.thr = thr; d.scale = scale; return d; }
 
 }  // namespace
@@ -519,22 +568,22 @@ extern "C" int unimm_mask_pack(const void* mask, int dtype, uint32_t* out, int64
   }
 }
 
-extern "C" int unimm_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
-                                   int32_t M, int32_t H, float eps, uint32_t drop_key, uint32_t drop_thr, float drop_scale,
-                                   void* stream) {
-  if (!x || !gamma || !beta || !y) return UNIMM_E_ARG;
+extern "C" int unimm_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y32, void* y16, float* mean,
+                                   float* rstd, int32_t M, int32_t H, float eps, uint32_t drop_key, uint32_t drop_thr,
+                                   float drop_scale, void* stream) {
+  if (!x || !gamma || !beta || (!y32 && !y16)) return UNIMM_E_ARG;
   if (M <= 0 || H <= 0 || H > MAXC * 512 || (H % 8)) return UNIMM_E_SHAPE;
   int blocks = (M + 3) / 4;
   blocks = blocks > 2048 ? 2048 : blocks;
-  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, gamma, beta,
-                     (bf16_t*)y, mean, rstd, M, H, eps, mk_drop(drop_key, drop_thr, drop_scale));
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y32,
+                     (bf16_t*)y16, mean, rstd, M, H, eps, mk_drop(drop_key, drop_thr, drop_scale));
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;
 }
 
 extern "C" int64_t unimm_colpartials_bytes(int32_t H) { return (int64_t)RED_BLOCKS * 4 * H * sizeof(float); }
 
-extern "C" int unimm_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+extern "C" int unimm_layernorm_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                                    void* dx, void* dx_drop, float* dgamma, float* dbeta, float* dbias, float* partials,
                                    int32_t M, int32_t H, uint32_t drop_key, uint32_t drop_thr, float drop_scale,
                                    uint32_t odrop_key, uint32_t odrop_thr, float odrop_scale, void* stream) {
@@ -543,7 +592,7 @@ extern "C" int unimm_layernorm_bwd(const void* dy, const void* x, const float* m
   int blocks = (M + 3) / 4;
   blocks = blocks > RED_BLOCKS ? RED_BLOCKS : blocks;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd,
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, s, (const bf16_t*)dy, x, mean, rstd,
                      gamma, (bf16_t*)dx, (bf16_t*)dx_drop, partials, M, H, mk_drop(drop_key, drop_thr, drop_scale),
                      mk_drop(odrop_key, odrop_thr, odrop_scale));
   UNIMM_CHECK_LAUNCH();
@@ -553,19 +602,20 @@ extern "C" int unimm_layernorm_bwd(const void* dy, const void* x, const float* m
   return UNIMM_OK;
 }
 
-extern "C" int unimm_embed_fwd(const unimm_embed_args* a, void* y, void* stream) {
-  if (!a || !a->ids || !a->pos || !a->typ || !a->word || !a->post || !a->type || !a->ext || !a->gamma || !a->beta || !y)
+extern "C" int unimm_embed_fwd(const unimm_embed_args* a, float* y32, void* y, void* stream) {
+  if (!a || !a->ids || !a->pos || !a->typ || !a->word || !a->post || !a->type || !a->ext || !a->gamma || !a->beta || !y ||
+      !y32)
     return UNIMM_E_ARG;
   if (a->M <= 0 || a->H <= 0 || a->H > MAXC * 512 || (a->H % 8)) return UNIMM_E_SHAPE;
   EmbArgs e;
   e.ids = a->ids; e.pos = a->pos; e.typ = a->typ;
-  e.word = (const bf16_t*)a->word; e.post = (const bf16_t*)a->post; e.type = (const bf16_t*)a->type;
-  e.ext = (const bf16_t*)a->ext; e.gamma = a->gamma; e.beta = a->beta;
+  e.word = a->word; e.post = a->post; e.type = a->type;
+  e.ext = a->ext; e.gamma = a->gamma; e.beta = a->beta;
   e.M = a->M; e.H = a->H; e.type_vocab = a->type_vocab; e.eps = a->eps;
   e.drop = mk_drop(a->drop_key, a->drop_thr, a->drop_scale);
   int blocks = (a->M + 3) / 4;
   blocks = blocks > 2048 ? 2048 : blocks;
-  hipLaunchKernelGGL(embed_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, e, (bf16_t*)y);
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, e, y32, (bf16_t*)y);
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;
 }
@@ -576,8 +626,8 @@ extern "C" int unimm_embed_bwd(const unimm_embed_args* a, const void* dy, float*
   if (a->M <= 0 || a->H <= 0 || a->H > MAXC * 512 || (a->H % 8) || a->type_vocab != 2) return UNIMM_E_SHAPE;
   EmbArgs e;
   e.ids = a->ids; e.pos = a->pos; e.typ = a->typ;
-  e.word = (const bf16_t*)a->word; e.post = (const bf16_t*)a->post; e.type = (const bf16_t*)a->type;
-  e.ext = (const bf16_t*)a->ext; e.gamma = a->gamma; e.beta = a->beta;
+  e.word = a->word; e.post = a->post; e.type = a->type;
+  e.ext = a->ext; e.gamma = a->gamma; e.beta = a->beta;
   e.M = a->M; e.H = a->H; e.type_vocab = a->type_vocab; e.eps = a->eps;
   e.drop = mk_drop(a->drop_key, a->drop_thr, a->drop_scale);
   int blocks = (a->M + 3) / 4;
@@ -649,6 +699,27 @@ extern "C" int unimm_mul_dropout_bwd(const void* a, const void* b, const void* d
   hipLaunchKernelGGL(mul_dropout_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)a, (const bf16_t*)b, (const bf16_t*)dout, (bf16_t*)da, (bf16_t*)db, (size_t)n,
                      mk_drop(drop_key, drop_thr, drop_scale));
+  UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
+}
+
+extern "C" int unimm_gelu_bwd(const void* dt, const void* u, void* du, int64_t n, void* stream) {
+  if (!dt || !u || !du || n <= 0 || (n % 8)) return UNIMM_E_ARG;
+  int64_t blocks = (n / 8 + 255) / 256;
+  blocks = blocks > 8192 ? 8192 : blocks;
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dt,
+                     (const bf16_t*)u, (bf16_t*)du, (size_t)(n / 8));
+  UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
+}
+
+extern "C" int unimm_gather_rows(const void* src, const int32_t* idx, void* dst, int32_t n, int32_t H, int32_t scatter,
+                                 void* stream) {
+  if (!src || !idx || !dst || n <= 0 || H <= 0 || (H % 8)) return UNIMM_E_ARG;
+  size_t blocks = ((size_t)n * (H / 8) + 255) / 256;
+  blocks = blocks > 8192 ? 8192 : blocks;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, idx,
+                     (bf16_t*)dst, n, H, scatter);
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;
 }

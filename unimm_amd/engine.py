@@ -1,0 +1,679 @@
+"""Hot-path engine: the explicit forward / backward schedule of the two-stream co-attention
+transformer over the hand-written HIP kernels (unimm_amd.lib), with weights in a flat arena.
+
+What the reference runs as ~600 eager torch ops per step through autograd
+(models/vilbert_dialog.py:1359-1626) is here a fixed launch schedule:
+
+  forward  : mask bit-pack -> text/image embeddings -> [T|V|C blocks in BertEncoder order] ->
+             poolers/NSP, row-sparse MLM decoder + fused log-softmax/UL loss, region head + KL
+  backward : the same blocks in reverse, each a handful of fused kernels; weight gradients are
+             accumulated straight into the flat fp32 gradient arena.
+
+Activations are bf16 [rows, hidden] row-major; GEMMs accumulate in fp32; LayerNorm statistics,
+softmax, log-sum-exp and all loss arithmetic are fp32.  There is no CPU / eager fallback here: every
+compute step is a C-ABI call and raises if the library is missing."""
+from __future__ import annotations
+
+import math
+import zlib
+from typing import Dict, List, Optional
+
+import torch
+
+from . import dropout as DR
+from . import lib as L
+from . import params as PM
+from .arena import FlatArena
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _site(name: str) -> int:
+    return zlib.crc32(name.encode()) & 0xFFFFFFFF
+
+
+def _rup(x, m):
+    return (x + m - 1) // m * m
+
+
+class _Lin:
+    """One (possibly fused) linear: bf16 weight [N,K], transposed bf16 copy [K,Npad], fp32 bias + grads."""
+    __slots__ = ("w", "wt", "bias", "gw", "gb", "N", "K", "gbs")
+
+    def __init__(self, w, wt, bias, gw, gb, gbs=None):
+        self.w, self.wt, self.bias, self.gw, self.gb = w, wt, bias, gw, gb
+        self.N, self.K = w.shape
+        self.gbs = gbs  # extra bias-gradient destinations (image embedding: b_feat and b_loc)
+
+
+class Engine:
+    def __init__(self, model, cfg):
+        self.model = model
+        self.cfg = cfg
+        self.arena: Optional[FlatArena] = None
+        self.seed = 0x5EED
+        self.step = 0
+        self._w_version = None
+        self.lin: Dict[str, _Lin] = {}
+        self.ln: Dict[str, tuple] = {}
+        self.grad_bucket_hook = None     # set by the data-parallel wrapper: f(group_name, lo, hi)
+        self._anchor = None
+        self.last_seq_t = None
+
+    # ------------------------------------------------------------------------------------------
+    # arenas + bf16 weight copies
+    # ------------------------------------------------------------------------------------------
+    def ensure(self, device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise L.UnimmHipError("unimm_amd runs on the GPU only (gfx950); move the model with .cuda() first")
+        L.lib()
+        if self.arena is not None and self.arena.is_current() and self.arena.device == device:
+            return
+        self.cfg.validate_for_hip()
+        named = {n: p for n, p in self.model.named_parameters()}   # tied decoder alias is deduplicated
+        self.arena = FlatArena(named, PM.arena_groups(self.cfg), device=device)
+        A = self.arena
+        self.w16 = torch.zeros(A.numel, dtype=BF16, device=device)
+        self._anchor = torch.zeros(1, device=device, requires_grad=True)
+        self._build_tables(device)
+        self._w_version = None
+
+    def _fused(self, names):
+        """bf16 / fp32 / grad views spanning several consecutive arena entries (fused QKV)."""
+        A = self.arena
+        o0, shape0 = A.offsets[names[0]]
+        rows = sum(A.offsets[n][1][0] for n in names)
+        tail = shape0[1:]
+        n_el = rows * (tail[0] if tail else 1)
+        shp = (rows,) + tail
+        # consecutive entries must be gap-free for the fused view to be valid
+        o = o0
+        for n in names:
+            oo, s = A.offsets[n]
+            assert oo == o, f"arena layout: {n} not contiguous"
+            o += s[0] * (s[1] if len(s) > 1 else 1)
+        return (self.w16[o0:o0 + n_el].view(shp), A.flat[o0:o0 + n_el].view(shp), A.grad_flat[o0:o0 + n_el].view(shp))
+
+    def _mk_lin(self, key, wnames, bnames, device, kpad=None, make_wt=True):
+        w16, _, gw = self._fused(wnames)
+        _, b32, gb = self._fused(bnames) if bnames else (None, None, None)
+        N, K = w16.shape
+        wt = None
+        if make_wt:
+            wt = torch.zeros((K, kpad or _rup(N, 64)), dtype=BF16, device=device)
+        self.lin[key] = _Lin(w16, wt, b32, gw, gb)
+        self._wt_src.append((key, wnames))
+
+    def _build_tables(self, device):
+        cfg, A = self.cfg, self.arena
+        self.lin.clear(); self.ln.clear()
+        self._wt_src = []
+
+        def ln(key, name):
+            self.ln[key] = (A.view(name + ".weight"), A.view(name + ".bias"), A.grad(name + ".weight"), A.grad(name + ".bias"))
+
+        def self_block(k, p):
+            a = p + "attention.self."
+            self._mk_lin(k + ".qkv", [a + n + ".weight" for n in ("query", "key", "value")],
+                         [a + n + ".bias" for n in ("query", "key", "value")], device)
+            self._mk_lin(k + ".so", [p + "attention.output.dense.weight"], [p + "attention.output.dense.bias"], device)
+            ln(k + ".ln1", p + "attention.output.LayerNorm")
+            self._mk_lin(k + ".ff1", [p + "intermediate.dense.weight"], [p + "intermediate.dense.bias"], device)
+            self._mk_lin(k + ".ff2", [p + "output.dense.weight"], [p + "output.dense.bias"], device)
+            ln(k + ".ln2", p + "output.LayerNorm")
+
+        for kind, i in PM.encoder_schedule(cfg):
+            if kind == "t":
+                self_block(f"t{i}", f"bert.encoder.layer.{i}.")
+            elif kind == "v":
+                self_block(f"v{i}", f"bert.encoder.v_layer.{i}.")
+            else:
+                p = f"bert.encoder.c_layer.{i}."
+                b = p + "biattention."
+                k = f"c{i}"
+                self._mk_lin(k + ".qkv1", [b + n + ".weight" for n in ("query1", "key1", "value1")],
+                             [b + n + ".bias" for n in ("query1", "key1", "value1")], device)
+                self._mk_lin(k + ".qkv2", [b + n + ".weight" for n in ("query2", "key2", "value2")],
+                             [b + n + ".bias" for n in ("query2", "key2", "value2")], device)
+                o = p + "biOutput."
+                self._mk_lin(k + ".d1", [o + "dense1.weight"], [o + "dense1.bias"], device)
+                ln(k + ".lnb1", o + "LayerNorm1")
+                self._mk_lin(k + ".d2", [o + "dense2.weight"], [o + "dense2.bias"], device)
+                ln(k + ".lnb2", o + "LayerNorm2")
+                self._mk_lin(k + ".vff1", [p + "v_intermediate.dense.weight"], [p + "v_intermediate.dense.bias"], device)
+                self._mk_lin(k + ".vff2", [p + "v_output.dense.weight"], [p + "v_output.dense.bias"], device)
+                ln(k + ".lnv", p + "v_output.LayerNorm")
+                self._mk_lin(k + ".tff1", [p + "t_intermediate.dense.weight"], [p + "t_intermediate.dense.bias"], device)
+                self._mk_lin(k + ".tff2", [p + "t_output.dense.weight"], [p + "t_output.dense.bias"], device)
+                ln(k + ".lnt", p + "t_output.LayerNorm")
+
+        ln("emb_t", "bert.embeddings.LayerNorm")
+        ln("emb_v", "bert.v_embeddings.LayerNorm")
+        self._mk_lin("tpool", ["bert.t_pooler.dense.weight"], ["bert.t_pooler.dense.bias"], device)
+        self._mk_lin("vpool", ["bert.v_pooler.dense.weight"], ["bert.v_pooler.dense.bias"], device)
+        self._mk_lin("lmtr", ["cls.predictions.transform.dense.weight"], ["cls.predictions.transform.dense.bias"], device)
+        ln("lmtr", "cls.predictions.transform.LayerNorm")
+        self._mk_lin("dec", [PM.WORD_EMB], None, device)
+        d = self.lin["dec"]
+        d.bias, d.gb = A.view("cls.predictions.bias"), A.grad("cls.predictions.bias")
+        self._mk_lin("nsp", ["cls.bi_seq_relationship.weight"], ["cls.bi_seq_relationship.bias"], device, kpad=64)
+        self._mk_lin("imgtr", ["cls.imagePredictions.transform.dense.weight"],
+                     ["cls.imagePredictions.transform.dense.bias"], device)
+        ln("imgtr", "cls.imagePredictions.transform.LayerNorm")
+        self._mk_lin("imgdec", ["cls.imagePredictions.decoder.weight"], ["cls.imagePredictions.decoder.bias"], device)
+        # image embedding: one GEMM over [feat | loc | 0] with W_cat = [W_feat | W_loc | 0], bias = b_feat + b_loc
+        F = cfg.v_feature_size
+        self.vemb_k = F + 64
+        self.vemb_w = torch.zeros((cfg.v_hidden_size, self.vemb_k), dtype=BF16, device=device)
+        self.vemb_b = torch.zeros(cfg.v_hidden_size, dtype=F32, device=device)
+        # embedding tables: gathered from the fp32 master weights
+        e = "bert.embeddings."
+        self.tab = {k: A.view(e + n + ".weight") for k, n in
+                    (("word", "word_embeddings"), ("pos", "position_embeddings"), ("type", "token_type_embeddings"),
+                     ("ext", "token_type_embeddings_extension"))}
+        self.part = {h: torch.empty(L.colpartials_bytes(h) // 4, dtype=F32, device=device)
+                     for h in {cfg.hidden_size, cfg.v_hidden_size}}
+
+    def refresh_weights(self, force=False):
+        """fp32 arena -> bf16 copies (one cast kernel) + transposed copies for the dgrad GEMMs."""
+        A = self.arena
+        ver = A.flat._version
+        if not force and ver == self._w_version:
+            return
+        L.cast_f32_bf16(A.flat, self.w16, A.numel)
+        for key, wnames in self._wt_src:
+            lin = self.lin[key]
+            if lin.wt is None:
+                continue
+            o0, _ = A.offsets[wnames[0]]
+            src = A.flat[o0:o0 + lin.N * lin.K]
+            L.transpose_cast(src, lin.wt, lin.N, lin.K, lin.wt.shape[1])
+        cfg = self.cfg
+        F = cfg.v_feature_size
+        v = "bert.v_embeddings."
+        self.vemb_w[:, :F].copy_(A.view(v + "image_embeddings.weight"))
+        self.vemb_w[:, F:F + 5].copy_(A.view(v + "image_location_embeddings.weight"))
+        torch.add(A.view(v + "image_embeddings.bias"), A.view(v + "image_location_embeddings.bias"), out=self.vemb_b)
+        self._w_version = ver
+
+    # ------------------------------------------------------------------------------------------
+    # small op helpers (each returns its output and pushes its backward onto the tape)
+    # ------------------------------------------------------------------------------------------
+    def _drop(self, name, p, train):
+        if not train or p <= 0.0:
+            return L.NO_DROP
+        return DR.drop_arg(p, DR.make_key(self.seed, self.step, _site(name)))
+
+    def _linear(self, x, lin, epi=L.EPI_BIAS, aux=None, want_u=False, drop=None, out_f32=False, ldo=None, M=None):
+        M = x.shape[0] if M is None else M
+        ldo = ldo or lin.N
+        out = torch.empty((M, ldo), dtype=F32 if out_f32 else BF16, device=x.device)
+        u = torch.empty((M, ldo), dtype=BF16, device=x.device) if want_u else None
+        L.gemm_nt(x, lin.w, out, bias=lin.bias, epilogue=epi, aux=aux, out2=u, drop=drop, M=M, N=lin.N, K=lin.K)
+        return (out, u) if want_u else out
+
+    def _linear_bwd(self, dy, x, lin, epi=L.EPI_BIAS, aux=None, need_dx=True, bias_grad=True, M=None, N=None, xk=None):
+        """dW += dy^T x ; db += colsum(dy) ; returns dx = epi(dy @ W)."""
+        M = dy.shape[0] if M is None else M
+        N = lin.N if N is None else N
+        L.gemm_tn(dy, x, lin.gw, M=M, N=N, K=lin.K if xk is None else xk)
+        if bias_grad and lin.gb is not None:
+            L.colsum(dy, lin.gb, M, N)
+        if not need_dx:
+            return None
+        dx = torch.empty((M, lin.K), dtype=BF16, device=dy.device)
+        kdim = lin.wt.shape[1]
+        L.gemm_nt(dy, lin.wt, dx, bias=None, epilogue=epi, aux=aux, M=M, N=lin.K, K=kdim)
+        return dx
+
+    def _layernorm(self, x, key, save, drop=L.NO_DROP, want32=True):
+        """x: fp32 pre-LayerNorm sum -> (y32 residual stream | None, y16 GEMM operand, mean, rstd)."""
+        gmm, bta, _, _ = self.ln[key]
+        M, H = x.shape
+        y32 = torch.empty((M, H), dtype=F32, device=x.device) if want32 else None
+        y16 = torch.empty((M, H), dtype=BF16, device=x.device)
+        mean = torch.empty(M, dtype=F32, device=x.device) if save else None
+        rstd = torch.empty(M, dtype=F32, device=x.device) if save else None
+        L.layernorm_fwd(x, gmm, bta, y32, y16, mean, rstd, M, H, drop=drop)
+        return y32, y16, mean, rstd
+
+    def _layernorm_bwd(self, dy, x, mean, rstd, key, dbias=None, drop=L.NO_DROP, out_drop=L.NO_DROP):
+        gmm, _, gg, gb = self.ln[key]
+        M, H = x.shape
+        dx = torch.empty((M, H), dtype=BF16, device=x.device)
+        dxd = torch.empty((M, H), dtype=BF16, device=x.device) if drop[1] != 0 else None
+        L.layernorm_bwd(dy, x, mean, rstd, gmm, dx, dxd, gg, gb, dbias, self.part[H], M, H, drop=drop, out_drop=out_drop)
+        return dx, (dxd if dxd is not None else dx)
+
+    # ------------------------------------------------------------------------------------------
+    # blocks
+    # ------------------------------------------------------------------------------------------
+    def _attn(self, q, k, v, mask, B, H, Tq, Tk, D, drop, save):
+        out = torch.empty((B * Tq, H * D), dtype=BF16, device=q.device)
+        lse = torch.empty((B, H, Tq), dtype=F32, device=q.device) if save else None
+        words, mq, mb = mask
+        L.attn_fwd(q, k, v, out, lse, words, B, H, Tq, Tk, D, 1.0 / math.sqrt(D), mq, mb, drop)
+        return out, lse
+
+    def _self_block(self, key, x32, x, mask, B, T, heads, pname, p_attn, p_hid, st):
+        """BertLayer / BertImageLayer (models/vilbert_dialog.py:385-483, :514-612).
+        (x32, x): fp32 residual stream and its bf16 copy (the GEMM operand)."""
+        train, tape = st["train"], st["tape"]
+        save = tape is not None
+        Hd = x.shape[1]
+        D = Hd // heads
+        qkv_l, so, ff1, ff2 = (self.lin[key + s] for s in (".qkv", ".so", ".ff1", ".ff2"))
+        qkv = self._linear(x, qkv_l)
+        q, k, v = qkv[:, :Hd], qkv[:, Hd:2 * Hd], qkv[:, 2 * Hd:]
+        d_attn = self._drop(pname + "attn", p_attn, train)
+        ctx, lse = self._attn(q, k, v, mask, B, heads, T, T, D, d_attn, save)
+        d_so = self._drop(pname + "so", p_hid, train)
+        pre1 = self._linear(ctx, so, L.EPI_BIAS_DROP_RESID, aux=x32, drop=d_so, out_f32=True)
+        x1_32, x1, m1, r1 = self._layernorm(pre1, key + ".ln1", save)
+        h, u = self._linear(x1, ff1, L.EPI_BIAS_GELU, want_u=True) if save else (self._linear(x1, ff1, L.EPI_BIAS_GELU), None)
+        d_out = self._drop(pname + "out", p_hid, train)
+        pre2 = self._linear(h, ff2, L.EPI_BIAS_DROP_RESID, aux=x1_32, drop=d_out, out_f32=True)
+        x2_32, x2, m2, r2 = self._layernorm(pre2, key + ".ln2", save)
+        if save:
+            def bwd(dx2):
+                dpre2, dpre2d = self._layernorm_bwd(dx2, pre2, m2, r2, key + ".ln2", dbias=ff2.gb, drop=d_out)
+                du = self._linear_bwd(dpre2d, h, ff2, L.EPI_DGELU, aux=u, bias_grad=False)
+                dx1 = self._linear_bwd(du, x1, ff1, L.EPI_ADD, aux=dpre2)
+                dpre1, dpre1d = self._layernorm_bwd(dx1, pre1, m1, r1, key + ".ln1", dbias=so.gb, drop=d_so)
+                dctx = self._linear_bwd(dpre1d, ctx, so, bias_grad=False)
+                dqkv = torch.empty_like(qkv)
+                delta = torch.empty_like(lse)
+                words, mq, mb = mask
+                L.attn_bwd(q, k, v, ctx, dctx, lse, delta, dqkv[:, :Hd], dqkv[:, Hd:2 * Hd], dqkv[:, 2 * Hd:], words,
+                           B, heads, T, T, D, 1.0 / math.sqrt(D), mq, mb, d_attn)
+                return self._linear_bwd(dqkv, x, qkv_l, L.EPI_ADD, aux=dpre1)
+            tape.append((key, bwd))
+        return x2_32, x2
+
+    def _conn_block(self, key, i, xv32, xv, xt32, xt, B, R, T, vmask, comask, st):
+        """BertConnectionLayer (models/vilbert_dialog.py:655-783)."""
+        cfg = self.cfg
+        train, tape = st["train"], st["tape"]
+        save = tape is not None
+        pn = f"bert.encoder.c_layer.{i}."
+        Hb, nh = cfg.bi_hidden_size, cfg.bi_num_attention_heads
+        D = Hb // nh
+        lq1, lq2, d1, d2 = (self.lin[key + s] for s in (".qkv1", ".qkv2", ".d1", ".d2"))
+        vff1, vff2, tff1, tff2 = (self.lin[key + s] for s in (".vff1", ".vff2", ".tff1", ".tff2"))
+        qkv1 = self._linear(xv, lq1)      # image side  [B*R, 3Hb]
+        qkv2 = self._linear(xt, lq2)      # text side   [B*T, 3Hb]
+        q1, k1, v1 = qkv1[:, :Hb], qkv1[:, Hb:2 * Hb], qkv1[:, 2 * Hb:]
+        q2, k2, v2 = qkv2[:, :Hb], qkv2[:, Hb:2 * Hb], qkv2[:, 2 * Hb:]
+        da1 = self._drop(pn + "attn1", cfg.v_attention_probs_dropout_prob, train)
+        da2 = self._drop(pn + "attn2", cfg.attention_probs_dropout_prob, train)
+        ctx_t, lse_t = self._attn(q2, k1, v1, vmask, B, nh, T, R, D, da1, save)     # text attends regions (:681-698)
+        ctx_v, lse_v = self._attn(q1, k2, v2, comask, B, nh, R, T, D, da2, save)    # regions attend text (:701-721)
+        db1 = self._drop(pn + "bo1", cfg.v_hidden_dropout_prob, train)
+        db2 = self._drop(pn + "bo2", cfg.hidden_dropout_prob, train)
+        prev = self._linear(ctx_v, d1, L.EPI_BIAS_DROP_RESID, aux=xv32, drop=db1, out_f32=True)   # BertBiOutput (:744-754, call order :775)
+        av32, av, mv1, rv1 = self._layernorm(prev, key + ".lnb1", save)
+        pret = self._linear(ctx_t, d2, L.EPI_BIAS_DROP_RESID, aux=xt32, drop=db2, out_f32=True)
+        at32, at, mt1, rt1 = self._layernorm(pret, key + ".lnb2", save)
+        dvo = self._drop(pn + "vout", cfg.v_hidden_dropout_prob, train)
+        dto = self._drop(pn + "tout", cfg.hidden_dropout_prob, train)
+        if save:
+            hv, uv = self._linear(av, vff1, L.EPI_BIAS_GELU, want_u=True)
+            ht, ut = self._linear(at, tff1, L.EPI_BIAS_GELU, want_u=True)
+        else:
+            hv, uv, ht, ut = self._linear(av, vff1, L.EPI_BIAS_GELU), None, self._linear(at, tff1, L.EPI_BIAS_GELU), None
+        prev2 = self._linear(hv, vff2, L.EPI_BIAS_DROP_RESID, aux=av32, drop=dvo, out_f32=True)
+        ov32, ov, mv2, rv2 = self._layernorm(prev2, key + ".lnv", save)
+        pret2 = self._linear(ht, tff2, L.EPI_BIAS_DROP_RESID, aux=at32, drop=dto, out_f32=True)
+        ot32, ot, mt2, rt2 = self._layernorm(pret2, key + ".lnt", save)
+        if save:
+            def bwd(dov, dot):
+                sc = 1.0 / math.sqrt(D)
+                # FFNs
+                dp, dpd = self._layernorm_bwd(dov, prev2, mv2, rv2, key + ".lnv", dbias=vff2.gb, drop=dvo)
+                duv = self._linear_bwd(dpd, hv, vff2, L.EPI_DGELU, aux=uv, bias_grad=False)
+                dav = self._linear_bwd(duv, av, vff1, L.EPI_ADD, aux=dp)
+                dp, dpd = self._layernorm_bwd(dot, pret2, mt2, rt2, key + ".lnt", dbias=tff2.gb, drop=dto)
+                dut = self._linear_bwd(dpd, ht, tff2, L.EPI_DGELU, aux=ut, bias_grad=False)
+                dat = self._linear_bwd(dut, at, tff1, L.EPI_ADD, aux=dp)
+                # bi-output
+                dprev, dprevd = self._layernorm_bwd(dav, prev, mv1, rv1, key + ".lnb1", dbias=d1.gb, drop=db1)
+                dctx_v = self._linear_bwd(dprevd, ctx_v, d1, bias_grad=False)
+                dpret, dpretd = self._layernorm_bwd(dat, pret, mt1, rt1, key + ".lnb2", dbias=d2.gb, drop=db2)
+                dctx_t = self._linear_bwd(dpretd, ctx_t, d2, bias_grad=False)
+                # attention cores: every slice of dqkv1 / dqkv2 is written exactly once
+                dqkv1, dqkv2 = torch.empty_like(qkv1), torch.empty_like(qkv2)
+                delta_t, delta_v = torch.empty_like(lse_t), torch.empty_like(lse_v)
+                w, mq, mb = vmask
+                L.attn_bwd(q2, k1, v1, ctx_t, dctx_t, lse_t, delta_t, dqkv2[:, :Hb], dqkv1[:, Hb:2 * Hb], dqkv1[:, 2 * Hb:],
+                           w, B, nh, T, R, D, sc, mq, mb, da1)
+                w, mq, mb = comask
+                L.attn_bwd(q1, k2, v2, ctx_v, dctx_v, lse_v, delta_v, dqkv1[:, :Hb], dqkv2[:, Hb:2 * Hb], dqkv2[:, 2 * Hb:],
+                           w, B, nh, R, T, D, sc, mq, mb, da2)
+                dxv = self._linear_bwd(dqkv1, xv, lq1, L.EPI_ADD, aux=dprev)
+                dxt = self._linear_bwd(dqkv2, xt, lq2, L.EPI_ADD, aux=dpret)
+                return dxv, dxt
+            tape.append((key, bwd))
+        return ov32, ov, ot32, ot
+
+    # ------------------------------------------------------------------------------------------
+    # inputs
+    # ------------------------------------------------------------------------------------------
+    @staticmethod
+    def _i32(x, device):
+        return x.to(device=device, dtype=torch.int32, non_blocking=True).contiguous()
+
+    def _pack_mask(self, m, device, rows_expected):
+        """-> (words, q_stride, b_stride).  m: [B, Tk] (key padding) or [B, Tq, Tk]."""
+        if m.dtype not in (torch.bool, torch.uint8, torch.int32, torch.int64, torch.float32):
+            m = m.float()
+        if not m.is_cuda and m.dtype == torch.int64:
+            m = m.to(torch.uint8)          # 8x less PCIe traffic for the reference's int64 masks
+        m = m.to(device, non_blocking=True)
+        words = L.mask_pack(m)
+        nw = words.shape[-1]
+        if m.dim() == 2:
+            return (words, 0, nw)
+        return (words, nw, m.shape[1] * nw)
+
+    # ------------------------------------------------------------------------------------------
+    # forward
+    # ------------------------------------------------------------------------------------------
+    def forward(self, inp: dict, train: bool, save: bool, lm_rows: str, want_pred_v: bool):
+        """Runs the trunk + heads.  Returns a dict of outputs and (when save) the tape for backward.
+        lm_rows: 'labelled' (decode only rows that carry a label / weight), 'all', or 'none'."""
+        cfg = self.cfg
+        dev = self.arena.device
+        self.refresh_weights()
+        ids = inp["input_ids"]
+        B, T = ids.shape
+        feat = inp["image_feat"]
+        R = feat.shape[1]
+        if T > 256 or R > 256:
+            raise ValueError("sequence / region count above 256 is not supported by the attention kernels")
+        H, Hv = cfg.hidden_size, cfg.v_hidden_size
+        st = dict(train=train, tape=[] if save else None)
+        tape = st["tape"]
+
+        # ---- masks (models/vilbert_dialog.py:1374-1431) ------------------------------------------
+        am = inp.get("attention_mask")
+        if am is None:
+            am = torch.ones((B, T), dtype=torch.uint8, device=dev)
+        if am.dim() not in (2, 3):
+            raise ValueError(f"Wrong shape for txt input_ids (shape {tuple(ids.shape)}) or attention_mask (shape {tuple(am.shape)})")
+        im = inp.get("image_attention_mask")
+        if im is None:
+            im = torch.ones((B, R), dtype=torch.uint8, device=dev)
+        if im.dim() not in (2, 3):
+            raise ValueError(f"Wrong shape for img input_ids (shape {tuple(feat.shape)}) or attention_mask (shape {tuple(im.shape)})")
+        cm = inp.get("co_attention_mask")
+        if cm is None:
+            cm = torch.ones((B, R, T), dtype=torch.uint8, device=dev)
+        assert cm.dim() == 3
+        tmask = self._pack_mask(am, dev, T)
+        vmask = self._pack_mask(im, dev, R)
+        comask = self._pack_mask(cm, dev, R)
+
+        # ---- embeddings --------------------------------------------------------------------------
+        tt = inp.get("token_type_ids")
+        ids32 = self._i32(ids.reshape(-1), dev)
+        typ32 = self._i32(tt.reshape(-1), dev) if tt is not None else torch.zeros(B * T, dtype=torch.int32, device=dev)
+        pos = inp.get("position_ids")
+        pos32 = self._i32(pos.reshape(-1), dev) if pos is not None else \
+            torch.arange(T, dtype=torch.int32, device=dev).repeat(B)
+        gmm, bta, ggm, gbt = self.ln["emb_t"]
+        d_embt = self._drop("emb_t", cfg.hidden_dropout_prob, train)
+        xt = torch.empty((B * T, H), dtype=BF16, device=dev)
+        xt32 = torch.empty((B * T, H), dtype=F32, device=dev)
+        tabs = (self.tab["word"], self.tab["pos"], self.tab["type"], self.tab["ext"])
+        L.embed_fwd(ids32, pos32, typ32, *tabs, gmm, bta, xt32, xt, B * T, H, cfg.type_vocab_size, drop=d_embt)
+        A = self.arena
+        e = "bert.embeddings."
+        if save:
+            def bwd_embt(dxt):
+                L.embed_bwd(ids32, pos32, typ32, *tabs, gmm, bta, dxt, A.grad(e + "word_embeddings.weight"),
+                            A.grad(e + "position_embeddings.weight"), A.grad(e + "token_type_embeddings.weight"),
+                            A.grad(e + "token_type_embeddings_extension.weight"), ggm, gbt, self.part[H], B * T, H,
+                            cfg.type_vocab_size, drop=d_embt)
+
+        F = cfg.v_feature_size
+        featd = feat.to(dev, dtype=F32, non_blocking=True).contiguous().view(B * R, F)
+        locd = inp["image_loc"].to(dev, dtype=F32, non_blocking=True).contiguous().view(B * R, 5)
+        packed = torch.empty((B * R, self.vemb_k), dtype=BF16, device=dev)
+        L.pack_image(featd, locd, packed, B * R, F, self.vemb_k)
+        prev = torch.empty((B * R, Hv), dtype=F32, device=dev)
+        L.gemm_nt(packed, self.vemb_w, prev, bias=self.vemb_b, M=B * R, N=Hv, K=self.vemb_k)
+        d_embv = self._drop("emb_v", cfg.hidden_dropout_prob, train)
+        xv32, xv, mv, rv = self._layernorm(prev, "emb_v", save, drop=d_embv)
+        if save:
+            v = "bert.v_embeddings."
+
+            def bwd_embv(dxv):
+                dbias = A.grad(v + "image_embeddings.bias")
+                before = dbias.clone()
+                dpre, _ = self._layernorm_bwd(dxv, prev, mv, rv, "emb_v", dbias=dbias, out_drop=d_embv)
+                A.grad(v + "image_location_embeddings.bias").add_(dbias - before)
+                L.gemm_tn(dpre, packed, A.grad(v + "image_embeddings.weight"), M=B * R, N=Hv, K=F)
+                L.gemm_tn(dpre, packed[:, F:], A.grad(v + "image_location_embeddings.weight"), M=B * R, N=Hv, K=5)
+
+        # ---- encoder (schedule of models/vilbert_dialog.py:842-929) ------------------------------
+        for kind, i in PM.encoder_schedule(cfg):
+            if kind == "t":
+                xt32, xt = self._self_block(f"t{i}", xt32, xt, tmask, B, T, cfg.num_attention_heads, f"bert.encoder.layer.{i}.",
+                                      cfg.attention_probs_dropout_prob, cfg.hidden_dropout_prob, st)
+                if save:
+                    tape[-1] = ("t", tape[-1][0], tape[-1][1])
+            elif kind == "v":
+                xv32, xv = self._self_block(f"v{i}", xv32, xv, vmask, B, R, cfg.v_num_attention_heads, f"bert.encoder.v_layer.{i}.",
+                                      cfg.v_attention_probs_dropout_prob, cfg.v_hidden_dropout_prob, st)
+                if save:
+                    tape[-1] = ("v", tape[-1][0], tape[-1][1])
+            else:
+                xv32, xv, xt32, xt = self._conn_block(f"c{i}", i, xv32, xv, xt32, xt, B, R, T, vmask, comask, st)
+                if save:
+                    tape[-1] = ("c", tape[-1][0], tape[-1][1])
+        seq_t, seq_v = xt, xv
+
+        out = dict(seq_out_t=seq_t, seq_out_v=seq_v, seq32_t=xt32, seq32_v=xv32, B=B, T=T, R=R)
+        # ---- poolers + NSP (models/vilbert_dialog.py:946-967, 1064-1070) -------------------------
+        tp, vp, nspl = self.lin["tpool"], self.lin["vpool"], self.lin["nsp"]
+        cls_t = seq_t.view(B, T * H)[:, :H]      # first-token rows, row stride T*H
+        cls_v = seq_v.view(B, R * Hv)[:, :Hv]
+        pooled_t = self._linear(cls_t, tp, L.EPI_BIAS_RELU, M=B)
+        pooled_v = self._linear(cls_v, vp, L.EPI_BIAS_RELU, M=B)
+        d_fuse = self._drop("fuse", 0.1, train)
+        fused = torch.empty_like(pooled_t)
+        L.mul_dropout(pooled_t, pooled_v, fused, fused.numel(), d_fuse)
+        nsp = self._linear(fused, nspl, out_f32=True, ldo=4)
+        out["nsp"] = nsp[:, :2]
+
+        # ---- MLM head: transform + tied decoder on the selected rows (:982-986, :1023-1026) -------
+        labels, weights = inp.get("masked_lm_labels"), inp.get("lm_weight")
+        V = cfg.vocab_size
+        Vp = _rup(V, 64)
+        lmtr, dec = self.lin["lmtr"], self.lin["dec"]
+        lm = None
+        if lm_rows == "labelled" and labels is not None:
+            lab_flat = labels.reshape(-1)
+            if weights is not None:
+                w_flat = weights.reshape(-1)
+                sel = torch.nonzero(w_flat != 0)[:, 0]
+                w_sel = w_flat[sel]
+            else:
+                sel = torch.nonzero(lab_flat != -1)[:, 0]
+                w_sel = torch.ones_like(sel)
+            n = int(sel.numel())
+            if n > 0:
+                idx = self._i32(sel, dev)
+                lab_sel = self._i32(lab_flat[sel], dev)
+                w_sel = self._i32(w_sel, dev)
+                xs = torch.empty((n, H), dtype=BF16, device=dev)
+                L.gather_rows(seq_t, idx, xs, n, H)
+                lm = self._lm_head(xs, n, lab_sel, w_sel, save)
+                lm.update(idx=idx, n=n)
+            out["lm"] = lm
+        elif lm_rows == "all":
+            out["pred_t"] = self.decode_rows(seq_t, B * T).view(B, T, Vp)[:, :, :V]
+
+        # ---- image head (:1001-1005, :1085-1088) + masked KL (:1569-1574) --------------------------
+        img = None
+        if want_pred_v or inp.get("image_target") is not None:
+            itr, idec = self.lin["imgtr"], self.lin["imgdec"]
+            C = cfg.v_target_size
+            if save:
+                tv, uvh = self._linear(seq_v, itr, L.EPI_BIAS_GELU, want_u=True, out_f32=True)
+            else:
+                tv, uvh = self._linear(seq_v, itr, L.EPI_BIAS_GELU, out_f32=True), None
+            _, hvn, mh, rh = self._layernorm(tv, "imgtr", save, want32=False)
+            pred_v = self._linear(hvn, idec, out_f32=True, ldo=_rup(C, 4))
+            out["pred_v"] = pred_v.view(B, R, -1)[:, :, :C]
+            img = dict(tv=tv, u=uvh, hn=hvn, mean=mh, rstd=rh, pred=pred_v)
+        out["img"] = img
+
+        if save:
+            out["bwd"] = dict(tape=tape, embt=bwd_embt, embv=bwd_embv, pooled_t=pooled_t, pooled_v=pooled_v, fused=fused,
+                              d_fuse=d_fuse, nsp_pad=nsp, cls_t=cls_t, cls_v=cls_v)
+        return out
+
+    def _lm_head(self, xs, n, lab_sel, w_sel, save):
+        cfg = self.cfg
+        V = cfg.vocab_size
+        Vp = _rup(V, 64)
+        lmtr, dec = self.lin["lmtr"], self.lin["dec"]
+        if save:
+            t1, u = self._linear(xs, lmtr, L.EPI_BIAS_GELU, want_u=True, out_f32=True)
+        else:
+            t1, u = self._linear(xs, lmtr, L.EPI_BIAS_GELU, out_f32=True), None
+        _, hn, mean, rstd = self._layernorm(t1, "lmtr", save, want32=False)
+        logits = self._linear(hn, dec, out_f32=True, ldo=Vp)
+        rowloss, rownll, lse = (torch.empty(n, dtype=F32, device=xs.device) for _ in range(3))
+        L.lm_loss_fwd(logits, lab_sel, w_sel, rowloss, rownll, lse, n, V)
+        return dict(xs=xs, t1=t1, u=u, hn=hn, mean=mean, rstd=rstd, logits=logits, rowloss=rowloss, rownll=rownll,
+                    lse=lse, labels=lab_sel, weights=w_sel)
+
+    def decode_rows(self, x, n):
+        """MLM transform + decoder for n rows of x, fp32 logits [n, Vpad] (no loss, nothing saved)."""
+        t1 = self._linear(x, self.lin["lmtr"], L.EPI_BIAS_GELU, M=n, out_f32=True)
+        _, hn, _, _ = self._layernorm(t1, "lmtr", False, want32=False)
+        return self._linear(hn, self.lin["dec"], out_f32=True, ldo=_rup(self.cfg.vocab_size, 64))
+
+    # ------------------------------------------------------------------------------------------
+    # losses + backward
+    # ------------------------------------------------------------------------------------------
+    def losses(self, out, inp):
+        """Three shape-[1] fp32 losses from the forward state (models/vilbert_dialog.py:1559-1621)."""
+        cfg = self.cfg
+        dev = self.arena.device
+        B, R = out["B"], out["R"]
+        res = {}
+        lm = out.get("lm")
+        lm_loss = torch.empty(1, dtype=F32, device=dev)
+        if lm is None:
+            lm_loss.fill_(float("nan"))        # 0 / 0 in the reference when nothing is labelled
+        else:
+            L.reduce_sum(lm["rowloss"], lm["n"], lm_loss, 1.0 / lm["n"])
+        res["lm_loss"] = lm_loss
+        # image KL
+        img = out["img"]
+        C = cfg.v_target_size
+        label = inp["image_label"]
+        n_img = int((label == 1).sum())
+        tgt = inp["image_target"].to(dev, dtype=F32, non_blocking=True).contiguous().view(B * R, C)
+        lab32 = self._i32(label.reshape(-1), dev)
+        rl, lse = torch.empty(B * R, dtype=F32, device=dev), torch.empty(B * R, dtype=F32, device=dev)
+        L.kl_loss_fwd(img["pred"], tgt, lab32, rl, lse, B * R, C)
+        img_loss = torch.empty(1, dtype=F32, device=dev)
+        inv_img = 1.0 / n_img if n_img > 0 else float("inf")
+        L.reduce_sum(rl, B * R, img_loss, inv_img)
+        img.update(target=tgt, label=lab32, lse=lse, inv=inv_img)
+        res["img_loss"] = img_loss
+        # NSP
+        nw = inp.get("nsp_weight")
+        if nw is None:
+            w0, w1 = 1.0, 1.0
+        else:
+            w = [float(x) for x in nw.reshape(-1, 2)[0].tolist()]
+            w0, w1 = 1.0, w[1] / w[0]
+        nlab = self._i32(inp["next_sentence_label"].reshape(-1), dev)
+        nsp_loss = torch.empty(1, dtype=F32, device=dev)
+        L.nsp_loss_fwd(out["bwd"]["nsp_pad"] if "bwd" in out else out["nsp"], nlab, w0, w1, nsp_loss, B)
+        out["nsp_state"] = (nlab, w0, w1)
+        res["nsp_loss"] = nsp_loss
+        return res
+
+    def backward(self, out, g_lm, g_img, g_nsp, g_nsp_scores=None):
+        """Accumulates every parameter gradient into the arena (+=)."""
+        cfg = self.cfg
+        dev = self.arena.device
+        bw = out["bwd"]
+        B, T, R = out["B"], out["T"], out["R"]
+        H, Hv = cfg.hidden_size, cfg.v_hidden_size
+        seq_t, seq_v = out["seq_out_t"], out["seq_out_v"]
+        self.arena.attach_grads()
+
+        def gvec(g):
+            return torch.zeros(1, dtype=F32, device=dev) if g is None else g.detach().to(F32).reshape(1).contiguous()
+
+        dseq_t = torch.zeros((B * T, H), dtype=BF16, device=dev)
+        # ---- MLM head ---------------------------------------------------------------------------
+        lm = out.get("lm")
+        if lm is not None:
+            n, V = lm["n"], cfg.vocab_size
+            Vp = _rup(V, 64)
+            lmtr, dec = self.lin["lmtr"], self.lin["dec"]
+            dlog = torch.empty((n, Vp), dtype=BF16, device=dev)
+            L.lm_loss_bwd(lm["logits"], lm["labels"], lm["weights"], lm["lse"], gvec(g_lm), 1.0 / n, dlog, n, V)
+            dhn = self._linear_bwd(dlog, lm["hn"], dec, M=n, N=V)             # dE += dlog^T hn ; dbias ; dhn = dlog @ E
+            dt1, _ = self._layernorm_bwd(dhn, lm["t1"], lm["mean"], lm["rstd"], "lmtr")
+            du = torch.empty_like(dt1)
+            L.gelu_bwd(dt1, lm["u"], du, du.numel())
+            dxs = self._linear_bwd(du, lm["xs"], lmtr)
+            L.gather_rows(dxs, lm["idx"], dseq_t, n, H, scatter=True)
+        # ---- image head --------------------------------------------------------------------------
+        img = out["img"]
+        C = cfg.v_target_size
+        itr, idec = self.lin["imgtr"], self.lin["imgdec"]
+        Cp = idec.wt.shape[1]
+        dpred = torch.empty((B * R, Cp), dtype=BF16, device=dev)
+        L.kl_loss_bwd(img["pred"], img["target"], img["label"], img["lse"], gvec(g_img), img["inv"], dpred, B * R, C)
+        dhn = self._linear_bwd(dpred, img["hn"], idec, M=B * R, N=C)
+        dtv, _ = self._layernorm_bwd(dhn, img["tv"], img["mean"], img["rstd"], "imgtr")
+        duv = torch.empty_like(dtv)
+        L.gelu_bwd(dtv, img["u"], duv, duv.numel())
+        dseq_v = self._linear_bwd(duv, seq_v, itr)
+        # ---- NSP + poolers ------------------------------------------------------------------------
+        nlab, w0, w1 = out["nsp_state"]
+        nspl, tp, vp = self.lin["nsp"], self.lin["tpool"], self.lin["vpool"]
+        dnsp = torch.empty((B, 64), dtype=BF16, device=dev)
+        L.nsp_loss_bwd(bw["nsp_pad"], nlab, w0, w1, gvec(g_nsp), dnsp, B)
+        if g_nsp_scores is not None:      # gradient arriving through the returned NSP scores (dense fine-tune ranking loss)
+            dnsp[:, :2] += g_nsp_scores.to(BF16)
+        dfused = self._linear_bwd(dnsp, bw["fused"], nspl, M=B, N=2)
+        dpt, dpv = torch.empty_like(dfused), torch.empty_like(dfused)
+        L.mul_dropout_bwd(bw["pooled_t"], bw["pooled_v"], dfused, dpt, dpv, dfused.numel(), bw["d_fuse"])
+        # pooler input gradients land on the first-token rows: out = acc + aux, in place on the strided view
+        for dp, lin, cls, dseq, Hd, Tn in ((dpt, tp, bw["cls_t"], dseq_t, H, T), (dpv, vp, bw["cls_v"], dseq_v, Hv, R)):
+            L.gemm_tn(dp, cls, lin.gw, M=B, N=lin.N, K=lin.K)
+            L.colsum(dp, lin.gb, B, lin.N)
+            dcls = dseq.view(B, Tn * Hd)[:, :Hd]
+            L.gemm_nt(dp, lin.wt, dcls, epilogue=L.EPI_ADD, aux=dcls, M=B, N=lin.K, K=lin.wt.shape[1])
+        self._bucket_done("heads")
+        # ---- encoder blocks in reverse -------------------------------------------------------------
+        gt, gv = dseq_t, dseq_v
+        for kind, key, fn in reversed(bw["tape"]):
+            if kind == "t":
+                gt = fn(gt)
+            elif kind == "v":
+                gv = fn(gv)
+            else:
+                gv, gt = fn(gv, gt)
+            self._bucket_done(key)
+        bw["embv"](gv)
+        self._bucket_done("image_embeddings")
+        bw["embt"](gt)
+        self._bucket_done("text_embeddings")
+
+    def _bucket_done(self, group):
+        if self.grad_bucket_hook is not None:
+            self.grad_bucket_hook(group)

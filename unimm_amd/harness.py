@@ -1,0 +1,63 @@
+"""Step harness: the caller-side contract of the hot path.
+
+`forward(...)` is the equivalent of the reference's `train.forward` (train.py:30-177): flatten the
+dataloader batch, optionally subsample `sample_size` sequences, call the encoder, combine the three
+losses.  `generative_scores` / `scores_to_ranks` are the arithmetic of val_lm.py:124-149 and
+utils/visdial_metrics.py:21-39."""
+from __future__ import annotations
+
+import torch
+
+
+def _flat(x, keep):
+    return x.reshape((-1,) + tuple(x.shape[-keep:])) if keep else x.reshape(-1)
+
+
+def forward(dialog_encoder, batch, params, output_nsp_scores=False, output_lm_scores=False, sample_size=None,
+            evaluation=False):
+    tokens = _flat(batch["tokens"], 1)
+    n = tokens.shape[0]
+    idx = torch.randperm(n)[:sample_size] if sample_size else torch.arange(n)
+
+    def take(key, keep):
+        t = _flat(batch[key], keep)
+        return t[idx.to(t.device)]
+
+    kw = dict(sep_indices=take("sep_indices", 1), sep_len=take("hist_len", 0) + 1, token_type_ids=take("segments", 1),
+              token_position_ids=take("positions", 1), masked_lm_labels=take("mask", 1),
+              attention_mask=take("txt_attention_mask", 2), co_attention_mask=take("co_attention_mask", 2),
+              image_attention_mask=take("image_mask", 1), lm_weight=take("weights", 1),
+              nsp_weight=params.get("nsp_weight"), output_nsp_scores=output_nsp_scores,
+              output_lm_scores=output_lm_scores)
+    if not evaluation:
+        kw.update(next_sentence_label=take("next_sentence_labels", 0), image_target=take("image_target", 2),
+                  image_label=take("image_label", 1))
+    res = dialog_encoder(tokens[idx.to(tokens.device)], take("image_feat", 2), take("image_loc", 2), **kw)
+    lm_loss, img_loss, nsp_loss = res[:3]
+    extra = list(res[3:])
+    loss = None
+    if not evaluation:
+        lm_loss, nsp_loss, img_loss = lm_loss.mean(), nsp_loss.mean(), img_loss.mean()
+        loss = params["lm_loss_coeff"] * lm_loss + params["nsp_loss_coeff"] * nsp_loss + params["img_loss_coeff"] * img_loss
+    if output_nsp_scores or output_lm_scores:
+        return (loss, lm_loss, nsp_loss, img_loss, *extra)
+    return loss, lm_loss.item(), nsp_loss.item(), img_loss.item()
+
+
+def generative_scores(lm_scores, masked_lm_labels, average=False):
+    """Sequence log-likelihood from dense LM scores (val_lm.py:131-136; token-mean: val_avg_lm.py:135)."""
+    b, t, v = lm_scores.shape
+    nll = torch.nn.functional.cross_entropy(lm_scores.reshape(b * t, v).float(), masked_lm_labels.reshape(-1).to(lm_scores.device),
+                                            ignore_index=-1, reduction="none").view(b, t)
+    if average:
+        return -(nll.sum(-1) / (masked_lm_labels != -1).sum(-1).to(nll.device))
+    return -nll.sum(-1)
+
+
+def scores_to_ranks(scores: torch.Tensor):
+    """[batch, rounds, options] scores -> 1-based ranks (descending, ties in sort order)."""
+    b, r, o = scores.shape
+    order = scores.reshape(-1, o).sort(1, descending=True)[1]
+    ranks = torch.empty_like(order)
+    ranks.scatter_(1, order, torch.arange(1, o + 1, device=scores.device).expand_as(order))
+    return ranks.view(b, r, o)

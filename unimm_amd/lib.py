@@ -71,7 +71,7 @@ SYMBOLS = ["unimm_version", "unimm_arch", "unimm_gemm_nt", "unimm_gemm_tn", "uni
            "unimm_embed_fwd", "unimm_embed_bwd", "unimm_colsum", "unimm_cast_f32_bf16", "unimm_transpose_cast",
            "unimm_pack_image", "unimm_mul_dropout", "unimm_mul_dropout_bwd", "unimm_lm_loss_fwd",
            "unimm_lm_loss_bwd", "unimm_kl_loss_fwd", "unimm_kl_loss_bwd", "unimm_nsp_loss_fwd",
-           "unimm_nsp_loss_bwd", "unimm_reduce_sum", "unimm_segment_sum"]
+           "unimm_nsp_loss_bwd", "unimm_reduce_sum", "unimm_segment_sum", "unimm_gelu_bwd", "unimm_gather_rows"]
 
 
 def _check(rc, what):
@@ -202,9 +202,9 @@ def colpartials_bytes(H):
     return int(lib().unimm_colpartials_bytes(C.c_int32(H)))
 
 
-def layernorm_fwd(x, gamma, beta, y, mean, rstd, M, H, eps=1e-12, drop=NO_DROP):
-    _dev(x, gamma, beta, y, mean, rstd)
-    _check(lib().unimm_layernorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), C.c_int32(M),
+def layernorm_fwd(x, gamma, beta, y32, y16, mean, rstd, M, H, eps=1e-12, drop=NO_DROP):
+    _dev(x, gamma, beta, y32, y16, mean, rstd)
+    _check(lib().unimm_layernorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y32), _ptr(y16), _ptr(mean), _ptr(rstd), C.c_int32(M),
                                      C.c_int32(H), C.c_float(eps), C.c_uint32(drop[0]), C.c_uint32(drop[1]),
                                      C.c_float(drop[2]), _stream()), "unimm_layernorm_fwd")
 
@@ -238,10 +238,10 @@ def _embed_args(ids, pos, typ, word, post, type_, ext, gamma, beta, M, H, type_v
     return a
 
 
-def embed_fwd(ids, pos, typ, word, post, type_, ext, gamma, beta, y, M, H, type_vocab=2, eps=1e-12, drop=NO_DROP):
+def embed_fwd(ids, pos, typ, word, post, type_, ext, gamma, beta, y32, y16, M, H, type_vocab=2, eps=1e-12, drop=NO_DROP):
     a = _embed_args(ids, pos, typ, word, post, type_, ext, gamma, beta, M, H, type_vocab, eps, drop)
-    _dev(y)
-    _check(lib().unimm_embed_fwd(C.byref(a), _ptr(y), _stream()), "unimm_embed_fwd")
+    _dev(y32, y16)
+    _check(lib().unimm_embed_fwd(C.byref(a), _ptr(y32), _ptr(y16), _stream()), "unimm_embed_fwd")
 
 
 def embed_bwd(ids, pos, typ, word, post, type_, ext, gamma, beta, dy, dword, dpos, dtype, dext, dgamma, dbeta,
@@ -341,3 +341,14 @@ def segment_sum(src, seg, dst, n, sign=1.0):
     _dev(src, seg, dst)
     _check(lib().unimm_segment_sum(_ptr(src), _ptr(seg), _ptr(dst), C.c_int64(n), C.c_float(sign), _stream()),
            "unimm_segment_sum")
+
+
+def gelu_bwd(dt, u, du, n):
+    _dev(dt, u, du)
+    _check(lib().unimm_gelu_bwd(_ptr(dt), _ptr(u), _ptr(du), C.c_int64(n), _stream()), "unimm_gelu_bwd")
+
+
+def gather_rows(src, idx, dst, n, H, scatter=False):
+    _dev(src, idx, dst)
+    _check(lib().unimm_gather_rows(_ptr(src), _ptr(idx), _ptr(dst), C.c_int32(n), C.c_int32(H),
+                                   C.c_int32(1 if scatter else 0), _stream()), "unimm_gather_rows")

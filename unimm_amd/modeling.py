@@ -1,0 +1,221 @@
+"""Drop-in model surface: `BertForMultiModalPreTraining(config)` and `VisualDialogEncoder(config_path)`
+with the reference's constructor / forward() signatures, return tuples and `state_dict` names
+(models/vilbert_dialog.py:1496-1626, models/visual_dialog_encoder.py:8-50), computed by the HIP
+engine (unimm_amd.engine).  The modules below only own parameters; all arithmetic is in the kernels.
+"""
+from __future__ import annotations
+
+import os
+import warnings
+
+import torch
+from torch import nn
+
+from . import params as PM
+from .config import BertConfig
+from .engine import Engine
+
+
+def _build_param_tree(root: nn.Module, cfg) -> None:
+    """Register every parameter under nested plain containers so that state_dict keys equal the
+    reference's ("bert.encoder.layer.0.attention.self.query.weight", ...).  Init follows
+    init_bert_weights (models/vilbert_dialog.py:1110-1121): N(0, initializer_range) for Linear /
+    Embedding weights, zero biases, LayerNorm weight 1 / bias 0."""
+    for name, shape in PM.state_dict_names(cfg).items():
+        if name == PM.TIED_DECODER:
+            continue
+        parts = name.split(".")
+        mod = root
+        for part in parts[:-1]:
+            if not hasattr(mod, part):
+                mod.add_module(part, nn.Module())
+            mod = getattr(mod, part)
+        if "LayerNorm" in name:
+            t = torch.ones(shape) if parts[-1] == "weight" else torch.zeros(shape)
+        elif parts[-1] == "weight":
+            t = torch.empty(shape).normal_(mean=0.0, std=cfg.initializer_range)
+        else:
+            t = torch.zeros(shape)
+        mod.register_parameter(parts[-1], nn.Parameter(t))
+    # tie the decoder to the word embeddings (models/vilbert_dialog.py:1020, :1504-1506)
+    root.cls.predictions.add_module("decoder", nn.Module())
+    root.cls.predictions.decoder.register_parameter("weight", root.bert.embeddings.word_embeddings.weight)
+
+
+class _HotPath(torch.autograd.Function):
+    """One autograd node for the whole forward/backward hot path.  Parameter gradients are
+    accumulated in place into the flat gradient arena (every Parameter's .grad is a view of it), so
+    backward returns no tensors; `anchor` only makes autograd call us."""
+
+    @staticmethod
+    def forward(ctx, anchor, engine, inp, opts):
+        ctx.set_materialize_grads(False)
+        out = engine.forward(inp, train=opts["train"], save=True, lm_rows="labelled", want_pred_v=True)
+        losses = engine.losses(out, inp)
+        ctx.engine, ctx.out = engine, out
+        engine.last_seq_t = (out["seq32_t"], out["seq_out_t"])
+        nsp = out["nsp"].clone()
+        return losses["lm_loss"], losses["img_loss"], losses["nsp_loss"], nsp
+
+    @staticmethod
+    def backward(ctx, g_lm, g_img, g_nsp, g_scores):
+        engine, out = ctx.engine, ctx.out
+        ctx.out = None
+        engine.backward(out, g_lm, g_img, g_nsp, g_scores)
+        return None, None, None, None
+
+
+class BertForMultiModalPreTraining(nn.Module):
+    """BERT model with multi modal pre-training heads (drop-in for models/vilbert_dialog.py:1496)."""
+
+    def __init__(self, config):
+        super().__init__()
+        if not isinstance(config, BertConfig):
+            raise ValueError(
+                "Parameter config in `{}(config)` should be an instance of class `BertConfig`. ".format(
+                    self.__class__.__name__))
+        self.config = config
+        _build_param_tree(self, config)
+        self.predict_feature = config.predict_feature
+        self._engine = Engine(self, config)
+
+    # -- construction helpers -----------------------------------------------------------------
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, config, default_gpu=True, state_dict=None, *inputs, **kwargs):
+        """The reference downloads 'bert-base-uncased' here (models/vilbert_dialog.py:1123-1296); there is
+        no network in this build, so weights come from `state_dict` or a local checkpoint file/dir when
+        one exists at the given path, otherwise the model keeps its fresh init (with a warning)."""
+        model = cls(config, *inputs, **kwargs)
+        if state_dict is None and isinstance(pretrained_model_name_or_path, str):
+            path = pretrained_model_name_or_path
+            if os.path.isdir(path):
+                path = os.path.join(path, "pytorch_model.bin")
+            if os.path.isfile(path):
+                state_dict = torch.load(path, map_location="cpu")
+        if state_dict is None:
+            warnings.warn(f"from_pretrained({pretrained_model_name_or_path!r}): no local weights found, "
+                          "keeping random initialisation (no network access)")
+            return model
+        state_dict = {k[len("bert_pretrained."):] if k.startswith("bert_pretrained.") else k: v
+                      for k, v in state_dict.items()}
+        own = model.state_dict()
+        usable = {k: v for k, v in state_dict.items() if k in own and tuple(v.shape) == tuple(own[k].shape)}
+        model.load_state_dict(usable, strict=False)   # key-intersection warm start, as train.py:355-364
+        return model
+
+    @property
+    def engine(self) -> Engine:
+        return self._engine
+
+    def set_dropout_seed(self, seed: int, step: int = 0):
+        self._engine.seed, self._engine.step = int(seed), int(step)
+
+    # -- forward ---------------------------------------------------------------------------------
+    def forward(self, input_ids, image_feat, image_loc, sep_indices=None, sep_len=None, token_type_ids=None,
+                position_ids=None, attention_mask=None, image_attention_mask=None, co_attention_mask=None,
+                masked_lm_labels=None, image_label=None, image_target=None, next_sentence_label=None,
+                output_all_attention_masks=False, nsp_weight=None, lm_weight=None,
+                _want_lm_scores=True, _want_pred_v=True):
+        """Same contract as models/vilbert_dialog.py:1519-1626.  `sep_indices` / `sep_len` are accepted and
+        ignored exactly as the reference's embeddings do (:326-356).  Train branch (labels, NSP label and
+        image target all given) -> (lm_loss[1], img_loss[1], nsp_loss[1], seq_out_t, pred_t, nsp[B,2]);
+        otherwise -> (pred_t, pred_v, nsp, seq_out_t, attention-lists).
+        `_want_lm_scores=False` (used by VisualDialogEncoder when the caller does not ask for LM scores)
+        skips materialising the dense [B,T,vocab] logits; the loss only ever needs the labelled rows."""
+        if output_all_attention_masks:
+            raise NotImplementedError("attention probabilities are never materialised on the HIP path")
+        eng = self._engine
+        dev = self._device()
+        eng.ensure(dev)
+        inp = dict(input_ids=input_ids, image_feat=image_feat, image_loc=image_loc, token_type_ids=token_type_ids,
+                   position_ids=position_ids, attention_mask=attention_mask, image_attention_mask=image_attention_mask,
+                   co_attention_mask=co_attention_mask, masked_lm_labels=masked_lm_labels, image_label=image_label,
+                   image_target=image_target, next_sentence_label=next_sentence_label, nsp_weight=nsp_weight,
+                   lm_weight=lm_weight)
+        B, T = input_ids.shape
+        H, V = self.config.hidden_size, self.config.vocab_size
+        train_branch = masked_lm_labels is not None and next_sentence_label is not None and image_target is not None
+        if self.training:
+            eng.step += 1
+        if train_branch:
+            if torch.is_grad_enabled():
+                lm_loss, img_loss, nsp_loss, nsp = _HotPath.apply(eng._anchor, eng, inp, dict(train=self.training))
+                seq_raw = eng.last_seq_t
+            else:
+                out = eng.forward(inp, train=self.training, save=False, lm_rows="labelled", want_pred_v=True)
+                ls = eng.losses(out, inp)
+                lm_loss, img_loss, nsp_loss, nsp = ls["lm_loss"], ls["img_loss"], ls["nsp_loss"], out["nsp"]
+                seq_raw = (out["seq32_t"], out["seq_out_t"])
+            eng.last_seq_t = None
+            seq_t = pred_t = None
+            if _want_lm_scores:
+                with torch.no_grad():   # dense scores are an output only; the loss path is row-sparse
+                    seq_t = seq_raw[0].view(B, T, H)
+                    pred_t = eng.decode_rows(seq_raw[1], B * T).view(B, T, -1)[:, :, :V]
+            return lm_loss, img_loss, nsp_loss, seq_t, pred_t, nsp
+        with torch.no_grad():
+            out = eng.forward(inp, train=self.training, save=False, lm_rows="all" if _want_lm_scores else "none",
+                              want_pred_v=_want_pred_v)
+        seq_t = out["seq32_t"].view(B, T, H)
+        return out.get("pred_t"), out.get("pred_v"), out["nsp"], seq_t, ([], [], [])
+
+    def _device(self):
+        return self.bert.embeddings.word_embeddings.weight.device
+
+    # generative scoring without the [B,T,vocab] tensor (val_lm.py:121-136 / val_avg_lm.py:135)
+    @torch.no_grad()
+    def sequence_log_likelihood(self, input_ids, image_feat, image_loc, masked_lm_labels, average=False, **kw):
+        """-sum_t CE(pred_t, labels, ignore_index=-1) per sequence, computed on the labelled rows only by
+        the fused decoder + log-softmax kernels.  Returns (scores[B] fp32, nsp[B,2])."""
+        eng = self._engine
+        eng.ensure(self._device())
+        inp = dict(input_ids=input_ids, image_feat=image_feat, image_loc=image_loc, masked_lm_labels=masked_lm_labels,
+                   lm_weight=None, **kw)
+        out = eng.forward(inp, train=False, save=False, lm_rows="labelled", want_pred_v=False)
+        B, T = input_ids.shape
+        scores = torch.zeros(B, dtype=torch.float32, device=eng.arena.device)
+        lm = out.get("lm")
+        if lm is not None:
+            from . import lib as L
+            seg = (lm["idx"] // T).to(torch.int32)
+            L.segment_sum(lm["rownll"], seg, scores, lm["n"], -1.0)
+            if average:
+                cnt = torch.bincount(seg.long(), minlength=B).clamp_min(1)
+                scores = scores / cnt
+        return scores, out["nsp"]
+
+
+class VisualDialogEncoder(nn.Module):
+    """Drop-in for models/visual_dialog_encoder.py:8-50 (what train.py / val_lm.py instantiate)."""
+
+    def __init__(self, config_path, pretrained="bert-base-uncased"):
+        super().__init__()
+        config = BertConfig.from_json_file(config_path)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            self.bert_pretrained = BertForMultiModalPreTraining.from_pretrained(pretrained, config)
+        self.bert_pretrained.train()
+
+    def forward(self, input_ids, image_feat, image_loc, sep_indices=None, sep_len=None, token_type_ids=None,
+                token_position_ids=None, attention_mask=None, masked_lm_labels=None, next_sentence_label=None,
+                head_mask=None, random_round_indices=None, output_nsp_scores=False, output_lm_scores=False,
+                image_attention_mask=None, co_attention_mask=None, image_label=None, image_target=None,
+                nsp_weight=None, lm_weight=None):
+        masked_lm_loss = masked_img_loss = nsp_loss = None
+        kw = dict(sep_indices=sep_indices, sep_len=sep_len, token_type_ids=token_type_ids,
+                  position_ids=token_position_ids, attention_mask=attention_mask, masked_lm_labels=masked_lm_labels,
+                  next_sentence_label=next_sentence_label, image_attention_mask=image_attention_mask,
+                  co_attention_mask=co_attention_mask, image_label=image_label, image_target=image_target,
+                  nsp_weight=nsp_weight, lm_weight=lm_weight, _want_lm_scores=output_lm_scores)
+        if next_sentence_label is not None and masked_lm_labels is not None and image_target is not None:
+            masked_lm_loss, masked_img_loss, nsp_loss, _, prediction_scores_t, seq_relationship_score = \
+                self.bert_pretrained(input_ids, image_feat, image_loc, **kw)
+        else:
+            prediction_scores_t, _, seq_relationship_score, _, _ = \
+                self.bert_pretrained(input_ids, image_feat, image_loc, _want_pred_v=False, **kw)
+        out = (masked_lm_loss, masked_img_loss, nsp_loss)
+        if output_nsp_scores:
+            out = out + (seq_relationship_score,)
+        if output_lm_scores:
+            out = out + (prediction_scores_t,)
+        return out
