@@ -224,6 +224,13 @@ int unimm_nsp_loss_bwd(const float* logits, const int32_t* labels, float w0, flo
 int unimm_reduce_sum(const float* src, int64_t n, float* dst, float scale, void* stream);
 int unimm_segment_sum(const float* src, const int32_t* seg, float* dst, int64_t n, float sign, void* stream);
 
+/* Launch profiler for bench.py's `roofline` block: HIP events around every GEMM launch on its own
+ * stream while enabled.  Variant index: 0..11 = unimm_gemm_nt (epilogue * 2 + out_f32), 12 = unimm_gemm_tn.
+ * unimm_prof_collect synchronises the events and returns per-variant summed milliseconds, algorithmic
+ * FLOPs (2*M*N*K per launch) and launch counts; arrays of >= 16 entries. */
+int unimm_prof_enable(int32_t on);
+int unimm_prof_collect(double* ms, double* flops, int32_t* count, int32_t nvar);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,7 @@
 // XCD-aware: each XCD walks a contiguous run of tiles with the N index fastest, so an X row panel is
 // fetched from HBM once per XCD and W stays L2/MALL resident.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -328,12 +329,40 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTnParams p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Launch profiler (bench.py's `roofline` block): when enabled, every GEMM launch is bracketed by HIP
+// events on the launch stream; unimm_prof_collect() sums elapsed time and algorithmic FLOPs per kernel
+// variant.  Off by default (no events, no overhead).
+// ------------------------------------------------------------------------------------------------
+struct ProfRec { hipEvent_t a, b; int variant; double flops; };
+constexpr int PROF_MAX = 1 << 16;
+constexpr int PROF_VARIANTS = 16;   // 0..11: gemm_nt epi*2+out_f32 ; 12: gemm_tn
+bool g_prof_on = false;
+ProfRec* g_prof = nullptr;
+int g_prof_n = 0;
+
+inline ProfRec* prof_begin(int variant, double flops, hipStream_t s) {
+  if (!g_prof_on || g_prof_n >= PROF_MAX) return nullptr;
+  ProfRec* r = &g_prof[g_prof_n];
+  if (r->a == nullptr) {
+    if (hipEventCreate(&r->a) != hipSuccess || hipEventCreate(&r->b) != hipSuccess) return nullptr;
+  }
+  r->variant = variant; r->flops = flops;
+  hipEventRecord(r->a, s);
+  ++g_prof_n;
+  return r;
+}
+inline void prof_end(ProfRec* r, hipStream_t s) { if (r) hipEventRecord(r->b, s); }
+
 template <int EPI>
 int launch_nt(const GemmNtParams& p, bool out_f32, hipStream_t s) {
   const int nwg = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   const size_t lds = 4 * TILE_BYTES;
+  ProfRec* pr = prof_begin(EPI * 2 + (out_f32 ? 1 : 0), 2.0 * p.M * (double)p.N * p.K, s);
   if (out_f32) hipLaunchKernelGGL((gemm_nt_kernel<EPI, true>), dim3(nwg), dim3(256), lds, s, p);
   else hipLaunchKernelGGL((gemm_nt_kernel<EPI, false>), dim3(nwg), dim3(256), lds, s, p);
+  prof_end(pr, s);
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;
 }
@@ -386,7 +415,35 @@ extern "C" int unimm_gemm_tn(const unimm_gemm_tn_args* a, void* stream) {
   rps = ((rps + TK - 1) / TK) * TK;
   splits = (a->M + rps - 1) / rps;
   p.rows_per_split = rps;
+  ProfRec* pr = prof_begin(12, 2.0 * a->M * (double)a->N * a->K, (hipStream_t)stream);
   hipLaunchKernelGGL(gemm_tn_kernel, dim3(ntile * splits), dim3(256), 4 * TN_TILE_BYTES, (hipStream_t)stream, p);
+  prof_end(pr, (hipStream_t)stream);
   UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
+}
+
+extern "C" int unimm_prof_enable(int32_t on) {
+  if (on && g_prof == nullptr) {
+    g_prof = (ProfRec*)calloc(PROF_MAX, sizeof(ProfRec));
+    if (g_prof == nullptr) return UNIMM_E_HIP;
+  }
+  g_prof_on = on != 0;
+  g_prof_n = 0;
+  return UNIMM_OK;
+}
+
+// Synchronises the recorded events (call after the timed region) and fills, per variant:
+// ms[v] = summed launch durations, flops[v] = summed algorithmic FLOPs, count[v] = launches.
+extern "C" int unimm_prof_collect(double* ms, double* flops, int32_t* count, int32_t nvar) {
+  if (!ms || !flops || !count || nvar < PROF_VARIANTS) return UNIMM_E_ARG;
+  for (int v = 0; v < nvar; ++v) { ms[v] = 0.0; flops[v] = 0.0; count[v] = 0; }
+  for (int i = 0; i < g_prof_n; ++i) {
+    ProfRec& r = g_prof[i];
+    if (hipEventSynchronize(r.b) != hipSuccess) return UNIMM_E_HIP;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) return UNIMM_E_HIP;
+    ms[r.variant] += t; flops[r.variant] += r.flops; count[r.variant] += 1;
+  }
+  g_prof_n = 0;
   return UNIMM_OK;
 }

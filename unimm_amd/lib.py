@@ -71,7 +71,7 @@ SYMBOLS = ["unimm_version", "unimm_arch", "unimm_gemm_nt", "unimm_gemm_tn", "uni
            "unimm_embed_fwd", "unimm_embed_bwd", "unimm_colsum", "unimm_cast_f32_bf16", "unimm_transpose_cast",
            "unimm_pack_image", "unimm_mul_dropout", "unimm_mul_dropout_bwd", "unimm_lm_loss_fwd",
            "unimm_lm_loss_bwd", "unimm_kl_loss_fwd", "unimm_kl_loss_bwd", "unimm_nsp_loss_fwd",
-           "unimm_nsp_loss_bwd", "unimm_reduce_sum", "unimm_segment_sum", "unimm_gelu_bwd", "unimm_gather_rows"]
+           "unimm_nsp_loss_bwd", "unimm_reduce_sum", "unimm_segment_sum", "unimm_gelu_bwd", "unimm_gather_rows", "unimm_prof_enable", "unimm_prof_collect"]
 
 
 def _check(rc, what):
@@ -352,3 +352,20 @@ def gather_rows(src, idx, dst, n, H, scatter=False):
     _dev(src, idx, dst)
     _check(lib().unimm_gather_rows(_ptr(src), _ptr(idx), _ptr(dst), C.c_int32(n), C.c_int32(H),
                                    C.c_int32(1 if scatter else 0), _stream()), "unimm_gather_rows")
+
+
+GEMM_VARIANTS = {0: "gemm_nt<BIAS,bf16>", 1: "gemm_nt<BIAS,f32>", 2: "gemm_nt<BIAS_GELU,bf16>", 3: "gemm_nt<BIAS_GELU,f32>",
+                 5: "gemm_nt<BIAS_DROP_RESID,f32>", 6: "gemm_nt<BIAS_RELU,bf16>", 8: "gemm_nt<DGELU,bf16>",
+                 10: "gemm_nt<ADD,bf16>", 12: "gemm_tn"}
+
+
+def prof_enable(on: bool):
+    _check(lib().unimm_prof_enable(C.c_int32(1 if on else 0)), "unimm_prof_enable")
+
+
+def prof_collect():
+    """-> {variant name: (total_ms, total_flops, launches)} for the launches since prof_enable(True)."""
+    n = 16
+    ms, fl, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_int32 * n)()
+    _check(lib().unimm_prof_collect(ms, fl, cnt, C.c_int32(n)), "unimm_prof_collect")
+    return {GEMM_VARIANTS.get(i, f"variant{i}"): (ms[i], fl[i], cnt[i]) for i in range(n) if cnt[i] > 0}
