@@ -64,13 +64,15 @@ typedef struct {
 
 int unimm_gemm_nt(const unimm_gemm_nt_args* args, void* stream);
 
-/* GEMM, "TN": DW[N,K] += DY[M,N]^T . X[M,K] (fp32 atomics; caller zeroes DW once per step).
+/* GEMM, "TN": DW[N,K] += DY[M,N]^T . X[M,K] (fp32 atomics; caller zeroes DW once per step) and,
+ * when dbias != NULL, dbias[N] += column sums of DY (the bias gradient, one extra MFMA per tile).
  * Weight-gradient half of every nn.Linear backward on the path.  Rows of DY / X must be readable
  * up to round_up(N, 8) / round_up(K, 8) columns; lddy, ldx % 8 == 0. */
 typedef struct {
   const void* dy; /* [M, N] bf16 */
   const void* x;  /* [M, K] bf16 */
   float* dw;      /* [N, K] fp32, row stride lddw */
+  float* dbias;   /* [N] fp32 or NULL */
   int32_t M, N, K;
   int32_t lddy, ldx, lddw;
 } unimm_gemm_tn_args;

@@ -108,11 +108,14 @@ def test_gemm_tn(M, N, K):
     x[:, :K] = _rand((M, K), g)
     init = torch.randn((N, K), generator=g, device="cuda")
     dw = init.clone()
-    lib.gemm_tn(dy, x, dw, N=N, K=K)
+    db = torch.ones(N, device="cuda")
+    lib.gemm_tn(dy, x, dw, N=N, K=K, dbias=db)
     torch.cuda.synchronize()
     ref = init + dy[:, :N].float().t() @ x[:, :K].float()
     err = (dw - ref).abs().max().item()
     assert err <= 2e-3 * max(1.0, ref.abs().max().item()), err
+    ref_b = 1 + dy[:, :N].float().sum(0)
+    assert (db - ref_b).abs().max().item() <= 2e-3 * max(1.0, ref_b.abs().max().item())
 
 
 def test_gemm_rejects_bad_arguments():

@@ -191,7 +191,7 @@ def test_full_config_b6_matches_reference_golden(golden_dir):
     close(nsp, g["nsp"], what="nsp")
     rows = T_(g["rows"]).cuda()
     close(pred_t.reshape(-1, pred_t.shape[-1])[rows][:, ::16], g["pred_t_rows"], what="MLM logits", scale_rel=True)
-    close(seq_t.reshape(-1, 768)[rows], g["seq_out_t_rows"], what="seq_out_t")
+    close(seq_t.reshape(-1, 768)[rows], g["seq_out_t_rows"], what="seq_out_t", scale_rel=True)
     # candidate log-likelihoods and their ranks (val_lm.py:131-149)
     want_ll = g["seq_loglik"]
     got = scores.cpu().numpy()

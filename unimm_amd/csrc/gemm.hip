@@ -269,6 +269,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTnParams p) {
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // bias gradient = column sums of DY: one extra MFMA against an all-ones operand, only in the first
+  // k-tile column and only in the waves that own k-subtile 0 (DY is already in LDS for the product)
+  const bool do_bias = p.dbias != nullptr && tk == 0 && wk == 0;
+  f32x4 accb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
 
   const int nsteps = (mend - mbeg + TK - 1) / TK;
 
@@ -308,9 +317,23 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTnParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, accb[i], 0, 0, 0);
+      }
     }
     __builtin_amdgcn_s_waitcnt(0x0f70);
     __syncthreads();
+  }
+
+  if (do_bias && (lane & 15) == 0) {   // every column of accb holds the same row sums
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = n0 + wn * 64 + i * 16 + 4 * (lane >> 4) + e;
+        if (n < p.N) atomicAdd(p.dbias + n, accb[i][e]);
+      }
   }
 
   // D[n][k]: lane holds k = .. + (lane&15) (column), n = .. + 4*(lane>>4) + e (rows)
@@ -403,7 +426,7 @@ extern "C" int unimm_gemm_tn(const unimm_gemm_tn_args* a, void* stream) {
   if ((a->lddy % 8) || (a->ldx % 8) || a->lddy < a->N || a->ldx < a->K || a->lddw < a->K) return UNIMM_E_ALIGN;
   if (((uintptr_t)a->dy | (uintptr_t)a->x) & 15) return UNIMM_E_ALIGN;
   GemmTnParams p;
-  p.dy = (const bf16_t*)a->dy; p.x = (const bf16_t*)a->x; p.dw = a->dw; p.dbias = nullptr;
+  p.dy = (const bf16_t*)a->dy; p.x = (const bf16_t*)a->x; p.dw = a->dw; p.dbias = a->dbias;
   p.M = a->M; p.N = a->N; p.K = a->K; p.lddy = a->lddy; p.ldx = a->ldx; p.lddw = a->lddw;
   const int ntile = ((a->N + 127) / 128) * ((a->K + 127) / 128);
   // enough workgroups for ~2 per CU, but keep >= 512 reduction rows per split

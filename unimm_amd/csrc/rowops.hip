@@ -256,16 +256,26 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
   }
 }
 
-// out[q][col] += sum_blocks partials[block][q][col]  (q-th quantity goes to dst[q], NULL = skip)
-__global__ void colpartials_finish_kernel(const float* __restrict__ partials, int nblocks, int nq, int H,
-                                          float* d0, float* d1, float* d2, float* d3) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+// out[q][col] += sum_blocks partials[block][q][col]  (q-th quantity goes to dst[q], NULL = skip).
+// 1024 threads = 64 columns x 16 slices of the block range; LDS tree over the slices.
+__global__ __launch_bounds__(1024) void colpartials_finish_kernel(const float* __restrict__ partials, int nblocks, int nq,
+                                                                  int H, float* d0, float* d1, float* d2, float* d3) {
+  __shared__ float red[16][64];
+  const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cl;
   const int qn = blockIdx.y;
   float* dst = qn == 0 ? d0 : (qn == 1 ? d1 : (qn == 2 ? d2 : d3));
-  if (col >= H || dst == nullptr) return;
   float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += partials[((size_t)b * nq + qn) * H + col];
-  dst[col] += s;
+  if (col < H && dst != nullptr)
+    for (int b = sl; b < nblocks; b += 16) s += partials[((size_t)b * nq + qn) * H + col];
+  red[sl][cl] = s;
+  __syncthreads();
+  if (sl == 0 && col < H && dst != nullptr) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][cl];
+    dst[col] += t;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -365,6 +375,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbArgs a, const bf16_t*
     float* wrow = dword + (size_t)id * a.H;
     float* prow = dpos + (size_t)pid * a.H;
     float* erow = (tt >= a.type_vocab) ? dext + (size_t)(tt - a.type_vocab) * a.H : nullptr;
+    float* mine = red + wv * 1024;   // this wave's row, re-read lane-contiguously for the atomics
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
       const int c = lane + 64 * i;
@@ -372,13 +383,20 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbArgs a, const bf16_t*
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float v = rstd * (dyv.v[i][j] - s1 - x.v[i][j] * s2);
-        const int col = c * 8 + j;
-        atomicAdd(wrow + col, v);
-        atomicAdd(prow + col, v);
-        if (erow != nullptr) atomicAdd(erow + col, v);
-        else if (tt == 0) dt0.v[i][j] += v;
-        else dt1.v[i][j] += v;   // type_vocab_size is 2 (config/bert_base_6layer_6conect.json:11)
+        mine[c * 8 + j] = v;
+        if (erow == nullptr) {
+          if (tt == 0) dt0.v[i][j] += v;
+          else dt1.v[i][j] += v;   // type_vocab_size is 2 (config/bert_base_6layer_6conect.json:11)
+        }
       }
+    }
+    // one atomic wave-instruction = 256 contiguous bytes of one row (full-rate shape; a lane-strided
+    // shape runs ~8x slower, MI355X_MICROARCH.md "Global float atomics")
+    for (int col = lane; col < a.H; col += 64) {
+      const float v = mine[col];
+      atomicAdd(wrow + col, v);
+      atomicAdd(prow + col, v);
+      if (erow != nullptr) atomicAdd(erow + col, v);
     }
   }
   for (int qn = 0; qn < 4; ++qn) {
@@ -596,7 +614,7 @@ extern "C" int unimm_layernorm_bwd(const void* dy, const float* x, const float* 
                      gamma, (bf16_t*)dx, (bf16_t*)dx_drop, partials, M, H, mk_drop(drop_key, drop_thr, drop_scale),
                      mk_drop(odrop_key, odrop_thr, odrop_scale));
   UNIMM_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colpartials_finish_kernel, dim3((H + 255) / 256, 3), dim3(256), 0, s, partials, blocks, 3, H, dgamma,
+  hipLaunchKernelGGL(colpartials_finish_kernel, dim3((H + 63) / 64, 3), dim3(1024), 0, s, partials, blocks, 3, H, dgamma,
                      dbeta, dbias, (float*)nullptr);
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;
@@ -635,7 +653,7 @@ extern "C" int unimm_embed_bwd(const unimm_embed_args* a, const void* dy, float*
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(embed_bwd_kernel, dim3(blocks), dim3(256), 0, s, e, (const bf16_t*)dy, dword, dpos, dext, partials);
   UNIMM_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colpartials_finish_kernel, dim3((a->H + 255) / 256, 4), dim3(256), 0, s, partials, blocks, 4, a->H,
+  hipLaunchKernelGGL(colpartials_finish_kernel, dim3((a->H + 63) / 64, 4), dim3(1024), 0, s, partials, blocks, 4, a->H,
                      dgamma, dbeta, dtype, dtype + a->H);
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;

@@ -218,9 +218,8 @@ class Engine:
         """dW += dy^T x ; db += colsum(dy) ; returns dx = epi(dy @ W)."""
         M = dy.shape[0] if M is None else M
         N = lin.N if N is None else N
-        L.gemm_tn(dy, x, lin.gw, M=M, N=N, K=lin.K if xk is None else xk)
-        if bias_grad and lin.gb is not None:
-            L.colsum(dy, lin.gb, M, N)
+        L.gemm_tn(dy, x, lin.gw, M=M, N=N, K=lin.K if xk is None else xk,
+                  dbias=lin.gb if (bias_grad and lin.gb is not None) else None)
         if not need_dx:
             return None
         dx = torch.empty((M, lin.K), dtype=BF16, device=dy.device)
@@ -654,8 +653,7 @@ class Engine:
         L.mul_dropout_bwd(bw["pooled_t"], bw["pooled_v"], dfused, dpt, dpv, dfused.numel(), bw["d_fuse"])
         # pooler input gradients land on the first-token rows: out = acc + aux, in place on the strided view
         for dp, lin, cls, dseq, Hd, Tn in ((dpt, tp, bw["cls_t"], dseq_t, H, T), (dpv, vp, bw["cls_v"], dseq_v, Hv, R)):
-            L.gemm_tn(dp, cls, lin.gw, M=B, N=lin.N, K=lin.K)
-            L.colsum(dp, lin.gb, B, lin.N)
+            L.gemm_tn(dp, cls, lin.gw, M=B, N=lin.N, K=lin.K, dbias=lin.gb)
             dcls = dseq.view(B, Tn * Hd)[:, :Hd]
             L.gemm_nt(dp, lin.wt, dcls, epilogue=L.EPI_ADD, aux=dcls, M=B, N=lin.K, K=lin.wt.shape[1])
         self._bucket_done("heads")

@@ -12,7 +12,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libunimm_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROP_RESID, EPI_BIAS_RELU, EPI_DGELU, EPI_ADD = range(6)
 
@@ -33,7 +33,7 @@ class GemmNtArgs(C.Structure):
 
 
 class GemmTnArgs(C.Structure):
-    _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p),
+    _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("dbias", C.c_void_p),
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
                 ("lddy", C.c_int32), ("ldx", C.c_int32), ("lddw", C.c_int32)]
 
@@ -111,11 +111,11 @@ def gemm_nt(x, w, out, bias=None, epilogue=EPI_BIAS, aux=None, out2=None, drop=N
     return out
 
 
-def gemm_tn(dy, x, dw, M=None, N=None, K=None):
-    """dw[N,K] += dy[M,N]^T @ x[M,K] (fp32 atomics)."""
-    _dev(dy, x, dw)
+def gemm_tn(dy, x, dw, M=None, N=None, K=None, dbias=None):
+    """dw[N,K] += dy[M,N]^T @ x[M,K] (fp32 atomics); dbias[N] += colsum(dy) when given."""
+    _dev(dy, x, dw, dbias)
     a = GemmTnArgs()
-    a.dy, a.x, a.dw = _ptr(dy), _ptr(x), _ptr(dw)
+    a.dy, a.x, a.dw, a.dbias = _ptr(dy), _ptr(x), _ptr(dw), _ptr(dbias)
     a.M = dy.shape[0] if M is None else M
     a.N = dy.shape[1] if N is None else N
     a.K = x.shape[1] if K is None else K
