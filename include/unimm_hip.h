@@ -63,6 +63,9 @@ typedef struct {
 } unimm_gemm_nt_args;
 
 int unimm_gemm_nt(const unimm_gemm_nt_args* args, void* stream);
+/* Tuning knob: block-tile configuration of unimm_gemm_nt.  0 = automatic (default), 1 = 128x128 tile /
+ * 2-stage ring / 2 workgroups per CU, 2 = 256x128 tile / 3-stage ring with counted vmcnt. */
+int unimm_gemm_set_tile(int32_t cfg);
 
 /* GEMM, "TN": DW[N,K] += DY[M,N]^T . X[M,K] (fp32 atomics; caller zeroes DW once per step) and,
  * when dbias != NULL, dbias[N] += column sums of DY (the bias gradient, one extra MFMA per tile).

@@ -21,9 +21,6 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
-
 struct GemmNtParams {
   const bf16_t* x; const bf16_t* w; const float* bias; const void* aux;  // aux: fp32 for DROP_RESID, bf16 otherwise
   void* out; bf16_t* out2;
@@ -31,155 +28,213 @@ struct GemmNtParams {
   DropoutArg drop;
 };
 
-// Stage one 128 x 64 bf16 operand tile: 16 wave-instructions of 1 KiB, 4 per wave.
-__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int ld, int row0, int nrows, int k0,
-                                           char* lds_tile, int wave, int lane) {
+// Block-tile configurations.  A wave owns a (16*MT)(m) x 64(n) output sub-tile (MT x 4 accumulators of
+// v_mfma_f32_16x16x32_bf16); WM x WN waves make the block tile; one ring slot holds one K-step of BK.
+// The ring is what hides HBM/L2 latency (~3-4k cycles under load): bytes staged per MFMA-cycle halve
+// with a 256x256 tile, so the same LDS covers twice the latency of the 128x128 tile.
+//   Cfg<2,2,4,64,2>: 128x128, 4 waves, 68 KiB LDS -> 2 workgroups per CU
+//   Cfg<2,4,8,32,4>: 256x256, 8 waves, BK=32, 4-slot ring (128 KiB): 3 K-steps in flight across barriers
+//   Cfg<2,4,8,64,2>: 256x256, 8 waves, BK=64, 2-slot ring (128 KiB)
+template <int WM_, int WN_, int MT_, int BK_, int STAGES_>
+struct Cfg {
+  static constexpr int WM = WM_, WN = WN_, MT = MT_, BK = BK_, STAGES = STAGES_;
+  static constexpr int BM = 16 * MT * WM, BN = 64 * WN, NW = WM * WN, THREADS = 64 * NW;
+  static constexpr int ROWB = BK * 2;                         // bytes per staged row
+  static constexpr int RPI = 1024 / ROWB;                     // rows per LDS-DMA wave-instruction
+  static constexpr int STAGE_BYTES = (BM + BN) * ROWB;
+  static constexpr int G = (BM + BN) / RPI / NW;              // LDS-DMA wave-instructions per wave per K-step
+  static constexpr int SLAB_BYTES = NW * 64 * 68 * 4;         // epilogue transpose slabs (64 rows per pass)
+  static constexpr int LDS = STAGES * STAGE_BYTES > SLAB_BYTES ? STAGES * STAGE_BYTES : SLAB_BYTES;
+  static constexpr int MIN_WAVES = (LDS <= 80 * 1024) ? (2 * NW + 3) / 4 : (NW + 3) / 4;
+  static_assert((BM + BN) % (RPI * NW) == 0, "tile rows must split evenly over the waves");
+};
+
+// 16-byte chunk swizzle of a staged row (conflict-free ds_read_b128 of 16 rows at one chunk):
+// 128-B rows (BK=64): chunk ^= (row>>1)&7 ; 64-B rows (BK=32): chunk ^= (row>>2)&3
+template <int BK> __device__ __forceinline__ int kswz(int row) { return BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
+
+// Stage one K-step of the block's [W tile (BN rows) | X tile (BM rows)] x BK bf16 into LDS by LDS-DMA:
+// 1 KiB per wave-instruction, lane-linear image, swizzle applied on the source side.
+template <class C>
+__device__ __forceinline__ void stage_step(const GemmNtParams& p, int n0, int m0, int k0, char* stage, int wave, int lane) {
+  constexpr int CPR = C::ROWB / 16;   // chunks per row
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = r * 32 + wave * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-    int grow = row0 + row;
-    grow = grow < nrows ? grow : nrows - 1;  // edge rows re-read a valid row; their outputs are never stored
-    const bf16_t* src = g + (size_t)grow * ld + k0 + chunk * 8;
-    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds_tile + (r * 32 + wave * 8) * 128), 16, 0, 0);
+  for (int r = 0; r < C::G; ++r) {
+    const int rr = (r * C::NW + wave) * C::RPI + lane / CPR;   // row in the concatenated tile
+    const int chunk = (lane % CPR) ^ kswz<C::BK>(rr);
+    const bf16_t* src;
+    if (rr < C::BN) {
+      int g = n0 + rr;
+      g = g < p.N ? g : p.N - 1;     // edge rows re-read a valid row; their outputs are never stored
+      src = p.w + (size_t)g * p.ldw + k0 + chunk * 8;
+    } else {
+      int g = m0 + rr - C::BN;
+      g = g < p.M ? g : p.M - 1;
+      src = p.x + (size_t)g * p.ldx + k0 + chunk * 8;
+    }
+    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(stage + (r * C::NW + wave) * 1024), 16, 0, 0);
   }
 }
 
-__device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int row, int chunk) {
-  return *reinterpret_cast<const bf16x8*>(lds_tile + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+template <int BK> __device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int row, int chunk) {
+  return *reinterpret_cast<const bf16x8*>(lds_tile + row * (BK * 2) + ((chunk ^ kswz<BK>(row)) << 4));
 }
 
-template <int EPI, bool OUT_F32>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNtParams p) {
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <class C, int EPI, bool OUT_F32>
+__global__ __launch_bounds__(C::THREADS, C::MIN_WAVES) void gemm_nt_kernel(GemmNtParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BM = C::BM, BN = C::BN, BK = C::BK, S = C::STAGES, G = C::G, MT = C::MT;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int nbn = (p.N + BN - 1) / BN;
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
   const int tm = lid / nbn, tn = lid - tm * nbn;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / C::WN, wn = wave % C::WN;
 
-  f32x4 acc[4][4];  // [n-subtile i][m-subtile j]
+  f32x4 acc[4][MT];  // [n-subtile i][m-subtile j]
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = p.K / BK;
-  // LDS: [stage][W tile | X tile]
-  stage_tile(p.w, p.ldw, n0, p.N, 0, smem, wave, lane);
-  stage_tile(p.x, p.ldx, m0, p.M, 0, smem + TILE_BYTES, wave, lane);
-  __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
-  __syncthreads();
+  // prologue: fill S-1 ring slots
+#pragma unroll
+  for (int s = 0; s < S - 1; ++s)
+    if (s < nk) stage_step<C>(p, n0, m0, s * BK, smem + s * C::STAGE_BYTES, wave, lane);
 
   for (int t = 0; t < nk; ++t) {
-    const int cur = t & 1;
-    if (t + 1 < nk) {
-      char* nxt = smem + (cur ^ 1) * 2 * TILE_BYTES;
-      stage_tile(p.w, p.ldw, n0, p.N, (t + 1) * BK, nxt, wave, lane);
-      stage_tile(p.x, p.ldx, m0, p.M, (t + 1) * BK, nxt + TILE_BYTES, wave, lane);
-    }
-    const char* tw = smem + cur * 2 * TILE_BYTES;
-    const char* tx = tw + TILE_BYTES;
+    // K-step t has landed once at most min(S-2, nk-1-t) younger steps are still in flight
+    const int rem = nk - 1 - t;
+    if constexpr (S == 2) wait_vmcnt<0>();
+    else if constexpr (S == 3) { if (rem >= 1) wait_vmcnt<G>(); else wait_vmcnt<0>(); }
+    else { if (rem >= 2) wait_vmcnt<2 * G>(); else if (rem == 1) wait_vmcnt<G>(); else wait_vmcnt<0>(); }
+    __builtin_amdgcn_s_barrier();            // every wave's loads of step t landed; step t-1 fully read
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + S - 1 < nk)                      // refill the slot step t-1 used
+      stage_step<C>(p, n0, m0, (t + S - 1) * BK, smem + ((t + S - 1) % S) * C::STAGE_BYTES, wave, lane);
+    const char* tw = smem + (t % S) * C::STAGE_BYTES;
+    const char* tx = tw + BN * C::ROWB;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 fw[4], fx[4];
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      bf16x8 fw[4], fx[MT];
       const int chunk = ks * 4 + (lane >> 4);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fw[i] = read_frag(tw, wn * 64 + i * 16 + (lane & 15), chunk);
+      for (int i = 0; i < 4; ++i) fw[i] = read_frag<BK>(tw, wn * 64 + i * 16 + (lane & 15), chunk);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fx[j] = read_frag(tx, wm * 64 + j * 16 + (lane & 15), chunk);
+      for (int j = 0; j < MT; ++j) fx[j] = read_frag<BK>(tx, wm * 16 * MT + j * 16 + (lane & 15), chunk);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < MT; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fx[j], acc[i][j], 0, 0, 0);
     }
-    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): next tile landed
-    __syncthreads();
   }
 
-  // ---- epilogue: lane holds rows m = .. + (lane&15), columns n = .. + 4*(lane>>4) + {0..3}
-  const int n_l = 4 * (lane >> 4);
+  // ---- epilogue.  The accumulator layout (lane = row m, 4 consecutive n per register quad) would need
+  // 16 strided 8-byte stores (+16 such loads of the residual) per lane, which is store-ISSUE bound and
+  // cost more than the 12-step main loop of the K=768 GEMMs.  Instead every wave transposes its tile,
+  // 64 rows at a time, through its own fp32 LDS slab (the ring is dead by now) and walks it
+  // row-contiguously: a lane owns 8 consecutive columns of one row -> 16-byte bias/residual loads and
+  // 16-byte stores, 8 full 128-byte row segments per wave-instruction.
+  constexpr int SLAB_LD = 68;                       // floats per slab row (64 + 4 pad)
+  __builtin_amdgcn_s_barrier();                      // all waves finished reading the ring
+  float* slab = reinterpret_cast<float*>(smem) + wave * (64 * SLAB_LD);
+  const int c0 = (lane & 7) * 8;
+  const int n = n0 + wn * 64 + c0;
+  const bool ncols_ok = n < p.N;
+  const bool full = (n + 7 < p.N);
+  float b[8];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int n = n0 + wn * 64 + i * 16 + n_l;
-    if (n >= p.N) continue;
-    const bool full = (n + 3 < p.N);
-    float b[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias != nullptr) {
+  for (int e = 0; e < 8; ++e) b[e] = (p.bias != nullptr && n + e < p.N) ? p.bias[n + e] : 0.f;
+  const bool vec_out = full && ((p.ldo * (OUT_F32 ? 4 : 2)) % 16 == 0);
+  const bool vec_aux = full && ((p.ldaux * (EPI == UNIMM_EPI_BIAS_DROP_RESID ? 4 : 2)) % 16 == 0);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) b[e] = (n + e < p.N) ? p.bias[n + e] : 0.f;
-    }
+  for (int pass = 0; pass < MT / 4; ++pass) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int m = m0 + wm * 64 + j * 16 + (lane & 15);
-      if (m >= p.M) continue;
-      float v[4], u[4];
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + b[e];
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<f32x4*>(slab + (j * 16 + (lane & 15)) * SLAB_LD + i * 16 + 4 * (lane >> 4)) = acc[i][pass * 4 + j];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = it * 8 + (lane >> 3);
+      const int m = m0 + wm * 16 * MT + pass * 64 + row;
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(slab + row * SLAB_LD + c0);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(slab + row * SLAB_LD + c0 + 4);
+      if (m >= p.M || !ncols_ok) continue;
+      float v[8], u[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = lo[e] + b[e]; v[4 + e] = hi[e] + b[4 + e]; }
       if constexpr (EPI == UNIMM_EPI_BIAS_DROP_RESID || EPI == UNIMM_EPI_DGELU || EPI == UNIMM_EPI_ADD) {
-        float a[4];
+        float a[8];
         if constexpr (EPI == UNIMM_EPI_BIAS_DROP_RESID) {   // fp32 residual stream
           const float* ap = reinterpret_cast<const float*>(p.aux) + (size_t)m * p.ldaux + n;
-          if (full) {
-            const f32x4 raw = *reinterpret_cast<const f32x4*>(ap);
-            a[0] = raw[0]; a[1] = raw[1]; a[2] = raw[2]; a[3] = raw[3];
+          if (vec_aux) {
+            const f32x4 r0 = *reinterpret_cast<const f32x4*>(ap), r1 = *reinterpret_cast<const f32x4*>(ap + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[e] = r0[e]; a[4 + e] = r1[e]; }
           } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) a[e] = (n + e < p.N) ? ap[e] : 0.f;
+            for (int e = 0; e < 8; ++e) a[e] = (n + e < p.N) ? ap[e] : 0.f;
           }
-        } else {
-          const bf16_t* ap = reinterpret_cast<const bf16_t*>(p.aux) + (size_t)m * p.ldaux + n;
-          if (full) {
-            const u32x2 raw = *reinterpret_cast<const u32x2*>(ap);
-            a[0] = __uint_as_float(raw[0] << 16); a[1] = __uint_as_float(raw[0] & 0xffff0000u);
-            a[2] = __uint_as_float(raw[1] << 16); a[3] = __uint_as_float(raw[1] & 0xffff0000u);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) a[e] = (n + e < p.N) ? bf2f(ap[e]) : 0.f;
-          }
-        }
-        if constexpr (EPI == UNIMM_EPI_BIAS_DROP_RESID) {
           if (p.drop.thr != 0u) {
             const uint32_t idx = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = drop_apply(p.drop, idx + e, v[e]);
+            for (int e = 0; e < 8; ++e) v[e] = drop_apply(p.drop, idx + e, v[e]);
           }
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += a[e];
-        } else if constexpr (EPI == UNIMM_EPI_DGELU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad(a[e]);
+          for (int e = 0; e < 8; ++e) v[e] += a[e];
         } else {
+          const bf16_t* ap = reinterpret_cast<const bf16_t*>(p.aux) + (size_t)m * p.ldaux + n;
+          if (vec_aux) {
+            const u32x4 raw = *reinterpret_cast<const u32x4*>(ap);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += a[e];
+            for (int e = 0; e < 4; ++e) { a[2 * e] = __uint_as_float(raw[e] << 16); a[2 * e + 1] = __uint_as_float(raw[e] & 0xffff0000u); }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = (n + e < p.N) ? bf2f(ap[e]) : 0.f;
+          }
+          if constexpr (EPI == UNIMM_EPI_DGELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad(a[e]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += a[e];
+          }
         }
       }
       if constexpr (EPI == UNIMM_EPI_BIAS_GELU) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { u[e] = v[e]; v[e] = gelu_erf(v[e]); }
+        for (int e = 0; e < 8; ++e) { u[e] = v[e]; v[e] = gelu_erf(v[e]); }
         if (p.out2 != nullptr) {
           bf16_t* up = p.out2 + (size_t)m * p.ldo + n;
-          if (full) *reinterpret_cast<u32x2*>(up) = u32x2{pack2bf(u[0], u[1]), pack2bf(u[2], u[3])};
+          if (full && (p.ldo % 8) == 0)
+            *reinterpret_cast<u32x4*>(up) = u32x4{pack2bf(u[0], u[1]), pack2bf(u[2], u[3]), pack2bf(u[4], u[5]), pack2bf(u[6], u[7])};
           else
-            for (int e = 0; e < 4; ++e) if (n + e < p.N) up[e] = f2bf(u[e]);
+            for (int e = 0; e < 8; ++e) if (n + e < p.N) up[e] = f2bf(u[e]);
         }
       }
       if constexpr (EPI == UNIMM_EPI_BIAS_RELU) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
       }
       if constexpr (OUT_F32) {
         float* op = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n;
-        if (full) *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
-        else
-          for (int e = 0; e < 4; ++e) if (n + e < p.N) op[e] = v[e];
+        if (vec_out) {
+          *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4*>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        } else {
+          for (int e = 0; e < 8; ++e) if (n + e < p.N) op[e] = v[e];
+        }
       } else {
         bf16_t* op = reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldo + n;
-        if (full) *reinterpret_cast<u32x2*>(op) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+        if (vec_out)
+          *reinterpret_cast<u32x4*>(op) = u32x4{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
         else
-          for (int e = 0; e < 4; ++e) if (n + e < p.N) op[e] = f2bf(v[e]);
+          for (int e = 0; e < 8; ++e) if (n + e < p.N) op[e] = f2bf(v[e]);
       }
     }
   }
@@ -207,12 +262,23 @@ struct GemmTnParams {
 // chunk pair, so the half-wave covers all 64 banks exactly once.
 __device__ __forceinline__ int tn_swz(int row) { return ((row & 3) | ((row >> 1) & 4)) << 1; }
 
-__device__ __forceinline__ void stage_tile_tn(const bf16_t* __restrict__ g, int ld, int m0, int mend, int c0,
-                                              int ncols, char* lds_tile, int wave, int lane) {
+// Stage one m-step: the block's DY columns [n0, n0+TNB) and X columns [k0, k0+TKB) for rows
+// [m0, m0+64), as [64][128]-column sub-tiles of 16 KiB (4 rows x 256 B per LDS-DMA wave-instruction).
+template <int NW, int NSUB_A, int NSUB_B>
+__device__ __forceinline__ void stage_step_tn(const GemmTnParams& p, int m0, int mend, int n0, int k0, char* stage,
+                                              int wave, int lane) {
+  constexpr int PER_WAVE = (NSUB_A + NSUB_B) * 16 / NW;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = r * 16 + wave * 4 + (lane >> 4);  // 4 rows of 256 B per wave-instruction
+  for (int r = 0; r < PER_WAVE; ++r) {
+    const int q = r * NW + wave;
+    const int sub = q >> 4, rg = q & 15;
+    const int row = rg * 4 + (lane >> 4);
     const int chunk = (lane & 15) ^ tn_swz(row);
+    const bool is_a = sub < NSUB_A;
+    const bf16_t* g = is_a ? p.dy : p.x;
+    const int ld = is_a ? p.lddy : p.ldx;
+    const int ncols = is_a ? p.N : p.K;
+    const int c0 = is_a ? n0 + sub * 128 : k0 + (sub - NSUB_A) * 128;
     int gm = m0 + row;
     int gc = c0 + chunk * 8;
     // rows past the end re-read the last row (masked to zero in the fragment); columns past
@@ -221,7 +287,7 @@ __device__ __forceinline__ void stage_tile_tn(const bf16_t* __restrict__ g, int 
     const int cmax = ((ncols + 7) & ~7) - 8;
     gc = gc <= cmax ? gc : cmax;
     const bf16_t* src = g + (size_t)gm * ld + gc;
-    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds_tile + (r * 16 + wave * 4) * 256), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(stage + sub * TN_TILE_BYTES + rg * 1024), 16, 0, 0);
   }
 }
 
@@ -248,100 +314,107 @@ __device__ __forceinline__ bf16x8 read_frag_tr(const char* lds_tile, int c16, in
   return __builtin_bit_cast(bf16x8, v);
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTnParams p) {
+// WN x WK waves; a wave owns (16*NT)(n) x 64(k) of the [TNB x TKB] output tile.
+//   <2,2,4>: 128x128 tile, 4 waves, 64 KiB LDS (2 workgroups per CU)      -- small problems
+//   <2,4,8>: 256x256 tile, 8 waves, 128 KiB LDS: half the staged bytes per MFMA, so one m-step of
+//            compute covers twice the load latency (same reasoning as Cfg<2,4,8,64,2> of gemm_nt)
+template <int WN, int WK, int NT>
+__global__ __launch_bounds__(64 * WN * WK, (WN * WK * (NT == 4 ? 2 : 1) + 3) / 4) void gemm_tn_kernel(GemmTnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NW = WN * WK, TNB = 16 * NT * WN, TKB = 64 * WK;
+  constexpr int NSUB_A = TNB / 128, NSUB_B = TKB / 128;
+  constexpr int STAGE_BYTES = (NSUB_A + NSUB_B) * TN_TILE_BYTES;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int nbn = (p.N + 127) / 128, nbk = (p.K + 127) / 128;
+  const int nbn = (p.N + TNB - 1) / TNB, nbk = (p.K + TKB - 1) / TKB;
   const int ntile = nbn * nbk;
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
   const int split = lid / ntile;
   const int tile = lid - split * ntile;
   const int tn = tile / nbk, tk = tile - tn * nbk;
-  const int n0 = tn * 128, k0 = tk * 128;
+  const int n0 = tn * TNB, k0 = tk * TKB;
   const int mbeg = split * p.rows_per_split;
   int mend = mbeg + p.rows_per_split;
   mend = mend < p.M ? mend : p.M;
   if (mbeg >= mend) return;
-  const int wn = wave >> 1, wk = wave & 1;
+  const int wn = wave / WK, wk = wave % WK;
 
-  f32x4 acc[4][4];  // [n-subtile i][k-subtile j]
+  f32x4 acc[NT][4];  // [n-subtile i][k-subtile j]
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NT; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // bias gradient = column sums of DY: one extra MFMA against an all-ones operand, only in the first
-  // k-tile column and only in the waves that own k-subtile 0 (DY is already in LDS for the product)
+  // bias gradient = column sums of DY, taken from the DY fragments that are in registers anyway: only in
+  // the first k-tile column and only in the waves that own k-subtile 0 (one float per n-subtile per lane)
   const bool do_bias = p.dbias != nullptr && tk == 0 && wk == 0;
-  f32x4 accb[4];
+  float accb[NT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  bf16x8 ones;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+  for (int i = 0; i < NT; ++i) accb[i] = 0.f;
 
   const int nsteps = (mend - mbeg + TK - 1) / TK;
-
-  stage_tile_tn(p.dy, p.lddy, mbeg, mend, n0, p.N, smem, wave, lane);
-  stage_tile_tn(p.x, p.ldx, mbeg, mend, k0, p.K, smem + TN_TILE_BYTES, wave, lane);
-  __builtin_amdgcn_s_waitcnt(0x0f70);
-  __syncthreads();
+  stage_step_tn<NW, NSUB_A, NSUB_B>(p, mbeg, mend, n0, k0, smem, wave, lane);
 
   for (int t = 0; t < nsteps; ++t) {
     const int cur = t & 1;
     const int mt = mbeg + t * TK;
-    if (t + 1 < nsteps) {
-      char* nxt = smem + (cur ^ 1) * 2 * TN_TILE_BYTES;
-      stage_tile_tn(p.dy, p.lddy, mt + TK, mend, n0, p.N, nxt, wave, lane);
-      stage_tile_tn(p.x, p.ldx, mt + TK, mend, k0, p.K, nxt + TN_TILE_BYTES, wave, lane);
-    }
-    const char* ta = smem + cur * 2 * TN_TILE_BYTES;
-    const char* tb = ta + TN_TILE_BYTES;
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();          // step t landed everywhere; step t-1 fully read
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 1 < nsteps) stage_step_tn<NW, NSUB_A, NSUB_B>(p, mt + TK, mend, n0, k0, smem + (cur ^ 1) * STAGE_BYTES, wave, lane);
+    const char* ta = smem + cur * STAGE_BYTES;
+    const char* tb = ta + NSUB_A * TN_TILE_BYTES;
     const int valid = mend - mt;  // rows of this step that exist (>= 1); others must contribute 0
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 fa[4], fb[4];
+      bf16x8 fa[NT], fb[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = read_frag_tr(ta, wn * 64 + i * 16, ks * 32, lane);
+      for (int i = 0; i < NT; ++i) {
+        const int c = wn * 16 * NT + i * 16;
+        fa[i] = read_frag_tr(ta + (c >> 7) * TN_TILE_BYTES, c & 127, ks * 32, lane);
+      }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = read_frag_tr(tb, wk * 64 + j * 16, ks * 32, lane);
+      for (int j = 0; j < 4; ++j) {
+        const int c = wk * 64 + j * 16;
+        fb[j] = read_frag_tr(tb + (c >> 7) * TN_TILE_BYTES, c & 127, ks * 32, lane);
+      }
       if (valid < TK) {  // ragged tail: zero the A-side elements of rows past the end
         const int rbase = ks * 32 + 8 * (lane >> 4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NT; ++i)
 #pragma unroll
           for (int e = 0; e < 8; ++e)
             if (rbase + e >= valid) fa[i][e] = (__bf16)0.0f;
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-      if (do_bias) {
+      if (do_bias) {   // lane holds DY[m = 8*(lane>>4)+e][n = lane&15] of each fragment
 #pragma unroll
-        for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, accb[i], 0, 0, 0);
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) accb[i] += (float)fa[i][e];
       }
     }
-    __builtin_amdgcn_s_waitcnt(0x0f70);
-    __syncthreads();
   }
 
-  if (do_bias && (lane & 15) == 0) {   // every column of accb holds the same row sums
+  if (do_bias) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int n = n0 + wn * 64 + i * 16 + 4 * (lane >> 4) + e;
-        if (n < p.N) atomicAdd(p.dbias + n, accb[i][e]);
-      }
+    for (int i = 0; i < NT; ++i) {
+      float v = accb[i];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      const int n = n0 + wn * 16 * NT + i * 16 + (lane & 15);
+      if (lane < 16 && n < p.N) atomicAdd(p.dbias + n, v);
+    }
   }
 
   // D[n][k]: lane holds k = .. + (lane&15) (column), n = .. + 4*(lane>>4) + e (rows)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NT; ++i) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int n = n0 + wn * 64 + i * 16 + 4 * (lane >> 4) + e;
+      const int n = n0 + wn * 16 * NT + i * 16 + 4 * (lane >> 4) + e;
       if (n >= p.N) continue;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -351,7 +424,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTnParams p) {
     }
   }
 }
-
 
 // ------------------------------------------------------------------------------------------------
 // Launch profiler (bench.py's `roofline` block): when enabled, every GEMM launch is bracketed by HIP
@@ -378,23 +450,47 @@ inline ProfRec* prof_begin(int variant, double flops, hipStream_t s) {
 }
 inline void prof_end(ProfRec* r, hipStream_t s) { if (r) hipEventRecord(r->b, s); }
 
-template <int EPI>
-int launch_nt(const GemmNtParams& p, bool out_f32, hipStream_t s) {
-  const int nwg = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  const size_t lds = 4 * TILE_BYTES;
+int g_nt_cfg = 0;   // 0 = auto, 1 = 128x128 BK64 x2, 2 = 256x256 BK32 x4, 3 = 256x256 BK64 x2  (unimm_gemm_set_tile)
+
+template <class C, int EPI>
+int launch_nt_cfg(const GemmNtParams& p, bool out_f32, hipStream_t s) {
+  const int nwg = ((p.M + C::BM - 1) / C::BM) * ((p.N + C::BN - 1) / C::BN);
+  auto k32 = gemm_nt_kernel<C, EPI, true>;
+  auto k16 = gemm_nt_kernel<C, EPI, false>;
+  if (C::LDS > 64 * 1024) {
+    static bool done32 = false, done16 = false;
+    bool& done = out_f32 ? done32 : done16;
+    if (!done) {
+      const void* fn = out_f32 ? (const void*)k32 : (const void*)k16;
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess) return UNIMM_E_HIP;
+      done = true;
+    }
+  }
   ProfRec* pr = prof_begin(EPI * 2 + (out_f32 ? 1 : 0), 2.0 * p.M * (double)p.N * p.K, s);
-  if (out_f32) hipLaunchKernelGGL((gemm_nt_kernel<EPI, true>), dim3(nwg), dim3(256), lds, s, p);
-  else hipLaunchKernelGGL((gemm_nt_kernel<EPI, false>), dim3(nwg), dim3(256), lds, s, p);
+  if (out_f32) hipLaunchKernelGGL(k32, dim3(nwg), dim3(C::THREADS), C::LDS, s, p);
+  else hipLaunchKernelGGL(k16, dim3(nwg), dim3(C::THREADS), C::LDS, s, p);
   prof_end(pr, s);
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;
+}
+
+template <int EPI>
+int launch_nt(const GemmNtParams& p, bool out_f32, hipStream_t s) {
+  int cfg = g_nt_cfg;
+  if (cfg == 0) {   // 256x256 tiles when they still give every CU >= 1.5 workgroups, else 128x128
+    const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+    cfg = (t256 >= 384) ? 3 : 1;
+  }
+  if (cfg == 2) return launch_nt_cfg<Cfg<2, 4, 8, 32, 4>, EPI>(p, out_f32, s);
+  if (cfg == 3) return launch_nt_cfg<Cfg<2, 4, 8, 64, 2>, EPI>(p, out_f32, s);
+  return launch_nt_cfg<Cfg<2, 2, 4, 64, 2>, EPI>(p, out_f32, s);
 }
 
 }  // namespace
 
 extern "C" int unimm_gemm_nt(const unimm_gemm_nt_args* a, void* stream) {
   if (a == nullptr || a->x == nullptr || a->w == nullptr || a->out == nullptr) return UNIMM_E_ARG;
-  if (a->M <= 0 || a->N <= 0 || a->K <= 0 || (a->K % BK) != 0) return UNIMM_E_SHAPE;
+  if (a->M <= 0 || a->N <= 0 || a->K <= 0 || (a->K % 64) != 0) return UNIMM_E_SHAPE;
   if ((a->ldx % 8) || (a->ldw % 8) || a->ldx < a->K || a->ldw < a->K || a->ldo < a->N) return UNIMM_E_ALIGN;
   if (((uintptr_t)a->x | (uintptr_t)a->w | (uintptr_t)a->out) & 15) return UNIMM_E_ALIGN;
   if (a->out_f32 ? (a->ldo % 4) : (a->ldo % 4)) return UNIMM_E_ALIGN;
@@ -420,6 +516,12 @@ extern "C" int unimm_gemm_nt(const unimm_gemm_nt_args* a, void* stream) {
   }
 }
 
+extern "C" int unimm_gemm_set_tile(int32_t cfg) {
+  if (cfg < 0 || cfg > 3) return UNIMM_E_ARG;
+  g_nt_cfg = cfg;
+  return UNIMM_OK;
+}
+
 extern "C" int unimm_gemm_tn(const unimm_gemm_tn_args* a, void* stream) {
   if (a == nullptr || a->dy == nullptr || a->x == nullptr || a->dw == nullptr) return UNIMM_E_ARG;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0) return UNIMM_E_SHAPE;
@@ -428,9 +530,13 @@ extern "C" int unimm_gemm_tn(const unimm_gemm_tn_args* a, void* stream) {
   GemmTnParams p;
   p.dy = (const bf16_t*)a->dy; p.x = (const bf16_t*)a->x; p.dw = a->dw; p.dbias = a->dbias;
   p.M = a->M; p.N = a->N; p.K = a->K; p.lddy = a->lddy; p.ldx = a->ldx; p.lddw = a->lddw;
-  const int ntile = ((a->N + 127) / 128) * ((a->K + 127) / 128);
-  // enough workgroups for ~2 per CU, but keep >= 512 reduction rows per split
-  int splits = (512 + ntile - 1) / ntile;
+  const bool big = a->N >= 256 && a->K >= 256 && a->M >= 4096;
+  const int tb = big ? 256 : 128;
+  const int ntile = ((a->N + tb - 1) / tb) * ((a->K + tb - 1) / tb);
+  // fill the chip with ONE wave of workgroups (256 CUs x 1 or 2 resident workgroups): rounding the
+  // split count UP overshoots the slots and costs a whole second round (270 workgroups ran 2x as long
+  // as 243), so round down; keep >= 512 reduction rows per split
+  int splits = (big ? 256 : 512) / ntile;
   const int max_splits = (a->M + 511) / 512;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
@@ -438,9 +544,21 @@ extern "C" int unimm_gemm_tn(const unimm_gemm_tn_args* a, void* stream) {
   rps = ((rps + TK - 1) / TK) * TK;
   splits = (a->M + rps - 1) / rps;
   p.rows_per_split = rps;
-  ProfRec* pr = prof_begin(12, 2.0 * a->M * (double)a->N * a->K, (hipStream_t)stream);
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3(ntile * splits), dim3(256), 4 * TN_TILE_BYTES, (hipStream_t)stream, p);
-  prof_end(pr, (hipStream_t)stream);
+  hipStream_t s = (hipStream_t)stream;
+  ProfRec* pr = prof_begin(12, 2.0 * a->M * (double)a->N * a->K, s);
+  if (big) {
+    auto kern = gemm_tn_kernel<2, 4, 8>;
+    static bool attr_done = false;
+    if (!attr_done) {
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * TN_TILE_BYTES) != hipSuccess)
+        return UNIMM_E_HIP;
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(ntile * splits), dim3(512), 8 * TN_TILE_BYTES, s, p);
+  } else {
+    hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 4>), dim3(ntile * splits), dim3(256), 4 * TN_TILE_BYTES, s, p);
+  }
+  prof_end(pr, s);
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;
 }
