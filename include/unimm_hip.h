@@ -43,7 +43,9 @@ enum {
   UNIMM_EPI_BIAS_DROP_RESID = 2, /* out(fp32) = dropout(acc + bias) + aux(fp32 residual stream) (:423-425, :466-468, ...) */
   UNIMM_EPI_BIAS_RELU = 3,       /* poolers (:950-951, :965-966)                                */
   UNIMM_EPI_DGELU = 4,           /* out = acc * GELU'(aux)           (backward of :453-454)     */
-  UNIMM_EPI_ADD = 5              /* out = acc + aux                  (residual gradient join)   */
+  UNIMM_EPI_ADD = 5,             /* out = acc + aux                  (residual gradient join)   */
+  UNIMM_EPI_MUL = 6,             /* out = acc * aux                  (backward of GELU with aux = GELU'(u)) */
+  UNIMM_EPI_BIAS_GELU_DG = 7     /* u = acc + bias; out = erf-GELU(u); out2 = GELU'(u) (training FFN) */
 };
 
 typedef struct {
@@ -232,7 +234,7 @@ int unimm_segment_sum(const float* src, const int32_t* seg, float* dst, int64_t 
 /* Launch profiler for bench.py's `roofline` block: HIP events around every GEMM launch on its own
  * stream while enabled.  Variant index: 0..11 = unimm_gemm_nt (epilogue * 2 + out_f32), 12 = unimm_gemm_tn.
  * unimm_prof_collect synchronises the events and returns per-variant summed milliseconds, algorithmic
- * FLOPs (2*M*N*K per launch) and launch counts; arrays of >= 16 entries. */
+ * FLOPs (2*M*N*K per launch) and launch counts; arrays of >= 20 entries. */
 int unimm_prof_enable(int32_t on);
 int unimm_prof_collect(double* ms, double* flops, int32_t* count, int32_t nvar);
 

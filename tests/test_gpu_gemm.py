@@ -89,6 +89,18 @@ def test_gemm_nt_strided_views_and_epilogues():
     torch.cuda.synchronize()
     ref = base * a32.grad
     assert (o.float() - ref).abs().max() <= 2 ** -7 * max(1.0, ref.abs().max().item())
+    # mul, and the fused GELU + GELU' epilogue of the training FFN
+    lib.gemm_nt(x, w, o, epilogue=lib.EPI_MUL, aux=aux)
+    torch.cuda.synchronize()
+    ref = base * aux.float()
+    assert (o.float() - ref).abs().max() <= 2 ** -7 * max(1.0, ref.abs().max().item())
+    dg = torch.empty_like(h)
+    lib.gemm_nt(x, w, h, bias=bias, epilogue=lib.EPI_BIAS_GELU_DG, out2=dg)
+    torch.cuda.synchronize()
+    u32 = (base + bias).requires_grad_(True)
+    _gelu(u32).sum().backward()
+    assert (h.float() - _gelu(base + bias)).abs().max() <= 2 ** -7 * (base + bias).abs().max()
+    assert (dg.float() - u32.grad).abs().max() <= 2 ** -7
     # add
     lib.gemm_nt(x, w, o, epilogue=lib.EPI_ADD, aux=aux)
     torch.cuda.synchronize()

@@ -58,6 +58,23 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return cdf + x * pdf;
 }
 
+// GELU and its derivative from ONE erf / ONE exp (exp(-x^2/2) is both erf's tail and the Gaussian pdf):
+// the forward FFN epilogue stores gelu'(u) instead of u, so the backward epilogue is a plain multiply.
+__device__ __forceinline__ void gelu_and_grad(float x, float& y, float& dy) {
+  const float t = x * 0.70710678118654752f;
+  const float ax = fabsf(t);
+  const float e = __expf(-ax * ax);
+  const float r = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(1.061405429f, r, -1.453152027f);
+  p = fmaf(p, r, 1.421413741f);
+  p = fmaf(p, r, -0.284496736f);
+  p = fmaf(p, r, 0.254829592f);
+  const float erfv = copysignf(1.0f - p * r * e, t);
+  const float cdf = 0.5f * (1.0f + erfv);
+  y = x * cdf;
+  dy = fmaf(x * 0.3989422804014327f, e, cdf);
+}
+
 // Counter-based dropout: keep(idx) = mix32(idx ^ key) >= thr, key = per-(step, site) word built on
 // the host (unimm_amd/dropout.py mirrors this bit for bit so the oracle can replay the masks).
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {

@@ -25,8 +25,22 @@ struct GemmNtParams {
   const bf16_t* x; const bf16_t* w; const float* bias; const void* aux;  // aux: fp32 for DROP_RESID, bf16 otherwise
   void* out; bf16_t* out2;
   int M, N, K, ldx, ldw, ldaux, ldo;
+  int gn;            // n-tiles per column group of the tile order (see tile_of)
   DropoutArg drop;
 };
+
+// Tile order.  Logical ids run group by group over the n-tiles (gn tile columns per group), inside a
+// group over the m-tiles, n fastest.  After the XCD remap every XCD walks a contiguous id range, so the
+// ~32 workgroups resident on one XCD cover (32/gn) row panels x gn column panels: both operands'
+// panels are shared through that XCD's 4 MiB L2.  gn >= the number of n-tiles = plain row-major order.
+__device__ __forceinline__ void tile_of(int lid, int nbm, int nbn, int gn, int& tm, int& tn) {
+  const int per_group = nbm * gn;
+  const int g = lid / per_group;
+  const int r = lid - g * per_group;
+  const int gw = (nbn - g * gn) < gn ? (nbn - g * gn) : gn;   // width of this (possibly last, narrower) group
+  tm = r / gw;
+  tn = g * gn + (r - tm * gw);
+}
 
 // Block-tile configurations.  A wave owns a (16*MT)(m) x 64(n) output sub-tile (MT x 4 accumulators of
 // v_mfma_f32_16x16x32_bf16); WM x WN waves make the block tile; one ring slot holds one K-step of BK.
@@ -87,9 +101,10 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES) void gemm_nt_kernel(GemmN
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BM = C::BM, BN = C::BN, BK = C::BK, S = C::STAGES, G = C::G, MT = C::MT;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int nbn = (p.N + BN - 1) / BN;
+  const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
-  const int tm = lid / nbn, tn = lid - tm * nbn;
+  int tm, tn;
+  tile_of(lid, nbm, nbn, p.gn, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
   const int wm = wave / C::WN, wn = wave % C::WN;
 
@@ -168,7 +183,7 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES) void gemm_nt_kernel(GemmN
       float v[8], u[8];
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[e] = lo[e] + b[e]; v[4 + e] = hi[e] + b[4 + e]; }
-      if constexpr (EPI == UNIMM_EPI_BIAS_DROP_RESID || EPI == UNIMM_EPI_DGELU || EPI == UNIMM_EPI_ADD) {
+      if constexpr (EPI == UNIMM_EPI_BIAS_DROP_RESID || EPI == UNIMM_EPI_DGELU || EPI == UNIMM_EPI_ADD || EPI == UNIMM_EPI_MUL) {
         float a[8];
         if constexpr (EPI == UNIMM_EPI_BIAS_DROP_RESID) {   // fp32 residual stream
           const float* ap = reinterpret_cast<const float*>(p.aux) + (size_t)m * p.ldaux + n;
@@ -200,15 +215,23 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES) void gemm_nt_kernel(GemmN
           if constexpr (EPI == UNIMM_EPI_DGELU) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad(a[e]);
+          } else if constexpr (EPI == UNIMM_EPI_MUL) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= a[e];
           } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += a[e];
           }
         }
       }
-      if constexpr (EPI == UNIMM_EPI_BIAS_GELU) {
+      if constexpr (EPI == UNIMM_EPI_BIAS_GELU || EPI == UNIMM_EPI_BIAS_GELU_DG) {
+        if constexpr (EPI == UNIMM_EPI_BIAS_GELU) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { u[e] = v[e]; v[e] = gelu_erf(v[e]); }
+          for (int e = 0; e < 8; ++e) { u[e] = v[e]; v[e] = gelu_erf(v[e]); }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const float x = v[e]; gelu_and_grad(x, v[e], u[e]); }
+        }
         if (p.out2 != nullptr) {
           bf16_t* up = p.out2 + (size_t)m * p.ldo + n;
           if (full && (p.ldo % 8) == 0)
@@ -432,7 +455,7 @@ __global__ __launch_bounds__(64 * WN * WK, (WN * WK * (NT == 4 ? 2 : 1) + 3) / 4
 // ------------------------------------------------------------------------------------------------
 struct ProfRec { hipEvent_t a, b; int variant; double flops; };
 constexpr int PROF_MAX = 1 << 16;
-constexpr int PROF_VARIANTS = 16;   // 0..11: gemm_nt epi*2+out_f32 ; 12: gemm_tn
+constexpr int PROF_VARIANTS = 20;   // 0..15: gemm_nt epi*2+out_f32 ; 16: gemm_tn
 bool g_prof_on = false;
 ProfRec* g_prof = nullptr;
 int g_prof_n = 0;
@@ -450,6 +473,7 @@ inline ProfRec* prof_begin(int variant, double flops, hipStream_t s) {
 }
 inline void prof_end(ProfRec* r, hipStream_t s) { if (r) hipEventRecord(r->b, s); }
 
+int g_nt_gn = 0;    // 0 = automatic
 int g_nt_cfg = 0;   // 0 = auto, 1 = 128x128 BK64 x2, 2 = 256x256 BK32 x4, 3 = 256x256 BK64 x2  (unimm_gemm_set_tile)
 
 template <class C, int EPI>
@@ -495,7 +519,7 @@ extern "C" int unimm_gemm_nt(const unimm_gemm_nt_args* a, void* stream) {
   if (((uintptr_t)a->x | (uintptr_t)a->w | (uintptr_t)a->out) & 15) return UNIMM_E_ALIGN;
   if (a->out_f32 ? (a->ldo % 4) : (a->ldo % 4)) return UNIMM_E_ALIGN;
   const bool needs_aux = a->epilogue == UNIMM_EPI_BIAS_DROP_RESID || a->epilogue == UNIMM_EPI_DGELU ||
-                         a->epilogue == UNIMM_EPI_ADD;
+                         a->epilogue == UNIMM_EPI_ADD || a->epilogue == UNIMM_EPI_MUL;
   if (needs_aux && (a->aux == nullptr || (a->ldaux % 4) || a->ldaux < a->N)) return UNIMM_E_ARG;
   if (a->epilogue == UNIMM_EPI_BIAS_DROP_RESID && !a->out_f32) return UNIMM_E_ARG;  // residual stream is fp32
   GemmNtParams p;
@@ -503,6 +527,7 @@ extern "C" int unimm_gemm_nt(const unimm_gemm_nt_args* a, void* stream) {
   p.out = a->out; p.out2 = (bf16_t*)a->out2;
   p.M = a->M; p.N = a->N; p.K = a->K; p.ldx = a->ldx; p.ldw = a->ldw; p.ldaux = a->ldaux; p.ldo = a->ldo;
   p.drop.key = a->drop_key; p.drop.thr = a->drop_thr; p.drop.scale = a->drop_scale;
+  p.gn = g_nt_gn > 0 ? g_nt_gn : 6;
   hipStream_t s = (hipStream_t)stream;
   const bool f32 = a->out_f32 != 0;
   switch (a->epilogue) {
@@ -512,13 +537,17 @@ extern "C" int unimm_gemm_nt(const unimm_gemm_nt_args* a, void* stream) {
     case UNIMM_EPI_BIAS_RELU: return launch_nt<UNIMM_EPI_BIAS_RELU>(p, f32, s);
     case UNIMM_EPI_DGELU: return launch_nt<UNIMM_EPI_DGELU>(p, f32, s);
     case UNIMM_EPI_ADD: return launch_nt<UNIMM_EPI_ADD>(p, f32, s);
+    case UNIMM_EPI_MUL: return launch_nt<UNIMM_EPI_MUL>(p, f32, s);
+    case UNIMM_EPI_BIAS_GELU_DG: return launch_nt<UNIMM_EPI_BIAS_GELU_DG>(p, f32, s);
     default: return UNIMM_E_ARG;
   }
 }
 
 extern "C" int unimm_gemm_set_tile(int32_t cfg) {
-  if (cfg < 0 || cfg > 3) return UNIMM_E_ARG;
-  g_nt_cfg = cfg;
+  if (cfg < 0 || cfg > 999 * 1000 + 999) return UNIMM_E_ARG;
+  g_nt_cfg = cfg % 1000;          // tile configuration
+  g_nt_gn = cfg / 1000;           // tuning: n-tiles per column group (0 = default)
+  if (g_nt_cfg > 3) return UNIMM_E_ARG;
   return UNIMM_OK;
 }
 
@@ -545,7 +574,7 @@ extern "C" int unimm_gemm_tn(const unimm_gemm_tn_args* a, void* stream) {
   splits = (a->M + rps - 1) / rps;
   p.rows_per_split = rps;
   hipStream_t s = (hipStream_t)stream;
-  ProfRec* pr = prof_begin(12, 2.0 * a->M * (double)a->N * a->K, s);
+  ProfRec* pr = prof_begin(16, 2.0 * a->M * (double)a->N * a->K, s);
   if (big) {
     auto kern = gemm_tn_kernel<2, 4, 8>;
     static bool attr_done = false;

@@ -271,14 +271,15 @@ class Engine:
         d_so = self._drop(pname + "so", p_hid, train)
         pre1 = self._linear(ctx, so, L.EPI_BIAS_DROP_RESID, aux=x32, drop=d_so, out_f32=True)
         x1_32, x1, m1, r1 = self._layernorm(pre1, key + ".ln1", save)
-        h, u = self._linear(x1, ff1, L.EPI_BIAS_GELU, want_u=True) if save else (self._linear(x1, ff1, L.EPI_BIAS_GELU), None)
+        # training keeps GELU'(u) (not u): the backward epilogue is then a plain multiply
+        h, u = self._linear(x1, ff1, L.EPI_BIAS_GELU_DG, want_u=True) if save else (self._linear(x1, ff1, L.EPI_BIAS_GELU), None)
         d_out = self._drop(pname + "out", p_hid, train)
         pre2 = self._linear(h, ff2, L.EPI_BIAS_DROP_RESID, aux=x1_32, drop=d_out, out_f32=True)
         x2_32, x2, m2, r2 = self._layernorm(pre2, key + ".ln2", save)
         if save:
             def bwd(dx2):
                 dpre2, dpre2d = self._layernorm_bwd(dx2, pre2, m2, r2, key + ".ln2", dbias=ff2.gb, drop=d_out)
-                du = self._linear_bwd(dpre2d, h, ff2, L.EPI_DGELU, aux=u, bias_grad=False)
+                du = self._linear_bwd(dpre2d, h, ff2, L.EPI_MUL, aux=u, bias_grad=False)
                 dx1 = self._linear_bwd(du, x1, ff1, L.EPI_ADD, aux=dpre2)
                 dpre1, dpre1d = self._layernorm_bwd(dx1, pre1, m1, r1, key + ".ln1", dbias=so.gb, drop=d_so)
                 dctx = self._linear_bwd(dpre1d, ctx, so, bias_grad=False)
@@ -318,8 +319,8 @@ class Engine:
         dvo = self._drop(pn + "vout", cfg.v_hidden_dropout_prob, train)
         dto = self._drop(pn + "tout", cfg.hidden_dropout_prob, train)
         if save:
-            hv, uv = self._linear(av, vff1, L.EPI_BIAS_GELU, want_u=True)
-            ht, ut = self._linear(at, tff1, L.EPI_BIAS_GELU, want_u=True)
+            hv, uv = self._linear(av, vff1, L.EPI_BIAS_GELU_DG, want_u=True)
+            ht, ut = self._linear(at, tff1, L.EPI_BIAS_GELU_DG, want_u=True)
         else:
             hv, uv, ht, ut = self._linear(av, vff1, L.EPI_BIAS_GELU), None, self._linear(at, tff1, L.EPI_BIAS_GELU), None
         prev2 = self._linear(hv, vff2, L.EPI_BIAS_DROP_RESID, aux=av32, drop=dvo, out_f32=True)
@@ -331,10 +332,10 @@ class Engine:
                 sc = 1.0 / math.sqrt(D)
                 # FFNs
                 dp, dpd = self._layernorm_bwd(dov, prev2, mv2, rv2, key + ".lnv", dbias=vff2.gb, drop=dvo)
-                duv = self._linear_bwd(dpd, hv, vff2, L.EPI_DGELU, aux=uv, bias_grad=False)
+                duv = self._linear_bwd(dpd, hv, vff2, L.EPI_MUL, aux=uv, bias_grad=False)
                 dav = self._linear_bwd(duv, av, vff1, L.EPI_ADD, aux=dp)
                 dp, dpd = self._layernorm_bwd(dot, pret2, mt2, rt2, key + ".lnt", dbias=tff2.gb, drop=dto)
-                dut = self._linear_bwd(dpd, ht, tff2, L.EPI_DGELU, aux=ut, bias_grad=False)
+                dut = self._linear_bwd(dpd, ht, tff2, L.EPI_MUL, aux=ut, bias_grad=False)
                 dat = self._linear_bwd(dut, at, tff1, L.EPI_ADD, aux=dp)
                 # bi-output
                 dprev, dprevd = self._layernorm_bwd(dav, prev, mv1, rv1, key + ".lnb1", dbias=d1.gb, drop=db1)

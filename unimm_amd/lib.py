@@ -14,7 +14,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libunimm_hip.so")
 ABI_VERSION = 2
 
-EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROP_RESID, EPI_BIAS_RELU, EPI_DGELU, EPI_ADD = range(6)
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROP_RESID, EPI_BIAS_RELU, EPI_DGELU, EPI_ADD, EPI_MUL, EPI_BIAS_GELU_DG = range(8)
 
 _ERR = {-1: "UNIMM_E_ARG", -2: "UNIMM_E_SHAPE", -3: "UNIMM_E_ALIGN", -4: "UNIMM_E_HIP"}
 
@@ -356,7 +356,7 @@ def gather_rows(src, idx, dst, n, H, scatter=False):
 
 GEMM_VARIANTS = {0: "gemm_nt<BIAS,bf16>", 1: "gemm_nt<BIAS,f32>", 2: "gemm_nt<BIAS_GELU,bf16>", 3: "gemm_nt<BIAS_GELU,f32>",
                  5: "gemm_nt<BIAS_DROP_RESID,f32>", 6: "gemm_nt<BIAS_RELU,bf16>", 8: "gemm_nt<DGELU,bf16>",
-                 10: "gemm_nt<ADD,bf16>", 12: "gemm_tn"}
+                 10: "gemm_nt<ADD,bf16>", 12: "gemm_nt<MUL,bf16>", 14: "gemm_nt<BIAS_GELU_DG,bf16>", 16: "gemm_tn"}
 
 
 def prof_enable(on: bool):
@@ -365,7 +365,7 @@ def prof_enable(on: bool):
 
 def prof_collect():
     """-> {variant name: (total_ms, total_flops, launches)} for the launches since prof_enable(True)."""
-    n = 16
+    n = 20
     ms, fl, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_int32 * n)()
     _check(lib().unimm_prof_collect(ms, fl, cnt, C.c_int32(n)), "unimm_prof_collect")
     return {GEMM_VARIANTS.get(i, f"variant{i}"): (ms[i], fl[i], cnt[i]) for i in range(n) if cnt[i] > 0}
