@@ -43,6 +43,8 @@ for (N, K) in [(2304, 768), (768, 768), (3072, 768), (768, 3072)]:
     dw = torch.zeros((N, K), device="cuda")
     t = timeit(lambda: lib.gemm_tn(dy, x, dw))
     fl = 2.0 * M * N * K
-    print(f"TN  N={N:5d} K={K:5d}: {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TFLOP/s")
+    db = torch.zeros(N, device="cuda")
+    tb = timeit(lambda: lib.gemm_tn(dy, x, dw, dbias=db))
+    print(f"TN  N={N:5d} K={K:5d}: {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TFLOP/s   with dbias: {tb*1e6:8.1f} us {fl/tb/1e12:7.1f} TFLOP/s")
     tt = timeit(lambda: torch.matmul(dy.t(), x))
     print(f"    torch matmul         : {tt*1e6:8.1f} us  {fl/tt/1e12:7.1f} TFLOP/s")

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnParams p) {
   for (int t = 0; t < NKT; ++t)
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const float pe = exp2f(s[t][e] * LOG2E - mxl);
+      const float pe = __builtin_amdgcn_exp2f(s[t][e] * LOG2E - mxl);
       s[t][e] = pe;
       sum += pe;
     }
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
       const int key = 32 * t + kk + 4 * h;
       float v = sacc[e] * p.scale;
       v += ((w >> kk) & 1u) ? 0.0f : -10000.0f;
-      const float pe = key < p.Tk ? exp2f(v * LOG2E - lse_l) : 0.f;
+      const float pe = key < p.Tk ? __builtin_amdgcn_exp2f(v * LOG2E - lse_l) : 0.f;
       float dp = dpacc[e];
       if (p.drop.thr != 0u) dp = drop_apply(p.drop, dbase + key, dp);
       ds[e] = pe * (dp - delta) * p.scale;
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
         const uint32_t w = mbase[(size_t)qi * p.mask_q_stride];
         float v = sacc[e] * p.scale;
         v += ((w >> r) & 1u) ? 0.0f : -10000.0f;
-        const float pe = kvalid ? exp2f(v * LOG2E - l4[i]) : 0.f;
+        const float pe = kvalid ? __builtin_amdgcn_exp2f(v * LOG2E - l4[i]) : 0.f;
         float dp = dpacc[e];
         float pdrop = pe;
         if (p.drop.thr != 0u) {

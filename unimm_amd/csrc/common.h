@@ -32,8 +32,11 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   return *reinterpret_cast<bf16_t*>(&b);
 }
 
+// two fp32 -> packed bf16x2 in ONE v_cvt_pk_bf16_f32 (scalar casts + shift/or cost 4 VALU ops per pair)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
 }
 
 // erf to fp32 accuracy (Abramowitz-Stegun 7.1.26, |abs err| <= 1.5e-7) in ~12 VALU ops: one v_rcp, one

@@ -399,13 +399,15 @@ __global__ __launch_bounds__(64 * WN * WK, (WN * WK * (NT == 4 ? 2 : 1) + 3) / 4
         const int c = wk * 64 + j * 16;
         fb[j] = read_frag_tr(tb + (c >> 7) * TN_TILE_BYTES, c & 127, ks * 32, lane);
       }
-      if (valid < TK) {  // ragged tail: zero the A-side elements of rows past the end
+      if (valid < TK) {  // ragged tail: zero the A-side elements of rows past the end (dword-wise AND masks)
         const int rbase = ks * 32 + 8 * (lane >> 4);
+        typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+        u4 keep;
 #pragma unroll
-        for (int i = 0; i < NT; ++i)
+        for (int e2 = 0; e2 < 4; ++e2)
+          keep[e2] = ((rbase + 2 * e2 < valid) ? 0x0000ffffu : 0u) | ((rbase + 2 * e2 + 1 < valid) ? 0xffff0000u : 0u);
 #pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if (rbase + e >= valid) fa[i][e] = (__bf16)0.0f;
+        for (int i = 0; i < NT; ++i) fa[i] = __builtin_bit_cast(bf16x8, __builtin_bit_cast(u4, fa[i]) & keep);
       }
 #pragma unroll
       for (int i = 0; i < NT; ++i)
