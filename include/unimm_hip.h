@@ -94,12 +94,18 @@ int unimm_gemm_tn(const unimm_gemm_tn_args* args, void* stream);
  * mask: bit-packed words [B][rows][ceil(Tk/32)] (unimm_mask_pack); mask_q_stride = 0 broadcasts
  * one row over all queries (key-padding mask).  lse (fp32 [B,H,Tq], log-sum-exp of the masked,
  * scaled scores) is what the backward kernels need; may be NULL for inference.
+ * Variable-length ("unpadded") mode: when q_off/q_len (int32 [B], device) are given, sequence b owns
+ * rows [q_off[b], q_off[b]+q_len[b]) of the packed q / out matrices (same for k_off/k_len and k, v);
+ * Tq / Tk remain the PADDED lengths that index mask, lse and the dropout counters.  Padding rows
+ * (fully masked queries that no valid row attends, models/vilbert_dialog.py:1418) are then never
+ * computed at all.
  * ------------------------------------------------------------------------------------------- */
 typedef struct {
   const void* q; const void* k; const void* v; /* bf16 */
-  void* out;                                   /* bf16 [B*Tq, ldo] */
+  void* out;                                   /* bf16 [rows, ldo] */
   float* lse;
   const uint32_t* mask;
+  const int32_t* q_off; const int32_t* q_len; const int32_t* k_off; const int32_t* k_len; /* or all NULL */
   int32_t B, H, Tq, Tk, D;
   int32_t ldq, ldk, ldv, ldo;
   int32_t mask_q_stride, mask_b_stride; /* in 32-bit words */
@@ -118,6 +124,7 @@ typedef struct {
   const float* lse; float* delta;
   void* dq; void* dk; void* dv; /* bf16 */
   const uint32_t* mask;
+  const int32_t* q_off; const int32_t* q_len; const int32_t* k_off; const int32_t* k_len; /* or all NULL */
   int32_t B, H, Tq, Tk, D;
   int32_t ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
   int32_t mask_q_stride, mask_b_stride;

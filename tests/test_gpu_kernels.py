@@ -290,3 +290,47 @@ def test_kl_and_nsp_losses_against_oracle():
     assert abs(loss.item() - want.item()) < 1e-5
     assert (dz[:, :2].float().cpu() - zt.grad).abs().max() < 2 ** -7 * zt.grad.abs().max()
     assert (dz[:, 2:] == 0).all()
+
+
+def test_attention_variable_length_matches_padded():
+    """Packed (unpadded) q/k/v with per-sequence offsets and lengths == the padded layout on the valid rows."""
+    from unimm_amd import lib
+    B, H, T, D = 3, 2, 256, 64
+    HD = H * D
+    g = torch.Generator(device=DEV).manual_seed(11)
+    lens = [200, 37, 129]
+    qkv = bf(torch.randn((B * T, 3 * HD), generator=g, device=DEV))
+    m = torch.zeros((B, T, T), dtype=torch.bool, device=DEV)
+    for b, l in enumerate(lens):
+        m[b, :l, :l] = torch.rand((l, l), generator=g, device=DEV) < 0.7
+        m[b, :l, 0] = True
+    packed = lib.mask_pack(m)
+    nw = T // 32
+    scale = D ** -0.5
+    out_p = torch.zeros((B * T, HD), device=DEV, dtype=torch.bfloat16)
+    lse_p = torch.zeros((B, H, T), device=DEV)
+    lib.attn_fwd(qkv[:, :HD], qkv[:, HD:2 * HD], qkv[:, 2 * HD:], out_p, lse_p, packed, B, H, T, T, D, scale, nw, T * nw)
+    rows = torch.cat([torch.arange(b * T, b * T + l, device=DEV) for b, l in enumerate(lens)])
+    off = torch.tensor([0, lens[0], lens[0] + lens[1]], dtype=torch.int32, device=DEV)
+    ln = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    qkv_v = qkv[rows].contiguous()
+    out_v = torch.zeros((rows.numel(), HD), device=DEV, dtype=torch.bfloat16)
+    lse_v = torch.zeros((B, H, T), device=DEV)
+    lib.attn_fwd(qkv_v[:, :HD], qkv_v[:, HD:2 * HD], qkv_v[:, 2 * HD:], out_v, lse_v, packed, B, H, T, T, D, scale, nw, T * nw,
+                 qvar=(off, ln), kvar=(off, ln))
+    torch.cuda.synchronize()
+    assert torch.equal(out_v, out_p[rows])
+    dout = bf(torch.randn((B * T, HD), generator=g, device=DEV))
+    keep = torch.zeros(B * T, dtype=torch.bool, device=DEV)
+    keep[rows] = True
+    dout[~keep] = 0                                   # padding rows carry no gradient
+    dqkv_p, dqkv_v = torch.zeros_like(qkv), torch.zeros_like(qkv_v)
+    delta = torch.zeros((B, H, T), device=DEV)
+    lib.attn_bwd(qkv[:, :HD], qkv[:, HD:2 * HD], qkv[:, 2 * HD:], out_p, dout, lse_p, delta, dqkv_p[:, :HD],
+                 dqkv_p[:, HD:2 * HD], dqkv_p[:, 2 * HD:], packed, B, H, T, T, D, scale, nw, T * nw)
+    dout_v = dout[rows].contiguous()
+    lib.attn_bwd(qkv_v[:, :HD], qkv_v[:, HD:2 * HD], qkv_v[:, 2 * HD:], out_v, dout_v, lse_v, delta, dqkv_v[:, :HD],
+                 dqkv_v[:, HD:2 * HD], dqkv_v[:, 2 * HD:], packed, B, H, T, T, D, scale, nw, T * nw,
+                 qvar=(off, ln), kvar=(off, ln))
+    torch.cuda.synchronize()
+    assert relerr(dqkv_v, dqkv_p[rows]) < 1e-2

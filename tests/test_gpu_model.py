@@ -133,13 +133,27 @@ def test_training_mode_dropout_matches_oracle_with_replayed_masks(golden_dir, sm
     model.set_dropout_seed(77, step=4)               # forward() bumps the step to 5
     model.zero_grad(set_to_none=True)
     lm, img, nsp_l, _, _, nsp = model(*args, **kw, _want_lm_scores=False)
+    plan0 = model.engine.last_plan
     (lm + img + nsp_l).sum().backward()
     torch.cuda.synchronize()
+
+    plan = plan0          # the engine ran the text stream on the valid rows only
+    assert plan is not None and plan["Mv"] < g["in::input_ids"].size
+    rows = plan["rows"].cpu()
 
     def drop_fn(site, x, p):
         key = DR.make_key(77, 5, zlib.crc32(site.encode()) & 0xFFFFFFFF)
         _, thr, scale = DR.drop_arg(p, key)
-        keep = torch.from_numpy(DR.keep_mask(key, thr, x.numel()).reshape(tuple(x.shape)))
+        text_rowwise = site == "emb_t" or (site.startswith("bert.encoder.layer.") and site.endswith((".so", ".out"))) \
+            or site.endswith((".bo2", ".tout"))
+        if text_rowwise:                    # element index = packed_row * N + col on the device
+            n = x.shape[-1]
+            keep_p = torch.from_numpy(DR.keep_mask(key, thr, rows.numel() * n).reshape(rows.numel(), n))
+            keep = torch.ones((x.shape[0] * x.shape[1], n), dtype=torch.bool)
+            keep[rows] = keep_p
+            keep = keep.view(x.shape)
+        else:
+            keep = torch.from_numpy(DR.keep_mask(key, thr, x.numel()).reshape(tuple(x.shape)))
         return x * keep * scale
 
     leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != R.TIED[0]}
@@ -198,3 +212,27 @@ def test_full_config_b6_matches_reference_golden(golden_dir):
     assert np.abs(got - want_ll).max() <= 1e-2 * np.abs(want_ll).max(), (got, want_ll)
     from unimm_amd.harness import scores_to_ranks
     assert torch.equal(scores_to_ranks(scores.view(1, 1, -1)).cpu(), R.scores_to_ranks(T_(want_ll).view(1, 1, -1)))
+
+
+def test_unpadded_run_equals_padded_run(golden_dir, small):
+    """The variable-length (valid rows only) schedule and the padded one give the same losses, scores and
+    gradients: padding rows are inert (SURVEY.md 7 'hard parts': they never reach a loss or a valid row)."""
+    model, _, _ = small
+    model.eval()
+    g = np.load(os.path.join(golden_dir, "small_mixed.npz"))
+    args, kw = kwargs_from(g)
+    res = {}
+    for unpad in (True, False):
+        model.engine.unpad = unpad
+        model.zero_grad(set_to_none=True)
+        lm, img, nsp_l, _, _, nsp = model(*args, **kw, _want_lm_scores=False)
+        assert (model.engine.last_plan is not None) == unpad
+        (lm + img + nsp_l).sum().backward()
+        torch.cuda.synchronize()
+        grads = torch.cat([p.grad.flatten() for p in model.parameters() if p.grad is not None]).clone()
+        res[unpad] = (torch.stack([lm, img, nsp_l]).flatten().clone(), nsp.clone(), grads)
+    model.engine.unpad = True
+    assert (res[True][0] - res[False][0]).abs().max() < 2e-3
+    assert (res[True][1] - res[False][1]).abs().max() < 2e-3
+    d = (res[True][2] - res[False][2]).abs().max() / res[False][2].abs().max()
+    assert d < 2e-2, d

@@ -24,6 +24,10 @@ struct AttnParams {
   const bf16_t* q; const bf16_t* k; const bf16_t* v;
   bf16_t* o; float* lse;
   const uint32_t* mask;  // [B][mask rows][nw] words, bit j of word t = key 32t+j may be attended
+  // variable-length ("unpadded") mode: sequence b owns rows [off[b], off[b]+len[b]) of the packed q / kv
+  // matrices; NULL = fixed layout (rows b*T .. b*T+T-1).  Tq/Tk stay the PADDED lengths: they index the
+  // mask, lse and dropout counters, so a packed run reproduces the padded run bit for bit on valid rows.
+  const int* q_off; const int* q_len; const int* k_off; const int* k_len;
   int B, H, Tq, Tk, ldq, ldk, ldv, ldo;
   int mask_q_stride, mask_b_stride;  // in words; q stride 0 = one row per sequence (key padding)
   float scale;
@@ -100,17 +104,21 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnParams p) {
   const int b = blockIdx.x / p.H, head = blockIdx.x % p.H;
   const int r = lane & 31, h = lane >> 5;
 
-  const bf16_t* kg = p.k + (size_t)b * p.Tk * p.ldk + head * D;
-  const bf16_t* vg = p.v + (size_t)b * p.Tk * p.ldv + head * D;
-  stage_head<D>(kg, p.ldk, p.Tk, KPAD, kimg, tid, blockDim.x);
-  stage_head<D>(vg, p.ldv, p.Tk, KPAD, vimg, tid, blockDim.x);
+  const int Tq_b = p.q_len ? p.q_len[b] : p.Tq, Tk_b = p.k_len ? p.k_len[b] : p.Tk;
+  const size_t qbase = p.q_off ? (size_t)p.q_off[b] : (size_t)b * p.Tq;
+  const size_t kbase = p.k_off ? (size_t)p.k_off[b] : (size_t)b * p.Tk;
+  const int kpad_b = ((Tk_b + 31) & ~31) < KPAD ? ((Tk_b + 31) & ~31) : KPAD;   // key tiles past it are skipped
+  const bf16_t* kg = p.k + kbase * p.ldk + head * D;
+  const bf16_t* vg = p.v + kbase * p.ldv + head * D;
+  stage_head<D>(kg, p.ldk, Tk_b, kpad_b, kimg, tid, blockDim.x);
+  stage_head<D>(vg, p.ldv, Tk_b, kpad_b, vimg, tid, blockDim.x);
 
   // Q fragments straight from HBM (each element is used once per key tile, by this wave only)
   const int q0 = wave * 32;
   int qrow = q0 + r;
-  const bool qvalid = qrow < p.Tq;
-  if (!qvalid) qrow = p.Tq - 1;
-  const bf16_t* qg = p.q + ((size_t)b * p.Tq + qrow) * p.ldq + head * D;
+  const bool qvalid = qrow < Tq_b;
+  if (!qvalid) qrow = Tq_b - 1;
+  const bf16_t* qg = p.q + (qbase + qrow) * p.ldq + head * D;
   bf16x8 qf[D / 16];
 #pragma unroll
   for (int ks = 0; ks < D / 16; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qg + 16 * ks + 8 * h);
@@ -123,16 +131,19 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnParams p) {
     for (int t = 0; t < NKT; ++t) mw[t] = mp[t];
   }
   __syncthreads();
+  if (q0 >= Tq_b) return;          // wave-uniform: this wave's query tile is entirely padding
 
-  // ---- S^T = K . Q^T, all key tiles kept in registers
+  // ---- S^T = K . Q^T, all (non-padding) key tiles kept in registers
   f32x16 s[NKT];
 #pragma unroll
   for (int t = 0; t < NKT; ++t) {
     f32x16 acc = {};
+    if (32 * t < Tk_b) {
 #pragma unroll
-    for (int ks = 0; ks < D / 16; ++ks) {
-      const bf16x8 kf = read_row_frag<D>(kimg, 32 * t + r, 2 * ks + h);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], acc, 0, 0, 0);
+      for (int ks = 0; ks < D / 16; ++ks) {
+        const bf16x8 kf = read_row_frag<D>(kimg, 32 * t + r, 2 * ks + h);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], acc, 0, 0, 0);
+      }
     }
     s[t] = acc;
   }
@@ -148,7 +159,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnParams p) {
       const int key = 32 * t + kk + 4 * h;
       float v = s[t][e] * p.scale;
       v += ((w >> kk) & 1u) ? 0.0f : -10000.0f;            // additive mask, fp32 (reference :1418)
-      v = key < p.Tk ? v : -INFINITY;                      // padded keys do not exist
+      v = key < Tk_b ? v : -INFINITY;                      // padded keys do not exist
       s[t][e] = v;
       mx = fmaxf(mx, v);
     }
@@ -181,6 +192,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnParams p) {
   for (int dt = 0; dt < D / 32; ++dt) o[dt] = f32x16{};
 #pragma unroll
   for (int t = 0; t < NKT; ++t) {
+    if (32 * t >= Tk_b) continue;
 #pragma unroll
     for (int ss = 0; ss < 2; ++ss) {
       float pv[8];
@@ -196,7 +208,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnParams p) {
   }
 
   if (qvalid) {
-    bf16_t* og = p.o + ((size_t)b * p.Tq + qrow) * p.ldo + head * D;
+    bf16_t* og = p.o + (qbase + qrow) * p.ldo + head * D;
 #pragma unroll
     for (int dt = 0; dt < D / 32; ++dt)
 #pragma unroll
@@ -220,6 +232,7 @@ struct AttnBwdParams {
   const float* lse; float* delta;
   bf16_t* dq; bf16_t* dk; bf16_t* dv;
   const uint32_t* mask;
+  const int* q_off; const int* q_len; const int* k_off; const int* k_len;
   int B, H, Tq, Tk, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
   int mask_q_stride, mask_b_stride;
   float scale;
@@ -236,13 +249,17 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
   const int b = blockIdx.x / p.H, head = blockIdx.x % p.H;
   const int r = lane & 31, h = lane >> 5;
 
-  stage_head<D>(p.k + (size_t)b * p.Tk * p.ldk + head * D, p.ldk, p.Tk, KPAD, kimg, tid, blockDim.x);
-  stage_head<D>(p.v + (size_t)b * p.Tk * p.ldv + head * D, p.ldv, p.Tk, KPAD, vimg, tid, blockDim.x);
+  const int Tq_b = p.q_len ? p.q_len[b] : p.Tq, Tk_b = p.k_len ? p.k_len[b] : p.Tk;
+  const size_t qbase = p.q_off ? (size_t)p.q_off[b] : (size_t)b * p.Tq;
+  const size_t kbase = p.k_off ? (size_t)p.k_off[b] : (size_t)b * p.Tk;
+  const int kpad_b = ((Tk_b + 31) & ~31) < KPAD ? ((Tk_b + 31) & ~31) : KPAD;
+  stage_head<D>(p.k + kbase * p.ldk + head * D, p.ldk, Tk_b, kpad_b, kimg, tid, blockDim.x);
+  stage_head<D>(p.v + kbase * p.ldv + head * D, p.ldv, Tk_b, kpad_b, vimg, tid, blockDim.x);
 
   int qrow = wave * 32 + r;
-  const bool qvalid = qrow < p.Tq;
-  if (!qvalid) qrow = p.Tq - 1;
-  const size_t grow = (size_t)b * p.Tq + qrow;
+  const bool qvalid = qrow < Tq_b;
+  if (!qvalid) qrow = Tq_b - 1;
+  const size_t grow = qbase + qrow;
   const bf16_t* qg = p.q + grow * p.ldq + head * D;
   const bf16_t* dog = p.dout + grow * p.lddo + head * D;
   const bf16_t* og = p.o + grow * p.ldo + head * D;
@@ -268,6 +285,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
     for (int t = 0; t < NKT; ++t) mw[t] = mp[t];
   }
   __syncthreads();
+  if (wave * 32 >= Tq_b) return;
 
   f32x16 dq[D / 32];
 #pragma unroll
@@ -276,7 +294,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
 
 #pragma unroll
   for (int t = 0; t < NKT; ++t) {
-    if (32 * t >= p.Tk) break;
+    if (32 * t >= Tk_b) break;
     f32x16 sacc = {}, dpacc = {};
 #pragma unroll
     for (int ks = 0; ks < D / 16; ++ks) {
@@ -293,7 +311,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
       const int key = 32 * t + kk + 4 * h;
       float v = sacc[e] * p.scale;
       v += ((w >> kk) & 1u) ? 0.0f : -10000.0f;
-      const float pe = key < p.Tk ? __builtin_amdgcn_exp2f(v * LOG2E - lse_l) : 0.f;
+      const float pe = key < Tk_b ? __builtin_amdgcn_exp2f(v * LOG2E - lse_l) : 0.f;
       float dp = dpacc[e];
       if (p.drop.thr != 0u) dp = drop_apply(p.drop, dbase + key, dp);
       ds[e] = pe * (dp - delta) * p.scale;
@@ -338,18 +356,22 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
   const int b = blockIdx.x / p.H, head = blockIdx.x % p.H;
   const int r = lane & 31, h = lane >> 5;
 
-  stage_head<D>(p.q + (size_t)b * p.Tq * p.ldq + head * D, p.ldq, p.Tq, QPAD, qimg, tid, blockDim.x);
-  stage_head<D>(p.dout + (size_t)b * p.Tq * p.lddo + head * D, p.lddo, p.Tq, QPAD, doimg, tid, blockDim.x);
-  for (int i = tid; i < QPAD; i += blockDim.x) {
+  const int Tq_b = p.q_len ? p.q_len[b] : p.Tq, Tk_b = p.k_len ? p.k_len[b] : p.Tk;
+  const size_t qbase = p.q_off ? (size_t)p.q_off[b] : (size_t)b * p.Tq;
+  const size_t kbase = p.k_off ? (size_t)p.k_off[b] : (size_t)b * p.Tk;
+  const int qpad_b = ((Tq_b + 31) & ~31) < QPAD ? ((Tq_b + 31) & ~31) : QPAD;
+  stage_head<D>(p.q + qbase * p.ldq + head * D, p.ldq, Tq_b, qpad_b, qimg, tid, blockDim.x);
+  stage_head<D>(p.dout + qbase * p.lddo + head * D, p.lddo, Tq_b, qpad_b, doimg, tid, blockDim.x);
+  for (int i = tid; i < qpad_b; i += blockDim.x) {
     const size_t stat = ((size_t)b * p.H + head) * p.Tq + i;
-    lse_s[i] = i < p.Tq ? p.lse[stat] * LOG2E : INFINITY;   // +inf => P = 0 for padded queries
-    del_s[i] = i < p.Tq ? p.delta[stat] : 0.f;
+    lse_s[i] = i < Tq_b ? p.lse[stat] * LOG2E : INFINITY;   // +inf => P = 0 for padded queries
+    del_s[i] = i < Tq_b ? p.delta[stat] : 0.f;
   }
 
   int krow = wave * 32 + r;
-  const bool kvalid = krow < p.Tk;
-  if (!kvalid) krow = p.Tk - 1;
-  const size_t grow = (size_t)b * p.Tk + krow;
+  const bool kvalid = krow < Tk_b;
+  if (!kvalid) krow = Tk_b - 1;
+  const size_t grow = kbase + krow;
   const bf16_t* kg = p.k + grow * p.ldk + head * D;
   const bf16_t* vg = p.v + grow * p.ldv + head * D;
   bf16x8 kf[D / 16], vf[D / 16];
@@ -359,6 +381,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
     vf[ks] = *reinterpret_cast<const bf16x8*>(vg + 16 * ks + 8 * h);
   }
   __syncthreads();
+  if (wave * 32 >= Tk_b) return;
 
   f32x16 dk[D / 32], dv[D / 32];
 #pragma unroll
@@ -368,7 +391,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
 
 #pragma unroll 1
   for (int qt = 0; qt < NQT; ++qt) {
-    if (32 * qt >= p.Tq) break;
+    if (32 * qt >= Tq_b) break;
     f32x16 sacc = {}, dpacc = {};
 #pragma unroll
     for (int ks = 0; ks < D / 16; ++ks) {
@@ -387,7 +410,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
       for (int i = 0; i < 4; ++i) {
         const int e = 4 * g4 + i;
         int qi = qb + i;
-        qi = qi < p.Tq ? qi : p.Tq - 1;
+        qi = qi < Tq_b ? qi : Tq_b - 1;
         const uint32_t w = mbase[(size_t)qi * p.mask_q_stride];
         float v = sacc[e] * p.scale;
         v += ((w >> r) & 1u) ? 0.0f : -10000.0f;
@@ -484,6 +507,8 @@ extern "C" int unimm_attn_fwd(const unimm_attn_args* a, void* stream) {
   AttnParams p;
   p.q = (const bf16_t*)a->q; p.k = (const bf16_t*)a->k; p.v = (const bf16_t*)a->v;
   p.o = (bf16_t*)a->out; p.lse = a->lse; p.mask = a->mask;
+  p.q_off = a->q_off; p.q_len = a->q_len; p.k_off = a->k_off; p.k_len = a->k_len;
+  if ((p.q_off == nullptr) != (p.q_len == nullptr) || (p.k_off == nullptr) != (p.k_len == nullptr)) return UNIMM_E_ARG;
   p.B = a->B; p.H = a->H; p.Tq = a->Tq; p.Tk = a->Tk;
   p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo;
   p.mask_q_stride = a->mask_q_stride; p.mask_b_stride = a->mask_b_stride;
@@ -510,6 +535,8 @@ extern "C" int unimm_attn_bwd(const unimm_attn_bwd_args* a, void* stream) {
   p.q = (const bf16_t*)a->q; p.k = (const bf16_t*)a->k; p.v = (const bf16_t*)a->v; p.o = (const bf16_t*)a->out;
   p.dout = (const bf16_t*)a->dout; p.lse = a->lse; p.delta = a->delta;
   p.dq = (bf16_t*)a->dq; p.dk = (bf16_t*)a->dk; p.dv = (bf16_t*)a->dv; p.mask = a->mask;
+  p.q_off = a->q_off; p.q_len = a->q_len; p.k_off = a->k_off; p.k_len = a->k_len;
+  if ((p.q_off == nullptr) != (p.q_len == nullptr) || (p.k_off == nullptr) != (p.k_len == nullptr)) return UNIMM_E_ARG;
   p.B = a->B; p.H = a->H; p.Tq = a->Tq; p.Tk = a->Tk;
   p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo; p.lddo = a->lddo;
   p.lddq = a->lddq; p.lddk = a->lddk; p.lddv = a->lddv;

@@ -60,6 +60,8 @@ class Engine:
         self.grad_bucket_hook = None     # set by the data-parallel wrapper: f(group_name, lo, hi)
         self._anchor = None
         self.last_seq_t = None
+        self.unpad = True                # run the text stream on valid rows only (see _varlen_plan)
+        self.last_plan = None
 
     # ------------------------------------------------------------------------------------------
     # arenas + bf16 weight copies
@@ -249,14 +251,14 @@ class Engine:
     # ------------------------------------------------------------------------------------------
     # blocks
     # ------------------------------------------------------------------------------------------
-    def _attn(self, q, k, v, mask, B, H, Tq, Tk, D, drop, save):
-        out = torch.empty((B * Tq, H * D), dtype=BF16, device=q.device)
+    def _attn(self, q, k, v, mask, B, H, Tq, Tk, D, drop, save, qvar=None, kvar=None):
+        out = torch.empty((q.shape[0], H * D), dtype=BF16, device=q.device)
         lse = torch.empty((B, H, Tq), dtype=F32, device=q.device) if save else None
         words, mq, mb = mask
-        L.attn_fwd(q, k, v, out, lse, words, B, H, Tq, Tk, D, 1.0 / math.sqrt(D), mq, mb, drop)
+        L.attn_fwd(q, k, v, out, lse, words, B, H, Tq, Tk, D, 1.0 / math.sqrt(D), mq, mb, drop, qvar=qvar, kvar=kvar)
         return out, lse
 
-    def _self_block(self, key, x32, x, mask, B, T, heads, pname, p_attn, p_hid, st):
+    def _self_block(self, key, x32, x, mask, B, T, heads, pname, p_attn, p_hid, st, var=None):
         """BertLayer / BertImageLayer (models/vilbert_dialog.py:385-483, :514-612).
         (x32, x): fp32 residual stream and its bf16 copy (the GEMM operand)."""
         train, tape = st["train"], st["tape"]
@@ -267,7 +269,7 @@ class Engine:
         qkv = self._linear(x, qkv_l)
         q, k, v = qkv[:, :Hd], qkv[:, Hd:2 * Hd], qkv[:, 2 * Hd:]
         d_attn = self._drop(pname + "attn", p_attn, train)
-        ctx, lse = self._attn(q, k, v, mask, B, heads, T, T, D, d_attn, save)
+        ctx, lse = self._attn(q, k, v, mask, B, heads, T, T, D, d_attn, save, qvar=var, kvar=var)
         d_so = self._drop(pname + "so", p_hid, train)
         pre1 = self._linear(ctx, so, L.EPI_BIAS_DROP_RESID, aux=x32, drop=d_so, out_f32=True)
         x1_32, x1, m1, r1 = self._layernorm(pre1, key + ".ln1", save)
@@ -287,12 +289,12 @@ class Engine:
                 delta = torch.empty_like(lse)
                 words, mq, mb = mask
                 L.attn_bwd(q, k, v, ctx, dctx, lse, delta, dqkv[:, :Hd], dqkv[:, Hd:2 * Hd], dqkv[:, 2 * Hd:], words,
-                           B, heads, T, T, D, 1.0 / math.sqrt(D), mq, mb, d_attn)
+                           B, heads, T, T, D, 1.0 / math.sqrt(D), mq, mb, d_attn, qvar=var, kvar=var)
                 return self._linear_bwd(dqkv, x, qkv_l, L.EPI_ADD, aux=dpre1)
             tape.append((key, bwd))
         return x2_32, x2
 
-    def _conn_block(self, key, i, xv32, xv, xt32, xt, B, R, T, vmask, comask, st):
+    def _conn_block(self, key, i, xv32, xv, xt32, xt, B, R, T, vmask, comask, st, var=None):
         """BertConnectionLayer (models/vilbert_dialog.py:655-783)."""
         cfg = self.cfg
         train, tape = st["train"], st["tape"]
@@ -308,8 +310,8 @@ class Engine:
         q2, k2, v2 = qkv2[:, :Hb], qkv2[:, Hb:2 * Hb], qkv2[:, 2 * Hb:]
         da1 = self._drop(pn + "attn1", cfg.v_attention_probs_dropout_prob, train)
         da2 = self._drop(pn + "attn2", cfg.attention_probs_dropout_prob, train)
-        ctx_t, lse_t = self._attn(q2, k1, v1, vmask, B, nh, T, R, D, da1, save)     # text attends regions (:681-698)
-        ctx_v, lse_v = self._attn(q1, k2, v2, comask, B, nh, R, T, D, da2, save)    # regions attend text (:701-721)
+        ctx_t, lse_t = self._attn(q2, k1, v1, vmask, B, nh, T, R, D, da1, save, qvar=var)     # text attends regions (:681-698)
+        ctx_v, lse_v = self._attn(q1, k2, v2, comask, B, nh, R, T, D, da2, save, kvar=var)    # regions attend text (:701-721)
         db1 = self._drop(pn + "bo1", cfg.v_hidden_dropout_prob, train)
         db2 = self._drop(pn + "bo2", cfg.hidden_dropout_prob, train)
         prev = self._linear(ctx_v, d1, L.EPI_BIAS_DROP_RESID, aux=xv32, drop=db1, out_f32=True)   # BertBiOutput (:744-754, call order :775)
@@ -347,10 +349,10 @@ class Engine:
                 delta_t, delta_v = torch.empty_like(lse_t), torch.empty_like(lse_v)
                 w, mq, mb = vmask
                 L.attn_bwd(q2, k1, v1, ctx_t, dctx_t, lse_t, delta_t, dqkv2[:, :Hb], dqkv1[:, Hb:2 * Hb], dqkv1[:, 2 * Hb:],
-                           w, B, nh, T, R, D, sc, mq, mb, da1)
+                           w, B, nh, T, R, D, sc, mq, mb, da1, qvar=var)
                 w, mq, mb = comask
                 L.attn_bwd(q1, k2, v2, ctx_v, dctx_v, lse_v, delta_v, dqkv1[:, :Hb], dqkv2[:, Hb:2 * Hb], dqkv2[:, 2 * Hb:],
-                           w, B, nh, R, T, D, sc, mq, mb, da2)
+                           w, B, nh, R, T, D, sc, mq, mb, da2, kvar=var)
                 dxv = self._linear_bwd(dqkv1, xv, lq1, L.EPI_ADD, aux=dprev)
                 dxt = self._linear_bwd(dqkv2, xt, lq2, L.EPI_ADD, aux=dpret)
                 return dxv, dxt
@@ -373,9 +375,42 @@ class Engine:
         m = m.to(device, non_blocking=True)
         words = L.mask_pack(m)
         nw = words.shape[-1]
+        self._dev_masks.append(m)
         if m.dim() == 2:
             return (words, 0, nw)
         return (words, nw, m.shape[1] * nw)
+
+    def _varlen_plan(self, am, cm, labels, weights, B, T, device):
+        """Valid prefix length of every sequence.  A text row is INERT when no valid row ever attends it
+        (its column of the text mask and of the co-attention mask is empty), it carries no label and it
+        is not the pooled first token: whatever it computes never reaches a loss or a valid row, and its
+        gradient is exactly zero (the reference still spends ~45 % of its token FLOPs there: rows past
+        each dialog's length, models/vilbert_dialog.py:1418 / utils/data_utils.py:207).  The engine runs
+        the text stream on rows [0, len_b) only; returns None when nothing can be dropped."""
+        if am.dim() == 3:
+            valid = am.ne(0).any(dim=1) | am.ne(0).any(dim=2)      # attended as key | attends something
+        else:
+            valid = am.ne(0)
+        valid = valid | cm.ne(0).any(dim=1)
+        if labels is not None:
+            valid = valid | labels.to(device).ne(-1)
+        if weights is not None:
+            valid = valid | weights.to(device).ne(0)
+        idx = torch.arange(1, T + 1, device=device, dtype=torch.int32)
+        lens = (valid.to(torch.int32) * idx).amax(dim=1).clamp_min(1)
+        lens_h = lens.tolist()                                         # one host sync per step
+        Mv = int(sum(lens_h))
+        if Mv == B * T:
+            return None
+        import numpy as np
+        ln = np.asarray(lens_h, dtype=np.int64)
+        off = np.concatenate([[0], np.cumsum(ln)[:-1]])
+        rows = np.concatenate([np.arange(b * T, b * T + l) for b, l in enumerate(lens_h)])
+        inv = np.full(B * T, -1, dtype=np.int64)
+        inv[rows] = np.arange(Mv)
+        return dict(Mv=Mv, lens_h=lens_h, rows=torch.from_numpy(rows).to(device),
+                    inv=torch.from_numpy(inv).to(device), inv_h=inv,
+                    var=(torch.from_numpy(off.astype(np.int32)).to(device), lens.contiguous()))
 
     # ------------------------------------------------------------------------------------------
     # forward
@@ -411,9 +446,18 @@ class Engine:
         if cm is None:
             cm = torch.ones((B, R, T), dtype=torch.uint8, device=dev)
         assert cm.dim() == 3
+        self._dev_masks = []
         tmask = self._pack_mask(am, dev, T)
         vmask = self._pack_mask(im, dev, R)
         comask = self._pack_mask(cm, dev, R)
+        plan = None
+        if self.unpad:
+            plan = self._varlen_plan(self._dev_masks[0], self._dev_masks[2], inp.get("masked_lm_labels"),
+                                     inp.get("lm_weight"), B, T, dev)
+        self._dev_masks = []
+        self.last_plan = plan
+        var = plan["var"] if plan is not None else None
+        Mt = plan["Mv"] if plan is not None else B * T      # text rows actually computed
 
         # ---- embeddings --------------------------------------------------------------------------
         tt = inp.get("token_type_ids")
@@ -422,19 +466,21 @@ class Engine:
         pos = inp.get("position_ids")
         pos32 = self._i32(pos.reshape(-1), dev) if pos is not None else \
             torch.arange(T, dtype=torch.int32, device=dev).repeat(B)
+        if plan is not None:
+            ids32, typ32, pos32 = (t.index_select(0, plan["rows"]) for t in (ids32, typ32, pos32))
         gmm, bta, ggm, gbt = self.ln["emb_t"]
         d_embt = self._drop("emb_t", cfg.hidden_dropout_prob, train)
-        xt = torch.empty((B * T, H), dtype=BF16, device=dev)
-        xt32 = torch.empty((B * T, H), dtype=F32, device=dev)
+        xt = torch.empty((Mt, H), dtype=BF16, device=dev)
+        xt32 = torch.empty((Mt, H), dtype=F32, device=dev)
         tabs = (self.tab["word"], self.tab["pos"], self.tab["type"], self.tab["ext"])
-        L.embed_fwd(ids32, pos32, typ32, *tabs, gmm, bta, xt32, xt, B * T, H, cfg.type_vocab_size, drop=d_embt)
+        L.embed_fwd(ids32, pos32, typ32, *tabs, gmm, bta, xt32, xt, Mt, H, cfg.type_vocab_size, drop=d_embt)
         A = self.arena
         e = "bert.embeddings."
         if save:
             def bwd_embt(dxt):
                 L.embed_bwd(ids32, pos32, typ32, *tabs, gmm, bta, dxt, A.grad(e + "word_embeddings.weight"),
                             A.grad(e + "position_embeddings.weight"), A.grad(e + "token_type_embeddings.weight"),
-                            A.grad(e + "token_type_embeddings_extension.weight"), ggm, gbt, self.part[H], B * T, H,
+                            A.grad(e + "token_type_embeddings_extension.weight"), ggm, gbt, self.part[H], Mt, H,
                             cfg.type_vocab_size, drop=d_embt)
 
         F = cfg.v_feature_size
@@ -461,7 +507,7 @@ class Engine:
         for kind, i in PM.encoder_schedule(cfg):
             if kind == "t":
                 xt32, xt = self._self_block(f"t{i}", xt32, xt, tmask, B, T, cfg.num_attention_heads, f"bert.encoder.layer.{i}.",
-                                      cfg.attention_probs_dropout_prob, cfg.hidden_dropout_prob, st)
+                                      cfg.attention_probs_dropout_prob, cfg.hidden_dropout_prob, st, var=var)
                 if save:
                     tape[-1] = ("t", tape[-1][0], tape[-1][1])
             elif kind == "v":
@@ -470,16 +516,20 @@ class Engine:
                 if save:
                     tape[-1] = ("v", tape[-1][0], tape[-1][1])
             else:
-                xv32, xv, xt32, xt = self._conn_block(f"c{i}", i, xv32, xv, xt32, xt, B, R, T, vmask, comask, st)
+                xv32, xv, xt32, xt = self._conn_block(f"c{i}", i, xv32, xv, xt32, xt, B, R, T, vmask, comask, st, var=var)
                 if save:
                     tape[-1] = ("c", tape[-1][0], tape[-1][1])
         seq_t, seq_v = xt, xv
 
-        out = dict(seq_out_t=seq_t, seq_out_v=seq_v, seq32_t=xt32, seq32_v=xv32, B=B, T=T, R=R)
+        out = dict(seq_out_t=seq_t, seq_out_v=seq_v, seq32_t=xt32, seq32_v=xv32, B=B, T=T, R=R, plan=plan, Mt=Mt)
         # ---- poolers + NSP (models/vilbert_dialog.py:946-967, 1064-1070) -------------------------
         tp, vp, nspl = self.lin["tpool"], self.lin["vpool"], self.lin["nsp"]
-        cls_t = seq_t.view(B, T * H)[:, :H]      # first-token rows, row stride T*H
-        cls_v = seq_v.view(B, R * Hv)[:, :Hv]
+        cls_idx_t = var[0] if var is not None else torch.arange(0, B * T, T, dtype=torch.int32, device=dev)
+        cls_idx_v = torch.arange(0, B * R, R, dtype=torch.int32, device=dev)
+        cls_t = torch.empty((B, H), dtype=BF16, device=dev)        # first-token rows (:949, :964)
+        cls_v = torch.empty((B, Hv), dtype=BF16, device=dev)
+        L.gather_rows(seq_t, cls_idx_t, cls_t, B, H)
+        L.gather_rows(seq_v, cls_idx_v, cls_v, B, Hv)
         pooled_t = self._linear(cls_t, tp, L.EPI_BIAS_RELU, M=B)
         pooled_v = self._linear(cls_v, vp, L.EPI_BIAS_RELU, M=B)
         d_fuse = self._drop("fuse", 0.1, train)
@@ -505,16 +555,17 @@ class Engine:
                 w_sel = torch.ones_like(sel)
             n = int(sel.numel())
             if n > 0:
-                idx = self._i32(sel, dev)
+                pos_idx = self._i32(sel, dev)                     # position in the padded [B*T] layout
+                idx = self._i32(plan["inv"][sel.to(dev)], dev) if plan is not None else pos_idx
                 lab_sel = self._i32(lab_flat[sel], dev)
                 w_sel = self._i32(w_sel, dev)
                 xs = torch.empty((n, H), dtype=BF16, device=dev)
                 L.gather_rows(seq_t, idx, xs, n, H)
                 lm = self._lm_head(xs, n, lab_sel, w_sel, save)
-                lm.update(idx=idx, n=n)
+                lm.update(idx=idx, pos_idx=pos_idx, n=n)
             out["lm"] = lm
         elif lm_rows == "all":
-            out["pred_t"] = self.decode_rows(seq_t, B * T).view(B, T, Vp)[:, :, :V]
+            out["pred_t"] = self.decode_rows(self.padded(out, seq_t), B * T).view(B, T, Vp)[:, :, :V]
 
         # ---- image head (:1001-1005, :1085-1088) + masked KL (:1569-1574) --------------------------
         img = None
@@ -533,8 +584,19 @@ class Engine:
 
         if save:
             out["bwd"] = dict(tape=tape, embt=bwd_embt, embv=bwd_embv, pooled_t=pooled_t, pooled_v=pooled_v, fused=fused,
-                              d_fuse=d_fuse, nsp_pad=nsp, cls_t=cls_t, cls_v=cls_v)
+                              d_fuse=d_fuse, nsp_pad=nsp, cls_t=cls_t, cls_v=cls_v, cls_idx_t=cls_idx_t,
+                              cls_idx_v=cls_idx_v)
         return out
+
+    @staticmethod
+    def padded(out, x):
+        """[rows computed, H] -> the reference's [B*T, H] layout (rows that were never computed are zero)."""
+        plan = out.get("plan")
+        if plan is None:
+            return x
+        full = torch.zeros((out["B"] * out["T"], x.shape[1]), dtype=x.dtype, device=x.device)
+        full.index_copy_(0, plan["rows"], x)
+        return full
 
     def _lm_head(self, xs, n, lab_sel, w_sel, save):
         cfg = self.cfg
@@ -615,7 +677,7 @@ class Engine:
         def gvec(g):
             return torch.zeros(1, dtype=F32, device=dev) if g is None else g.detach().to(F32).reshape(1).contiguous()
 
-        dseq_t = torch.zeros((B * T, H), dtype=BF16, device=dev)
+        dseq_t = torch.zeros((out["Mt"], H), dtype=BF16, device=dev)
         # ---- MLM head ---------------------------------------------------------------------------
         lm = out.get("lm")
         if lm is not None:
@@ -652,11 +714,12 @@ class Engine:
         dfused = self._linear_bwd(dnsp, bw["fused"], nspl, M=B, N=2)
         dpt, dpv = torch.empty_like(dfused), torch.empty_like(dfused)
         L.mul_dropout_bwd(bw["pooled_t"], bw["pooled_v"], dfused, dpt, dpv, dfused.numel(), bw["d_fuse"])
-        # pooler input gradients land on the first-token rows: out = acc + aux, in place on the strided view
-        for dp, lin, cls, dseq, Hd, Tn in ((dpt, tp, bw["cls_t"], dseq_t, H, T), (dpv, vp, bw["cls_v"], dseq_v, Hv, R)):
+        # pooler input gradients land on the first-token rows
+        for dp, lin, cls, dseq, cidx in ((dpt, tp, bw["cls_t"], dseq_t, bw["cls_idx_t"]), (dpv, vp, bw["cls_v"], dseq_v, bw["cls_idx_v"])):
             L.gemm_tn(dp, cls, lin.gw, M=B, N=lin.N, K=lin.K, dbias=lin.gb)
-            dcls = dseq.view(B, Tn * Hd)[:, :Hd]
-            L.gemm_nt(dp, lin.wt, dcls, epilogue=L.EPI_ADD, aux=dcls, M=B, N=lin.K, K=lin.wt.shape[1])
+            dcls = torch.empty((B, lin.K), dtype=BF16, device=dev)
+            L.gemm_nt(dp, lin.wt, dcls, M=B, N=lin.K, K=lin.wt.shape[1])
+            dseq.index_add_(0, cidx.long(), dcls)
         self._bucket_done("heads")
         # ---- encoder blocks in reverse -------------------------------------------------------------
         gt, gv = dseq_t, dseq_v

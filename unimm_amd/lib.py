@@ -12,7 +12,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libunimm_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROP_RESID, EPI_BIAS_RELU, EPI_DGELU, EPI_ADD, EPI_MUL, EPI_BIAS_GELU_DG = range(8)
 
@@ -130,6 +130,7 @@ def gemm_tn(dy, x, dw, M=None, N=None, K=None, dbias=None):
 class AttnArgs(C.Structure):
     _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("out", C.c_void_p),
                 ("lse", C.c_void_p), ("mask", C.c_void_p),
+                ("q_off", C.c_void_p), ("q_len", C.c_void_p), ("k_off", C.c_void_p), ("k_len", C.c_void_p),
                 ("B", C.c_int32), ("H", C.c_int32), ("Tq", C.c_int32), ("Tk", C.c_int32), ("D", C.c_int32),
                 ("ldq", C.c_int32), ("ldk", C.c_int32), ("ldv", C.c_int32), ("ldo", C.c_int32),
                 ("mask_q_stride", C.c_int32), ("mask_b_stride", C.c_int32), ("scale", C.c_float),
@@ -140,6 +141,7 @@ class AttnBwdArgs(C.Structure):
     _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("out", C.c_void_p), ("dout", C.c_void_p),
                 ("lse", C.c_void_p), ("delta", C.c_void_p),
                 ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p), ("mask", C.c_void_p),
+                ("q_off", C.c_void_p), ("q_len", C.c_void_p), ("k_off", C.c_void_p), ("k_len", C.c_void_p),
                 ("B", C.c_int32), ("H", C.c_int32), ("Tq", C.c_int32), ("Tk", C.c_int32), ("D", C.c_int32),
                 ("ldq", C.c_int32), ("ldk", C.c_int32), ("ldv", C.c_int32), ("ldo", C.c_int32), ("lddo", C.c_int32),
                 ("lddq", C.c_int32), ("lddk", C.c_int32), ("lddv", C.c_int32),
@@ -150,11 +152,17 @@ class AttnBwdArgs(C.Structure):
 NO_DROP = (0, 0, 1.0)
 
 
-def attn_fwd(q, k, v, out, lse, mask, B, H, Tq, Tk, D, scale, mask_q_stride, mask_b_stride, drop=NO_DROP):
-    """q/k/v/out: 2-D bf16 views [B*T, >=H*D] (row stride = stride(0)); mask: packed uint32 words."""
+def attn_fwd(q, k, v, out, lse, mask, B, H, Tq, Tk, D, scale, mask_q_stride, mask_b_stride, drop=NO_DROP,
+             qvar=None, kvar=None):
+    """q/k/v/out: 2-D bf16 views [rows, >=H*D] (row stride = stride(0)); mask: packed uint32 words.
+    qvar / kvar: (offsets, lengths) int32 [B] tensors for the variable-length layout, or None."""
     _dev(q, k, v, out, lse, mask)
     a = AttnArgs()
     a.q, a.k, a.v, a.out, a.lse, a.mask = _ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), _ptr(mask)
+    if qvar is not None:
+        a.q_off, a.q_len = _ptr(qvar[0]), _ptr(qvar[1])
+    if kvar is not None:
+        a.k_off, a.k_len = _ptr(kvar[0]), _ptr(kvar[1])
     a.B, a.H, a.Tq, a.Tk, a.D = B, H, Tq, Tk, D
     a.ldq, a.ldk, a.ldv, a.ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
     a.mask_q_stride, a.mask_b_stride, a.scale = mask_q_stride, mask_b_stride, scale
@@ -163,9 +171,13 @@ def attn_fwd(q, k, v, out, lse, mask, B, H, Tq, Tk, D, scale, mask_q_stride, mas
 
 
 def attn_bwd(q, k, v, out, dout, lse, delta, dq, dk, dv, mask, B, H, Tq, Tk, D, scale, mask_q_stride,
-             mask_b_stride, drop=NO_DROP):
+             mask_b_stride, drop=NO_DROP, qvar=None, kvar=None):
     _dev(q, k, v, out, dout, lse, delta, dq, dk, dv, mask)
     a = AttnBwdArgs()
+    if qvar is not None:
+        a.q_off, a.q_len = _ptr(qvar[0]), _ptr(qvar[1])
+    if kvar is not None:
+        a.k_off, a.k_len = _ptr(kvar[0]), _ptr(kvar[1])
     a.q, a.k, a.v, a.out, a.dout = _ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(dout)
     a.lse, a.delta, a.dq, a.dk, a.dv, a.mask = _ptr(lse), _ptr(delta), _ptr(dq), _ptr(dk), _ptr(dv), _ptr(mask)
     a.B, a.H, a.Tq, a.Tk, a.D = B, H, Tq, Tk, D

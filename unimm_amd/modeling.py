@@ -53,7 +53,8 @@ class _HotPath(torch.autograd.Function):
         out = engine.forward(inp, train=opts["train"], save=True, lm_rows="labelled", want_pred_v=True)
         losses = engine.losses(out, inp)
         ctx.engine, ctx.out = engine, out
-        engine.last_seq_t = (out["seq32_t"], out["seq_out_t"])
+        engine.last_seq_t = (engine.padded(out, out["seq32_t"]) if opts["want_seq"] else None,
+                             engine.padded(out, out["seq_out_t"]) if opts["want_seq"] else None)
         nsp = out["nsp"].clone()
         return losses["lm_loss"], losses["img_loss"], losses["nsp_loss"], nsp
 
@@ -139,13 +140,14 @@ class BertForMultiModalPreTraining(nn.Module):
             eng.step += 1
         if train_branch:
             if torch.is_grad_enabled():
-                lm_loss, img_loss, nsp_loss, nsp = _HotPath.apply(eng._anchor, eng, inp, dict(train=self.training))
+                lm_loss, img_loss, nsp_loss, nsp = _HotPath.apply(eng._anchor, eng, inp,
+                                                                  dict(train=self.training, want_seq=_want_lm_scores))
                 seq_raw = eng.last_seq_t
             else:
                 out = eng.forward(inp, train=self.training, save=False, lm_rows="labelled", want_pred_v=True)
                 ls = eng.losses(out, inp)
                 lm_loss, img_loss, nsp_loss, nsp = ls["lm_loss"], ls["img_loss"], ls["nsp_loss"], out["nsp"]
-                seq_raw = (out["seq32_t"], out["seq_out_t"])
+                seq_raw = (eng.padded(out, out["seq32_t"]), eng.padded(out, out["seq_out_t"])) if _want_lm_scores else None
             eng.last_seq_t = None
             seq_t = pred_t = None
             if _want_lm_scores:
@@ -156,7 +158,7 @@ class BertForMultiModalPreTraining(nn.Module):
         with torch.no_grad():
             out = eng.forward(inp, train=self.training, save=False, lm_rows="all" if _want_lm_scores else "none",
                               want_pred_v=_want_pred_v)
-        seq_t = out["seq32_t"].view(B, T, H)
+        seq_t = eng.padded(out, out["seq32_t"]).view(B, T, H)
         return out.get("pred_t"), out.get("pred_v"), out["nsp"], seq_t, ([], [], [])
 
     def _device(self):
@@ -177,7 +179,7 @@ class BertForMultiModalPreTraining(nn.Module):
         lm = out.get("lm")
         if lm is not None:
             from . import lib as L
-            seg = (lm["idx"] // T).to(torch.int32)
+            seg = (lm["pos_idx"] // T).to(torch.int32)
             L.segment_sum(lm["rownll"], seg, scores, lm["n"], -1.0)
             if average:
                 cnt = torch.bincount(seg.long(), minlength=B).clamp_min(1)
