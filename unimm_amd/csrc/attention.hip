@@ -152,6 +152,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnParams p) {
   float mx = -INFINITY;
 #pragma unroll
   for (int t = 0; t < NKT; ++t) {
+    if (32 * t >= Tk_b) continue;                          // (wave-uniform) tile holds padding keys only
     const uint32_t w = mw[t] >> (4 * h);
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -168,22 +169,26 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnParams p) {
   const float mxl = mx * LOG2E;
   float sum = 0.f;
 #pragma unroll
-  for (int t = 0; t < NKT; ++t)
+  for (int t = 0; t < NKT; ++t) {
+    if (32 * t >= Tk_b) continue;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const float pe = __builtin_amdgcn_exp2f(s[t][e] * LOG2E - mxl);
       s[t][e] = pe;
       sum += pe;
     }
+  }
   sum += __shfl_xor(sum, 32, 64);
   const float inv = 1.0f / sum;
 
   if (p.drop.thr != 0u) {
     const uint32_t base = (((uint32_t)b * p.H + head) * p.Tq + (uint32_t)qrow) * (uint32_t)p.Tk;
 #pragma unroll
-    for (int t = 0; t < NKT; ++t)
+    for (int t = 0; t < NKT; ++t) {
+      if (32 * t >= Tk_b) continue;
 #pragma unroll
       for (int e = 0; e < 16; ++e) s[t][e] = drop_apply(p.drop, base + 32 * t + key_of_reg(e, h), s[t][e]);
+    }
   }
 
   // ---- O^T = V^T . P^T
@@ -352,6 +357,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
   char* doimg = smem + QPAD * 2 * D;
   float* lse_s = reinterpret_cast<float*>(smem + 2 * QPAD * 2 * D);
   float* del_s = lse_s + QPAD;
+  uint32_t* mw_s = reinterpret_cast<uint32_t*>(del_s + QPAD);   // [key tile (wave)][query] mask words
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int b = blockIdx.x / p.H, head = blockIdx.x % p.H;
   const int r = lane & 31, h = lane >> 5;
@@ -366,6 +372,15 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
     const size_t stat = ((size_t)b * p.H + head) * p.Tq + i;
     lse_s[i] = i < Tq_b ? p.lse[stat] * LOG2E : INFINITY;   // +inf => P = 0 for padded queries
     del_s[i] = i < Tq_b ? p.delta[stat] : 0.f;
+  }
+  {
+    const int nkt_b = (Tk_b + 31) >> 5;
+    const uint32_t* mb = p.mask + (size_t)b * p.mask_b_stride;
+    for (int i = tid; i < nkt_b * qpad_b; i += blockDim.x) {
+      const int kt = i / qpad_b, qi = i - kt * qpad_b;
+      const int qc = qi < Tq_b ? qi : Tq_b - 1;
+      mw_s[kt * QPAD + qi] = mb[(size_t)qc * p.mask_q_stride + kt];
+    }
   }
 
   int krow = wave * 32 + r;
@@ -386,7 +401,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
   f32x16 dk[D / 32], dv[D / 32];
 #pragma unroll
   for (int dt = 0; dt < D / 32; ++dt) { dk[dt] = f32x16{}; dv[dt] = f32x16{}; }
-  const uint32_t* mbase = p.mask + (size_t)b * p.mask_b_stride + wave;
+  const uint32_t* mrow = mw_s + wave * QPAD;
   const uint32_t hbase = ((uint32_t)b * p.H + head) * (uint32_t)p.Tq;
 
 #pragma unroll 1
@@ -406,14 +421,14 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
       const int qb = 32 * qt + 8 * g4 + 4 * h;   // 4 consecutive queries for registers 4*g4 .. 4*g4+3
       const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qb);
       const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + qb);
+      const u32x4 w4 = *reinterpret_cast<const u32x4*>(mrow + qb);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int e = 4 * g4 + i;
         int qi = qb + i;
         qi = qi < Tq_b ? qi : Tq_b - 1;
-        const uint32_t w = mbase[(size_t)qi * p.mask_q_stride];
         float v = sacc[e] * p.scale;
-        v += ((w >> r) & 1u) ? 0.0f : -10000.0f;
+        v += ((w4[i] >> r) & 1u) ? 0.0f : -10000.0f;
         const float pe = kvalid ? __builtin_amdgcn_exp2f(v * LOG2E - l4[i]) : 0.f;
         float dp = dpacc[e];
         float pdrop = pe;
@@ -477,7 +492,7 @@ int launch_bwd_dq(const AttnBwdParams& p, hipStream_t s) {
 
 template <int D, int NQT>
 int launch_bwd_dkv(const AttnBwdParams& p, hipStream_t s) {
-  const size_t lds = (size_t)2 * NQT * 32 * 2 * D + 2 * NQT * 32 * sizeof(float);
+  const size_t lds = (size_t)2 * NQT * 32 * 2 * D + 2 * NQT * 32 * sizeof(float) + (size_t)8 * NQT * 32 * sizeof(uint32_t);
   auto kern = attn_bwd_dkv_kernel<D, NQT>;
   if (set_lds(kern, lds) != UNIMM_OK) return UNIMM_E_HIP;
   hipLaunchKernelGGL(kern, dim3(p.B * p.H), dim3(((p.Tk + 31) / 32) * 64), lds, s, p);
