@@ -198,6 +198,12 @@ def main():
         achieved = fl / (ms * 1e-3) / 1e12
         gemm_ms = sum(v[0] for v in prof.values())
         gemm_fl = sum(v[1] for v in prof.values())
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "traffic_dominant_kernel.json")
+        if os.path.exists(tpath):          # HBM bytes per launch from the committed rocprofv3 --pmc passes
+            tj = json.load(open(tpath))    # (PMC counters cannot be read from inside the process)
+            if tj.get("kernel") == name:
+                traffic, traffic_src = round(tj["bytes_per_launch_corrected"]), tj["source"]
         f_fwd = F_FWD_BASE_GF + F_DEC_ROW_GF * n_lm_rows / per_gpu     # reference-equivalent (padded to 256 tokens)
         plan = model.engine.last_plan
         valid_rows = plan["Mv"] if plan is not None else per_gpu * 256
@@ -216,7 +222,8 @@ def main():
                        "gflop_per_seq_fwd_padded_equivalent": round(f_fwd, 3),
                        "gemm_gflop_per_seq_executed_fwd_bwd": round(exec_gf_seq, 3), "loss": round(loss_val, 4)},
             "roofline": {"bound": "mfma", "kernel": name, "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE)", "traffic_source": traffic_src,
                          "launches_per_step": cnt // args.steps, "avg_launch_us": round(ms * 1e3 / cnt, 2),
                          "all_gemm_tflops": round(gemm_fl / (gemm_ms * 1e-3) / 1e12, 1),
                          "gemm_share_of_step": round(gemm_ms * 1e-3 / dt, 3),
