@@ -133,6 +133,9 @@ typedef struct {
 } unimm_attn_bwd_args;
 
 int unimm_attn_bwd(const unimm_attn_bwd_args* args, void* stream);
+/* Tuning knob: workgroups per (sequence, head) item of the attention kernels: 0 = automatic, 1 = one
+ * workgroup of up to 8 waves (= 1, the default), 2 = two 4-wave workgroups. */
+int unimm_attn_set_parts(int32_t parts);
 
 /* ---------------------------------------------------------------------------------------------
  * Row kernels (HBM-bound).

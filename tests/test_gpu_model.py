@@ -236,3 +236,44 @@ def test_unpadded_run_equals_padded_run(golden_dir, small):
     assert (res[True][1] - res[False][1]).abs().max() < 2e-3
     d = (res[True][2] - res[False][2]).abs().max() / res[False][2].abs().max()
     assert d < 2e-2, d
+
+
+def test_data_parallel_wrapper_over_rccl_single_rank(golden_dir):
+    """The RCCL path of DataParallelRCCL on a real GPU (1 rank: this pool has one GPU per box): parameter
+    broadcast, per-bucket all-reduce issued from inside backward on the side stream, the join before the
+    optimizer.  With one rank the average is the identity, so gradients must equal the unwrapped run."""
+    import torch.distributed as dist
+    from unimm_amd.parallel import DataParallelRCCL
+    model, _, _ = build_small(golden_dir)
+    model.eval()
+    g = np.load(os.path.join(golden_dir, "small_mixed.npz"))
+    args, kw = kwargs_from(g)
+    model.zero_grad(set_to_none=True)
+    lm, img, nsp_l, _, _, _ = model(*args, **kw, _want_lm_scores=False)
+    (lm + img + nsp_l).sum().backward()
+    torch.cuda.synchronize()
+    want = model.engine.arena.grad_flat.clone()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29571")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        dp = DataParallelRCCL(model, reduce_when_single=True)
+        seen = []
+        orig = dp._reduce_slice
+        dp._reduce_slice = lambda lo, hi: (seen.append((lo, hi)), orig(lo, hi))[1]
+        model.engine.arena.zero_grads()
+        lm, img, nsp_l, _, _, _ = dp(*args, **kw, _want_lm_scores=False)
+        (lm + img + nsp_l).sum().backward()
+        torch.cuda.synchronize()
+        assert len(seen) == len(model.engine.arena.buckets)          # every bucket reduced exactly once, in backward
+        assert sorted(seen) == sorted((lo, hi) for _, lo, hi in model.engine.arena.buckets)
+        got = model.engine.arena.grad_flat
+        assert (got - want).abs().max() <= 1e-2 * want.abs().max()   # fp32 atomics order differs run to run
+        with dp.no_sync():
+            n0 = len(seen)
+            lm, img, nsp_l, _, _, _ = dp(*args, **kw, _want_lm_scores=False)
+            (lm + img + nsp_l).sum().backward()
+            assert len(seen) == n0
+    finally:
+        model.engine.grad_bucket_hook = None
+        dist.destroy_process_group()

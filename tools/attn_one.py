@@ -28,10 +28,12 @@ def run():
     lib.attn_fwd(qkv[:, :HD], qkv[:, HD:2*HD], qkv[:, 2*HD:], out, lse, packed, B, H, T, T, D, D ** -0.5, nw, T * nw, drop, qvar=var, kvar=var)
     lib.attn_bwd(qkv[:, :HD], qkv[:, HD:2*HD], qkv[:, 2*HD:], out, dout, lse, delta, dqkv[:, :HD], dqkv[:, HD:2*HD], dqkv[:, 2*HD:],
                  packed, B, H, T, T, D, D ** -0.5, nw, T * nw, drop, qvar=var, kvar=var)
-for _ in range(3): run()
-torch.cuda.synchronize()
-s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-s.record()
-for _ in range(5): run()
-e.record(); torch.cuda.synchronize()
-print(f"varlen={varlen} rows={Mv} fwd+bwd {s.elapsed_time(e) / 5 * 1e3:.1f} us")
+for parts in (1, 2, 1, 2):
+    lib.attn_set_parts(parts)
+    for _ in range(3): run()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(5): run()
+    e.record(); torch.cuda.synchronize()
+    print(f"varlen={varlen} rows={Mv} parts={parts} fwd+bwd {s.elapsed_time(e) / 5 * 1e3:.1f} us")

@@ -30,6 +30,7 @@ struct AttnParams {
   const int* q_off; const int* q_len; const int* k_off; const int* k_len;
   int B, H, Tq, Tk, ldq, ldk, ldv, ldo;
   int mask_q_stride, mask_b_stride;  // in words; q stride 0 = one row per sequence (key padding)
+  int parts;                          // workgroups per (sequence, head): each owns a contiguous run of 32-row tiles
   float scale;
   DropoutArg drop;
 };
@@ -101,10 +102,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnParams p) {
   char* kimg = smem;
   char* vimg = smem + KPAD * 2 * D;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int b = blockIdx.x / p.H, head = blockIdx.x % p.H;
+  const int item = blockIdx.x / p.parts, part = blockIdx.x % p.parts;
+  const int b = item / p.H, head = item % p.H;
+  const int wt = part * (blockDim.x >> 6) + wave;      // this wave's 32-query tile
   const int r = lane & 31, h = lane >> 5;
 
   const int Tq_b = p.q_len ? p.q_len[b] : p.Tq, Tk_b = p.k_len ? p.k_len[b] : p.Tk;
+  if (part * (int)(blockDim.x >> 6) * 32 >= Tq_b) return;   // whole workgroup is padding: nothing staged
   const size_t qbase = p.q_off ? (size_t)p.q_off[b] : (size_t)b * p.Tq;
   const size_t kbase = p.k_off ? (size_t)p.k_off[b] : (size_t)b * p.Tk;
   const int kpad_b = ((Tk_b + 31) & ~31) < KPAD ? ((Tk_b + 31) & ~31) : KPAD;   // key tiles past it are skipped
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnParams p) {
   stage_head<D>(vg, p.ldv, Tk_b, kpad_b, vimg, tid, blockDim.x);
 
   // Q fragments straight from HBM (each element is used once per key tile, by this wave only)
-  const int q0 = wave * 32;
+  const int q0 = wt * 32;
   int qrow = q0 + r;
   const bool qvalid = qrow < Tq_b;
   if (!qvalid) qrow = Tq_b - 1;
@@ -240,6 +244,7 @@ struct AttnBwdParams {
   const int* q_off; const int* q_len; const int* k_off; const int* k_len;
   int B, H, Tq, Tk, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
   int mask_q_stride, mask_b_stride;
+  int parts;
   float scale;
   DropoutArg drop;
 };
@@ -251,17 +256,20 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
   char* kimg = smem;
   char* vimg = smem + KPAD * 2 * D;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int b = blockIdx.x / p.H, head = blockIdx.x % p.H;
+  const int item = blockIdx.x / p.parts, part = blockIdx.x % p.parts;
+  const int b = item / p.H, head = item % p.H;
+  const int wt = part * (blockDim.x >> 6) + wave;
   const int r = lane & 31, h = lane >> 5;
 
   const int Tq_b = p.q_len ? p.q_len[b] : p.Tq, Tk_b = p.k_len ? p.k_len[b] : p.Tk;
+  if (part * (int)(blockDim.x >> 6) * 32 >= Tq_b) return;
   const size_t qbase = p.q_off ? (size_t)p.q_off[b] : (size_t)b * p.Tq;
   const size_t kbase = p.k_off ? (size_t)p.k_off[b] : (size_t)b * p.Tk;
   const int kpad_b = ((Tk_b + 31) & ~31) < KPAD ? ((Tk_b + 31) & ~31) : KPAD;
   stage_head<D>(p.k + kbase * p.ldk + head * D, p.ldk, Tk_b, kpad_b, kimg, tid, blockDim.x);
   stage_head<D>(p.v + kbase * p.ldv + head * D, p.ldv, Tk_b, kpad_b, vimg, tid, blockDim.x);
 
-  int qrow = wave * 32 + r;
+  int qrow = wt * 32 + r;
   const bool qvalid = qrow < Tq_b;
   if (!qvalid) qrow = Tq_b - 1;
   const size_t grow = qbase + qrow;
@@ -290,7 +298,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
     for (int t = 0; t < NKT; ++t) mw[t] = mp[t];
   }
   __syncthreads();
-  if (wave * 32 >= Tq_b) return;
+  if (wt * 32 >= Tq_b) return;
 
   f32x16 dq[D / 32];
 #pragma unroll
@@ -359,10 +367,13 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
   float* del_s = lse_s + QPAD;
   uint32_t* mw_s = reinterpret_cast<uint32_t*>(del_s + QPAD);   // [key tile (wave)][query] mask words
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int b = blockIdx.x / p.H, head = blockIdx.x % p.H;
+  const int item = blockIdx.x / p.parts, part = blockIdx.x % p.parts;
+  const int b = item / p.H, head = item % p.H;
+  const int wt = part * (blockDim.x >> 6) + wave;      // this wave's 32-key tile
   const int r = lane & 31, h = lane >> 5;
 
   const int Tq_b = p.q_len ? p.q_len[b] : p.Tq, Tk_b = p.k_len ? p.k_len[b] : p.Tk;
+  if (part * (int)(blockDim.x >> 6) * 32 >= Tk_b) return;
   const size_t qbase = p.q_off ? (size_t)p.q_off[b] : (size_t)b * p.Tq;
   const size_t kbase = p.k_off ? (size_t)p.k_off[b] : (size_t)b * p.Tk;
   const int qpad_b = ((Tq_b + 31) & ~31) < QPAD ? ((Tq_b + 31) & ~31) : QPAD;
@@ -383,7 +394,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
     }
   }
 
-  int krow = wave * 32 + r;
+  int krow = wt * 32 + r;
   const bool kvalid = krow < Tk_b;
   if (!kvalid) krow = Tk_b - 1;
   const size_t grow = kbase + krow;
@@ -396,12 +407,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
     vf[ks] = *reinterpret_cast<const bf16x8*>(vg + 16 * ks + 8 * h);
   }
   __syncthreads();
-  if (wave * 32 >= Tk_b) return;
+  if (wt * 32 >= Tk_b) return;
 
   f32x16 dk[D / 32], dv[D / 32];
 #pragma unroll
   for (int dt = 0; dt < D / 32; ++dt) { dk[dt] = f32x16{}; dv[dt] = f32x16{}; }
-  const uint32_t* mrow = mw_s + wave * QPAD;
+  const uint32_t* mrow = mw_s + wt * QPAD;
   const uint32_t hbase = ((uint32_t)b * p.H + head) * (uint32_t)p.Tq;
 
 #pragma unroll 1
@@ -472,6 +483,16 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
   }
 }
 
+// Workgroups per (sequence, head).  Default: one workgroup (up to 8 waves) per item.  Two 4-wave
+// workgroups per item fit two to a CU and overlap each other's staging, but both stage the full K/V
+// (or Q/dO) images: measured 589 vs 545 us for the text fwd+bwd trio, so it stays a tuning knob.
+int g_attn_parts = 0;   // 0 = automatic (unimm_attn_set_parts)
+inline int parts_for(int tiles, size_t lds) {
+  (void)lds;
+  if (g_attn_parts > 0) return tiles > 4 ? g_attn_parts : 1;
+  return 1;
+}
+
 template <typename K>
 int set_lds(K kern, size_t lds) {
   if (lds > 64 * 1024 &&
@@ -485,7 +506,10 @@ int launch_bwd_dq(const AttnBwdParams& p, hipStream_t s) {
   const size_t lds = (size_t)2 * NKT * 32 * 2 * D;
   auto kern = attn_bwd_dq_kernel<D, NKT>;
   if (set_lds(kern, lds) != UNIMM_OK) return UNIMM_E_HIP;
-  hipLaunchKernelGGL(kern, dim3(p.B * p.H), dim3(((p.Tq + 31) / 32) * 64), lds, s, p);
+  AttnBwdParams q = p;
+  const int tiles = (p.Tq + 31) / 32;
+  q.parts = parts_for(tiles, lds);
+  hipLaunchKernelGGL(kern, dim3(p.B * p.H * q.parts), dim3(((tiles + q.parts - 1) / q.parts) * 64), lds, s, q);
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;
 }
@@ -495,7 +519,10 @@ int launch_bwd_dkv(const AttnBwdParams& p, hipStream_t s) {
   const size_t lds = (size_t)2 * NQT * 32 * 2 * D + 2 * NQT * 32 * sizeof(float) + (size_t)8 * NQT * 32 * sizeof(uint32_t);
   auto kern = attn_bwd_dkv_kernel<D, NQT>;
   if (set_lds(kern, lds) != UNIMM_OK) return UNIMM_E_HIP;
-  hipLaunchKernelGGL(kern, dim3(p.B * p.H), dim3(((p.Tk + 31) / 32) * 64), lds, s, p);
+  AttnBwdParams q = p;
+  const int tiles = (p.Tk + 31) / 32;
+  q.parts = parts_for(tiles, lds);
+  hipLaunchKernelGGL(kern, dim3(p.B * p.H * q.parts), dim3(((tiles + q.parts - 1) / q.parts) * 64), lds, s, q);
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;
 }
@@ -506,7 +533,9 @@ int launch_fwd(const AttnParams& p, hipStream_t s) {
   const size_t lds = (size_t)2 * NKT * 32 * 2 * D;
   auto kern = attn_fwd_kernel<D, NKT>;
   if (set_lds(kern, lds) != UNIMM_OK) return UNIMM_E_HIP;
-  hipLaunchKernelGGL(kern, dim3(p.B * p.H), dim3(waves * 64), lds, s, p);
+  AttnParams q = p;
+  q.parts = parts_for(waves, lds);
+  hipLaunchKernelGGL(kern, dim3(p.B * p.H * q.parts), dim3(((waves + q.parts - 1) / q.parts) * 64), lds, s, q);
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;
 }
@@ -566,4 +595,10 @@ extern "C" int unimm_attn_bwd(const unimm_attn_bwd_args* a, void* stream) {
   if (rc != UNIMM_OK) return rc;
   if (a->D == 64) return small_q ? launch_bwd_dkv<64, 2>(p, s) : launch_bwd_dkv<64, 8>(p, s);
   return small_q ? launch_bwd_dkv<128, 2>(p, s) : launch_bwd_dkv<128, 8>(p, s);
+}
+
+extern "C" int unimm_attn_set_parts(int32_t parts) {
+  if (parts < 0 || parts > 2) return UNIMM_E_ARG;
+  g_attn_parts = parts;
+  return UNIMM_OK;
 }

@@ -71,7 +71,7 @@ SYMBOLS = ["unimm_version", "unimm_arch", "unimm_gemm_nt", "unimm_gemm_tn", "uni
            "unimm_embed_fwd", "unimm_embed_bwd", "unimm_colsum", "unimm_cast_f32_bf16", "unimm_transpose_cast",
            "unimm_pack_image", "unimm_mul_dropout", "unimm_mul_dropout_bwd", "unimm_lm_loss_fwd",
            "unimm_lm_loss_bwd", "unimm_kl_loss_fwd", "unimm_kl_loss_bwd", "unimm_nsp_loss_fwd",
-           "unimm_nsp_loss_bwd", "unimm_reduce_sum", "unimm_segment_sum", "unimm_gelu_bwd", "unimm_gather_rows", "unimm_prof_enable", "unimm_prof_collect", "unimm_gemm_set_tile"]
+           "unimm_nsp_loss_bwd", "unimm_reduce_sum", "unimm_segment_sum", "unimm_gelu_bwd", "unimm_gather_rows", "unimm_prof_enable", "unimm_prof_collect", "unimm_gemm_set_tile", "unimm_attn_set_parts"]
 
 
 def _check(rc, what):
@@ -385,3 +385,7 @@ def prof_collect():
 
 def gemm_set_tile(cfg: int):
     _check(lib().unimm_gemm_set_tile(C.c_int32(cfg)), "unimm_gemm_set_tile")
+
+
+def attn_set_parts(parts: int):
+    _check(lib().unimm_attn_set_parts(C.c_int32(parts)), "unimm_attn_set_parts")

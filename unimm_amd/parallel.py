@@ -23,11 +23,12 @@ from .arena import FlatArena
 
 
 class DataParallelRCCL(nn.Module):
-    def __init__(self, module: nn.Module, process_group=None, device=None, broadcast_params=True):
+    def __init__(self, module: nn.Module, process_group=None, device=None, broadcast_params=True, reduce_when_single=False):
         super().__init__()
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self._single_ok = reduce_when_single and dist.is_initialized()   # tests: run the exchange with 1 rank too
         self._sync = True
         self._pending = []
         self._comm_stream = None
@@ -83,7 +84,7 @@ class DataParallelRCCL(nn.Module):
 
     def _on_bucket(self, group):
         """Called by the engine when backward has finished every gradient of one arena group."""
-        if not self._sync or self.world == 1:
+        if not self._sync or (self.world == 1 and not self._single_ok):
             return
         lo, hi = self._ranges[group]
         self._reduce_slice(lo, hi)
@@ -94,7 +95,7 @@ class DataParallelRCCL(nn.Module):
     def sync_gradients(self):
         """Explicit reduction of whatever has not been reduced yet (generic modules without the engine
         hook call this after backward)."""
-        if self.world == 1 or not self._sync:
+        if (self.world == 1 and not self._single_ok) or not self._sync:
             return
         for g, (lo, hi) in self._ranges.items():
             if g not in self._done:
