@@ -47,6 +47,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=240, help="sequences per step (per GPU when --scaling weak)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--workload", choices=["train", "dense", "scoring"], default="train",
+                    help="train = BASELINE configs[1]/[2] (the headline metric); dense = configs[3] micro-step "
+                         "(100 sequences, nsp_loss_coeff 0, gradient accumulation: no exchange inside the step); "
+                         "scoring = configs[4] (val_lm: 1 image = 10 rounds x 100 candidates in 4 chunks of 250, "
+                         "forward + sequence log-likelihood + ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--config", default=os.path.join(ROOT, "unimm_amd", "config", "bert_base_6layer_6conect.json"))
@@ -116,6 +121,85 @@ def cpu_baseline(cfg_path, steps):
                       f"decoder on all 256 rows as the reference computes it), 1 warm-up + {steps} timed steps, {dt:.2f} s/step"}
 
 
+def scoring(args, world, rank, dev, enc, lib, synth, dist):
+    """BASELINE configs[4]: val_lm.py generative scoring.  One step = one image: 10 rounds x 100 candidate answers =
+    1000 sequences, run as 4 chunks of 250 (val_lm.py:104-136, chunk size from the reference's val_lm.log), each chunk a
+    forward + per-sequence log-likelihood on the labelled rows, then ranks per round (utils/visdial_metrics.py:21-39).
+    Ranks process different images (weak scaling, no collective)."""
+    from unimm_amd import harness
+    model = enc.bert_pretrained
+    enc.eval()
+    cfg = model.config
+    chunks = []
+    for c in range(4):                            # gen-mode sequences, no random masking: labels = the answer copy
+        b = synth.make_batch(n_seq=250, cfg=cfg, seed=4321 + 16 * rank + c, device=dev, modes=["gen"] * 250, mask_prob=0.0,
+                             sequences_per_image=250)
+        chunks.append(b)
+    n_rows = sum(int((b["masked_lm_labels"] != -1).sum()) for b in chunks)
+
+    def step():
+        sc = []
+        for b in chunks:
+            s, _ = model.sequence_log_likelihood(b["input_ids"], b["image_feat"], b["image_loc"], b["masked_lm_labels"],
+                                                 token_type_ids=b["token_type_ids"], position_ids=b["token_position_ids"],
+                                                 attention_mask=b["attention_mask"], image_attention_mask=b["image_attention_mask"],
+                                                 co_attention_mask=b["co_attention_mask"])
+            sc.append(s)
+        return harness.scores_to_ranks(torch.cat(sc).view(1, 10, 100))
+
+    log(f"scoring: 4 chunks x 250 sequences ready on {dev}, {n_rows} decoded rows per image")
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    lib.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ranks = step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = lib.prof_collect()
+    lib.prof_enable(False)
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t)
+    value = 1000 * world * args.steps / dt
+    if rank == 0:
+        name, (ms, fl, cnt) = max(prof.items(), key=lambda kv: kv[1][0])
+        gemm_ms = sum(v[0] for v in prof.values())
+        gemm_fl = sum(v[1] for v in prof.values())
+        achieved = fl / (ms * 1e-3) / 1e12
+        f_fwd = F_FWD_BASE_GF + F_DEC_ROW_GF * n_rows / 1000
+        out = {"metric": "candidate dialog-sequences/sec (forward + sequence log-likelihood + ranks) at chunk=250 seq=256 regions=36(+1 <IMG>)",
+               "value": round(value, 2), "unit": "dialog-sequences/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": "val_lm generative scoring (BASELINE configs[4]): 1 image = 10 rounds x 100 candidates per step, "
+                                      "4 chunks of 250 sequences, forward only, row-sparse decoder on the answer-copy rows, "
+                                      "per-sequence log-likelihood, ranks per round",
+                          "global_batch": 1000 * world, "per_gpu_batch": 1000, "chunk": 250, "seq_len": 256, "regions": 37,
+                          "parallelism": f"dp{world}", "lm_rows_decoded_per_seq": round(n_rows / 1000, 2),
+                          "gflop_per_seq_fwd_padded_equivalent": round(f_fwd, 3),
+                          "gemm_gflop_per_seq_executed": round(gemm_fl / args.steps / 1000 / 1e9, 3),
+                          "rank_checksum": int(ranks.sum())},
+               "roofline": {"bound": "mfma", "kernel": name, "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
+                            "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                            "launches_per_step": cnt // args.steps, "avg_launch_us": round(ms * 1e3 / cnt, 2),
+                            "all_gemm_tflops": round(gemm_fl / (gemm_ms * 1e-3) / 1e12, 1),
+                            "gemm_share_of_step": round(gemm_ms * 1e-3 / dt, 3),
+                            "padded_equivalent_tflops": round(f_fwd * 1e9 * value / 1e12, 1)}}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -141,14 +225,22 @@ def main():
     net = DataParallelRCCL(enc, device=dev) if world > 1 else enc
     cfg = model.config
 
+    if args.workload == "scoring":
+        return scoring(args, world, rank, dev, enc, lib, synth, dist)
+    if args.workload == "dense" and args.batch == 240:
+        args.batch = 100                          # dense_annotation_finetuning.py: 1 image x 100 options per micro-step
     per_gpu = args.batch if args.scaling == "weak" else args.batch // world
-    batch = synth.make_batch(n_seq=per_gpu, cfg=cfg, seed=1234 + rank, device=dev)
+    if args.workload == "dense":                  # discriminative inputs, 2 sequences share an image (configs[3])
+        batch = synth.make_batch(n_seq=per_gpu, cfg=cfg, seed=1234 + rank, device=dev, modes=["dis"] * per_gpu,
+                                 sequences_per_image=2)
+        coeff = dict(lm=1.0, nsp=0.0, img=1.0)
+    else:
+        batch = synth.make_batch(n_seq=per_gpu, cfg=cfg, seed=1234 + rank, device=dev)
+        coeff = dict(lm=1.0, nsp=1.0, img=1.0)    # options.py:68-70 defaults
     nsp_w = batch.pop("nsp_weight")
     n_lm_rows = int((batch["lm_weight"] != 0).sum())
-    coeff = dict(lm=1.0, nsp=1.0, img=1.0)        # options.py:68-70 defaults
 
-    def step():
-        model.engine.arena.zero_grads()
+    def fwd_bwd():
         lm, img, nsp = net(batch["input_ids"], batch["image_feat"], batch["image_loc"], sep_indices=batch["sep_indices"],
                            sep_len=batch["sep_len"], token_type_ids=batch["token_type_ids"],
                            token_position_ids=batch["token_position_ids"], attention_mask=batch["attention_mask"],
@@ -159,6 +251,23 @@ def main():
         loss = coeff["lm"] * lm.mean() + coeff["nsp"] * nsp.mean() + coeff["img"] * img.mean()   # train.py:164-168
         loss.backward()
         return loss
+
+    micro = [0]
+
+    def step():
+        if args.workload == "dense":
+            # batch_multiply = 16 (dense_annotation_finetuning.py:299): gradients accumulate over 16 micro-steps
+            # and are exchanged on the 16th only; one bench step = one micro-step.
+            micro[0] += 1
+            last = micro[0] % 16 == 0
+            if micro[0] % 16 == 1:
+                model.engine.arena.zero_grads()
+            if world > 1 and not last:
+                with net.no_sync():
+                    return fwd_bwd()
+            return fwd_bwd()
+        model.engine.arena.zero_grads()
+        return fwd_bwd()
 
     model.engine.ensure(dev)
     model.engine.arena.attach_grads()
@@ -200,7 +309,7 @@ def main():
         gemm_fl = sum(v[1] for v in prof.values())
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_dominant_kernel.json")
-        if os.path.exists(tpath):          # HBM bytes per launch from the committed rocprofv3 --pmc passes
+        if os.path.exists(tpath) and args.workload == "train" and per_gpu == 240:   # HBM bytes per launch from the committed rocprofv3 --pmc passes
             tj = json.load(open(tpath))    # (PMC counters cannot be read from inside the process)
             if tj.get("kernel") == name:
                 traffic, traffic_src = round(tj["bytes_per_launch_corrected"]), tj["source"]
@@ -208,14 +317,22 @@ def main():
         plan = model.engine.last_plan
         valid_rows = plan["Mv"] if plan is not None else per_gpu * 256
         exec_gf_seq = gemm_fl / args.steps / per_gpu / 1e9                # GEMM FLOPs actually executed, fwd+bwd
+        if args.workload == "dense":
+            metric = f"dialog-sequences/sec (fwd+bwd) dense-annotation fine-tune micro-step at bs={per_gpu} seq=256 regions=36(+1 <IMG>)"
+            wl = ("dense-annotation fine-tune micro-step (BASELINE configs[3]): bert_base_6layer_6conect, discriminative inputs, "
+                  "sequences_per_image=2, nsp_loss_coeff=0, batch_multiply=16 (gradient exchange every 16th step), bf16, "
+                  "fwd+bwd, ranking loss and optimizer not included")
+        else:
+            metric = "dialog-sequences/sec (fwd+bwd) at bs=240 seq=256 regions=36(+1 <IMG>)"
+            wl = ("UniMM-UL sparse training step (BASELINE configs[1]): bert_base_6layer_6conect, "
+                  "sequences_per_image=6, num_negative_samples=5, mask_prob=0.15, dropout on, "
+                  "MLM+UL / NSP / region-KL losses, fwd+bwd, optimizer step not included")
         out = {
-            "metric": "dialog-sequences/sec (fwd+bwd) at bs=240 seq=256 regions=36(+1 <IMG>)",
+            "metric": metric,
             "value": round(value, 2), "unit": "dialog-sequences/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "UniMM-UL sparse training step (BASELINE configs[1]): bert_base_6layer_6conect, "
-                                   "sequences_per_image=6, num_negative_samples=5, mask_prob=0.15, dropout on, "
-                                   "MLM+UL / NSP / region-KL losses, fwd+bwd, optimizer step not included",
+            "config": {"workload": wl,
                        "global_batch": per_gpu * world, "per_gpu_batch": per_gpu, "seq_len": 256, "regions": 37,
                        "parallelism": f"dp{world}", "lm_rows_decoded_per_seq": round(n_lm_rows / per_gpu, 2),
                        "valid_token_rows": valid_rows, "token_rows_padded": per_gpu * 256,
