@@ -83,6 +83,11 @@ typedef struct {
 } unimm_gemm_tn_args;
 
 int unimm_gemm_tn(const unimm_gemm_tn_args* args, void* stream);
+/* `count` independent TN problems (host array) in as few grids as possible: the weight gradients of one
+ * encoder block (models/vilbert_dialog.py:386-388, 423-425, 453-454, 466-468 and twins) in one launch.
+ * Same result as `count` calls of unimm_gemm_tn; the problems must not alias each other's dw / dbias
+ * unless they are meant to accumulate (fp32 atomics make that safe). */
+int unimm_gemm_tn_grouped(const unimm_gemm_tn_args* args, int32_t count, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused attention core: out = dropout(softmax(Q K^T * scale + additive(mask))) V per (sequence,

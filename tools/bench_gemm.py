@@ -17,9 +17,9 @@ M = int(sys.argv[1]) if len(sys.argv) > 1 else 61440
 CFGS = [int(c) for c in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["1", "2"])]
 g = torch.Generator(device="cuda").manual_seed(0)
 print(f"M={M}")
-for (N, K, epi) in [(2304, 768, lib.EPI_BIAS), (768, 768, lib.EPI_BIAS_DROP_RESID), (3072, 768, lib.EPI_BIAS_GELU),
-                    (768, 3072, lib.EPI_BIAS_DROP_RESID), (3072, 768, lib.EPI_DGELU), (768, 2304, lib.EPI_ADD),
-                    (768, 3072, lib.EPI_ADD), (768, 1024, lib.EPI_BIAS)]:
+for (N, K, epi) in [(2304, 768, lib.EPI_BIAS), (768, 768, lib.EPI_BIAS_DROP_RESID), (3072, 768, lib.EPI_BIAS_GELU_DG),
+                    (768, 3072, lib.EPI_BIAS_DROP_RESID), (3072, 768, lib.EPI_MUL), (768, 2304, lib.EPI_ADD),
+                    (768, 3072, lib.EPI_ADD), (768, 768, lib.EPI_ADD), (768, 1024, lib.EPI_BIAS)]:
     x = (torch.randn((M, K), generator=g, device="cuda")).to(torch.bfloat16)
     w = (torch.randn((N, K), generator=g, device="cuda") * 0.05).to(torch.bfloat16)
     b = torch.randn(N, device="cuda")
@@ -32,7 +32,7 @@ for (N, K, epi) in [(2304, 768, lib.EPI_BIAS), (768, 768, lib.EPI_BIAS_DROP_RESI
     ax = torch.randn((M, N), device="cuda") if resid else aux
     for cfg in CFGS:
         lib.gemm_set_tile(cfg)
-        t = timeit(lambda: lib.gemm_nt(x, w, o, bias=b, epilogue=epi, aux=ax, out2=out2 if epi == lib.EPI_BIAS_GELU else None))
+        t = timeit(lambda: lib.gemm_nt(x, w, o, bias=b, epilogue=epi, aux=ax, out2=out2 if epi == lib.EPI_BIAS_GELU_DG else None))
         print(f"NT  N={N:5d} K={K:5d} epi={epi} cfg={cfg}: {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TFLOP/s")
     lib.gemm_set_tile(0)
     tt = timeit(lambda: torch.matmul(x, w.t()))

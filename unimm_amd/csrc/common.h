@@ -39,12 +39,12 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
 }
 
-// erf to fp32 accuracy (Abramowitz-Stegun 7.1.26, |abs err| <= 1.5e-7) in ~12 VALU ops: one v_rcp, one
+// erf to fp32 accuracy (Abramowitz-Stegun 7.1.26, |abs err| <= 1.5e-7) in ~12 VALU ops: one v_rcp (the raw 1-ulp instruction: 1/x or __frcp_rn expand to the ~10-instruction IEEE division), one
 // v_exp and a 5-term Horner chain.  The library erff costs ~4x that and dominated the GELU epilogues of
 // the K=768 GEMMs (64 values per lane per tile).
 __device__ __forceinline__ float fast_erf(float x) {
   const float ax = fabsf(x);
-  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
   float p = fmaf(1.061405429f, t, -1.453152027f);
   p = fmaf(p, t, 1.421413741f);
   p = fmaf(p, t, -0.284496736f);
@@ -67,7 +67,7 @@ __device__ __forceinline__ void gelu_and_grad(float x, float& y, float& dy) {
   const float t = x * 0.70710678118654752f;
   const float ax = fabsf(t);
   const float e = __expf(-ax * ax);
-  const float r = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  const float r = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
   float p = fmaf(1.061405429f, r, -1.453152027f);
   p = fmaf(p, r, 1.421413741f);
   p = fmaf(p, r, -0.284496736f);

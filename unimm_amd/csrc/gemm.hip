@@ -90,8 +90,54 @@ __device__ __forceinline__ void stage_step(const GemmNtParams& p, int n0, int m0
   }
 }
 
+// ---- hand-counted LDS fragment reads (see the main loop of gemm_nt_kernel) -------------------------
+template <int OFF> __device__ __forceinline__ bf16x8 lds_read_b128(uint32_t addr) {
+  bf16x8 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+template <int OFF> __device__ __forceinline__ s16x4 lds_read_tr(uint32_t addr) {
+  s16x4 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+// acc + sum of the 8 bf16 elements of a fragment: 4 v_dot2c_f32_bf16 against (1, 1)
+__device__ __forceinline__ float dot_ones(bf16x8 f, float acc) {
+  const bf16x2_t ones2 = {(__bf16)1.0f, (__bf16)1.0f};
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 0, 1), ones2, acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 2, 3), ones2, acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 4, 5), ones2, acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 6, 7), ones2, acc, false);
+  return acc;
+}
+// wait until at most N of this wave's LDS reads are outstanding; `a` is tied to the wait so that no
+// consumer of the fragment can be scheduled above it
+template <int N> __device__ __forceinline__ void lds_wait(bf16x8& a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N)); }
+
+// Issue plan of the fragment pipeline: phase(-1) = [W(0,0..3), X(0), X(1)]; phase(v) = [X(v+2)] +
+// [WPN W fragments of the next sub-step while j = v % MT is in [WP0, WP0 + 4/WPN)], all of which are
+// requested before the first X fragment of that sub-step.  pending(u) = reads requested after X(u)
+// by the time unit u waits for it.
+template <int MT, int KS> struct FragPipe {
+  static constexpr int WP0 = MT == 8 ? 2 : 0, WPN = MT == 8 ? 1 : 2;
+  static constexpr int npref_w(int v) {
+    return (v >= 0 && v / MT + 1 < KS && v % MT >= WP0 && v % MT < WP0 + 4 / WPN) ? WPN : 0;
+  }
+  static constexpr int nx(int v) { return v + 2 < KS * MT ? 1 : 0; }
+  static constexpr int pending(int u) {
+    int c = u >= 2 ? npref_w(u - 2) : (u == 0 ? 1 : 0);
+    for (int v = (u >= 2 ? u - 1 : 0); v <= u; ++v) c += nx(v) + npref_w(v);
+    return c;
+  }
+};
+
+#ifndef UNIMM_EXP
+#define UNIMM_EXP 0   // bottleneck experiments of tools/exp_gemm.cpp; 0 in the product build
+#endif
+
 template <int BK> __device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int row, int chunk) {
-  return *reinterpret_cast<const bf16x8*>(lds_tile + row * (BK * 2) + ((chunk ^ kswz<BK>(row)) << 4));
+  typedef __attribute__((address_space(3))) const bf16x8* lds_frag_ptr;
+  return *(lds_frag_ptr)LDS_PTR(lds_tile + row * (BK * 2) + ((chunk ^ kswz<BK>(row)) << 4));
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -114,6 +160,18 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES) void gemm_nt_kernel(GemmN
 #pragma unroll
     for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // LDS byte addresses of this lane's fragments in ring slot 0, per 32-deep sub-step (the XOR swizzle
+  // makes the second sub-step a second base, not a constant offset)
+  uint32_t aw0[BK / 32], ax0[BK / 32];
+  {
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)LDS_PTR(smem);
+    const int rw = wn * 64 + (lane & 15), rx = wm * 16 * MT + (lane & 15), cq = lane >> 4;
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      aw0[ks] = lds0 + rw * C::ROWB + (((ks * 4 + cq) ^ kswz<BK>(rw)) << 4);
+      ax0[ks] = lds0 + (BN + rx) * C::ROWB + (((ks * 4 + cq) ^ kswz<BK>(rx)) << 4);
+    }
+  }
   const int nk = p.K / BK;
   // prologue: fill S-1 ring slots
 #pragma unroll
@@ -128,10 +186,13 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES) void gemm_nt_kernel(GemmN
     else { if (rem >= 2) wait_vmcnt<2 * G>(); else if (rem == 1) wait_vmcnt<G>(); else wait_vmcnt<0>(); }
     __builtin_amdgcn_s_barrier();            // every wave's loads of step t landed; step t-1 fully read
     __builtin_amdgcn_sched_barrier(0);
+#if UNIMM_EXP != 3                           // (experiment 3: no global->LDS staging inside the loop)
     if (t + S - 1 < nk)                      // refill the slot step t-1 used
       stage_step<C>(p, n0, m0, (t + S - 1) * BK, smem + ((t + S - 1) % S) * C::STAGE_BYTES, wave, lane);
+#endif
     const char* tw = smem + (t % S) * C::STAGE_BYTES;
     const char* tx = tw + BN * C::ROWB;
+#if UNIMM_EXP == 5                           // (experiment 5: the previous, compiler-scheduled fragment loop)
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
       bf16x8 fw[4], fx[MT];
@@ -146,7 +207,62 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES) void gemm_nt_kernel(GemmN
         for (int j = 0; j < MT; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fx[j], acc[i][j], 0, 0, 0);
     }
+#else
+    // Software-pipelined fragment stream.  Left alone, the compiler reads all 12 fragments of a 32-deep
+    // sub-step, waits lgkmcnt(0), and only then issues its 32 MFMAs; the 8 waves of the block run in
+    // lock-step behind the barrier, so the matrix pipes idle while 96 KiB of fragments cross the LDS
+    // array (measured: 1.41 PFLOP/s-equivalent for the MFMA + LDS-read loop alone).  Here a "unit" is
+    // one X fragment (16 rows) against the wave's four W fragments = 4 MFMAs; the X fragment of unit
+    // u+2 and the W fragments of the next 32-deep sub-step are requested while unit u's MFMAs run.
+    // The reads are inline asm with hand-counted s_waitcnt lgkmcnt(N): the compiler's own waitcnt
+    // insertion falls back to lgkmcnt(0) here (the outstanding LDS-DMA loads count as "pending flat"
+    // accesses), which would expose every prefetch again.  LDS returns in order, so waiting for X(u)
+    // also covers every W fragment requested before it.
+    {
+      constexpr int KS = BK / 32, U = KS * MT, RB = C::ROWB;
+      constexpr int WP0 = FragPipe<MT, KS>::WP0, WPN = FragPipe<MT, KS>::WPN;
+      bf16x8 fw[2][4], fx[3];
+      const uint32_t so = (uint32_t)((t % S) * C::STAGE_BYTES);
+      uint32_t aw[KS], ax[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) { aw[ks] = aw0[ks] + so; ax[ks] = ax0[ks] + so; }
+      fw[0][0] = lds_read_b128<0 * 16 * RB>(aw[0]);
+      fw[0][1] = lds_read_b128<1 * 16 * RB>(aw[0]);
+      fw[0][2] = lds_read_b128<2 * 16 * RB>(aw[0]);
+      fw[0][3] = lds_read_b128<3 * 16 * RB>(aw[0]);
+      fx[0] = lds_read_b128<0>(ax[0]);
+      fx[1] = lds_read_b128<16 * RB>(ax[0]);
+#define UNIMM_UNIT(u)                                                                                        \
+      if constexpr ((u) < U) {                                                                               \
+        constexpr int ks_ = (u) / MT, j_ = (u) % MT;                                                         \
+        if constexpr ((u) + 2 < U) fx[((u) + 2) % 3] = lds_read_b128<(((u) + 2) % MT) * 16 * RB>(ax[((u) + 2) / MT]); \
+        if constexpr (FragPipe<MT, KS>::npref_w(u) > 0) {                                                    \
+          constexpr int w_ = (j_ - WP0) * WPN, kn_ = (ks_ + 1 < KS) ? ks_ + 1 : 0;                           \
+          fw[kn_ & 1][w_] = lds_read_b128<w_ * 16 * RB>(aw[kn_]);                                            \
+          if constexpr (WPN == 2) fw[kn_ & 1][w_ + 1] = lds_read_b128<(w_ + 1) * 16 * RB>(aw[kn_]);          \
+        }                                                                                                    \
+        lds_wait<FragPipe<MT, KS>::pending(u)>(fx[(u) % 3]);                                                 \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                        \
+          acc[i][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ks_ & 1][i], fx[(u) % 3], acc[i][j_], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+      }
+      UNIMM_UNIT(0) UNIMM_UNIT(1) UNIMM_UNIT(2) UNIMM_UNIT(3) UNIMM_UNIT(4) UNIMM_UNIT(5) UNIMM_UNIT(6) UNIMM_UNIT(7)
+      UNIMM_UNIT(8) UNIMM_UNIT(9) UNIMM_UNIT(10) UNIMM_UNIT(11) UNIMM_UNIT(12) UNIMM_UNIT(13) UNIMM_UNIT(14) UNIMM_UNIT(15)
+#undef UNIMM_UNIT
+    }
+#endif
   }
+#if UNIMM_EXP == 4                           // (experiment 4: no epilogue; one guarded store keeps acc live)
+  {
+    float sacc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (sacc == 12345.678f) reinterpret_cast<float*>(p.out)[0] = sacc;
+    return;
+  }
+#endif
 
   // ---- epilogue.  The accumulator layout (lane = row m, 4 consecutive n per register quad) would need
   // 16 strided 8-byte stores (+16 such loads of the residual) per lane, which is store-ISSUE bound and
@@ -278,6 +394,16 @@ constexpr int TN_TILE_BYTES = TK * 128 * 2;  // 16 KiB
 struct GemmTnParams {
   const bf16_t* dy; const bf16_t* x; float* dw; float* dbias;
   int M, N, K, lddy, ldx, lddw, rows_per_split;
+  int tile0;   // first tile index of this problem inside a grouped launch
+};
+// A grouped launch: the weight gradients of one encoder block in ONE grid.  Every launch ends with a
+// drain of one fp32 partial tile per resident workgroup (256 x 256 KiB = 67 MB of memory-side atomics,
+// ~43 us, whatever the shape), so a block's 4-10 weight gradients pay that tail once instead of once each,
+// and the bigger tile pool lets the split count land on a whole number of rounds.
+constexpr int TN_MAXG = 12;
+struct GemmTnGroup {
+  int count, total_tiles;
+  GemmTnParams pr[TN_MAXG];
 };
 
 // [64 m][128 c] bf16 tile, 256-B rows = 16 chunks of 16 B.  A transposed read's 32-lane half touches
@@ -342,17 +468,22 @@ __device__ __forceinline__ bf16x8 read_frag_tr(const char* lds_tile, int c16, in
 //   <2,4,8>: 256x256 tile, 8 waves, 128 KiB LDS: half the staged bytes per MFMA, so one m-step of
 //            compute covers twice the load latency (same reasoning as Cfg<2,4,8,64,2> of gemm_nt)
 template <int WN, int WK, int NT>
-__global__ __launch_bounds__(64 * WN * WK, (WN * WK * (NT == 4 ? 2 : 1) + 3) / 4) void gemm_tn_kernel(GemmTnParams p) {
+__global__ __launch_bounds__(64 * WN * WK, (WN * WK * (NT == 4 ? 2 : 1) + 3) / 4) void gemm_tn_kernel(GemmTnGroup grp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NW = WN * WK, TNB = 16 * NT * WN, TKB = 64 * WK;
   constexpr int NSUB_A = TNB / 128, NSUB_B = TKB / 128;
   constexpr int STAGE_BYTES = (NSUB_A + NSUB_B) * TN_TILE_BYTES;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int nbn = (p.N + TNB - 1) / TNB, nbk = (p.K + TKB - 1) / TKB;
-  const int ntile = nbn * nbk;
+  // split-major order: all tiles of one reduction range run together and share its DY / X rows in L2
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
-  const int split = lid / ntile;
-  const int tile = lid - split * ntile;
+  const int split = lid / grp.total_tiles;
+  int tile = lid - split * grp.total_tiles;
+  int gi = 0;
+  for (int i = 1; i < grp.count; ++i) gi = (tile >= grp.pr[i].tile0) ? i : gi;
+  gi = __builtin_amdgcn_readfirstlane(gi);   // wave-uniform: the descriptor is fetched once, into SGPRs
+  const GemmTnParams p = grp.pr[gi];
+  tile -= p.tile0;
+  const int nbk = (p.K + TKB - 1) / TKB;
   const int tn = tile / nbk, tk = tile - tn * nbk;
   const int n0 = tn * TNB, k0 = tk * TKB;
   const int mbeg = split * p.rows_per_split;
@@ -373,6 +504,20 @@ __global__ __launch_bounds__(64 * WN * WK, (WN * WK * (NT == 4 ? 2 : 1) + 3) / 4
 #pragma unroll
   for (int i = 0; i < NT; ++i) accb[i] = 0.f;
 
+  // LDS byte address of this lane's transposed reads in ring slot 0 (see read_frag_tr): rows 8g+q,
+  // element columns 4p..4p+3 of a 16-column fragment; the fragment's column offset c16 enters the 16-byte
+  // chunk field by XOR with the row swizzle, so fragment x of a wave is (base ^ 32x) -- every other term
+  // (sub-tile, 32-row sub-step, +4 rows, ring slot) is a disjoint bit field and goes into the immediate.
+  uint32_t la, lb;
+  {
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int row = 8 * g + q;
+    const uint32_t lc = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)LDS_PTR(smem) +
+                        row * 256 + ((tn_swz(row) | (pp >> 1)) << 4) + (pp & 1) * 8;
+    const int ca = wn * 16 * NT, cb = wk * 64;
+    la = (lc ^ (uint32_t)((ca & 127) * 2)) + (ca >> 7) * TN_TILE_BYTES;
+    lb = (lc ^ (uint32_t)((cb & 127) * 2)) + (NSUB_A + (cb >> 7)) * TN_TILE_BYTES;
+  }
   const int nsteps = (mend - mbeg + TK - 1) / TK;
   stage_step_tn<NW, NSUB_A, NSUB_B>(p, mbeg, mend, n0, k0, smem, wave, lane);
 
@@ -386,40 +531,52 @@ __global__ __launch_bounds__(64 * WN * WK, (WN * WK * (NT == 4 ? 2 : 1) + 3) / 4
     const char* ta = smem + cur * STAGE_BYTES;
     const char* tb = ta + NSUB_A * TN_TILE_BYTES;
     const int valid = mend - mt;  // rows of this step that exist (>= 1); others must contribute 0
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 fa[NT], fb[4];
-#pragma unroll
-      for (int i = 0; i < NT; ++i) {
-        const int c = wn * 16 * NT + i * 16;
-        fa[i] = read_frag_tr(ta + (c >> 7) * TN_TILE_BYTES, c & 127, ks * 32, lane);
+    if (valid < TK) {
+      // Ragged last step of a split: the staged rows past the end are re-reads of the last row.  Zero them
+      // on the DY side (whole 256-byte rows, so the chunk swizzle does not matter) and every product and
+      // column sum they feed is zero.  Kept out of the MFMA path: a second code path over the 128
+      // accumulator registers made the compiler spill them at the join.
+      const int ninv = (TK - valid) * 16 * NSUB_A;          // 16-byte chunks to clear
+      for (int idx = tid; idx < ninv; idx += 64 * NW) {
+        const int sub = idx / ((TK - valid) * 16), rem = idx - sub * ((TK - valid) * 16);
+        *reinterpret_cast<u32x4*>(const_cast<char*>(ta) + sub * TN_TILE_BYTES + (valid + (rem >> 4)) * 256 + (rem & 15) * 16) =
+            u32x4{0u, 0u, 0u, 0u};
       }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int c = wk * 64 + j * 16;
-        fb[j] = read_frag_tr(tb + (c >> 7) * TN_TILE_BYTES, c & 127, ks * 32, lane);
+      __syncthreads();
+    }
+    {
+      // Software-pipelined fragment stream, the same scheme as gemm_nt_kernel's (inline-asm transposed
+      // reads with hand-counted lgkmcnt; a "unit" = one DY fragment against the wave's four X fragments =
+      // 4 MFMAs; the DY fragment of unit u+2 and the X fragments of the next 32-row sub-step are requested
+      // while unit u computes).  Every fragment is two ds_read_b64_tr_b16.
+      typedef __attribute__((ext_vector_type(8))) short s16x8;
+      bf16x8 fb[2][4], fa[3];
+      const uint32_t sa = la + (uint32_t)(cur * STAGE_BYTES), sb = lb + (uint32_t)(cur * STAGE_BYTES);
+#define UNIMM_TR(base, x, ks) __builtin_bit_cast(bf16x8, __builtin_shufflevector(                                 \
+          lds_read_tr<(ks) * 8192>((base) ^ (uint32_t)((x) * 32)), lds_read_tr<(ks) * 8192 + 1024>((base) ^ (uint32_t)((x) * 32)), \
+          0, 1, 2, 3, 4, 5, 6, 7))
+      fb[0][0] = UNIMM_TR(sb, 0, 0); fb[0][1] = UNIMM_TR(sb, 1, 0); fb[0][2] = UNIMM_TR(sb, 2, 0); fb[0][3] = UNIMM_TR(sb, 3, 0);
+      fa[0] = UNIMM_TR(sa, 0, 0);
+      fa[1] = UNIMM_TR(sa, 1, 0);
+#define UNIMM_UNIT(u)                                                                                        \
+      if constexpr ((u) < 2 * NT) {                                                                          \
+        constexpr int ks_ = (u) / NT, i_ = (u) % NT;                                                         \
+        if constexpr ((u) + 2 < 2 * NT) fa[((u) + 2) % 3] = UNIMM_TR(sa, ((u) + 2) % NT, ((u) + 2) / NT);    \
+        if constexpr (FragPipe<NT, 2>::npref_w(u) > 0) {                                                     \
+          constexpr int w_ = (i_ - FragPipe<NT, 2>::WP0) * FragPipe<NT, 2>::WPN;                             \
+          fb[1][w_] = UNIMM_TR(sb, w_, 1);                                                                   \
+          if constexpr (FragPipe<NT, 2>::WPN == 2) fb[1][w_ + 1] = UNIMM_TR(sb, w_ + 1, 1);                  \
+        }                                                                                                    \
+        lds_wait<2 * FragPipe<NT, 2>::pending(u)>(fa[(u) % 3]);                                              \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
+          acc[i_][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[(u) % 3], fb[ks_][j], acc[i_][j], 0, 0, 0); \
+        accb[i_] = dot_ones(fa[(u) % 3], accb[i_]);                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
       }
-      if (valid < TK) {  // ragged tail: zero the A-side elements of rows past the end (dword-wise AND masks)
-        const int rbase = ks * 32 + 8 * (lane >> 4);
-        typedef __attribute__((ext_vector_type(4))) unsigned int u4;
-        u4 keep;
-#pragma unroll
-        for (int e2 = 0; e2 < 4; ++e2)
-          keep[e2] = ((rbase + 2 * e2 < valid) ? 0x0000ffffu : 0u) | ((rbase + 2 * e2 + 1 < valid) ? 0xffff0000u : 0u);
-#pragma unroll
-        for (int i = 0; i < NT; ++i) fa[i] = __builtin_bit_cast(bf16x8, __builtin_bit_cast(u4, fa[i]) & keep);
-      }
-#pragma unroll
-      for (int i = 0; i < NT; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-      if (do_bias) {   // lane holds DY[m = 8*(lane>>4)+e][n = lane&15] of each fragment
-#pragma unroll
-        for (int i = 0; i < NT; ++i)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) accb[i] += (float)fa[i][e];
-      }
+      UNIMM_UNIT(0) UNIMM_UNIT(1) UNIMM_UNIT(2) UNIMM_UNIT(3) UNIMM_UNIT(4) UNIMM_UNIT(5) UNIMM_UNIT(6) UNIMM_UNIT(7)
+      UNIMM_UNIT(8) UNIMM_UNIT(9) UNIMM_UNIT(10) UNIMM_UNIT(11) UNIMM_UNIT(12) UNIMM_UNIT(13) UNIMM_UNIT(14) UNIMM_UNIT(15)
+#undef UNIMM_UNIT
+#undef UNIMM_TR
     }
   }
 
@@ -434,6 +591,17 @@ __global__ __launch_bounds__(64 * WN * WK, (WN * WK * (NT == 4 ? 2 : 1) + 3) / 4
     }
   }
 
+#if UNIMM_EXP == 6                           // (experiment 6: no atomic epilogue; one guarded store keeps acc live)
+  {
+    float sacc = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (sacc == 12345.678f) p.dw[0] = sacc;
+    return;
+  }
+#endif
   // D[n][k]: lane holds k = .. + (lane&15) (column), n = .. + 4*(lane>>4) + e (rows)
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
@@ -553,30 +721,53 @@ extern "C" int unimm_gemm_set_tile(int32_t cfg) {
   return UNIMM_OK;
 }
 
-extern "C" int unimm_gemm_tn(const unimm_gemm_tn_args* a, void* stream) {
-  if (a == nullptr || a->dy == nullptr || a->x == nullptr || a->dw == nullptr) return UNIMM_E_ARG;
+namespace {
+
+int check_tn(const unimm_gemm_tn_args* a) {
+  if (a->dy == nullptr || a->x == nullptr || a->dw == nullptr) return UNIMM_E_ARG;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0) return UNIMM_E_SHAPE;
   if ((a->lddy % 8) || (a->ldx % 8) || a->lddy < a->N || a->ldx < a->K || a->lddw < a->K) return UNIMM_E_ALIGN;
   if (((uintptr_t)a->dy | (uintptr_t)a->x) & 15) return UNIMM_E_ALIGN;
-  GemmTnParams p;
-  p.dy = (const bf16_t*)a->dy; p.x = (const bf16_t*)a->x; p.dw = a->dw; p.dbias = a->dbias;
-  p.M = a->M; p.N = a->N; p.K = a->K; p.lddy = a->lddy; p.ldx = a->ldx; p.lddw = a->lddw;
-  const bool big = a->N >= 256 && a->K >= 256 && a->M >= 4096;
+  return UNIMM_OK;
+}
+
+inline bool tn_is_big(const unimm_gemm_tn_args* a) { return a->N >= 256 && a->K >= 256 && a->M >= 4096; }
+
+// One launch of `count` (<= TN_MAXG) problems that all use the same tile size.
+int launch_tn_group(const unimm_gemm_tn_args* const* a, int count, bool big, hipStream_t s) {
+  GemmTnGroup g;
   const int tb = big ? 256 : 128;
-  const int ntile = ((a->N + tb - 1) / tb) * ((a->K + tb - 1) / tb);
-  // fill the chip with ONE wave of workgroups (256 CUs x 1 or 2 resident workgroups): rounding the
-  // split count UP overshoots the slots and costs a whole second round (270 workgroups ran 2x as long
-  // as 243), so round down; keep >= 512 reduction rows per split
-  int splits = (big ? 256 : 512) / ntile;
-  const int max_splits = (a->M + 511) / 512;
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
-  int rps = (a->M + splits - 1) / splits;
-  rps = ((rps + TK - 1) / TK) * TK;
-  splits = (a->M + rps - 1) / rps;
-  p.rows_per_split = rps;
-  hipStream_t s = (hipStream_t)stream;
-  ProfRec* pr = prof_begin(16, 2.0 * a->M * (double)a->N * a->K, s);
+  int tiles = 0, max_m = 0;
+  double flops = 0.0;
+  for (int i = 0; i < count; ++i) {
+    GemmTnParams& p = g.pr[i];
+    p.dy = (const bf16_t*)a[i]->dy; p.x = (const bf16_t*)a[i]->x; p.dw = a[i]->dw; p.dbias = a[i]->dbias;
+    p.M = a[i]->M; p.N = a[i]->N; p.K = a[i]->K; p.lddy = a[i]->lddy; p.ldx = a[i]->ldx; p.lddw = a[i]->lddw;
+    p.tile0 = tiles;
+    tiles += ((p.N + tb - 1) / tb) * ((p.K + tb - 1) / tb);
+    max_m = p.M > max_m ? p.M : max_m;
+    flops += 2.0 * p.M * (double)p.N * p.K;
+  }
+  g.count = count; g.total_tiles = tiles;
+  // Split the reduction (M) `splits` ways, the same for every problem of the group.  Workgroups run in
+  // rounds of `slots` (256 CUs x 1 or 2 resident); cost ~ rounds(s) / s, so pick the s that wastes the
+  // least of its last round (270 workgroups ran 2x as long as 243), smallest s on ties (fewer partial
+  // tiles to drain), keeping >= 1024 reduction rows per split of the longest problem.
+  const int slots = big ? 256 : 512;
+  int max_s = max_m / 1024;
+  max_s = max_s < 1 ? 1 : (max_s > 32 ? 32 : max_s);
+  int splits = 1;
+  double best = 1e30;
+  for (int sp = 1; sp <= max_s; ++sp) {
+    const int rounds = (tiles * sp + slots - 1) / slots;
+    const double cost = (double)rounds / sp;
+    if (cost < best * 0.98) { best = cost; splits = sp; }
+  }
+  for (int i = 0; i < count; ++i) {
+    int rps = (g.pr[i].M + splits - 1) / splits;
+    g.pr[i].rows_per_split = ((rps + TK - 1) / TK) * TK;
+  }
+  ProfRec* pr = prof_begin(16, flops, s);
   if (big) {
     auto kern = gemm_tn_kernel<2, 4, 8>;
     static bool attr_done = false;
@@ -585,13 +776,48 @@ extern "C" int unimm_gemm_tn(const unimm_gemm_tn_args* a, void* stream) {
         return UNIMM_E_HIP;
       attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(ntile * splits), dim3(512), 8 * TN_TILE_BYTES, s, p);
+    hipLaunchKernelGGL(kern, dim3(tiles * splits), dim3(512), 8 * TN_TILE_BYTES, s, g);
   } else {
-    hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 4>), dim3(ntile * splits), dim3(256), 4 * TN_TILE_BYTES, s, p);
+    hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 4>), dim3(tiles * splits), dim3(256), 4 * TN_TILE_BYTES, s, g);
   }
   prof_end(pr, s);
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;
+}
+
+}  // namespace
+
+extern "C" int unimm_gemm_tn_grouped(const unimm_gemm_tn_args* a, int32_t count, void* stream) {
+  if (a == nullptr || count <= 0) return UNIMM_E_ARG;
+  for (int i = 0; i < count; ++i) {
+    const int rc = check_tn(a + i);
+    if (rc != UNIMM_OK) return rc;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const unimm_gemm_tn_args* sel[TN_MAXG];
+  for (int pass = 0; pass < 2; ++pass) {           // big-tile problems share launches; so do the small ones
+    const bool big = pass == 0;
+    int n = 0;
+    for (int i = 0; i < count; ++i) {
+      if (tn_is_big(a + i) != big) continue;
+      sel[n++] = a + i;
+      if (n == TN_MAXG) {
+        const int rc = launch_tn_group(sel, n, big, s);
+        if (rc != UNIMM_OK) return rc;
+        n = 0;
+      }
+    }
+    if (n > 0) {
+      const int rc = launch_tn_group(sel, n, big, s);
+      if (rc != UNIMM_OK) return rc;
+    }
+  }
+  return UNIMM_OK;
+}
+
+extern "C" int unimm_gemm_tn(const unimm_gemm_tn_args* a, void* stream) {
+  if (a == nullptr) return UNIMM_E_ARG;
+  return unimm_gemm_tn_grouped(a, 1, stream);
 }
 
 extern "C" int unimm_prof_enable(int32_t on) {

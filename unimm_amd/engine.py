@@ -61,8 +61,7 @@ class Engine:
         self._anchor = None
         self.last_seq_t = None
         self.unpad = True                # run the text stream on valid rows only (see _varlen_plan)
-        self.wgrad_stream = False        # option: weight-gradient GEMMs on a side stream (measured: no gain, 72.0 vs 71.7 ms)
-        self._side = None
+        self._wq = []                    # queued weight-gradient problems of the block being back-propagated
         self.last_plan = None
 
     # ------------------------------------------------------------------------------------------
@@ -219,24 +218,15 @@ class Engine:
         return (out, u) if want_u else out
 
     def _wgrad(self, dy, x, gw, M, N, K, dbias=None):
-        """dW += dy^T x (+ bias gradient).  Independent of everything else in the backward chain, so it goes
-        to a side stream: its workgroups fill the partial last rounds, atomic-drain tails and LayerNorm /
-        attention phases of the main stream instead of serialising behind them."""
-        if not self.wgrad_stream:
-            L.gemm_tn(dy, x, gw, M=M, N=N, K=K, dbias=dbias)
-            return
-        main = torch.cuda.current_stream()
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=dy.device)
-        self._side.wait_stream(main)              # dy (and this step's arena memset) are ordered before us
-        with torch.cuda.stream(self._side):
-            L.gemm_tn(dy, x, gw, M=M, N=N, K=K, dbias=dbias)
-        dy.record_stream(self._side)              # keep the caching allocator from recycling them early
-        x.record_stream(self._side)
+        """dW += dy^T x (+ bias gradient).  Nothing downstream in the backward chain reads a weight gradient,
+        so the call is only queued; `_flush_wgrad` (end of each encoder block = one gradient bucket) hands
+        the block's whole list to one grouped launch.  dy / x stay referenced by the queue until then."""
+        self._wq.append((dy, x, gw, M, N, K, dbias))
 
-    def _join_wgrad(self):
-        if self.wgrad_stream and self._side is not None:
-            torch.cuda.current_stream().wait_stream(self._side)
+    def _flush_wgrad(self):
+        if self._wq:
+            L.gemm_tn_grouped(self._wq)
+            self._wq = []
 
     def _linear_bwd(self, dy, x, lin, epi=L.EPI_BIAS, aux=None, need_dx=True, bias_grad=True, M=None, N=None, xk=None):
         """dW += dy^T x ; db += colsum(dy) ; returns dx = epi(dy @ W)."""
@@ -759,8 +749,6 @@ class Engine:
         self._bucket_done("text_embeddings")
 
     def _bucket_done(self, group):
+        self._flush_wgrad()                       # the bucket's queued weight gradients
         if self.grad_bucket_hook is not None:
-            self._join_wgrad()                    # the bucket's weight gradients live on the side stream
             self.grad_bucket_hook(group)
-        elif group == "text_embeddings":          # last group: everything joined before the optimizer
-            self._join_wgrad()

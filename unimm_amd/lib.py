@@ -66,7 +66,7 @@ def lib():
 
 
 # every symbol include/unimm_hip.h declares (tests check the .so exports each of them)
-SYMBOLS = ["unimm_version", "unimm_arch", "unimm_gemm_nt", "unimm_gemm_tn", "unimm_attn_fwd", "unimm_attn_bwd",
+SYMBOLS = ["unimm_version", "unimm_arch", "unimm_gemm_nt", "unimm_gemm_tn", "unimm_gemm_tn_grouped", "unimm_attn_fwd", "unimm_attn_bwd",
            "unimm_mask_pack", "unimm_layernorm_fwd", "unimm_colpartials_bytes", "unimm_layernorm_bwd",
            "unimm_embed_fwd", "unimm_embed_bwd", "unimm_colsum", "unimm_cast_f32_bf16", "unimm_transpose_cast",
            "unimm_pack_image", "unimm_mul_dropout", "unimm_mul_dropout_bwd", "unimm_lm_loss_fwd",
@@ -122,6 +122,23 @@ def gemm_tn(dy, x, dw, M=None, N=None, K=None, dbias=None):
     a.lddy, a.ldx, a.lddw = dy.stride(0), x.stride(0), dw.stride(0)
     _check(lib().unimm_gemm_tn(C.byref(a), _stream()), "unimm_gemm_tn")
     return dw
+
+
+def gemm_tn_grouped(problems):
+    """problems: list of (dy, x, dw, M, N, K, dbias) -- every dw[N,K] += dy[:M,:N]^T @ x[:M,:K] in as few
+    launches as possible (one per <= 12 problems of the same tile class)."""
+    n = len(problems)
+    if n == 0:
+        return
+    arr = (GemmTnArgs * n)()
+    for a, (dy, x, dw, M, N, K, dbias) in zip(arr, problems):
+        _dev(dy, x, dw, dbias)
+        a.dy, a.x, a.dw, a.dbias = dy.data_ptr(), x.data_ptr(), dw.data_ptr(), (dbias.data_ptr() if dbias is not None else None)
+        a.M = dy.shape[0] if M is None else M
+        a.N = dy.shape[1] if N is None else N
+        a.K = x.shape[1] if K is None else K
+        a.lddy, a.ldx, a.lddw = dy.stride(0), x.stride(0), dw.stride(0)
+    _check(lib().unimm_gemm_tn_grouped(arr, C.c_int32(n), _stream()), "unimm_gemm_tn_grouped")
 
 
 # ---------------------------------------------------------------------------------------------
