@@ -130,6 +130,46 @@ def test_gemm_tn(M, N, K):
     assert (db - ref_b).abs().max().item() <= 2e-3 * max(1.0, ref_b.abs().max().item())
 
 
+def test_gemm_tn_grouped_matches_single_launches():
+    """One grouped call over mixed problems (big-tile and small-tile classes, different M, ragged M tails,
+    ragged N/K, a bias gradient on some, two problems accumulating into ONE dw as the tied decoder /
+    embedding weight does) == the same problems one by one == fp32 torch."""
+    from unimm_amd import lib
+    g = torch.Generator(device="cuda").manual_seed(77)
+    shapes = [(9000, 768, 768, True), (9000, 2304, 768, True), (4133, 1024, 1024, False), (9000, 768, 3072, False),
+              (500, 200, 136, True), (37 * 7, 1601, 1024, True), (240, 2, 768, False), (5000, 512, 256, False),
+              (4096, 256, 512, True), (7777, 320, 264, False), (6000, 1024, 768, True), (4100, 768, 1024, False),
+              (8192, 3072, 768, True), (64, 64, 64, False)]            # 14 > 12: the big class needs two launches
+    probs, refs = [], []
+    for (M, N, K, wb) in shapes:
+        dy = torch.zeros((M, (N + 7) // 8 * 8), device="cuda", dtype=torch.bfloat16)
+        x = torch.zeros((M, (K + 7) // 8 * 8), device="cuda", dtype=torch.bfloat16)
+        dy[:, :N] = _rand((M, N), g, 0.5)
+        x[:, :K] = _rand((M, K), g, 0.5)
+        dw = torch.randn((N, K), generator=g, device="cuda")
+        db = torch.randn(N, generator=g, device="cuda") if wb else None
+        refs.append((dw + dy[:, :N].float().t() @ x[:, :K].float(), None if db is None else db + dy[:, :N].float().sum(0)))
+        probs.append((dy, x, dw, M, N, K, db))
+    # shared accumulator: problems 0 and 1' both add into dw of problem 0
+    dy2, x2 = _rand((4500, 768), g, 0.5), _rand((4500, 768), g, 0.5)
+    probs.append((dy2, x2, probs[0][2], 4500, 768, 768, None))
+    refs[0] = (refs[0][0] + dy2.float().t() @ x2.float(), refs[0][1])
+    singles = [(dy, x, dw.clone(), M, N, K, None if db is None else db.clone()) for (dy, x, dw, M, N, K, db) in probs]
+    singles[-1] = singles[-1][:2] + (singles[0][2],) + singles[-1][3:]
+    lib.gemm_tn_grouped(probs)
+    for (dy, x, dw, M, N, K, db) in singles:
+        lib.gemm_tn(dy, x, dw, M=M, N=N, K=K, dbias=db)
+    torch.cuda.synchronize()
+    for (pr, sg, (rw, rb)) in zip(probs, singles, refs):
+        tol = 2e-3 * max(1.0, rw.abs().max().item())
+        assert (pr[2] - rw).abs().max().item() <= tol
+        assert (sg[2] - rw).abs().max().item() <= tol
+        if rb is not None:
+            assert (pr[6] - rb).abs().max().item() <= 2e-3 * max(1.0, rb.abs().max().item())
+    with pytest.raises(lib.UnimmHipError):                   # one bad problem rejects the whole group, nothing launched
+        lib.gemm_tn_grouped([probs[0], (probs[1][0][:, 1:], probs[1][1], probs[1][2], 9000, 2303, 768, None)])
+
+
 def test_gemm_rejects_bad_arguments():
     from unimm_amd import lib
     x = torch.zeros((128, 100), device="cuda", dtype=torch.bfloat16)      # K % 64 != 0

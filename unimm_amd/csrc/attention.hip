@@ -48,18 +48,30 @@ template <int D> __device__ __forceinline__ int swz(int row) {
   else return ((row & 3) << 2) | ((row >> 2) & 3);
 }
 
-// cooperative stage of `nrows_pad` rows of one head (rows >= nrows are zero-filled)
+// Cooperative stage of `nrows_pad` (multiple of 32) rows of one head; rows >= nrows are zero-filled.
+// LDS-DMA: one wave-instruction lands 1 KiB lane-linearly (4 rows of D=128, 8 rows of D=64), so lane l
+// of a group supplies the 16-byte chunk that belongs at physical position l of those rows -- the chunk
+// swizzle is applied on the SOURCE address.  Every load of both images is in flight before the first
+// one returns (the register-staged version paid a load->ds_write round trip per 16 bytes per thread).
+// The caller waits vmcnt(0) before its barrier.
 template <int D>
 __device__ __forceinline__ void stage_head(const bf16_t* __restrict__ g, int ld, int nrows, int nrows_pad,
                                            char* img, int tid, int nthreads) {
-  constexpr int CPR = D / 8;  // chunks per row
-  for (int c = tid; c < nrows_pad * CPR; c += nthreads) {
-    const int row = c / CPR, ch = c % CPR;
-    u32x4 val = {0u, 0u, 0u, 0u};
-    if (row < nrows) val = *reinterpret_cast<const u32x4*>(g + (size_t)row * ld + ch * 8);
-    *reinterpret_cast<u32x4*>(img + row * (2 * D) + ((ch ^ swz<D>(row)) << 4)) = val;
+  constexpr int CPR = D / 8;        // 16-byte chunks per row
+  constexpr int RPI = 64 / CPR;     // rows per wave-instruction
+  const int wave = tid >> 6, lane = tid & 63, nwaves = nthreads >> 6;
+  const int rl = lane / CPR, pc = lane % CPR;
+  for (int grp = wave; grp < nrows_pad / RPI; grp += nwaves) {
+    const int row = grp * RPI + rl;
+    if (row < nrows) {
+      const bf16_t* src = g + (size_t)row * ld + ((pc ^ swz<D>(row)) << 3);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(img + grp * 1024), 16, 0, 0);
+    } else {
+      *reinterpret_cast<u32x4*>(img + grp * 1024 + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+    }
   }
 }
+__device__ __forceinline__ void stage_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 template <int D> __device__ __forceinline__ bf16x8 read_row_frag(const char* img, int row, int chunk) {
   return *reinterpret_cast<const bf16x8*>(img + row * (2 * D) + ((chunk ^ swz<D>(row)) << 4));
@@ -134,6 +146,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
     for (int t = 0; t < NKT; ++t) mw[t] = mp[t];
   }
+  stage_wait();
   __syncthreads();
   if (q0 >= Tq_b) return;          // wave-uniform: this wave's query tile is entirely padding
 
@@ -297,6 +310,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
 #pragma unroll
     for (int t = 0; t < NKT; ++t) mw[t] = mp[t];
   }
+  stage_wait();
   __syncthreads();
   if (wt * 32 >= Tq_b) return;
 
@@ -406,6 +420,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
     kf[ks] = *reinterpret_cast<const bf16x8*>(kg + 16 * ks + 8 * h);
     vf[ks] = *reinterpret_cast<const bf16x8*>(vg + 16 * ks + 8 * h);
   }
+  stage_wait();
   __syncthreads();
   if (wt * 32 >= Tk_b) return;
 
@@ -487,9 +502,18 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
 // workgroups per item fit two to a CU and overlap each other's staging, but both stage the full K/V
 // (or Q/dO) images: measured 589 vs 545 us for the text fwd+bwd trio, so it stays a tuning knob.
 int g_attn_parts = 0;   // 0 = automatic (unimm_attn_set_parts)
+// Threads per workgroup: one wave per 32-row tile that computes, but never fewer than the staging needs.
+// The co-attention direction with 37 region queries (or keys) has 2 compute waves and 2 x 64 KiB of text
+// K/V (or Q/dO) to stage; with 128 threads that is 32 dependent load->ds_write rounds per image.  Extra
+// waves stage, then leave at the per-wave exit right after the barrier.  (g_attn_parts == 99: off, for A/B.)
+inline int block_threads(int tiles_per_part, int staged_rows) {
+  int waves = tiles_per_part;
+  if (g_attn_parts != 99 && staged_rows >= 128 && waves < 8) waves = 8;
+  return waves * 64;
+}
 inline int parts_for(int tiles, size_t lds) {
   (void)lds;
-  if (g_attn_parts > 0) return tiles > 4 ? g_attn_parts : 1;
+  if (g_attn_parts > 0 && g_attn_parts != 99) return tiles > 4 ? g_attn_parts : 1;
   return 1;
 }
 
@@ -509,7 +533,7 @@ int launch_bwd_dq(const AttnBwdParams& p, hipStream_t s) {
   AttnBwdParams q = p;
   const int tiles = (p.Tq + 31) / 32;
   q.parts = parts_for(tiles, lds);
-  hipLaunchKernelGGL(kern, dim3(p.B * p.H * q.parts), dim3(((tiles + q.parts - 1) / q.parts) * 64), lds, s, q);
+  hipLaunchKernelGGL(kern, dim3(p.B * p.H * q.parts), dim3(block_threads((tiles + q.parts - 1) / q.parts, NKT * 32)), lds, s, q);
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;
 }
@@ -522,7 +546,7 @@ int launch_bwd_dkv(const AttnBwdParams& p, hipStream_t s) {
   AttnBwdParams q = p;
   const int tiles = (p.Tk + 31) / 32;
   q.parts = parts_for(tiles, lds);
-  hipLaunchKernelGGL(kern, dim3(p.B * p.H * q.parts), dim3(((tiles + q.parts - 1) / q.parts) * 64), lds, s, q);
+  hipLaunchKernelGGL(kern, dim3(p.B * p.H * q.parts), dim3(block_threads((tiles + q.parts - 1) / q.parts, NQT * 32)), lds, s, q);
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;
 }
@@ -535,7 +559,7 @@ int launch_fwd(const AttnParams& p, hipStream_t s) {
   if (set_lds(kern, lds) != UNIMM_OK) return UNIMM_E_HIP;
   AttnParams q = p;
   q.parts = parts_for(waves, lds);
-  hipLaunchKernelGGL(kern, dim3(p.B * p.H * q.parts), dim3(((waves + q.parts - 1) / q.parts) * 64), lds, s, q);
+  hipLaunchKernelGGL(kern, dim3(p.B * p.H * q.parts), dim3(block_threads((waves + q.parts - 1) / q.parts, NKT * 32)), lds, s, q);
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;
 }
@@ -598,7 +622,7 @@ extern "C" int unimm_attn_bwd(const unimm_attn_bwd_args* a, void* stream) {
 }
 
 extern "C" int unimm_attn_set_parts(int32_t parts) {
-  if (parts < 0 || parts > 2) return UNIMM_E_ARG;
+  if ((parts < 0 || parts > 2) && parts != 99) return UNIMM_E_ARG;
   g_attn_parts = parts;
   return UNIMM_OK;
 }
