@@ -130,6 +130,31 @@ def test_gemm_tn(M, N, K):
     assert (db - ref_b).abs().max().item() <= 2e-3 * max(1.0, ref_b.abs().max().item())
 
 
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("M,N,K", [(300, 200, 64), (1000, 1000, 768), (515, 2304, 128), (4096, 768, 3072), (257, 257 * 3, 320)])
+def test_gemm_nt_every_tile_configuration(cfg, M, N, K):
+    """All block-tile / ring configurations of unimm_gemm_nt give the same result (the automatic choice only
+    covers some of them at a given shape): ragged M and N, K from 2 to 96 ring steps, fp32 residual epilogue."""
+    from unimm_amd import lib
+    g = torch.Generator(device="cuda").manual_seed(M + 3 * N + K)
+    x, w = _rand((M, K), g), _rand((N, K), g, 0.05)
+    bias = torch.randn(N, generator=g, device="cuda")
+    ldo = (N + 7) // 8 * 8
+    resid = torch.randn((M, ldo), generator=g, device="cuda")
+    ref = x.float() @ w.float().t() + bias + resid[:, :N]
+    out = torch.full((M, ldo), float("nan"), device="cuda")
+    lib.gemm_set_tile(cfg)
+    try:
+        lib.gemm_nt(x, w, out, bias=bias, epilogue=lib.EPI_BIAS_DROP_RESID, aux=resid, N=N)
+        torch.cuda.synchronize()
+    finally:
+        lib.gemm_set_tile(0)
+    err = (out[:, :N] - ref).abs().max().item()
+    assert err <= 2e-3 * max(1.0, ref.abs().max().item()), err
+    if ldo > N:
+        assert torch.isnan(out[:, N:]).all()
+
+
 def test_gemm_tn_grouped_matches_single_launches():
     """One grouped call over mixed problems (big-tile and small-tile classes, different M, ragged M tails,
     ragged N/K, a bias gradient on some, two problems accumulating into ONE dw as the tied decoder /

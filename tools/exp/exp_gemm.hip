@@ -12,9 +12,9 @@ int main(int argc, char** argv) {
   void *x, *w, *bias, *aux, *out, *out2;
   hipMalloc(&x, (size_t)M * K * 2); hipMalloc(&w, (size_t)N * K * 2); hipMalloc(&bias, N * 4);
   hipMalloc(&aux, (size_t)M * N * 4); hipMalloc(&out, (size_t)M * N * 4); hipMalloc(&out2, (size_t)M * N * 2);
-  std::vector<uint16_t> h((size_t)M * K);
+  std::vector<uint16_t> h((size_t)(M > N ? M : N) * K);
   for (size_t i = 0; i < h.size(); ++i) h[i] = 0x3c00 + (rand() & 0x1ff);   // small positive bf16 values
-  hipMemcpy(x, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+  hipMemcpy(x, h.data(), (size_t)M * K * 2, hipMemcpyHostToDevice);
   hipMemcpy(w, h.data(), (size_t)N * K * 2, hipMemcpyHostToDevice);
   hipMemset(bias, 0, N * 4); hipMemset(aux, 0, (size_t)M * N * 4);
   unimm_gemm_nt_args a{};
@@ -42,7 +42,7 @@ int main(int argc, char** argv) {
     return 0;
   }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int i = 0; i < 3; ++i) if (unimm_gemm_nt(&a, nullptr) != 0) { printf("launch failed\n"); return 1; }
+  for (int i = 0; i < 3; ++i) { int rc = unimm_gemm_nt(&a, nullptr); if (rc != 0) { printf("launch failed rc=%d hip=%s\n", rc, hipGetErrorString(hipGetLastError())); return 1; } }
   hipDeviceSynchronize();
   hipEventRecord(e0, nullptr);
   const int it = 20;

@@ -70,24 +70,26 @@ template <int BK> __device__ __forceinline__ int kswz(int row) { return BK == 64
 // Stage one K-step of the block's [W tile (BN rows) | X tile (BM rows)] x BK bf16 into LDS by LDS-DMA:
 // 1 KiB per wave-instruction, lane-linear image, swizzle applied on the source side.
 template <class C>
-__device__ __forceinline__ void stage_step(const GemmNtParams& p, int n0, int m0, int k0, char* stage, int wave, int lane) {
+__device__ __forceinline__ void stage_one(const GemmNtParams& p, int n0, int m0, int k0, char* stage, int wave, int lane, int r) {
   constexpr int CPR = C::ROWB / 16;   // chunks per row
-#pragma unroll
-  for (int r = 0; r < C::G; ++r) {
-    const int rr = (r * C::NW + wave) * C::RPI + lane / CPR;   // row in the concatenated tile
-    const int chunk = (lane % CPR) ^ kswz<C::BK>(rr);
-    const bf16_t* src;
-    if (rr < C::BN) {
-      int g = n0 + rr;
-      g = g < p.N ? g : p.N - 1;     // edge rows re-read a valid row; their outputs are never stored
-      src = p.w + (size_t)g * p.ldw + k0 + chunk * 8;
-    } else {
-      int g = m0 + rr - C::BN;
-      g = g < p.M ? g : p.M - 1;
-      src = p.x + (size_t)g * p.ldx + k0 + chunk * 8;
-    }
-    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(stage + (r * C::NW + wave) * 1024), 16, 0, 0);
+  const int rr = (r * C::NW + wave) * C::RPI + lane / CPR;   // row in the concatenated tile
+  const int chunk = (lane % CPR) ^ kswz<C::BK>(rr);
+  const bf16_t* src;
+  if (rr < C::BN) {
+    int g = n0 + rr;
+    g = g < p.N ? g : p.N - 1;     // edge rows re-read a valid row; their outputs are never stored
+    src = p.w + (size_t)g * p.ldw + k0 + chunk * 8;
+  } else {
+    int g = m0 + rr - C::BN;
+    g = g < p.M ? g : p.M - 1;
+    src = p.x + (size_t)g * p.ldx + k0 + chunk * 8;
   }
+  __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(stage + (r * C::NW + wave) * 1024), 16, 0, 0);
+}
+template <class C>
+__device__ __forceinline__ void stage_step(const GemmNtParams& p, int n0, int m0, int k0, char* stage, int wave, int lane) {
+#pragma unroll
+  for (int r = 0; r < C::G; ++r) stage_one<C>(p, n0, m0, k0, stage, wave, lane, r);
 }
 
 // ---- hand-counted LDS fragment reads (see the main loop of gemm_nt_kernel) -------------------------
@@ -142,128 +144,12 @@ template <int BK> __device__ __forceinline__ bf16x8 read_frag(const char* lds_ti
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// Shared epilogue of the NT kernels (inlined): bias / activation / residual / dropout on the wave's
+// [16*MT rows][64 columns] accumulator tile, stored row-contiguously.
 template <class C, int EPI, bool OUT_F32>
-__global__ __launch_bounds__(C::THREADS, C::MIN_WAVES) void gemm_nt_kernel(GemmNtParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int BM = C::BM, BN = C::BN, BK = C::BK, S = C::STAGES, G = C::G, MT = C::MT;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
-  const int lid = xcd_remap(blockIdx.x, gridDim.x);
-  int tm, tn;
-  tile_of(lid, nbm, nbn, p.gn, tm, tn);
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int wm = wave / C::WN, wn = wave % C::WN;
-
-  f32x4 acc[4][MT];  // [n-subtile i][m-subtile j]
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // LDS byte addresses of this lane's fragments in ring slot 0, per 32-deep sub-step (the XOR swizzle
-  // makes the second sub-step a second base, not a constant offset)
-  uint32_t aw0[BK / 32], ax0[BK / 32];
-  {
-    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)LDS_PTR(smem);
-    const int rw = wn * 64 + (lane & 15), rx = wm * 16 * MT + (lane & 15), cq = lane >> 4;
-#pragma unroll
-    for (int ks = 0; ks < BK / 32; ++ks) {
-      aw0[ks] = lds0 + rw * C::ROWB + (((ks * 4 + cq) ^ kswz<BK>(rw)) << 4);
-      ax0[ks] = lds0 + (BN + rx) * C::ROWB + (((ks * 4 + cq) ^ kswz<BK>(rx)) << 4);
-    }
-  }
-  const int nk = p.K / BK;
-  // prologue: fill S-1 ring slots
-#pragma unroll
-  for (int s = 0; s < S - 1; ++s)
-    if (s < nk) stage_step<C>(p, n0, m0, s * BK, smem + s * C::STAGE_BYTES, wave, lane);
-
-  for (int t = 0; t < nk; ++t) {
-    // K-step t has landed once at most min(S-2, nk-1-t) younger steps are still in flight
-    const int rem = nk - 1 - t;
-    if constexpr (S == 2) wait_vmcnt<0>();
-    else if constexpr (S == 3) { if (rem >= 1) wait_vmcnt<G>(); else wait_vmcnt<0>(); }
-    else { if (rem >= 2) wait_vmcnt<2 * G>(); else if (rem == 1) wait_vmcnt<G>(); else wait_vmcnt<0>(); }
-    __builtin_amdgcn_s_barrier();            // every wave's loads of step t landed; step t-1 fully read
-    __builtin_amdgcn_sched_barrier(0);
-#if UNIMM_EXP != 3                           // (experiment 3: no global->LDS staging inside the loop)
-    if (t + S - 1 < nk)                      // refill the slot step t-1 used
-      stage_step<C>(p, n0, m0, (t + S - 1) * BK, smem + ((t + S - 1) % S) * C::STAGE_BYTES, wave, lane);
-#endif
-    const char* tw = smem + (t % S) * C::STAGE_BYTES;
-    const char* tx = tw + BN * C::ROWB;
-#if UNIMM_EXP == 5                           // (experiment 5: the previous, compiler-scheduled fragment loop)
-#pragma unroll
-    for (int ks = 0; ks < BK / 32; ++ks) {
-      bf16x8 fw[4], fx[MT];
-      const int chunk = ks * 4 + (lane >> 4);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) fw[i] = read_frag<BK>(tw, wn * 64 + i * 16 + (lane & 15), chunk);
-#pragma unroll
-      for (int j = 0; j < MT; ++j) fx[j] = read_frag<BK>(tx, wm * 16 * MT + j * 16 + (lane & 15), chunk);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < MT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fx[j], acc[i][j], 0, 0, 0);
-    }
-#else
-    // Software-pipelined fragment stream.  Left alone, the compiler reads all 12 fragments of a 32-deep
-    // sub-step, waits lgkmcnt(0), and only then issues its 32 MFMAs; the 8 waves of the block run in
-    // lock-step behind the barrier, so the matrix pipes idle while 96 KiB of fragments cross the LDS
-    // array (measured: 1.41 PFLOP/s-equivalent for the MFMA + LDS-read loop alone).  Here a "unit" is
-    // one X fragment (16 rows) against the wave's four W fragments = 4 MFMAs; the X fragment of unit
-    // u+2 and the W fragments of the next 32-deep sub-step are requested while unit u's MFMAs run.
-    // The reads are inline asm with hand-counted s_waitcnt lgkmcnt(N): the compiler's own waitcnt
-    // insertion falls back to lgkmcnt(0) here (the outstanding LDS-DMA loads count as "pending flat"
-    // accesses), which would expose every prefetch again.  LDS returns in order, so waiting for X(u)
-    // also covers every W fragment requested before it.
-    {
-      constexpr int KS = BK / 32, U = KS * MT, RB = C::ROWB;
-      constexpr int WP0 = FragPipe<MT, KS>::WP0, WPN = FragPipe<MT, KS>::WPN;
-      bf16x8 fw[2][4], fx[3];
-      const uint32_t so = (uint32_t)((t % S) * C::STAGE_BYTES);
-      uint32_t aw[KS], ax[KS];
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) { aw[ks] = aw0[ks] + so; ax[ks] = ax0[ks] + so; }
-      fw[0][0] = lds_read_b128<0 * 16 * RB>(aw[0]);
-      fw[0][1] = lds_read_b128<1 * 16 * RB>(aw[0]);
-      fw[0][2] = lds_read_b128<2 * 16 * RB>(aw[0]);
-      fw[0][3] = lds_read_b128<3 * 16 * RB>(aw[0]);
-      fx[0] = lds_read_b128<0>(ax[0]);
-      fx[1] = lds_read_b128<16 * RB>(ax[0]);
-#define UNIMM_UNIT(u)                                                                                        \
-      if constexpr ((u) < U) {                                                                               \
-        constexpr int ks_ = (u) / MT, j_ = (u) % MT;                                                         \
-        if constexpr ((u) + 2 < U) fx[((u) + 2) % 3] = lds_read_b128<(((u) + 2) % MT) * 16 * RB>(ax[((u) + 2) / MT]); \
-        if constexpr (FragPipe<MT, KS>::npref_w(u) > 0) {                                                    \
-          constexpr int w_ = (j_ - WP0) * WPN, kn_ = (ks_ + 1 < KS) ? ks_ + 1 : 0;                           \
-          fw[kn_ & 1][w_] = lds_read_b128<w_ * 16 * RB>(aw[kn_]);                                            \
-          if constexpr (WPN == 2) fw[kn_ & 1][w_ + 1] = lds_read_b128<(w_ + 1) * 16 * RB>(aw[kn_]);          \
-        }                                                                                                    \
-        lds_wait<FragPipe<MT, KS>::pending(u)>(fx[(u) % 3]);                                                 \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                        \
-          acc[i][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ks_ & 1][i], fx[(u) % 3], acc[i][j_], 0, 0, 0); \
-        __builtin_amdgcn_sched_barrier(0);                                                                   \
-      }
-      UNIMM_UNIT(0) UNIMM_UNIT(1) UNIMM_UNIT(2) UNIMM_UNIT(3) UNIMM_UNIT(4) UNIMM_UNIT(5) UNIMM_UNIT(6) UNIMM_UNIT(7)
-      UNIMM_UNIT(8) UNIMM_UNIT(9) UNIMM_UNIT(10) UNIMM_UNIT(11) UNIMM_UNIT(12) UNIMM_UNIT(13) UNIMM_UNIT(14) UNIMM_UNIT(15)
-#undef UNIMM_UNIT
-    }
-#endif
-  }
-#if UNIMM_EXP == 4                           // (experiment 4: no epilogue; one guarded store keeps acc live)
-  {
-    float sacc = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < MT; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-    if (sacc == 12345.678f) reinterpret_cast<float*>(p.out)[0] = sacc;
-    return;
-  }
-#endif
-
+__device__ __forceinline__ void nt_epilogue(const GemmNtParams& p, f32x4 (&acc)[4][C::MT], char* smem, int m0, int n0,
+                                            int wm, int wn, int wave, int lane) {
+  constexpr int MT = C::MT;
   // ---- epilogue.  The accumulator layout (lane = row m, 4 consecutive n per register quad) would need
   // 16 strided 8-byte stores (+16 such loads of the residual) per lane, which is store-ISSUE bound and
   // cost more than the 12-step main loop of the K=768 GEMMs.  Instead every wave transposes its tile,
@@ -377,6 +263,267 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES) void gemm_nt_kernel(GemmN
       }
     }
   }
+}
+
+template <class C, int EPI, bool OUT_F32>
+__global__ __launch_bounds__(C::THREADS, C::MIN_WAVES) void gemm_nt_kernel(GemmNtParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BM = C::BM, BN = C::BN, BK = C::BK, S = C::STAGES, G = C::G, MT = C::MT;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  int tm, tn;
+  tile_of(lid, nbm, nbn, p.gn, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int wm = wave / C::WN, wn = wave % C::WN;
+
+  f32x4 acc[4][MT];  // [n-subtile i][m-subtile j]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // LDS byte addresses of this lane's fragments in ring slot 0, per 32-deep sub-step (the XOR swizzle
+  // makes the second sub-step a second base, not a constant offset)
+  uint32_t aw0[BK / 32], ax0[BK / 32];
+  {
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)LDS_PTR(smem);
+    const int rw = wn * 64 + (lane & 15), rx = wm * 16 * MT + (lane & 15), cq = lane >> 4;
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      aw0[ks] = lds0 + rw * C::ROWB + (((ks * 4 + cq) ^ kswz<BK>(rw)) << 4);
+      ax0[ks] = lds0 + (BN + rx) * C::ROWB + (((ks * 4 + cq) ^ kswz<BK>(rx)) << 4);
+    }
+  }
+  const int nk = p.K / BK;
+  // One 8-wave workgroup per CU: spread the ring refill over the MFMA units (see the main loop).  With two
+  // 4-wave workgroups per CU the other workgroup's MFMAs already cover the issue phase and the later
+  // issue only shortens the time the loads have to land (measured 15-20 % slower), so those refill at
+  // the top of the step.
+  constexpr bool SPREAD = (S == 2 && C::NW == 8);
+  // prologue: fill S-1 ring slots
+#pragma unroll
+  for (int s = 0; s < S - 1; ++s)
+#if UNIMM_EXP == 7                           // (experiment 7: every block stages the SAME tiles -> all L2 hits)
+    if (s < nk) stage_step<C>(p, 0, 0, s * BK, smem + s * C::STAGE_BYTES, wave, lane);
+#else
+    if (s < nk) stage_step<C>(p, n0, m0, s * BK, smem + s * C::STAGE_BYTES, wave, lane);
+#endif
+
+  for (int t = 0; t < nk; ++t) {
+    // K-step t has landed once at most min(S-2, nk-1-t) younger steps are still in flight
+    const int rem = nk - 1 - t;
+    if constexpr (S == 2) wait_vmcnt<0>();
+    else if constexpr (S == 3) { if (rem >= 1) wait_vmcnt<G>(); else wait_vmcnt<0>(); }
+    else { if (rem >= 2) wait_vmcnt<2 * G>(); else if (rem == 1) wait_vmcnt<G>(); else wait_vmcnt<0>(); }
+    __builtin_amdgcn_s_barrier();            // every wave's loads of step t landed; step t-1 fully read
+    __builtin_amdgcn_sched_barrier(0);
+#if UNIMM_EXP != 3                           // (experiment 3: no global->LDS staging inside the loop)
+    if (t + S - 1 < nk)                      // refill the slot step t-1 used
+#if UNIMM_EXP == 7
+      stage_step<C>(p, 0, 0, (t + S - 1) * BK, smem + ((t + S - 1) % S) * C::STAGE_BYTES, wave, lane);
+#elif UNIMM_EXP == 5
+      stage_step<C>(p, n0, m0, (t + S - 1) * BK, smem + ((t + S - 1) % S) * C::STAGE_BYTES, wave, lane);
+#else
+      if constexpr (!SPREAD) stage_step<C>(p, n0, m0, (t + S - 1) * BK, smem + ((t + S - 1) % S) * C::STAGE_BYTES, wave, lane);
+#endif
+#endif
+    const char* tw = smem + (t % S) * C::STAGE_BYTES;
+    const char* tx = tw + BN * C::ROWB;
+#if UNIMM_EXP == 5                           // (experiment 5: the previous, compiler-scheduled fragment loop)
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      bf16x8 fw[4], fx[MT];
+      const int chunk = ks * 4 + (lane >> 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fw[i] = read_frag<BK>(tw, wn * 64 + i * 16 + (lane & 15), chunk);
+#pragma unroll
+      for (int j = 0; j < MT; ++j) fx[j] = read_frag<BK>(tx, wm * 16 * MT + j * 16 + (lane & 15), chunk);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fx[j], acc[i][j], 0, 0, 0);
+    }
+#else
+    // Software-pipelined fragment stream.  Left alone, the compiler reads all 12 fragments of a 32-deep
+    // sub-step, waits lgkmcnt(0), and only then issues its 32 MFMAs; the 8 waves of the block run in
+    // lock-step behind the barrier, so the matrix pipes idle while 96 KiB of fragments cross the LDS
+    // array (measured: 1.41 PFLOP/s-equivalent for the MFMA + LDS-read loop alone).  Here a "unit" is
+    // one X fragment (16 rows) against the wave's four W fragments = 4 MFMAs; the X fragment of unit
+    // u+2 and the W fragments of the next 32-deep sub-step are requested while unit u's MFMAs run.
+    // The reads are inline asm with hand-counted s_waitcnt lgkmcnt(N): the compiler's own waitcnt
+    // insertion falls back to lgkmcnt(0) here (the outstanding LDS-DMA loads count as "pending flat"
+    // accesses), which would expose every prefetch again.  LDS returns in order, so waiting for X(u)
+    // also covers every W fragment requested before it.  With SPREAD the refill of the other ring slot
+    // is spread over the first G units, one LDS-DMA behind each unit's MFMAs, instead of 8 back-to-back
+    // issues (and their address arithmetic) at the top of the step while the matrix pipes wait.
+    {
+      constexpr int KS = BK / 32, U = KS * MT, RB = C::ROWB;
+      constexpr int WP0 = FragPipe<MT, KS>::WP0, WPN = FragPipe<MT, KS>::WPN;
+      bf16x8 fw[2][4], fx[3];
+      const uint32_t so = (uint32_t)((t % S) * C::STAGE_BYTES);
+      uint32_t aw[KS], ax[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) { aw[ks] = aw0[ks] + so; ax[ks] = ax0[ks] + so; }
+      fw[0][0] = lds_read_b128<0 * 16 * RB>(aw[0]);
+      fw[0][1] = lds_read_b128<1 * 16 * RB>(aw[0]);
+      fw[0][2] = lds_read_b128<2 * 16 * RB>(aw[0]);
+      fw[0][3] = lds_read_b128<3 * 16 * RB>(aw[0]);
+      fx[0] = lds_read_b128<0>(ax[0]);
+      fx[1] = lds_read_b128<16 * RB>(ax[0]);
+#define UNIMM_UNIT(u)                                                                                        \
+      if constexpr ((u) < U) {                                                                               \
+        constexpr int ks_ = (u) / MT, j_ = (u) % MT;                                                         \
+        if constexpr ((u) + 2 < U) fx[((u) + 2) % 3] = lds_read_b128<(((u) + 2) % MT) * 16 * RB>(ax[((u) + 2) / MT]); \
+        if constexpr (FragPipe<MT, KS>::npref_w(u) > 0) {                                                    \
+          constexpr int w_ = (j_ - WP0) * WPN, kn_ = (ks_ + 1 < KS) ? ks_ + 1 : 0;                           \
+          fw[kn_ & 1][w_] = lds_read_b128<w_ * 16 * RB>(aw[kn_]);                                            \
+          if constexpr (WPN == 2) fw[kn_ & 1][w_ + 1] = lds_read_b128<(w_ + 1) * 16 * RB>(aw[kn_]);          \
+        }                                                                                                    \
+        lds_wait<FragPipe<MT, KS>::pending(u)>(fx[(u) % 3]);                                                 \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                        \
+          acc[i][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ks_ & 1][i], fx[(u) % 3], acc[i][j_], 0, 0, 0); \
+        if constexpr (SPREAD && UNIMM_EXP != 7 && UNIMM_EXP != 3 && (u) < G) {   /* refill, one LDS-DMA per unit */ \
+          if (t + 1 < nk) stage_one<C>(p, n0, m0, (t + 1) * BK, smem + ((t + 1) & 1) * C::STAGE_BYTES, wave, lane, u); \
+        }                                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+      }
+      UNIMM_UNIT(0) UNIMM_UNIT(1) UNIMM_UNIT(2) UNIMM_UNIT(3) UNIMM_UNIT(4) UNIMM_UNIT(5) UNIMM_UNIT(6) UNIMM_UNIT(7)
+      UNIMM_UNIT(8) UNIMM_UNIT(9) UNIMM_UNIT(10) UNIMM_UNIT(11) UNIMM_UNIT(12) UNIMM_UNIT(13) UNIMM_UNIT(14) UNIMM_UNIT(15)
+#undef UNIMM_UNIT
+    }
+#endif
+  }
+#if UNIMM_EXP == 4                           // (experiment 4: no epilogue; one guarded store keeps acc live)
+  {
+    float sacc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (sacc == 12345.678f) reinterpret_cast<float*>(p.out)[0] = sacc;
+    return;
+  }
+#endif
+
+  nt_epilogue<C, EPI, OUT_F32>(p, acc, smem, m0, n0, wm, wn, wave, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm_nt2: the same tiles behind a deeper ring.  With a 2-slot ring one K-step (64 KiB per CU) is in
+// flight while the previous one is computed, and a load needs ~1.5 us under load against ~1.1 us of
+// MFMA per step: every step stalls (measured: the staging costs 40 us of a 167 us GEMM even when every
+// block reads the SAME tiles, i.e. with perfect L2 hits; without it the loop runs at 1.16 PFLOP/s).
+// Here the ring has S = 5 slots of BK = 32, the barrier at the top of step t certifies stage t+1 (not t),
+// and three stages (96 KiB per CU) stay in flight across it.  Because stage t+1 is already readable
+// during step t, the fragment pipeline never drains at a step boundary: the last two units of step t
+// request the first X fragments of step t+1 and units 0..3 its W fragments (second register buffer).
+// ------------------------------------------------------------------------------------------------
+template <int MT, bool LAST> struct FragPipe2 {
+  static constexpr int WPN = MT == 8 ? 1 : 2, WPU = 4 / WPN;          // W fragments per unit, units that fetch them
+  static constexpr int nwp(int u) { return (!LAST && ((u % MT + MT) % MT) < WPU) ? WPN : 0; }
+  // reads requested after X(u) by the time unit u waits for it
+  static constexpr int pending(int u) {
+    if (LAST) return (u + 1 < MT ? 1 : 0) + (u + 2 < MT ? 1 : 0);
+    return nwp(u - 2) + nwp(u - 1) + nwp(u) + 2;
+  }
+};
+
+template <int G, int S> __device__ __forceinline__ void wait_stages(int n) {
+  static_assert(S == 5, "wait_stages: written for a 5-slot ring");
+  if (n >= 2) wait_vmcnt<2 * G>(); else if (n == 1) wait_vmcnt<G>(); else wait_vmcnt<0>();
+}
+
+template <class C, int EPI, bool OUT_F32>
+__global__ __launch_bounds__(C::THREADS, C::MIN_WAVES) void gemm_nt2_kernel(GemmNtParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BM = C::BM, BN = C::BN, BK = C::BK, S = C::STAGES, G = C::G, MT = C::MT, RB = C::ROWB;
+  static_assert(BK == 32, "gemm_nt2: one 32-deep sub-step per ring slot");
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  int tm, tn;
+  tile_of(lid, nbm, nbn, p.gn, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int wm = wave / C::WN, wn = wave % C::WN;
+
+  f32x4 acc[4][MT];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  uint32_t aw0, ax0;   // this lane's fragment addresses in ring slot 0
+  {
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)LDS_PTR(smem);
+    const int rw = wn * 64 + (lane & 15), rx = wm * 16 * MT + (lane & 15), cq = lane >> 4;
+    aw0 = lds0 + rw * RB + ((cq ^ kswz<BK>(rw)) << 4);
+    ax0 = lds0 + (BN + rx) * RB + ((cq ^ kswz<BK>(rx)) << 4);
+  }
+  const int nk = p.K / BK;   // even (K % 64 == 0)
+#pragma unroll
+  for (int s = 0; s < S - 1; ++s)
+    if (s < nk) stage_step<C>(p, n0, m0, s * BK, smem + s * C::STAGE_BYTES, wave, lane);
+
+  // top of step t: stage t+1 has landed everywhere, step t-1 is fully read; refill the slot it used
+#define UNIMM_TOP(t_)                                                                                        \
+  {                                                                                                          \
+    const int issued_ = ((t_) + S - 2 < nk - 1) ? (t_) + S - 2 : nk - 1;                                     \
+    wait_stages<G, S>(issued_ - ((t_) + 1));                                                                 \
+    __builtin_amdgcn_s_barrier();                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    if (UNIMM_EXP != 3 && (t_) + S - 1 < nk)                                                                 \
+      stage_step<C>(p, n0, m0, ((t_) + S - 1) * BK, smem + (((t_) + S - 1) % S) * C::STAGE_BYTES, wave, lane); \
+  }
+
+  bf16x8 fw[2][4], fx[4];
+#define UNIMM_UNIT2(P, LAST, u)                                                                              \
+  {                                                                                                          \
+    if constexpr ((u) + 2 < MT) fx[((u) + 2) % 4] = lds_read_b128<((u) + 2) * 16 * RB>(axc);                 \
+    else if constexpr (!(LAST)) fx[((u) + 2) % 4] = lds_read_b128<((u) + 2 - MT) * 16 * RB>(axn);            \
+    if constexpr (FragPipe2<MT, LAST>::nwp(u) > 0) {                                                         \
+      constexpr int w_ = (u) * FragPipe2<MT, LAST>::WPN;                                                     \
+      fw[(P) ^ 1][w_] = lds_read_b128<w_ * 16 * RB>(awn);                                                    \
+      if constexpr (FragPipe2<MT, LAST>::WPN == 2) fw[(P) ^ 1][w_ + 1] = lds_read_b128<(w_ + 1) * 16 * RB>(awn); \
+    }                                                                                                        \
+    lds_wait<FragPipe2<MT, LAST>::pending(u)>(fx[(u) % 4]);                                                  \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                            \
+      acc[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[P][i], fx[(u) % 4], acc[i][u], 0, 0, 0);        \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+  }
+#define UNIMM_UNITS(P, LAST, t_)                                                                             \
+  {                                                                                                          \
+    const uint32_t axc = ax0 + (uint32_t)(((t_) % S) * C::STAGE_BYTES);                                      \
+    const uint32_t son_ = (uint32_t)((((t_) + 1) % S) * C::STAGE_BYTES);                                     \
+    const uint32_t axn = ax0 + son_, awn = aw0 + son_;                                                       \
+    (void)axn; (void)awn;                                                                                    \
+    UNIMM_UNIT2(P, LAST, 0) UNIMM_UNIT2(P, LAST, 1) UNIMM_UNIT2(P, LAST, 2) UNIMM_UNIT2(P, LAST, 3)          \
+    if constexpr (MT == 8) {                                                                                 \
+      UNIMM_UNIT2(P, LAST, 4) UNIMM_UNIT2(P, LAST, 5) UNIMM_UNIT2(P, LAST, 6) UNIMM_UNIT2(P, LAST, 7)        \
+    }                                                                                                        \
+  }
+
+  UNIMM_TOP(0)
+  fw[0][0] = lds_read_b128<0 * 16 * RB>(aw0);
+  fw[0][1] = lds_read_b128<1 * 16 * RB>(aw0);
+  fw[0][2] = lds_read_b128<2 * 16 * RB>(aw0);
+  fw[0][3] = lds_read_b128<3 * 16 * RB>(aw0);
+  fx[0] = lds_read_b128<0>(ax0);
+  fx[1] = lds_read_b128<16 * RB>(ax0);
+  int t = 0;
+  for (; t + 2 < nk; t += 2) {
+    UNIMM_UNITS(0, false, t)
+    UNIMM_TOP(t + 1)
+    UNIMM_UNITS(1, false, t + 1)
+    UNIMM_TOP(t + 2)
+  }
+  UNIMM_UNITS(0, false, t)
+  UNIMM_UNITS(1, true, t + 1)          // stage nk-1 was certified by the top of step nk-2
+#undef UNIMM_UNITS
+#undef UNIMM_UNIT2
+#undef UNIMM_TOP
+  nt_epilogue<C, EPI, OUT_F32>(p, acc, smem, m0, n0, wm, wn, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -646,11 +793,16 @@ inline void prof_end(ProfRec* r, hipStream_t s) { if (r) hipEventRecord(r->b, s)
 int g_nt_gn = 0;    // 0 = automatic
 int g_nt_cfg = 0;   // 0 = auto, 1 = 128x128 BK64 x2, 2 = 256x256 BK32 x4, 3 = 256x256 BK64 x2  (unimm_gemm_set_tile)
 
+template <class C, int EPI, bool F32> constexpr auto pick_nt_kernel() {
+  if constexpr (C::STAGES == 5) return &gemm_nt2_kernel<C, EPI, F32>;   // deep-ring kernel
+  else return &gemm_nt_kernel<C, EPI, F32>;
+}
+
 template <class C, int EPI>
 int launch_nt_cfg(const GemmNtParams& p, bool out_f32, hipStream_t s) {
   const int nwg = ((p.M + C::BM - 1) / C::BM) * ((p.N + C::BN - 1) / C::BN);
-  auto k32 = gemm_nt_kernel<C, EPI, true>;
-  auto k16 = gemm_nt_kernel<C, EPI, false>;
+  auto k32 = pick_nt_kernel<C, EPI, true>();
+  auto k16 = pick_nt_kernel<C, EPI, false>();
   if (C::LDS > 64 * 1024) {
     static bool done32 = false, done16 = false;
     bool& done = out_f32 ? done32 : done16;
@@ -676,6 +828,8 @@ int launch_nt(const GemmNtParams& p, bool out_f32, hipStream_t s) {
     cfg = (t256 >= 384) ? 3 : 1;
   }
   if (cfg == 2) return launch_nt_cfg<Cfg<2, 4, 8, 32, 4>, EPI>(p, out_f32, s);
+  if (cfg == 4) return launch_nt_cfg<Cfg<2, 4, 8, 32, 5>, EPI>(p, out_f32, s);
+  if (cfg == 5) return launch_nt_cfg<Cfg<2, 2, 4, 32, 5>, EPI>(p, out_f32, s);
   if (cfg == 3) return launch_nt_cfg<Cfg<2, 4, 8, 64, 2>, EPI>(p, out_f32, s);
   return launch_nt_cfg<Cfg<2, 2, 4, 64, 2>, EPI>(p, out_f32, s);
 }
@@ -717,7 +871,7 @@ extern "C" int unimm_gemm_set_tile(int32_t cfg) {
   if (cfg < 0 || cfg > 999 * 1000 + 999) return UNIMM_E_ARG;
   g_nt_cfg = cfg % 1000;          // tile configuration
   g_nt_gn = cfg / 1000;           // tuning: n-tiles per column group (0 = default)
-  if (g_nt_cfg > 3) return UNIMM_E_ARG;
+  if (g_nt_cfg > 5) return UNIMM_E_ARG;
   return UNIMM_OK;
 }
 
