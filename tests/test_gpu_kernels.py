@@ -54,7 +54,7 @@ def _attn_case(B, H, Tq, Tk, D, dense_mask, seed, p_drop=0.0):
     s = qf @ kf.transpose(-1, -2) * scale + ((1.0 - m.float()) * -10000.0)[:, None]
     pr = torch.softmax(s, -1)
     if p_drop > 0:
-        keep = DR.keep_mask(drop[0], drop[1], B * H * Tq * Tk).reshape(B, H, Tq, Tk)
+        keep = DR.keep_mask_nd(drop[0], drop[1], (B, H, Tq, Tk))
         pr = pr * torch.from_numpy(keep).to(DEV) * drop[2]
     ref = (pr @ vf).permute(0, 2, 1, 3).reshape(B * Tq, HD)
     torch.cuda.synchronize()
@@ -140,7 +140,7 @@ def test_layernorm_fwd_bwd(M, H):
     lib.layernorm_bwd(dy, x, mean, rstd, gamma, dx, dxd, dg, db, dbias, part, M, H, drop=drop)
     torch.cuda.synchronize()
     assert relerr(dx, xr.grad) < 2 ** -6
-    keep = torch.from_numpy(DR.keep_mask(drop[0], drop[1], M * H).reshape(M, H)).to(DEV)
+    keep = torch.from_numpy(DR.keep_mask2d(drop[0], drop[1], M, H)).to(DEV)
     want_dxd = xr.grad * keep * drop[2]
     assert relerr(dxd, want_dxd) < 2 ** -6
     assert relerr(dg - 1, gr.grad) < 5e-3 and relerr(db - 1, br.grad) < 5e-3      # accumulate (+=) semantics

@@ -146,14 +146,14 @@ def test_training_mode_dropout_matches_oracle_with_replayed_masks(golden_dir, sm
         _, thr, scale = DR.drop_arg(p, key)
         text_rowwise = site == "emb_t" or (site.startswith("bert.encoder.layer.") and site.endswith((".so", ".out"))) \
             or site.endswith((".bo2", ".tout"))
-        if text_rowwise:                    # element index = packed_row * N + col on the device
+        if text_rowwise:                    # device coordinates: (packed row, column)
             n = x.shape[-1]
-            keep_p = torch.from_numpy(DR.keep_mask(key, thr, rows.numel() * n).reshape(rows.numel(), n))
+            keep_p = torch.from_numpy(DR.keep_mask2d(key, thr, rows.numel(), n))
             keep = torch.ones((x.shape[0] * x.shape[1], n), dtype=torch.bool)
             keep[rows] = keep_p
             keep = keep.view(x.shape)
         else:
-            keep = torch.from_numpy(DR.keep_mask(key, thr, x.numel()).reshape(tuple(x.shape)))
+            keep = torch.from_numpy(DR.keep_mask_nd(key, thr, tuple(x.shape)))
         return x * keep * scale
 
     leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != R.TIED[0]}

@@ -199,12 +199,17 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnParams p) {
   const float inv = 1.0f / sum;
 
   if (p.drop.thr != 0u) {
-    const uint32_t base = (((uint32_t)b * p.H + head) * p.Tq + (uint32_t)qrow) * (uint32_t)p.Tk;
+    // one hash per two neighbouring keys (registers e, e+1 with e even hold keys k, k+1 with k even)
+    const uint32_t wb = drop_wbase(((uint32_t)b * p.H + head) * p.Tq + (uint32_t)qrow, (uint32_t)p.Tk, 0u);
 #pragma unroll
     for (int t = 0; t < NKT; ++t) {
       if (32 * t >= Tk_b) continue;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) s[t][e] = drop_apply(p.drop, base + 32 * t + key_of_reg(e, h), s[t][e]);
+      for (int e = 0; e < 16; e += 2) {
+        const uint32_t w = drop_word(p.drop, wb + (uint32_t)((32 * t + key_of_reg(e, h)) >> 1));
+        s[t][e] = drop_sel(p.drop, w, 0u, s[t][e]);
+        s[t][e + 1] = drop_sel(p.drop, w, 1u, s[t][e + 1]);
+      }
     }
   }
 
@@ -317,7 +322,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
   f32x16 dq[D / 32];
 #pragma unroll
   for (int dt = 0; dt < D / 32; ++dt) dq[dt] = f32x16{};
-  const uint32_t dbase = (((uint32_t)b * p.H + head) * p.Tq + (uint32_t)qrow) * (uint32_t)p.Tk;
+  const uint32_t dwb = drop_wbase(((uint32_t)b * p.H + head) * p.Tq + (uint32_t)qrow, (uint32_t)p.Tk, 0u);
 
 #pragma unroll
   for (int t = 0; t < NKT; ++t) {
@@ -332,6 +337,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
     }
     const uint32_t w = mw[t] >> (4 * h);
     float ds[16];
+    uint32_t dw[8];   // dropout words: one hash per two neighbouring keys
+    if (p.drop.thr != 0u) {
+#pragma unroll
+      for (int e2 = 0; e2 < 8; ++e2) dw[e2] = drop_word(p.drop, dwb + (uint32_t)((32 * t + key_of_reg(2 * e2, h)) >> 1));
+    }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int kk = (e & 3) + 8 * (e >> 2);
@@ -340,7 +350,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
       v += ((w >> kk) & 1u) ? 0.0f : -10000.0f;
       const float pe = key < Tk_b ? __builtin_amdgcn_exp2f(v * LOG2E - lse_l) : 0.f;
       float dp = dpacc[e];
-      if (p.drop.thr != 0u) dp = drop_apply(p.drop, dbase + key, dp);
+      if (p.drop.thr != 0u) dp = drop_sel(p.drop, dw[e >> 1], (uint32_t)(e & 1), dp);
       ds[e] = pe * (dp - delta) * p.scale;
     }
 #pragma unroll
@@ -459,8 +469,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
         float dp = dpacc[e];
         float pdrop = pe;
         if (p.drop.thr != 0u) {
-          const uint32_t idx = (hbase + (uint32_t)qi) * (uint32_t)p.Tk + (uint32_t)krow;
-          const bool keep = mix32(idx ^ p.drop.key) >= p.drop.thr;
+          const uint32_t dw = drop_word(p.drop, drop_wbase(hbase + (uint32_t)qi, (uint32_t)p.Tk, (uint32_t)krow));
+          const bool keep = drop_keep(p.drop, dw, (uint32_t)krow & 1u);
           dp = keep ? dp * p.drop.scale : 0.f;
           pdrop = keep ? pe * p.drop.scale : 0.f;
         }

@@ -78,8 +78,11 @@ __device__ __forceinline__ void gelu_and_grad(float x, float& y, float& dy) {
   dy = fmaf(x * 0.3989422804014327f, e, cdf);
 }
 
-// Counter-based dropout: keep(idx) = mix32(idx ^ key) >= thr, key = per-(step, site) word built on
-// the host (unimm_amd/dropout.py mirrors this bit for bit so the oracle can replay the masks).
+// Counter-based dropout.  Element (row, col) of a [rows, ncols] activation is kept iff the 16-bit field
+// (col & 1) of  mix32((row * ceil(ncols / 2) + (col >> 1)) ^ key)  is >= thr >> 16, key = per-(step, site)
+// word built on the host (unimm_amd/dropout.py mirrors this bit for bit so the oracle can replay the
+// masks).  One hash serves two neighbouring columns: the two 32-bit multiplies of mix32 were 25 % of the
+// text-attention forward and a third of the dropout GEMM epilogue.  p is resolved to 2^-16.
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU;
   x ^= x >> 15; x *= 0x846ca68bU;
@@ -88,11 +91,32 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
 }
 struct DropoutArg {
   uint32_t key;    // 0 with thr == 0 => disabled
-  uint32_t thr;    // p * 2^32
+  uint32_t thr;    // p * 2^32 (the kernels compare 16-bit fields against thr >> 16)
   float scale;     // 1 / (1 - p)
 };
-__device__ __forceinline__ float drop_apply(const DropoutArg& d, uint32_t idx, float v) {
-  return (mix32(idx ^ d.key) >= d.thr) ? v * d.scale : 0.0f;
+__device__ __forceinline__ uint32_t drop_word(const DropoutArg& d, uint32_t widx) { return mix32(widx ^ d.key); }
+__device__ __forceinline__ uint32_t drop_wbase(uint32_t row, uint32_t ncols, uint32_t col) { return row * ((ncols + 1u) >> 1) + (col >> 1); }
+__device__ __forceinline__ bool drop_keep(const DropoutArg& d, uint32_t w, uint32_t odd) {
+  return (odd ? (w >> 16) : (w & 0xffffu)) >= (d.thr >> 16);
+}
+__device__ __forceinline__ float drop_sel(const DropoutArg& d, uint32_t w, uint32_t odd, float v) {
+  return drop_keep(d, w, odd) ? v * d.scale : 0.0f;
+}
+// one element
+__device__ __forceinline__ float drop_apply(const DropoutArg& d, uint32_t row, uint32_t ncols, uint32_t col, float v) {
+  return drop_sel(d, drop_word(d, drop_wbase(row, ncols, col)), col & 1u, v);
+}
+// keep bits of 8 consecutive columns col0 .. col0+7 (col0 % 8 == 0): 4 hashes
+__device__ __forceinline__ uint32_t drop_bits8(const DropoutArg& d, uint32_t row, uint32_t ncols, uint32_t col0) {
+  const uint32_t wb = drop_wbase(row, ncols, col0), t16 = d.thr >> 16;
+  uint32_t bits = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint32_t w = drop_word(d, wb + q);
+    bits |= ((w & 0xffffu) >= t16 ? 1u : 0u) << (2 * q);
+    bits |= ((w >> 16) >= t16 ? 1u : 0u) << (2 * q + 1);
+  }
+  return bits;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -198,9 +198,9 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtParams& p, f32x4 (&acc)[
             for (int e = 0; e < 8; ++e) a[e] = (n + e < p.N) ? ap[e] : 0.f;
           }
           if (p.drop.thr != 0u) {
-            const uint32_t idx = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;
+            const uint32_t kb = drop_bits8(p.drop, (uint32_t)m, (uint32_t)p.N, (uint32_t)n);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = drop_apply(p.drop, idx + e, v[e]);
+            for (int e = 0; e < 8; ++e) v[e] = ((kb >> e) & 1u) ? v[e] * p.drop.scale : 0.f;
           }
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += a[e];

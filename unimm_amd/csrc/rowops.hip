@@ -160,13 +160,15 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     float mean, rstd;
     row_stats(xv, H, mean, rstd, eps);
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i)
+    for (int i = 0; i < MAXC; ++i) {
+      const uint32_t kb = drop.thr != 0u ? drop_bits8(drop, (uint32_t)row, (uint32_t)H, (uint32_t)((lane + 64 * i) * 8)) : 0u;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float v = (xv.v[i][j] - mean) * rstd * g.v[i][j] + b.v[i][j];
-        if (drop.thr != 0u) v = drop_apply(drop, (uint32_t)row * (uint32_t)H + (uint32_t)((lane + 64 * i) * 8 + j), v);
+        if (drop.thr != 0u) v = ((kb >> j) & 1u) ? v * drop.scale : 0.f;
         xv.v[i][j] = v;
       }
+    }
     if (y32 != nullptr) store_row_f32(y32 + (size_t)row * H, H, lane, xv);
     if (y != nullptr) store_row_bf16(y + (size_t)row * H, H, lane, xv);
     if (lane == 0 && mean_o != nullptr) { mean_o[row] = mean; rstd_o[row] = rstd; }
@@ -205,12 +207,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
     const float mean = mean_i[row], rstd = rstd_i[row];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i)
+    for (int i = 0; i < MAXC; ++i) {
+      // forward applied dropout AFTER this LayerNorm (embeddings)
+      const uint32_t kbo = out_drop.thr != 0u ? drop_bits8(out_drop, (uint32_t)row, (uint32_t)H, (uint32_t)((lane + 64 * i) * 8)) : 0u;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float d = dyv.v[i][j];
-        if (out_drop.thr != 0u)  // forward applied dropout AFTER this LayerNorm (embeddings)
-          d = drop_apply(out_drop, (uint32_t)row * (uint32_t)H + (uint32_t)((lane + 64 * i) * 8 + j), d);
+        if (out_drop.thr != 0u) d = ((kbo >> j) & 1u) ? d * out_drop.scale : 0.f;
         const float xh = (xv.v[i][j] - mean) * rstd;
         const float gg = d * g.v[i][j];
         dg.v[i][j] += d * xh;
@@ -220,20 +223,23 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
         dyv.v[i][j] = gg;
         xv.v[i][j] = xh;
       }
+    }
     s1 = wave_sum(s1) * invH;
     s2 = wave_sum(s2) * invH;
     Row8 dd;
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i)
+    for (int i = 0; i < MAXC; ++i) {
+      const uint32_t kb = drop.thr != 0u ? drop_bits8(drop, (uint32_t)row, (uint32_t)H, (uint32_t)((lane + 64 * i) * 8)) : 0u;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float v = rstd * (dyv.v[i][j] - s1 - xv.v[i][j] * s2);
         dyv.v[i][j] = v;
         float vd = v;
-        if (drop.thr != 0u) vd = drop_apply(drop, (uint32_t)row * (uint32_t)H + (uint32_t)((lane + 64 * i) * 8 + j), v);
+        if (drop.thr != 0u) vd = ((kb >> j) & 1u) ? v * drop.scale : 0.f;
         dd.v[i][j] = vd;
         dbias.v[i][j] += vd;
       }
+    }
     store_row_bf16(dx + (size_t)row * H, H, lane, dyv);
     if (dx_drop != nullptr) store_row_bf16(dx_drop + (size_t)row * H, H, lane, dd);
   }
@@ -322,8 +328,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(EmbArgs a, float* __rest
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float v = (x.v[i][j] - mean) * rstd * g.v[i][j] + b.v[i][j];
-        if (a.drop.thr != 0u)
-          v = drop_apply(a.drop, (uint32_t)row * (uint32_t)a.H + (uint32_t)((lane + 64 * i) * 8 + j), v);
+        if (a.drop.thr != 0u) v = drop_apply(a.drop, (uint32_t)row, (uint32_t)a.H, (uint32_t)((lane + 64 * i) * 8 + j), v);
         x.v[i][j] = v;
       }
     store_row_f32(y32 + (size_t)row * a.H, a.H, lane, x);
@@ -361,8 +366,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbArgs a, const bf16_t*
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float d = dyv.v[i][j];
-        if (a.drop.thr != 0u)
-          d = drop_apply(a.drop, (uint32_t)row * (uint32_t)a.H + (uint32_t)((lane + 64 * i) * 8 + j), d);
+        if (a.drop.thr != 0u) d = drop_apply(a.drop, (uint32_t)row, (uint32_t)a.H, (uint32_t)((lane + 64 * i) * 8 + j), d);
         const float xh = (x.v[i][j] - mean) * rstd;
         const float gg = d * g.v[i][j];
         dg.v[i][j] += d * xh;
@@ -517,7 +521,7 @@ __global__ void mul_dropout_kernel(const bf16_t* __restrict__ a, const bf16_t* _
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float v = bf2f(a[i]) * bf2f(b[i]);
-  if (drop.thr != 0u) v = drop_apply(drop, (uint32_t)i, v);
+  if (drop.thr != 0u) v = drop_apply(drop, 0u, (uint32_t)n, (uint32_t)i, v);
   out[i] = f2bf(v);
 }
 
@@ -528,7 +532,7 @@ __global__ void mul_dropout_bwd_kernel(const bf16_t* __restrict__ a, const bf16_
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float d = bf2f(dout[i]);
-  if (drop.thr != 0u) d = drop_apply(drop, (uint32_t)i, d);
+  if (drop.thr != 0u) d = drop_apply(drop, 0u, (uint32_t)n, (uint32_t)i, d);
   // ReLU of the poolers (:951,:966) is folded in: a, b are post-ReLU, gradient is zero where they are
   const float av = bf2f(a[i]), bv = bf2f(b[i]);
   da[i] = f2bf(av > 0.f ? d * bv : 0.f);

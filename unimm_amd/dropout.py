@@ -1,4 +1,4 @@
-"""Counter-based dropout shared by every kernel: keep(idx) = mix32(idx ^ key) >= thr.
+"""Counter-based dropout shared by every kernel (one mix32 hash per two neighbouring columns).
 
 The kernels never store a mask: the backward pass regenerates it from (key, thr).  `key` is one
 32-bit word per (seed, step, site); `keep_mask` is the bit-exact host mirror of the device hash
@@ -33,12 +33,30 @@ def drop_arg(p: float, key: int):
     return (key & 0xFFFFFFFF, thr, 1.0 / (1.0 - p))
 
 
-def keep_mask(key: int, thr: int, n: int) -> np.ndarray:
-    """Host mirror: boolean keep mask for linear element indices 0..n-1."""
-    x = np.arange(n, dtype=np.uint64) ^ np.uint64(key)
+def keep_mask2d(key: int, thr: int, rows: int, cols: int) -> np.ndarray:
+    """Host mirror of the device rule (unimm_amd/csrc/common.h): element (row, col) of a [rows, cols]
+    activation is kept iff the 16-bit field (col & 1) of mix32((row * ceil(cols / 2) + (col >> 1)) ^ key)
+    is >= thr >> 16.  Returns a boolean [rows, cols] array."""
+    half = (cols + 1) // 2
+    r = np.arange(rows, dtype=np.uint64)[:, None]
+    c = np.arange(cols, dtype=np.uint64)[None, :]
+    x = ((r * np.uint64(half) + (c >> np.uint64(1))) & np.uint64(0xFFFFFFFF)) ^ np.uint64(key)
     x ^= x >> np.uint64(16)
     x = (x * np.uint64(_M1)) & np.uint64(0xFFFFFFFF)
     x ^= x >> np.uint64(15)
     x = (x * np.uint64(_M2)) & np.uint64(0xFFFFFFFF)
     x ^= x >> np.uint64(16)
-    return x >= np.uint64(thr)
+    field = np.where((c & np.uint64(1)) == 1, x >> np.uint64(16), x & np.uint64(0xFFFF))
+    return field >= np.uint64(thr >> 16)
+
+
+def keep_mask_nd(key: int, thr: int, shape) -> np.ndarray:
+    """Keep mask of an activation of the given shape: the last dimension is the column."""
+    shape = tuple(int(d) for d in shape)
+    rows = int(np.prod(shape[:-1], dtype=np.int64)) if len(shape) > 1 else 1
+    return keep_mask2d(key, thr, rows, shape[-1]).reshape(shape)
+
+
+def keep_mask(key: int, thr: int, n: int) -> np.ndarray:
+    """1-D activation of n elements (one row)."""
+    return keep_mask2d(key, thr, 1, n)[0]

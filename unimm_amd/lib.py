@@ -46,11 +46,12 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("UNIMM_HIP_LIB", LIB_PATH)      # A/B runs of two builds in one process tree (tools only)
+    if not os.path.exists(path):
         raise UnimmHipError(
-            f"{LIB_PATH} is missing: build it with `python -m unimm_amd.build` (hipcc, gfx950). "
+            f"{path} is missing: build it with `python -m unimm_amd.build` (hipcc, gfx950). "
             "unimm_amd has no CPU or PyTorch fallback for its kernels.")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     L.unimm_version.restype = C.c_int
     L.unimm_arch.restype = C.c_char_p
     if L.unimm_version() != ABI_VERSION:
