@@ -52,6 +52,9 @@ def parse():
                          "(100 sequences, nsp_loss_coeff 0, gradient accumulation: no exchange inside the step); "
                          "scoring = configs[4] (val_lm: 1 image = 10 rounds x 100 candidates in 4 chunks of 250, "
                          "forward + sequence log-likelihood + ranks)")
+    ap.add_argument("--with-optimizer", action="store_true",
+                    help="also run the fused AdamW step (train.py:322-348 grouping and schedule) inside the timed step; "
+                         "NOT the headline metric, which is fwd+bwd (the config block says which was run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--config", default=os.path.join(ROOT, "unimm_amd", "config", "bert_base_6layer_6conect.json"))
@@ -252,9 +255,25 @@ def main():
         loss.backward()
         return loss
 
+    opt = sched = None
+    if args.with_optimizer:
+        from unimm_amd.optim import FusedAdamW, WarmupLinearScheduleNonZero, default_language_weights, reference_param_groups
+        groups = reference_param_groups(enc, lr=2e-5, image_lr=2e-5, language_weights=default_language_weights(enc))
+        opt = FusedAdamW(groups, model.engine, lr=2e-5)
+        sched = WarmupLinearScheduleNonZero(opt, warmup_steps=10000, t_total=200000)
+
     micro = [0]
 
     def step():
+        loss = step_fb()
+        if opt is not None:
+            if world > 1:
+                net.sync_gradients()        # no-op when every bucket was reduced during backward
+            opt.step()
+            sched.step()
+        return loss
+
+    def step_fb():
         if args.workload == "dense":
             # batch_multiply = 16 (dense_annotation_finetuning.py:299): gradients accumulate over 16 micro-steps
             # and are exchanged on the 16th only; one bench step = one micro-step.
@@ -326,7 +345,9 @@ def main():
             metric = "dialog-sequences/sec (fwd+bwd) at bs=240 seq=256 regions=36(+1 <IMG>)"
             wl = ("UniMM-UL sparse training step (BASELINE configs[1]): bert_base_6layer_6conect, "
                   "sequences_per_image=6, num_negative_samples=5, mask_prob=0.15, dropout on, "
-                  "MLM+UL / NSP / region-KL losses, fwd+bwd, optimizer step not included")
+                  "MLM+UL / NSP / region-KL losses, fwd+bwd, " +
+                  ("PLUS the fused AdamW step and weight-copy refresh (--with-optimizer)" if args.with_optimizer
+                   else "optimizer step not included"))
         out = {
             "metric": metric,
             "value": round(value, 2), "unit": "dialog-sequences/sec", "n_gpus": world, "steps": args.steps,

@@ -197,6 +197,15 @@ int unimm_colsum(const void* dy, float* db, int32_t M, int32_t N, int32_t ld, vo
  * R..ldd-1 zero-filled) for the transposed copies the input-gradient GEMMs read. */
 int unimm_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
 int unimm_transpose_cast(const float* src, void* dst, int32_t R, int32_t C, int32_t ldd, void* stream);
+/* The same for `count` matrices in one launch.  `table` is a DEVICE array; entry i owns blocks
+ * [tile0_i, tile0_{i+1}) with ceil(C/32) * ceil(ldd/32) blocks each (tile0 ascending, tile0_0 = 0);
+ * total_tiles = their sum.  Used after the optimizer step to rebuild every transposed weight copy. */
+typedef struct {
+  const float* src;  /* fp32 [R, C] */
+  void* dst;         /* bf16 [C, ldd] */
+  int32_t R, C, ldd, tile0;
+} unimm_transpose_desc;
+int unimm_transpose_cast_grouped(const unimm_transpose_desc* table, int32_t count, int32_t total_tiles, void* stream);
 
 /* Region features fp32 [rows, F] + box geometry fp32 [rows, 5] -> bf16 [rows, ld] = [feat | loc | 0]:
  * the operand of the single image-embedding GEMM (models/vilbert_dialog.py:1488-1489). */
@@ -245,6 +254,38 @@ int unimm_nsp_loss_bwd(const float* logits, const int32_t* labels, float w0, flo
 /* dst[0] = scale * sum(src) (fixed order, deterministic); dst[seg[i]] += sign * src[i] */
 int unimm_reduce_sum(const float* src, int64_t n, float* dst, float scale, void* stream);
 int unimm_segment_sum(const float* src, const int32_t* seg, float* dst, int64_t n, float sign, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused AdamW over the flat arenas.  Replaces the optimizer of train.py:322-347 /
+ * :458 (`pytorch_transformers.AdamW`, one parameter group per tensor: lr in {lr, image_lr} by
+ * config/language_weights.json, weight_decay in {0.01, 0}); the lr values are whatever the caller's
+ * scheduler (utils/optim_utils.py:8-26) set for this step.  Per element, in fp32:
+ *   g *= grad_scale;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
+ *   p -= lr_g * [sqrt(1-b2^step)/(1-b1^step) if correct_bias] * m / (sqrt(v) + eps);  p -= lr_g * wd_g * p
+ * group[i] (uint8, device) is the (lr, wd) group of elements [64 i, 64 i + 64); values >=
+ * UNIMM_ADAMW_MAX_GROUPS mark parameters that never receive a gradient (skipped entirely, as the
+ * reference skips `p.grad is None`).  w16 (bf16, may be NULL) receives the updated parameters: the
+ * GEMM-operand copy, so no separate cast pass.  zero_grad != 0 clears g in the same pass. */
+#define UNIMM_ADAMW_MAX_GROUPS 8
+typedef struct {
+  float* p;              /* [n] fp32 parameters (updated in place) */
+  const float* g;        /* [n] fp32 gradients */
+  float* m;              /* [n] fp32 exp_avg */
+  float* v;              /* [n] fp32 exp_avg_sq */
+  void* w16;             /* [n] bf16 copy of p or NULL */
+  const uint8_t* group;  /* [n / 64] group id per 64-element chunk */
+  int64_t n;             /* multiple of 64 */
+  int32_t n_groups;      /* <= UNIMM_ADAMW_MAX_GROUPS */
+  int32_t step;          /* 1-based step count t */
+  double lr[UNIMM_ADAMW_MAX_GROUPS];           /* doubles: the scalar factors (1 - beta, lr * correction,    */
+  double weight_decay[UNIMM_ADAMW_MAX_GROUPS]; /* lr * wd) are formed in double and rounded to fp32 once,    */
+  double beta1, beta2, eps;                    /* as the reference's Python-float arithmetic does            */
+  float grad_scale;      /* 1 / loss scale (or 1 / batch_multiply); 1 = none */
+  int32_t correct_bias;
+  int32_t zero_grad;
+} unimm_adamw_args;
+
+int unimm_adamw_step(const unimm_adamw_args* args, void* stream);
 
 /* Launch profiler for bench.py's `roofline` block: HIP events around every GEMM launch on its own
  * stream while enabled.  Variant index: 0..11 = unimm_gemm_nt (epilogue * 2 + out_f32), 12 = unimm_gemm_tn.

@@ -270,11 +270,38 @@ def gen_ranks(vm):
     save("ranks.npz", scores=s, ranks=vm.scores_to_ranks(T_(s.copy())))
 
 
+def gen_sched():
+    """G7: learning-rate schedule of the training loop (utils/optim_utils.py:8-26; train.py:348 uses
+    warmup_steps=10000, t_total=200000), stepped exactly as train.py:463 steps it."""
+    import utils.optim_utils as ou
+    steps = [0, 1, 2, 57, 5000, 9999, 10000, 10001, 64000, 150000, 190000, 197000, 199999, 200000, 200001, 250000]
+    out = {}
+    for tag, (w, t, mn, bases) in {"train": (10000, 200000, 1e-5, [2e-5, 1e-4]), "short": (3, 10, 1e-5, [5e-5, 2e-5])}.items():
+        ps = [torch.nn.Parameter(torch.zeros(1)) for _ in bases]
+        opt = torch.optim.SGD([{"params": [p], "lr": b} for p, b in zip(ps, bases)], lr=bases[0])
+        sch = ou.WarmupLinearScheduleNonZero(opt, warmup_steps=w, t_total=t, min_lr=mn)
+        want = steps if tag == "train" else list(range(0, 14))
+        lrs, k = [], 0
+        for s in range(0, max(want) + 1):
+            if s == want[k]:
+                lrs.append([g["lr"] for g in opt.param_groups])
+                k += 1
+                if k == len(want):
+                    break
+            opt.step()
+            sch.step()
+        out[tag + "_steps"] = np.array(want, dtype=np.int64)
+        out[tag + "_lrs"] = np.array(lrs, dtype=np.float64)
+        out[tag + "_cfg"] = np.array([w, t, mn] + bases, dtype=np.float64)
+    save("sched.npz", **out)
+
+
 if __name__ == "__main__":
-    groups = sys.argv[1:] or ["masks", "ranks", "small", "blocks", "losses", "full"]
+    groups = sys.argv[1:] or ["masks", "ranks", "small", "blocks", "losses", "full", "sched"]
     vd, du, vm = import_reference()
     torch.manual_seed(0)
     torch.set_num_threads(8)
     for g in groups:
         {"masks": lambda: gen_masks(du), "ranks": lambda: gen_ranks(vm), "small": lambda: gen_small(vd),
-         "blocks": lambda: gen_blocks(vd), "losses": lambda: gen_losses(vd), "full": lambda: gen_full(vd)}[g]()
+         "blocks": lambda: gen_blocks(vd), "losses": lambda: gen_losses(vd), "full": lambda: gen_full(vd),
+         "sched": gen_sched}[g]()

@@ -487,6 +487,33 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __rest
   }
 }
 
+// the same for a table of matrices in ONE launch (all transposed weight copies after an optimizer step:
+// ~190 launches of a few microseconds each otherwise).  Block b belongs to the last entry with tile0 <= b.
+__global__ __launch_bounds__(256) void transpose_cast_grouped_kernel(const unimm_transpose_desc* __restrict__ tab, int count) {
+  __shared__ float tile[32][33];
+  int lo = 0, hi = count - 1;                 // wave-uniform binary search over the prefix sums
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].tile0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const unimm_transpose_desc d = tab[lo];
+  const int local = blockIdx.x - d.tile0, nbx = (d.C + 31) / 32;
+  const int r0 = (local / nbx) * 32, c0 = (local % nbx) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  bf16_t* dst = reinterpret_cast<bf16_t*>(d.dst);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + ty + 8 * k, c = c0 + tx;
+    tile[ty + 8 * k][tx] = (r < d.R && c < d.C) ? d.src[(size_t)r * d.C + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c0 + ty + 8 * k, r = r0 + tx;
+    if (c < d.C && r < d.ldd) dst[(size_t)c * d.ldd + r] = f2bf(tile[tx][ty + 8 * k]);
+  }
+}
+
 // region features: fp32 [rows, F] + fp32 loc [rows, 5] -> bf16 [rows, ld] = [feat | loc | 0...]
 // (operand of the single image-embedding GEMM; models/vilbert_dialog.py:1488-1489)
 __global__ void pack_image_kernel(const float* __restrict__ feat, const float* __restrict__ loc, bf16_t* __restrict__ out,
@@ -689,6 +716,13 @@ extern "C" int unimm_transpose_cast(const float* src, void* dst, int32_t R, int3
   if (!src || !dst || R <= 0 || C <= 0 || ldd < R) return UNIMM_E_ARG;
   hipLaunchKernelGGL(transpose_cast_kernel, dim3((C + 31) / 32, (ldd + 31) / 32), dim3(256), 0, (hipStream_t)stream, src,
                      (bf16_t*)dst, R, C, ldd);
+  UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
+}
+
+extern "C" int unimm_transpose_cast_grouped(const unimm_transpose_desc* table, int32_t count, int32_t total_tiles, void* stream) {
+  if (!table || count <= 0 || total_tiles <= 0) return UNIMM_E_ARG;
+  hipLaunchKernelGGL(transpose_cast_grouped_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, table, count);
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;
 }

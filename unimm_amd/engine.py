@@ -82,6 +82,7 @@ class Engine:
         self._anchor = torch.zeros(1, device=device, requires_grad=True)
         self._build_tables(device)
         self._w_version = None
+        self._wt_table = None
 
     def _fused(self, names):
         """bf16 / fp32 / grad views spanning several consecutive arena entries (fused QKV)."""
@@ -179,20 +180,25 @@ class Engine:
         self.part = {h: torch.empty(L.colpartials_bytes(h) // 4, dtype=F32, device=device)
                      for h in {cfg.hidden_size, cfg.v_hidden_size}}
 
-    def refresh_weights(self, force=False):
-        """fp32 arena -> bf16 copies (one cast kernel) + transposed copies for the dgrad GEMMs."""
+    def refresh_weights(self, force=False, cast=True):
+        """fp32 arena -> bf16 copies (one cast kernel) + transposed copies for the dgrad GEMMs.
+        cast=False: the caller (the fused AdamW step) has already written the bf16 copy."""
         A = self.arena
         ver = A.flat._version
         if not force and ver == self._w_version:
             return
-        L.cast_f32_bf16(A.flat, self.w16, A.numel)
-        for key, wnames in self._wt_src:
-            lin = self.lin[key]
-            if lin.wt is None:
-                continue
-            o0, _ = A.offsets[wnames[0]]
-            src = A.flat[o0:o0 + lin.N * lin.K]
-            L.transpose_cast(src, lin.wt, lin.N, lin.K, lin.wt.shape[1])
+        if cast:
+            L.cast_f32_bf16(A.flat, self.w16, A.numel)
+        if self._wt_table is None:          # one descriptor table for every transposed copy, built once
+            ents = []
+            for key, wnames in self._wt_src:
+                lin = self.lin[key]
+                if lin.wt is None:
+                    continue
+                o0, _ = A.offsets[wnames[0]]
+                ents.append((A.flat[o0:o0 + lin.N * lin.K].view(lin.N, lin.K), lin.wt))
+            self._wt_table = L.transpose_table(ents, A.flat.device)
+        L.transpose_cast_grouped(*self._wt_table)
         cfg = self.cfg
         F = cfg.v_feature_size
         v = "bert.v_embeddings."

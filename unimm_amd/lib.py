@@ -72,7 +72,7 @@ SYMBOLS = ["unimm_version", "unimm_arch", "unimm_gemm_nt", "unimm_gemm_tn", "uni
            "unimm_embed_fwd", "unimm_embed_bwd", "unimm_colsum", "unimm_cast_f32_bf16", "unimm_transpose_cast",
            "unimm_pack_image", "unimm_mul_dropout", "unimm_mul_dropout_bwd", "unimm_lm_loss_fwd",
            "unimm_lm_loss_bwd", "unimm_kl_loss_fwd", "unimm_kl_loss_bwd", "unimm_nsp_loss_fwd",
-           "unimm_nsp_loss_bwd", "unimm_reduce_sum", "unimm_segment_sum", "unimm_gelu_bwd", "unimm_gather_rows", "unimm_prof_enable", "unimm_prof_collect", "unimm_gemm_set_tile", "unimm_attn_set_parts"]
+           "unimm_nsp_loss_bwd", "unimm_reduce_sum", "unimm_segment_sum", "unimm_gelu_bwd", "unimm_gather_rows", "unimm_prof_enable", "unimm_prof_collect", "unimm_gemm_set_tile", "unimm_attn_set_parts", "unimm_adamw_step", "unimm_transpose_cast_grouped"]
 
 
 def _check(rc, what):
@@ -300,6 +300,29 @@ def transpose_cast(src, dst, R, C_, ldd):
            "unimm_transpose_cast")
 
 
+class TransposeDesc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("R", C.c_int32), ("C", C.c_int32), ("ldd", C.c_int32),
+                ("tile0", C.c_int32)]
+
+
+def transpose_table(entries, device):
+    """entries: list of (src fp32 [R, C] tensor, dst bf16 [C, ldd] tensor) -> (device table tensor, count, tiles)."""
+    arr = (TransposeDesc * len(entries))()
+    tiles = 0
+    for d, (src, dst) in zip(arr, entries):
+        _dev(src, dst)
+        R, Cc = src.shape
+        d.src, d.dst, d.R, d.C, d.ldd, d.tile0 = src.data_ptr(), dst.data_ptr(), R, Cc, dst.shape[1], tiles
+        tiles += ((Cc + 31) // 32) * ((dst.shape[1] + 31) // 32)
+    raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+    return raw, len(entries), tiles
+
+
+def transpose_cast_grouped(table, count, tiles):
+    _check(lib().unimm_transpose_cast_grouped(_ptr(table), C.c_int32(count), C.c_int32(tiles), _stream()),
+           "unimm_transpose_cast_grouped")
+
+
 def pack_image(feat, loc, out, rows, F, ld):
     _dev(feat, loc, out)
     _check(lib().unimm_pack_image(_ptr(feat), _ptr(loc), _ptr(out), C.c_int32(rows), C.c_int32(F), C.c_int32(ld),
@@ -387,6 +410,35 @@ def gather_rows(src, idx, dst, n, H, scatter=False):
 GEMM_VARIANTS = {0: "gemm_nt<BIAS,bf16>", 1: "gemm_nt<BIAS,f32>", 2: "gemm_nt<BIAS_GELU,bf16>", 3: "gemm_nt<BIAS_GELU,f32>",
                  5: "gemm_nt<BIAS_DROP_RESID,f32>", 6: "gemm_nt<BIAS_RELU,bf16>", 8: "gemm_nt<DGELU,bf16>",
                  10: "gemm_nt<ADD,bf16>", 12: "gemm_nt<MUL,bf16>", 14: "gemm_nt<BIAS_GELU_DG,bf16>", 16: "gemm_tn"}
+
+
+ADAMW_MAX_GROUPS = 8
+ADAMW_SKIP = 255          # chunk group id of parameters that never receive a gradient
+
+
+class AdamWArgs(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("w16", C.c_void_p),
+                ("group", C.c_void_p), ("n", C.c_int64), ("n_groups", C.c_int32), ("step", C.c_int32),
+                ("lr", C.c_double * ADAMW_MAX_GROUPS), ("weight_decay", C.c_double * ADAMW_MAX_GROUPS),
+                ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("grad_scale", C.c_float),
+                ("correct_bias", C.c_int32), ("zero_grad", C.c_int32)]
+
+
+def adamw_step(p, g, m, v, group, lrs, wds, step, beta1=0.9, beta2=0.999, eps=1e-6, w16=None, grad_scale=1.0,
+               correct_bias=True, zero_grad=False):
+    """One fused AdamW step over flat fp32 arenas (see include/unimm_hip.h: unimm_adamw_step)."""
+    _dev(p, g, m, v, group, w16)
+    if len(lrs) != len(wds) or not 1 <= len(lrs) <= ADAMW_MAX_GROUPS:
+        raise UnimmHipError(f"adamw_step: 1..{ADAMW_MAX_GROUPS} (lr, weight_decay) groups, got {len(lrs)}")
+    a = AdamWArgs()
+    a.p, a.g, a.m, a.v, a.w16, a.group = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), \
+        (w16.data_ptr() if w16 is not None else None), group.data_ptr()
+    a.n, a.n_groups, a.step = p.numel(), len(lrs), int(step)
+    for i, (lr, wd) in enumerate(zip(lrs, wds)):
+        a.lr[i], a.weight_decay[i] = float(lr), float(wd)
+    a.beta1, a.beta2, a.eps, a.grad_scale = beta1, beta2, eps, grad_scale
+    a.correct_bias, a.zero_grad = int(bool(correct_bias)), int(bool(zero_grad))
+    _check(lib().unimm_adamw_step(C.byref(a), _stream()), "unimm_adamw_step")
 
 
 def prof_enable(on: bool):
