@@ -15,6 +15,7 @@ compute step is a C-ABI call and raises if the library is missing."""
 from __future__ import annotations
 
 import math
+import os
 import zlib
 from typing import Dict, List, Optional
 
@@ -62,6 +63,8 @@ class Engine:
         self.last_seq_t = None
         self.unpad = True                # run the text stream on valid rows only (see _varlen_plan)
         self._wq = []                    # queued weight-gradient problems of the block being back-propagated
+        self.wgrad_stream = os.environ.get("UNIMM_WGRAD_STREAM", "1") == "1"   # grouped launches on a side stream
+        self._side = None
         self.last_plan = None
 
     # ------------------------------------------------------------------------------------------
@@ -230,9 +233,28 @@ class Engine:
         self._wq.append((dy, x, gw, M, N, K, dbias))
 
     def _flush_wgrad(self):
-        if self._wq:
+        if not self._wq:
+            return
+        if not self.wgrad_stream:
             L.gemm_tn_grouped(self._wq)
             self._wq = []
+            return
+        # side stream: the grouped launch ends with a partial last round and a memory-side atomic drain during
+        # which most CUs idle; the next block's input-gradient GEMMs can fill them
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.arena.flat.device)
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            L.gemm_tn_grouped(self._wq)
+        for dy, x, *_ in self._wq:              # keep the caching allocator from recycling them early
+            dy.record_stream(self._side)
+            x.record_stream(self._side)
+        self._wq = []
+
+    def _join_wgrad(self):
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
 
     def _linear_bwd(self, dy, x, lin, epi=L.EPI_BIAS, aux=None, need_dx=True, bias_grad=True, M=None, N=None, xk=None):
         """dW += dy^T x ; db += colsum(dy) ; returns dx = epi(dy @ W)."""
@@ -757,4 +779,7 @@ class Engine:
     def _bucket_done(self, group):
         self._flush_wgrad()                       # the bucket's queued weight gradients
         if self.grad_bucket_hook is not None:
+            self._join_wgrad()                    # the exchange reads them
             self.grad_bucket_hook(group)
+        elif group == "text_embeddings":          # last bucket: everything joined before the caller continues
+            self._join_wgrad()
