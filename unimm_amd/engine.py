@@ -63,7 +63,11 @@ class Engine:
         self.last_seq_t = None
         self.unpad = True                # run the text stream on valid rows only (see _varlen_plan)
         self._wq = []                    # queued weight-gradient problems of the block being back-propagated
-        self.wgrad_stream = os.environ.get("UNIMM_WGRAD_STREAM", "1") == "1"   # grouped launches on a side stream
+        # Option: grouped weight-gradient launches on a side stream (UNIMM_WGRAD_STREAM=1): +1.8 % throughput in
+        # interleaved runs (61.2 -> 60.1 ms) because the next block's GEMMs fill the partial last round and the
+        # atomic drain.  Off by default: overlapped kernels stretch each other's durations, so per-kernel event /
+        # rocprof timings (bench.py's roofline block) would no longer be exclusive.
+        self.wgrad_stream = os.environ.get("UNIMM_WGRAD_STREAM", "0") == "1"
         self._side = None
         self.last_plan = None
 
