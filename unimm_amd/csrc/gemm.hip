@@ -830,6 +830,7 @@ int launch_nt(const GemmNtParams& p, bool out_f32, hipStream_t s) {
   if (cfg == 2) return launch_nt_cfg<Cfg<2, 4, 8, 32, 4>, EPI>(p, out_f32, s);
   if (cfg == 4) return launch_nt_cfg<Cfg<2, 4, 8, 32, 5>, EPI>(p, out_f32, s);
   if (cfg == 5) return launch_nt_cfg<Cfg<2, 2, 4, 32, 5>, EPI>(p, out_f32, s);
+  if (cfg == 6) return launch_nt_cfg<Cfg<4, 2, 4, 64, 2>, EPI>(p, out_f32, s);
   if (cfg == 3) return launch_nt_cfg<Cfg<2, 4, 8, 64, 2>, EPI>(p, out_f32, s);
   return launch_nt_cfg<Cfg<2, 2, 4, 64, 2>, EPI>(p, out_f32, s);
 }
@@ -871,7 +872,7 @@ extern "C" int unimm_gemm_set_tile(int32_t cfg) {
   if (cfg < 0 || cfg > 999 * 1000 + 999) return UNIMM_E_ARG;
   g_nt_cfg = cfg % 1000;          // tile configuration
   g_nt_gn = cfg / 1000;           // tuning: n-tiles per column group (0 = default)
-  if (g_nt_cfg > 5) return UNIMM_E_ARG;
+  if (g_nt_cfg > 6) return UNIMM_E_ARG;
   return UNIMM_OK;
 }
 
