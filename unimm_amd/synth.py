@@ -147,3 +147,19 @@ def make_batch(n_seq=240, T=256, R=37, cfg=None, seed=1234, dis_rate=0.5, num_ne
     if device != "cpu":
         batch = {k: (v.to(device) if k != "nsp_weight" else v) for k, v in batch.items()}
     return batch
+
+
+def make_loader_batch(n_img=2, rounds=2, samples=3, T=256, R=37, cfg=None, seed=1234, **kw):
+    """The same content in the DATALOADER's layout (what train.py's `forward` receives, train.py:30-112):
+    text fields [n_img, rounds, samples, ...], image fields per image [n_img, R, ...] (train.py:413-432
+    expands them; unimm_amd.trainer.expand_image_fields does the same)."""
+    spi = rounds * samples
+    b = make_batch(n_seq=n_img * spi, T=T, R=R, cfg=cfg, seed=seed, sequences_per_image=spi, **kw)
+    shp = lambda t: t.reshape((n_img, rounds, samples) + tuple(t.shape[1:]))
+    per_img = lambda t: t[::spi].contiguous()
+    return dict(tokens=shp(b["input_ids"]), segments=shp(b["token_type_ids"]), positions=shp(b["token_position_ids"]),
+                mask=shp(b["masked_lm_labels"]), weights=shp(b["lm_weight"]), txt_attention_mask=shp(b["attention_mask"]),
+                co_attention_mask=shp(b["co_attention_mask"]), next_sentence_labels=shp(b["next_sentence_label"]),
+                sep_indices=shp(b["sep_indices"]), hist_len=shp(b["sep_len"]) - 1,
+                image_feat=per_img(b["image_feat"]), image_loc=per_img(b["image_loc"]), image_target=per_img(b["image_target"]),
+                image_label=per_img(b["image_label"]), image_mask=per_img(b["image_attention_mask"])), b["nsp_weight"]
