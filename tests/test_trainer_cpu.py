@@ -1,0 +1,63 @@
+"""CPU tests of the training-loop shell's host logic (no kernels): dataloader-layout batches, the image
+expansion of train.py:413-432, the checkpoint dict of train.py:503-505 with warm start and resume, and the
+optimizer / scheduler cadence of train_step under batch_multiply (with a stand-in model and torch SGD)."""
+import os
+
+import torch
+
+from unimm_amd import synth, trainer
+from unimm_amd.optim import WarmupLinearScheduleNonZero
+
+
+def test_loader_batch_layout_and_image_expansion():
+    b, nsp_w = synth.make_loader_batch(n_img=3, rounds=2, samples=4, T=64, R=37, seed=3)
+    assert b["tokens"].shape == (3, 2, 4, 64) and b["txt_attention_mask"].shape == (3, 2, 4, 64, 64)
+    assert b["image_feat"].shape[:2] == (3, 37) and b["co_attention_mask"].shape == (3, 2, 4, 37, 64)
+    e = trainer.expand_image_fields(b)
+    assert e["image_feat"].shape[:4] == (3, 2, 4, 37) and e["image_label"].shape == (3, 2, 4, 37)
+    assert torch.equal(e["image_feat"][1, 0, 0], e["image_feat"][1, 1, 3])      # one image, every round and sample
+    assert torch.equal(e["tokens"], b["tokens"]) and nsp_w.shape == (1, 2)
+
+
+class _Enc(torch.nn.Module):
+    """Stand-in with the call signature harness.forward uses; losses depend on the parameters."""
+
+    def __init__(self):
+        super().__init__()
+        self.bert_pretrained = torch.nn.Linear(4, 3)
+
+    def forward(self, tokens, feat, loc, **kw):
+        z = self.bert_pretrained(feat.float().mean(1)[:, :4])
+        return z[:, 0].pow(2).mean().reshape(1), z[:, 1].pow(2).mean().reshape(1), z[:, 2].pow(2).mean().reshape(1)
+
+
+def test_train_step_cadence_and_checkpoint_roundtrip(tmp_path):
+    torch.manual_seed(0)
+    enc = _Enc()
+    opt = torch.optim.SGD(enc.parameters(), lr=0.1)
+    sch = WarmupLinearScheduleNonZero(opt, warmup_steps=2, t_total=10, min_lr=1e-5)
+    b, nsp_w = synth.make_loader_batch(n_img=1, rounds=1, samples=2, T=64, seed=1)
+    b = trainer.expand_image_fields(b)
+    params = dict(lm_loss_coeff=1.0, nsp_loss_coeff=1.0, img_loss_coeff=1.0, nsp_weight=nsp_w, batch_multiply=3)
+    w0 = enc.bert_pretrained.weight.detach().clone()
+    steps = []
+    real = opt.step
+    opt.step = lambda *a, **k: (steps.append(sch.last_epoch), real(*a, **k))[1]
+    for it in range(1, 7):
+        trainer.train_step(enc, opt, sch, b, params, it)
+        if it < 3:
+            assert torch.equal(enc.bert_pretrained.weight, w0)                 # still accumulating
+    assert steps == [2, 5] and sch.last_epoch == 6                             # optimizer on iterations 3 and 6 only
+    assert all(p.grad is None or float(p.grad.abs().max()) == 0 for p in enc.parameters())   # zero_grad after each step
+    path = trainer.save_checkpoint(os.path.join(tmp_path, "c.ckpt"), enc, opt, sch, 6)
+    d = torch.load(path)
+    assert set(d) == {"model_state_dict", "scheduler_state_dict", "optimizer_state_dict", "iter_id"}
+    enc2 = _Enc()
+    opt2 = torch.optim.SGD(enc2.parameters(), lr=0.1)
+    sch2 = WarmupLinearScheduleNonZero(opt2, warmup_steps=2, t_total=10, min_lr=1e-5)
+    assert trainer.load_checkpoint(path, enc2, opt2, sch2, resume=True) == 6
+    assert torch.equal(enc2.bert_pretrained.weight, enc.bert_pretrained.weight) and sch2.last_epoch == 6
+    assert opt2.param_groups[0]["lr"] == opt.param_groups[0]["lr"]
+    enc3 = _Enc()
+    sd = dict(d["model_state_dict"]); sd["extra.key"] = torch.zeros(1); sd.pop("bert_pretrained.bias")
+    assert trainer.load_checkpoint({"model_state_dict": sd}, enc3) == 1 and torch.equal(enc3.bert_pretrained.weight, enc.bert_pretrained.weight)
