@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--with-optimizer", action="store_true",
                     help="also run the fused AdamW step (train.py:322-348 grouping and schedule) inside the timed step; "
                          "NOT the headline metric, which is fwd+bwd (the config block says which was run)")
+    ap.add_argument("--compact-inputs", action="store_true",
+                    help="feed mask descriptors + per-image tensors + image_index (SURVEY 8 row F3) instead of the "
+                         "reference-shaped dense masks and per-sequence image copies")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--config", default=os.path.join(ROOT, "unimm_amd", "config", "bert_base_6layer_6conect.json"))
@@ -238,12 +241,23 @@ def main():
                                  sequences_per_image=2)
         coeff = dict(lm=1.0, nsp=0.0, img=1.0)
     else:
-        batch = synth.make_batch(n_seq=per_gpu, cfg=cfg, seed=1234 + rank, device=dev)
+        batch = synth.make_batch(n_seq=per_gpu, cfg=cfg, seed=1234 + rank, device=dev, compact=args.compact_inputs)
         coeff = dict(lm=1.0, nsp=1.0, img=1.0)    # options.py:68-70 defaults
     nsp_w = batch.pop("nsp_weight")
     n_lm_rows = int((batch["lm_weight"] != 0).sum())
 
     def fwd_bwd():
+        if args.compact_inputs and args.workload == "train":
+            lm, img, nsp = net(batch["input_ids"], batch["image_feat_unique"], batch["image_loc_unique"],
+                               sep_indices=batch["sep_indices"], sep_len=batch["sep_len"], token_type_ids=batch["token_type_ids"],
+                               token_position_ids=batch["token_position_ids"], attention_mask=batch["mask_spec"],
+                               masked_lm_labels=batch["masked_lm_labels"], next_sentence_label=batch["next_sentence_label"],
+                               image_attention_mask=batch["image_attention_mask"], image_label=batch["image_label"],
+                               image_target=batch["image_target_unique"], nsp_weight=nsp_w, lm_weight=batch["lm_weight"],
+                               image_index=batch["image_index"])
+            loss = coeff["lm"] * lm.mean() + coeff["nsp"] * nsp.mean() + coeff["img"] * img.mean()
+            loss.backward()
+            return loss
         lm, img, nsp = net(batch["input_ids"], batch["image_feat"], batch["image_loc"], sep_indices=batch["sep_indices"],
                            sep_len=batch["sep_len"], token_type_ids=batch["token_type_ids"],
                            token_position_ids=batch["token_position_ids"], attention_mask=batch["attention_mask"],
@@ -347,7 +361,8 @@ def main():
                   "sequences_per_image=6, num_negative_samples=5, mask_prob=0.15, dropout on, "
                   "MLM+UL / NSP / region-KL losses, fwd+bwd, " +
                   ("PLUS the fused AdamW step and weight-copy refresh (--with-optimizer)" if args.with_optimizer
-                   else "optimizer step not included"))
+                   else "optimizer step not included") +
+                  ("; compact inputs (mask descriptors, per-image tensors)" if args.compact_inputs else ""))
         out = {
             "metric": metric,
             "value": round(value, 2), "unit": "dialog-sequences/sec", "n_gpus": world, "steps": args.steps,

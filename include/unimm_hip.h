@@ -151,6 +151,14 @@ enum { UNIMM_DT_U8 = 0, UNIMM_DT_I32 = 1, UNIMM_DT_I64 = 2, UNIMM_DT_F32 = 3 };
  * ceil(t/32) words per row.  Replaces the fp32 (1-m)*-10000 mask tensors of
  * models/vilbert_dialog.py:1415-1431 (the -10000 is applied inside the attention kernels). */
 int unimm_mask_pack(const void* mask, int dtype, uint32_t* out, int64_t rows, int32_t t, void* stream);
+/* The same words without the dense mask: the text mask [B, T, ceil(T/32)] and the
+ * co-attention key mask [B, ceil(T/32)] (one row per sequence, mask_q_stride = 0) of B sequences from three
+ * int32 device arrays: mode (0 = discriminative, utils/data_utils.py:391-396; 1 = generative, :199-210),
+ * len = L (tokens up to and including the answer's [SEP]; L <= T) and nans = n (answer length + 1, the size
+ * of the [MASK]-copy block; ignored when mode = 0).  Removes the 512 KiB per sequence of int64 mask the
+ * reference ships to the device. */
+int unimm_mask_synth(const int32_t* mode, const int32_t* len, const int32_t* nans, uint32_t* text_words, uint32_t* co_words,
+                     int32_t B, int32_t T, void* stream);
 
 /* y = LayerNorm(x) (eps inside sqrt, torch.nn.LayerNorm; models/vilbert_dialog.py:279) with optional
  * dropout on y.  The residual stream is fp32 (as under the reference's autocast, where layer_norm and

@@ -334,3 +334,38 @@ def test_attention_variable_length_matches_padded():
                  qvar=(off, ln), kvar=(off, ln))
     torch.cuda.synchronize()
     assert relerr(dqkv_v, dqkv_p[rows]) < 1e-2
+
+
+def test_mask_synth_matches_the_oracle_encoders_bit_for_bit():
+    """unimm_mask_synth against oracle/masks.py (itself pinned to the reference's encode_input_gen / _dis by golden
+    G5): packed text and co-attention words for generative and discriminative sequences, incl. one-token answers,
+    a copy block cut by the sequence end, and other T."""
+    from oracle import masks as OM
+    from unimm_amd import lib
+    from unimm_amd.inputs import DialogMaskSpec
+    for T in (256, 64, 96):
+        cases = []
+        rng = np.random.default_rng(T)
+        for _ in range(40):
+            n_utt = int(rng.integers(1, 6))
+            a = int(rng.integers(1, 9))
+            lens = [int(rng.integers(1, max(2, (T - 3 * a) // (2 * n_utt)))) for _ in range(n_utt)] + [a]
+            cases.append((int(rng.integers(0, 2)), lens))
+        cases += [(1, [3, 1]), (1, [1, 1]), (0, [2, 2]), (1, [T - 14, 9]), (0, [T - 3])]     # [T-14, 9]: copy block cut at T
+        mode, Ls, ns, txt, co = [], [], [], [], []
+        for m, lens in cases:
+            utts = [list(range(1000, 1000 + l)) for l in lens]
+            enc = (OM.encode_gen if m else OM.encode_dis)(utts, max_seq_len=T)
+            L = 1 + sum(l + 1 for l in lens)
+            if L > T:
+                continue
+            mode.append(m); Ls.append(L); ns.append(lens[-1] + 1)
+            txt.append(np.asarray(enc["txt_attention_mask"][0]) != 0); co.append(np.asarray(enc["co_attention_mask"][0]) != 0)
+        spec = DialogMaskSpec(mode, Ls, ns)
+        tw, cw = lib.mask_synth(*spec.to_device(DEV), T)
+        want_t = lib.mask_pack(torch.from_numpy(np.stack(txt)).to(DEV))
+        want_c = lib.mask_pack(torch.from_numpy(np.stack(co)).to(DEV))
+        torch.cuda.synchronize()
+        assert torch.equal(tw, want_t) and torch.equal(cw, want_c)
+        dt, dc = spec.dense(T)                                   # the host-side dense form agrees too
+        assert torch.equal(dt, torch.from_numpy(np.stack(txt))) and torch.equal(dc, torch.from_numpy(np.stack(co)))

@@ -277,3 +277,31 @@ def test_data_parallel_wrapper_over_rccl_single_rank(golden_dir):
     finally:
         model.engine.grad_bucket_hook = None
         dist.destroy_process_group()
+
+
+def test_compact_inputs_equal_dense_inputs(golden_dir):
+    """Row F3: mask descriptors + one image entry per image + image_index give the same losses and gradients as the
+    reference-shaped inputs (dense [B,T,T] / [B,R,T] masks, per-sequence copies of the image tensors)."""
+    from unimm_amd import synth
+    model, _, _ = build_small(golden_dir)
+    model.eval()
+    b = synth.make_batch(n_seq=12, T=64, R=37, cfg=model.config, seed=21, sequences_per_image=6, compact=True, device="cuda")
+    common = dict(token_type_ids=b["token_type_ids"], position_ids=b["token_position_ids"], image_attention_mask=b["image_attention_mask"],
+                  masked_lm_labels=b["masked_lm_labels"], image_label=b["image_label"], next_sentence_label=b["next_sentence_label"],
+                  nsp_weight=b["nsp_weight"], lm_weight=b["lm_weight"], _want_lm_scores=False)
+    outs = []
+    for compact in (False, True):
+        model.zero_grad(set_to_none=True)
+        if compact:
+            r = model(b["input_ids"], b["image_feat_unique"], b["image_loc_unique"], attention_mask=b["mask_spec"],
+                      image_target=b["image_target_unique"], image_index=b["image_index"], **common)
+            assert model.engine.last_plan is not None                 # the unpadded schedule came from the descriptors
+        else:
+            r = model(b["input_ids"], b["image_feat"], b["image_loc"], attention_mask=b["attention_mask"],
+                      co_attention_mask=b["co_attention_mask"], image_target=b["image_target"], **common)
+        (r[0] + r[1] + r[2]).sum().backward()
+        torch.cuda.synchronize()
+        outs.append(([float(x.detach()) for x in r[:3]], r[5].detach().clone(), model.engine.arena.grad_flat.clone()))
+    (l0, n0, g0), (l1, n1, g1) = outs
+    assert l0 == l1 and torch.equal(n0, n1)                           # same kernels on the same words: bit-identical
+    assert (g0 - g1).abs().max() <= 1e-5 * g0.abs().max()             # (atomics order)

@@ -43,6 +43,46 @@ __global__ void mask_pack_generic_kernel(const T* __restrict__ m, uint32_t* __re
   out[i] = bits;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Packed text / co-attention masks straight from per-sequence descriptors: what
+// utils/data_utils.py:199-210 (generative) and :391-396 (discriminative) write as dense [T, T] int64
+// matrices, as words.  L = tokens up to and including the answer's [SEP], n = answer length + 1
+// (0 in the discriminative regime), c = L - n:
+//   generative:  row 0 -> [0, L+n);  rows [1, c) -> [1, c);  rows [c, L) -> [1, row];
+//                copy rows r in [L, L+n) -> [1, c + (r - L)) plus r itself;  rows >= L+n -> empty
+//   discriminative: rows [0, L) -> [0, L)
+//   co-attention (one row per sequence): generative [1, c), discriminative [0, L)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t range_bits(int lo, int hi, int w) {   // bits of [lo, hi) inside word w
+  const int a = lo - 32 * w, b = hi - 32 * w;
+  const int x = a < 0 ? 0 : a, y = b > 32 ? 32 : b;
+  if (x >= y) return 0u;
+  const uint32_t upto_y = y == 32 ? 0xffffffffu : ((1u << y) - 1u);
+  return upto_y & ~((1u << x) - 1u);
+}
+
+__global__ void mask_synth_kernel(const int* __restrict__ mode, const int* __restrict__ len, const int* __restrict__ nans,
+                                  uint32_t* __restrict__ text, uint32_t* __restrict__ co, int B, int T) {
+  const int nw = (T + 31) >> 5;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * T * nw) return;
+  const int w = (int)(i % nw), row = (int)((i / nw) % T), b = (int)(i / ((size_t)nw * T));
+  const int L = len[b], n = nans[b], c = L - n;
+  uint32_t bits;
+  if (mode[b] == 0) {
+    bits = row < L ? range_bits(0, L, w) : 0u;
+  } else {
+    if (row == 0) bits = range_bits(0, L + n, w);
+    else if (row < c) bits = range_bits(1, c, w);
+    else if (row < L) bits = range_bits(1, row + 1, w);
+    else if (row < L + n) bits = range_bits(1, c + (row - L), w) | range_bits(row, row + 1, w);
+    else bits = 0u;
+  }
+  bits &= range_bits(0, T, w);
+  text[i] = bits;
+  if (row == 0) co[(size_t)b * nw + w] = (mode[b] == 0 ? range_bits(0, L, w) : range_bits(1, c, w)) & range_bits(0, T, w);
+}
+
 template <typename T>
 int mask_pack_impl(const void* m, uint32_t* out, size_t rows, int t, hipStream_t s) {
   const int nw = (t + 31) / 32;
@@ -716,6 +756,16 @@ extern "C" int unimm_transpose_cast(const float* src, void* dst, int32_t R, int3
   if (!src || !dst || R <= 0 || C <= 0 || ldd < R) return UNIMM_E_ARG;
   hipLaunchKernelGGL(transpose_cast_kernel, dim3((C + 31) / 32, (ldd + 31) / 32), dim3(256), 0, (hipStream_t)stream, src,
                      (bf16_t*)dst, R, C, ldd);
+  UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
+}
+
+extern "C" int unimm_mask_synth(const int32_t* mode, const int32_t* len, const int32_t* nans, uint32_t* text_words,
+                                uint32_t* co_words, int32_t B, int32_t T, void* stream) {
+  if (!mode || !len || !nans || !text_words || !co_words || B <= 0 || T <= 0) return UNIMM_E_ARG;
+  const size_t total = (size_t)B * T * ((T + 31) / 32);
+  hipLaunchKernelGGL(mask_synth_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mode, len,
+                     nans, text_words, co_words, B, T);
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;
 }

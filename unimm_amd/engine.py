@@ -25,6 +25,7 @@ from . import dropout as DR
 from . import lib as L
 from . import params as PM
 from .arena import FlatArena
+from .inputs import DialogMaskSpec
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -443,6 +444,11 @@ class Engine:
         idx = torch.arange(1, T + 1, device=device, dtype=torch.int32)
         lens = (valid.to(torch.int32) * idx).amax(dim=1).clamp_min(1)
         lens_h = lens.tolist()                                         # one host sync per step
+        return self._plan_from_lengths(lens_h, lens, B, T, device)
+
+    @staticmethod
+    def _plan_from_lengths(lens_h, lens, B, T, device):
+        """Row maps of the unpadded schedule from the per-sequence valid lengths (host list [+ device copy])."""
         Mv = int(sum(lens_h))
         if Mv == B * T:
             return None
@@ -452,6 +458,8 @@ class Engine:
         rows = np.concatenate([np.arange(b * T, b * T + l) for b, l in enumerate(lens_h)])
         inv = np.full(B * T, -1, dtype=np.int64)
         inv[rows] = np.arange(Mv)
+        if lens is None:
+            lens = torch.from_numpy(ln.astype(np.int32)).to(device)
         return dict(Mv=Mv, lens_h=lens_h, rows=torch.from_numpy(rows).to(device),
                     inv=torch.from_numpy(inv).to(device), inv_h=inv,
                     var=(torch.from_numpy(off.astype(np.int32)).to(device), lens.contiguous()))
@@ -469,6 +477,13 @@ class Engine:
         B, T = ids.shape
         feat = inp["image_feat"]
         R = feat.shape[1]
+        img_idx = inp.get("image_index")
+        if img_idx is not None:
+            img_idx = img_idx.to(dev, dtype=torch.int64, non_blocking=True).reshape(-1)
+            if img_idx.numel() != B:
+                raise ValueError("image_index needs one entry per sequence")
+        elif feat.shape[0] != B:
+            raise ValueError(f"image_feat has {feat.shape[0]} rows for {B} sequences and no image_index was given")
         if T > 256 or R > 256:
             raise ValueError("sequence / region count above 256 is not supported by the attention kernels")
         H, Hv = cfg.hidden_size, cfg.v_hidden_size
@@ -477,6 +492,14 @@ class Engine:
 
         # ---- masks (models/vilbert_dialog.py:1374-1431) ------------------------------------------
         am = inp.get("attention_mask")
+        spec = am if isinstance(am, DialogMaskSpec) else None
+        if spec is not None:
+            if len(spec) != B or int(spec.length.max()) > T:
+                raise ValueError(f"DialogMaskSpec for {len(spec)} sequences / max length {int(spec.length.max())} "
+                                 f"does not fit input_ids of shape {tuple(ids.shape)}")
+            if inp.get("co_attention_mask") is not None:
+                raise ValueError("co_attention_mask must be None when attention_mask is a DialogMaskSpec (it is derived)")
+            am = torch.ones((B, T), dtype=torch.uint8, device=dev)      # placeholder, never packed
         if am is None:
             am = torch.ones((B, T), dtype=torch.uint8, device=dev)
         if am.dim() not in (2, 3):
@@ -486,18 +509,28 @@ class Engine:
             im = torch.ones((B, R), dtype=torch.uint8, device=dev)
         if im.dim() not in (2, 3):
             raise ValueError(f"Wrong shape for img input_ids (shape {tuple(feat.shape)}) or attention_mask (shape {tuple(im.shape)})")
-        cm = inp.get("co_attention_mask")
-        if cm is None:
-            cm = torch.ones((B, R, T), dtype=torch.uint8, device=dev)
-        assert cm.dim() == 3
         self._dev_masks = []
-        tmask = self._pack_mask(am, dev, T)
-        vmask = self._pack_mask(im, dev, R)
-        comask = self._pack_mask(cm, dev, R)
         plan = None
-        if self.unpad:
-            plan = self._varlen_plan(self._dev_masks[0], self._dev_masks[2], inp.get("masked_lm_labels"),
-                                     inp.get("lm_weight"), B, T, dev)
+        if spec is not None:
+            # masks synthesised on the device from (mode, L, n); valid lengths known on the host: no sync
+            tw, cw = L.mask_synth(*spec.to_device(dev), T)
+            nw = tw.shape[-1]
+            tmask, comask = (tw, nw, T * nw), (cw, 0, nw)
+            vmask = self._pack_mask(im, dev, R)
+            if self.unpad:
+                lens_h = spec.valid_lengths(T).tolist()
+                plan = self._plan_from_lengths(lens_h, None, B, T, dev)
+        else:
+            cm = inp.get("co_attention_mask")
+            if cm is None:
+                cm = torch.ones((B, R, T), dtype=torch.uint8, device=dev)
+            assert cm.dim() == 3
+            tmask = self._pack_mask(am, dev, T)
+            vmask = self._pack_mask(im, dev, R)
+            comask = self._pack_mask(cm, dev, R)
+            if self.unpad:
+                plan = self._varlen_plan(self._dev_masks[0], self._dev_masks[2], inp.get("masked_lm_labels"),
+                                         inp.get("lm_weight"), B, T, dev)
         self._dev_masks = []
         self.last_plan = plan
         var = plan["var"] if plan is not None else None
@@ -528,8 +561,11 @@ class Engine:
                             cfg.type_vocab_size, drop=d_embt)
 
         F = cfg.v_feature_size
-        featd = feat.to(dev, dtype=F32, non_blocking=True).contiguous().view(B * R, F)
-        locd = inp["image_loc"].to(dev, dtype=F32, non_blocking=True).contiguous().view(B * R, 5)
+        featd = feat.to(dev, dtype=F32, non_blocking=True)
+        locd = inp["image_loc"].to(dev, dtype=F32, non_blocking=True)
+        if img_idx is not None:             # one entry per image on the wire, expanded on the device (train.py:413-432)
+            featd, locd = featd.index_select(0, img_idx), locd.index_select(0, img_idx)
+        featd, locd = featd.contiguous().view(B * R, F), locd.contiguous().view(B * R, 5)
         packed = torch.empty((B * R, self.vemb_k), dtype=BF16, device=dev)
         L.pack_image(featd, locd, packed, B * R, F, self.vemb_k)
         prev = torch.empty((B * R, Hv), dtype=F32, device=dev)
@@ -685,7 +721,10 @@ class Engine:
         C = cfg.v_target_size
         label = inp["image_label"]
         n_img = int((label == 1).sum())
-        tgt = inp["image_target"].to(dev, dtype=F32, non_blocking=True).contiguous().view(B * R, C)
+        tgt = inp["image_target"].to(dev, dtype=F32, non_blocking=True)
+        if inp.get("image_index") is not None and tgt.shape[0] != B:
+            tgt = tgt.index_select(0, inp["image_index"].to(dev, dtype=torch.int64).reshape(-1))
+        tgt = tgt.contiguous().view(B * R, C)
         lab32 = self._i32(label.reshape(-1), dev)
         rl, lse = torch.empty(B * R, dtype=F32, device=dev), torch.empty(B * R, dtype=F32, device=dev)
         L.kl_loss_fwd(img["pred"], tgt, lab32, rl, lse, B * R, C)

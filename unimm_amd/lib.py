@@ -72,7 +72,7 @@ SYMBOLS = ["unimm_version", "unimm_arch", "unimm_gemm_nt", "unimm_gemm_tn", "uni
            "unimm_embed_fwd", "unimm_embed_bwd", "unimm_colsum", "unimm_cast_f32_bf16", "unimm_transpose_cast",
            "unimm_pack_image", "unimm_mul_dropout", "unimm_mul_dropout_bwd", "unimm_lm_loss_fwd",
            "unimm_lm_loss_bwd", "unimm_kl_loss_fwd", "unimm_kl_loss_bwd", "unimm_nsp_loss_fwd",
-           "unimm_nsp_loss_bwd", "unimm_reduce_sum", "unimm_segment_sum", "unimm_gelu_bwd", "unimm_gather_rows", "unimm_prof_enable", "unimm_prof_collect", "unimm_gemm_set_tile", "unimm_attn_set_parts", "unimm_adamw_step", "unimm_transpose_cast_grouped"]
+           "unimm_nsp_loss_bwd", "unimm_reduce_sum", "unimm_segment_sum", "unimm_gelu_bwd", "unimm_gather_rows", "unimm_prof_enable", "unimm_prof_collect", "unimm_gemm_set_tile", "unimm_attn_set_parts", "unimm_adamw_step", "unimm_transpose_cast_grouped", "unimm_mask_synth"]
 
 
 def _check(rc, what):
@@ -292,6 +292,17 @@ def cast_f32_bf16(src, dst, n=None):
     _dev(src, dst)
     _check(lib().unimm_cast_f32_bf16(_ptr(src), _ptr(dst), C.c_int64(src.numel() if n is None else n), _stream()),
            "unimm_cast_f32_bf16")
+
+
+def mask_synth(mode, length, nans, T):
+    """Packed text mask [B, T, ceil(T/32)] and co-attention key mask [B, ceil(T/32)] from int32 descriptors."""
+    _dev(mode, length, nans)
+    B, nw = mode.numel(), (T + 31) // 32
+    text = torch.empty((B, T, nw), dtype=torch.int32, device=mode.device)
+    co = torch.empty((B, nw), dtype=torch.int32, device=mode.device)
+    _check(lib().unimm_mask_synth(_ptr(mode), _ptr(length), _ptr(nans), _ptr(text), _ptr(co), C.c_int32(B), C.c_int32(T),
+                                  _stream()), "unimm_mask_synth")
+    return text, co
 
 
 def transpose_cast(src, dst, R, C_, ldd):

@@ -116,13 +116,16 @@ class BertForMultiModalPreTraining(nn.Module):
                 position_ids=None, attention_mask=None, image_attention_mask=None, co_attention_mask=None,
                 masked_lm_labels=None, image_label=None, image_target=None, next_sentence_label=None,
                 output_all_attention_masks=False, nsp_weight=None, lm_weight=None,
-                _want_lm_scores=True, _want_pred_v=True):
+                _want_lm_scores=True, _want_pred_v=True, image_index=None):
         """Same contract as models/vilbert_dialog.py:1519-1626.  `sep_indices` / `sep_len` are accepted and
         ignored exactly as the reference's embeddings do (:326-356).  Train branch (labels, NSP label and
         image target all given) -> (lm_loss[1], img_loss[1], nsp_loss[1], seq_out_t, pred_t, nsp[B,2]);
         otherwise -> (pred_t, pred_v, nsp, seq_out_t, attention-lists).
         `_want_lm_scores=False` (used by VisualDialogEncoder when the caller does not ask for LM scores)
-        skips materialising the dense [B,T,vocab] logits; the loss only ever needs the labelled rows."""
+        skips materialising the dense [B,T,vocab] logits; the loss only ever needs the labelled rows.
+        Extensions (unimm_amd/inputs.py): `attention_mask` may be a `DialogMaskSpec`
+        (then `co_attention_mask` must be None) and `image_feat` / `image_loc` / `image_target` may hold one
+        entry per IMAGE with `image_index` [B] mapping sequences to them."""
         if output_all_attention_masks:
             raise NotImplementedError("attention probabilities are never materialised on the HIP path")
         eng = self._engine
@@ -132,7 +135,7 @@ class BertForMultiModalPreTraining(nn.Module):
                    position_ids=position_ids, attention_mask=attention_mask, image_attention_mask=image_attention_mask,
                    co_attention_mask=co_attention_mask, masked_lm_labels=masked_lm_labels, image_label=image_label,
                    image_target=image_target, next_sentence_label=next_sentence_label, nsp_weight=nsp_weight,
-                   lm_weight=lm_weight)
+                   lm_weight=lm_weight, image_index=image_index)
         B, T = input_ids.shape
         H, V = self.config.hidden_size, self.config.vocab_size
         train_branch = masked_lm_labels is not None and next_sentence_label is not None and image_target is not None
@@ -202,13 +205,13 @@ class VisualDialogEncoder(nn.Module):
                 token_position_ids=None, attention_mask=None, masked_lm_labels=None, next_sentence_label=None,
                 head_mask=None, random_round_indices=None, output_nsp_scores=False, output_lm_scores=False,
                 image_attention_mask=None, co_attention_mask=None, image_label=None, image_target=None,
-                nsp_weight=None, lm_weight=None):
+                nsp_weight=None, lm_weight=None, image_index=None):
         masked_lm_loss = masked_img_loss = nsp_loss = None
         kw = dict(sep_indices=sep_indices, sep_len=sep_len, token_type_ids=token_type_ids,
                   position_ids=token_position_ids, attention_mask=attention_mask, masked_lm_labels=masked_lm_labels,
                   next_sentence_label=next_sentence_label, image_attention_mask=image_attention_mask,
                   co_attention_mask=co_attention_mask, image_label=image_label, image_target=image_target,
-                  nsp_weight=nsp_weight, lm_weight=lm_weight, _want_lm_scores=output_lm_scores)
+                  nsp_weight=nsp_weight, lm_weight=lm_weight, _want_lm_scores=output_lm_scores, image_index=image_index)
         if next_sentence_label is not None and masked_lm_labels is not None and image_target is not None:
             masked_lm_loss, masked_img_loss, nsp_loss, _, prediction_scores_t, seq_relationship_score = \
                 self.bert_pretrained(input_ids, image_feat, image_loc, **kw)

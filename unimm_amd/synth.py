@@ -105,7 +105,7 @@ def random_utterances(rng, T=256, c_range=(40, 200), a_range=(2, 12)):
 
 
 def make_batch(n_seq=240, T=256, R=37, cfg=None, seed=1234, dis_rate=0.5, num_negative=5, mask_prob=0.15,
-               sequences_per_image=6, device="cpu", mask_dtype=torch.bool, modes=None):
+               sequences_per_image=6, device="cpu", mask_dtype=torch.bool, modes=None, compact=False):
     """A full training batch (keyword names = VisualDialogEncoder.forward's).  One image per
     `sequences_per_image` sequences (features expanded per sequence, as train.py:422-432 does)."""
     vocab = cfg.vocab_size if cfg is not None else 30522
@@ -119,6 +119,7 @@ def make_batch(n_seq=240, T=256, R=37, cfg=None, seed=1234, dis_rate=0.5, num_ne
         rows.append(build_sequence(random_utterances(rng, T), mode, neg, T=T, vocab=vocab, mask_prob=mask_prob, rng=rng,
                                    start_segment=int(rng.integers(0, 2))))
         rows[-1]["neg"] = neg
+        rows[-1]["mode"] = mode
     stack = lambda k: torch.from_numpy(np.stack([r[k] for r in rows]))
     n_img = (n_seq + sequences_per_image - 1) // sequences_per_image
     feat = np.maximum(rng.standard_normal((n_img, R, F), dtype=np.float32), 0)
@@ -146,6 +147,19 @@ def make_batch(n_seq=240, T=256, R=37, cfg=None, seed=1234, dis_rate=0.5, num_ne
     )
     if device != "cpu":
         batch = {k: (v.to(device) if k != "nsp_weight" else v) for k, v in batch.items()}
+    if compact:
+        # the same batch without the dense masks and the per-sequence copies of the image tensors (row F3):
+        # mask descriptors + one entry per image + an image index per sequence
+        from .inputs import DialogMaskSpec
+        batch["mask_spec"] = DialogMaskSpec([1 if r["mode"] == "gen" else 0 for r in rows], [r["L"] for r in rows],
+                                            [r["n"] for r in rows])
+        batch["image_index"] = torch.from_numpy(img_of.astype(np.int64))
+        batch["image_feat_unique"] = torch.from_numpy(feat)
+        batch["image_loc_unique"] = torch.from_numpy(loc)
+        batch["image_target_unique"] = torch.from_numpy(tgt)
+        if device != "cpu":
+            for k in ("image_index", "image_feat_unique", "image_loc_unique", "image_target_unique"):
+                batch[k] = batch[k].to(device)
     return batch
 
 
