@@ -61,3 +61,27 @@ def test_train_step_cadence_and_checkpoint_roundtrip(tmp_path):
     enc3 = _Enc()
     sd = dict(d["model_state_dict"]); sd["extra.key"] = torch.zeros(1); sd.pop("bert_pretrained.bias")
     assert trainer.load_checkpoint({"model_state_dict": sd}, enc3) == 1 and torch.equal(enc3.bert_pretrained.weight, enc.bert_pretrained.weight)
+
+
+def test_dialog_mask_spec_dense_form_matches_the_oracle_encoders():
+    """DialogMaskSpec.dense (host) == oracle/masks.py, which golden G5 pins to the reference's encoders; also the
+    valid lengths the unpadded schedule takes from the descriptors."""
+    import numpy as np
+    from oracle import masks as OM
+    from unimm_amd.inputs import DialogMaskSpec
+    T = 64
+    cases = [(1, [5, 3, 4]), (0, [5, 3, 4]), (1, [2, 1]), (1, [T - 14, 9]), (0, [T - 3]), (1, [10, 10, 10, 2])]
+    mode, Ls, ns, txt, co = [], [], [], [], []
+    for m, lens in cases:
+        utts = [list(range(1000, 1000 + l)) for l in lens]
+        enc = (OM.encode_gen if m else OM.encode_dis)(utts, max_seq_len=T)
+        mode.append(m); Ls.append(1 + sum(l + 1 for l in lens)); ns.append(lens[-1] + 1)
+        txt.append(np.asarray(enc["txt_attention_mask"][0]) != 0); co.append(np.asarray(enc["co_attention_mask"][0]) != 0)
+    spec = DialogMaskSpec(mode, Ls, ns)
+    dt, dc = spec.dense(T)
+    assert np.array_equal(dt.numpy(), np.stack(txt)) and np.array_equal(dc.numpy(), np.stack(co))
+    want = [min(T, L + (n if m else 0)) for m, L, n in zip(mode, Ls, ns)]
+    assert spec.valid_lengths(T).tolist() == want
+    import pytest
+    with pytest.raises(ValueError):
+        DialogMaskSpec([1], [4], [4])            # the answer cannot be the whole sequence
