@@ -155,6 +155,32 @@ def test_gemm_nt_every_tile_configuration(cfg, M, N, K):
         assert torch.isnan(out[:, N:]).all()
 
 
+@pytest.mark.parametrize("cfg", [101, 103, 201, 203])
+def test_gemm_nt_persistent_workgroups(cfg):
+    """x1xx = persistent workgroups (one per CU slot walking several tiles), x2xx = one workgroup per tile: same
+    result on a grid of several rounds, ragged M edge, GELU epilogue with its second output."""
+    from unimm_amd import lib
+    M, N, K = 8300, 3072, 768
+    g = torch.Generator(device="cuda").manual_seed(cfg)
+    x, w = _rand((M, K), g), _rand((N, K), g, 0.05)
+    bias = torch.randn(N, generator=g, device="cuda")
+    u = x.float() @ w.float().t() + bias
+    out = torch.zeros((M, N), device="cuda", dtype=torch.bfloat16)
+    out2 = torch.zeros_like(out)
+    lib.gemm_set_tile(cfg)
+    try:
+        for _ in range(2):                      # twice: a persistent workgroup must leave no state behind
+            lib.gemm_nt(x, w, out, bias=bias, epilogue=lib.EPI_BIAS_GELU_DG, out2=out2)
+        torch.cuda.synchronize()
+    finally:
+        lib.gemm_set_tile(0)
+    ref = _gelu(u)
+    assert (out.float() - ref).abs().max().item() <= 2 ** -6 * max(1.0, ref.abs().max().item())
+    cdf = 0.5 * (1 + torch.erf(u / math.sqrt(2.0)))
+    dref = cdf + u * torch.exp(-0.5 * u * u) / math.sqrt(2 * math.pi)
+    assert (out2.float() - dref).abs().max().item() <= 2 ** -6
+
+
 def test_gemm_tn_grouped_matches_single_launches():
     """One grouped call over mixed problems (big-tile and small-tile classes, different M, ragged M tails,
     ragged N/K, a bias gradient on some, two problems accumulating into ONE dw as the tied decoder /

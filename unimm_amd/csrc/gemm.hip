@@ -133,6 +133,9 @@ template <int MT, int KS> struct FragPipe {
   }
 };
 
+#ifndef UNIMM_NT_PERSIST_DEFAULT
+#define UNIMM_NT_PERSIST_DEFAULT 0
+#endif
 #ifndef UNIMM_EXP
 #define UNIMM_EXP 0   // bottleneck experiments of tools/exp_gemm.cpp; 0 in the product build
 #endif
@@ -265,13 +268,12 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtParams& p, f32x4 (&acc)[
   }
 }
 
+// One output tile (logical tile id `lid`, already XCD-remapped): ring-staged main loop + epilogue.
 template <class C, int EPI, bool OUT_F32>
-__global__ __launch_bounds__(C::THREADS, C::MIN_WAVES) void gemm_nt_kernel(GemmNtParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void nt_tile(const GemmNtParams& p, char* smem, int lid) {
   constexpr int BM = C::BM, BN = C::BN, BK = C::BK, S = C::STAGES, G = C::G, MT = C::MT;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
-  const int lid = xcd_remap(blockIdx.x, gridDim.x);
   int tm, tn;
   tile_of(lid, nbm, nbn, p.gn, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
@@ -408,6 +410,25 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES) void gemm_nt_kernel(GemmN
 #endif
 
   nt_epilogue<C, EPI, OUT_F32>(p, acc, smem, m0, n0, wm, wn, wave, lane);
+}
+
+template <class C, int EPI, bool OUT_F32>
+__global__ __launch_bounds__(C::THREADS, C::MIN_WAVES) void gemm_nt_kernel(GemmNtParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  nt_tile<C, EPI, OUT_F32>(p, smem, xcd_remap(blockIdx.x, gridDim.x));
+}
+
+// Persistent form: one workgroup per CU slot walks tiles blockIdx, blockIdx + grid, ...  A tile's epilogue
+// stores are fire-and-forget; here they drain under the NEXT tile's first ring stage instead of holding the
+// workgroup (and its CU slot) until they complete and a new workgroup is launched.  grid % 8 == 0 keeps a
+// workgroup's tiles on its own XCD's chunk of the tile order.
+template <class C, int EPI, bool OUT_F32>
+__global__ __launch_bounds__(C::THREADS, C::MIN_WAVES) void gemm_ntp_kernel(GemmNtParams p, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  for (int lt = blockIdx.x; lt < ntiles; lt += gridDim.x) {
+    if (lt != (int)blockIdx.x) __builtin_amdgcn_s_barrier();   // every wave has left its epilogue slab (it aliases the ring)
+    nt_tile<C, EPI, OUT_F32>(p, smem, xcd_remap(lt, ntiles));
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -798,6 +819,18 @@ template <class C, int EPI, bool F32> constexpr auto pick_nt_kernel() {
   else return &gemm_nt_kernel<C, EPI, F32>;
 }
 
+int g_nt_persist = -1;   // -1 automatic, 0 one workgroup per tile, 1 persistent workgroups (unimm_gemm_set_tile)
+inline int cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
 template <class C, int EPI>
 int launch_nt_cfg(const GemmNtParams& p, bool out_f32, hipStream_t s) {
   const int nwg = ((p.M + C::BM - 1) / C::BM) * ((p.N + C::BN - 1) / C::BN);
@@ -810,6 +843,30 @@ int launch_nt_cfg(const GemmNtParams& p, bool out_f32, hipStream_t s) {
       const void* fn = out_f32 ? (const void*)k32 : (const void*)k16;
       if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess) return UNIMM_E_HIP;
       done = true;
+    }
+  }
+  bool persist = false;
+  if constexpr (C::STAGES != 5) {
+    const int slots = (cu_count() & ~7) * (C::LDS <= 80 * 1024 ? 2 : 1);
+    persist = (g_nt_persist < 0 ? (UNIMM_NT_PERSIST_DEFAULT && C::NW == 4) : g_nt_persist != 0) && nwg > slots && slots > 0;
+    if (persist) {
+      auto p32 = gemm_ntp_kernel<C, EPI, true>;
+      auto p16 = gemm_ntp_kernel<C, EPI, false>;
+      if (C::LDS > 64 * 1024) {
+        static bool pdone32 = false, pdone16 = false;
+        bool& pdone = out_f32 ? pdone32 : pdone16;
+        if (!pdone) {
+          const void* fn = out_f32 ? (const void*)p32 : (const void*)p16;
+          if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess) return UNIMM_E_HIP;
+          pdone = true;
+        }
+      }
+      ProfRec* pr = prof_begin(EPI * 2 + (out_f32 ? 1 : 0), 2.0 * p.M * (double)p.N * p.K, s);
+      if (out_f32) hipLaunchKernelGGL(p32, dim3(slots), dim3(C::THREADS), C::LDS, s, p, nwg);
+      else hipLaunchKernelGGL(p16, dim3(slots), dim3(C::THREADS), C::LDS, s, p, nwg);
+      prof_end(pr, s);
+      UNIMM_CHECK_LAUNCH();
+      return UNIMM_OK;
     }
   }
   ProfRec* pr = prof_begin(EPI * 2 + (out_f32 ? 1 : 0), 2.0 * p.M * (double)p.N * p.K, s);
@@ -870,6 +927,8 @@ extern "C" int unimm_gemm_nt(const unimm_gemm_nt_args* a, void* stream) {
 
 extern "C" int unimm_gemm_set_tile(int32_t cfg) {
   if (cfg < 0 || cfg > 999 * 1000 + 999) return UNIMM_E_ARG;
+  g_nt_persist = (cfg % 1000) / 100 == 0 ? -1 : ((cfg % 1000) / 100 == 1 ? 1 : 0);   // x1xx persistent, x2xx not, else auto
+  cfg = cfg - ((cfg % 1000) / 100) * 100;
   g_nt_cfg = cfg % 1000;          // tile configuration
   g_nt_gn = cfg / 1000;           // tuning: n-tiles per column group (0 = default)
   if (g_nt_cfg > 6) return UNIMM_E_ARG;
