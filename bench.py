@@ -214,11 +214,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # Rehearsal of the N > 1 path on a one-GPU box: UNIMM_BENCH_REHEARSAL=1 puts every rank on device 0 and
+    # exchanges gradients over gloo (RCCL refuses two ranks on one device).  Never set by the driver.
+    rehearsal = os.environ.get("UNIMM_BENCH_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from unimm_amd import VisualDialogEncoder, lib, synth
     from unimm_amd.parallel import DataParallelRCCL
