@@ -8,7 +8,8 @@ dropout on, all three losses) at batch 240 x 256 tokens x 37 regions on N MI355X
 
 Prints ONE JSON line on rank 0 (contract: see the task statement).  A "step" = zero the gradient
 arena, forward, the reference's loss combination, backward into the flat gradient arena, and (N > 1)
-the bucketed RCCL gradient all-reduce.  The engine runs the text stream on the valid token rows only
+the bucketed RCCL gradient all-reduce.  N > 1 keeps the GLOBAL batch of 240 (BASELINE configs[2]: "same config
+data-parallel over 8 x MI355X" = 30 sequences per GPU; `"scaling": "strong"`); `--scaling weak` runs 240 per GPU.  The engine runs the text stream on the valid token rows only
 (padding rows are inert), so `roofline` prices the FLOPs actually executed
 (2*M*N*K of every launch) -- the padded-equivalent figure is reported separately and never used for
 `achieved`.  Inputs are synthetic (unimm_amd.synth) and resident in HBM
@@ -45,8 +46,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=240, help="sequences per step (per GPU when --scaling weak)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--batch", type=int, default=240, help="sequences per step: the GLOBAL batch, split evenly over the ranks "
+                                                           "(--scaling strong, default) or per GPU (--scaling weak)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                    help="strong (default): BASELINE configs[1]/[2], batch_size=240 in total = 30 per GPU on 8 (SURVEY 8d/8e); "
+                         "weak: 240 per GPU")
     ap.add_argument("--workload", choices=["train", "dense", "scoring"], default="train",
                     help="train = BASELINE configs[1]/[2] (the headline metric); dense = configs[3] micro-step "
                          "(100 sequences, nsp_loss_coeff 0, gradient accumulation: no exchange inside the step); "
@@ -243,7 +247,14 @@ def main():
         return scoring(args, world, rank, dev, enc, lib, synth, dist)
     if args.workload == "dense" and args.batch == 240:
         args.batch = 100                          # dense_annotation_finetuning.py: 1 image x 100 options per micro-step
-    per_gpu = args.batch if args.scaling == "weak" else args.batch // world
+    if args.scaling == "weak":
+        per_gpu, global_batch = args.batch, args.batch * world
+    else:                                         # even split of the global batch (unimm_amd.parallel.shard_range)
+        from unimm_amd.parallel import shard_range
+        lo, hi = shard_range(args.batch, rank, world)
+        per_gpu, global_batch = hi - lo, args.batch
+        if per_gpu < 1:
+            raise SystemExit(f"--batch {args.batch} leaves rank {rank} of {world} without a sequence")
     if args.workload == "dense":                  # discriminative inputs, 2 sequences share an image (configs[3])
         batch = synth.make_batch(n_seq=per_gpu, cfg=cfg, seed=1234 + rank, device=dev, modes=["dis"] * per_gpu,
                                  sequences_per_image=2)
@@ -339,7 +350,7 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t)
-    total_seq = per_gpu * world * args.steps
+    total_seq = global_batch * args.steps
     value = total_seq / dt
 
     if rank == 0:
@@ -377,7 +388,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": wl,
-                       "global_batch": per_gpu * world, "per_gpu_batch": per_gpu, "seq_len": 256, "regions": 37,
+                       "global_batch": global_batch, "per_gpu_batch": per_gpu, "seq_len": 256, "regions": 37,
                        "parallelism": f"dp{world}", "lm_rows_decoded_per_seq": round(n_lm_rows / per_gpu, 2),
                        "valid_token_rows": valid_rows, "token_rows_padded": per_gpu * 256,
                        "gflop_per_seq_fwd_padded_equivalent": round(f_fwd, 3),
