@@ -49,6 +49,8 @@ __device__ __forceinline__ void tile_of(int lid, int nbm, int nbn, int gn, int& 
 //   Cfg<2,2,4,64,2>: 128x128, 4 waves, 68 KiB LDS -> 2 workgroups per CU
 //   Cfg<2,4,8,32,4>: 256x256, 8 waves, BK=32, 4-slot ring (128 KiB): 3 K-steps in flight across barriers
 //   Cfg<2,4,8,64,2>: 256x256, 8 waves, BK=64, 2-slot ring (128 KiB)
+//   Cfg<2,2,2,64,2>:  64x128, 4 waves of 32x64 (48 KiB, 3 workgroups per CU): twice the waves of the 128x128 tile
+//                     for grids that do not fill the chip (per-GPU batches of 30-60 sequences under strong scaling)
 template <int WM_, int WN_, int MT_, int BK_, int STAGES_>
 struct Cfg {
   static constexpr int WM = WM_, WN = WN_, MT = MT_, BK = BK_, STAGES = STAGES_;
@@ -57,9 +59,11 @@ struct Cfg {
   static constexpr int RPI = 1024 / ROWB;                     // rows per LDS-DMA wave-instruction
   static constexpr int STAGE_BYTES = (BM + BN) * ROWB;
   static constexpr int G = (BM + BN) / RPI / NW;              // LDS-DMA wave-instructions per wave per K-step
-  static constexpr int SLAB_BYTES = NW * 64 * 68 * 4;         // epilogue transpose slabs (64 rows per pass)
+  static constexpr int SLAB_ROWS = 16 * (MT < 4 ? MT : 4);    // rows of a wave's tile per epilogue pass
+  static constexpr int SLAB_BYTES = NW * SLAB_ROWS * 68 * 4;  // epilogue transpose slabs
   static constexpr int LDS = STAGES * STAGE_BYTES > SLAB_BYTES ? STAGES * STAGE_BYTES : SLAB_BYTES;
-  static constexpr int MIN_WAVES = (LDS <= 80 * 1024) ? (2 * NW + 3) / 4 : (NW + 3) / 4;
+  static constexpr int WG_PER_CU = LDS <= 53 * 1024 ? 3 : (LDS <= 80 * 1024 ? 2 : 1);
+  static constexpr int MIN_WAVES = (WG_PER_CU * NW + 3) / 4;
   static_assert((BM + BN) % (RPI * NW) == 0, "tile rows must split evenly over the waves");
 };
 
@@ -161,7 +165,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtParams& p, f32x4 (&acc)[
   // 16-byte stores, 8 full 128-byte row segments per wave-instruction.
   constexpr int SLAB_LD = 68;                       // floats per slab row (64 + 4 pad)
   __builtin_amdgcn_s_barrier();                      // all waves finished reading the ring
-  float* slab = reinterpret_cast<float*>(smem) + wave * (64 * SLAB_LD);
+  float* slab = reinterpret_cast<float*>(smem) + wave * (C::SLAB_ROWS * SLAB_LD);
   const int c0 = (lane & 7) * 8;
   const int n = n0 + wn * 64 + c0;
   const bool ncols_ok = n < p.N;
@@ -171,17 +175,18 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtParams& p, f32x4 (&acc)[
   for (int e = 0; e < 8; ++e) b[e] = (p.bias != nullptr && n + e < p.N) ? p.bias[n + e] : 0.f;
   const bool vec_out = full && ((p.ldo * (OUT_F32 ? 4 : 2)) % 16 == 0);
   const bool vec_aux = full && ((p.ldaux * (EPI == UNIMM_EPI_BIAS_DROP_RESID ? 4 : 2)) % 16 == 0);
+  constexpr int JP = MT < 4 ? MT : 4;               // 16-row sub-tiles per pass (a 32-row wave tile has only two)
 #pragma unroll
-  for (int pass = 0; pass < MT / 4; ++pass) {
+  for (int pass = 0; pass < MT / JP; ++pass) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        *reinterpret_cast<f32x4*>(slab + (j * 16 + (lane & 15)) * SLAB_LD + i * 16 + 4 * (lane >> 4)) = acc[i][pass * 4 + j];
+      for (int j = 0; j < JP; ++j)
+        *reinterpret_cast<f32x4*>(slab + (j * 16 + (lane & 15)) * SLAB_LD + i * 16 + 4 * (lane >> 4)) = acc[i][pass * JP + j];
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
+    for (int it = 0; it < 2 * JP; ++it) {
       const int row = it * 8 + (lane >> 3);
-      const int m = m0 + wm * 16 * MT + pass * 64 + row;
+      const int m = m0 + wm * 16 * MT + pass * 16 * JP + row;
       const f32x4 lo = *reinterpret_cast<const f32x4*>(slab + row * SLAB_LD + c0);
       const f32x4 hi = *reinterpret_cast<const f32x4*>(slab + row * SLAB_LD + c0 + 4);
       if (m >= p.M || !ncols_ok) continue;
@@ -847,7 +852,7 @@ int launch_nt_cfg(const GemmNtParams& p, bool out_f32, hipStream_t s) {
   }
   bool persist = false;
   if constexpr (C::STAGES != 5) {
-    const int slots = (cu_count() & ~7) * (C::LDS <= 80 * 1024 ? 2 : 1);
+    const int slots = (cu_count() & ~7) * C::WG_PER_CU;
     persist = (g_nt_persist < 0 ? (UNIMM_NT_PERSIST_DEFAULT && C::NW == 4) : g_nt_persist != 0) && nwg > slots && slots > 0;
     if (persist) {
       auto p32 = gemm_ntp_kernel<C, EPI, true>;
@@ -882,12 +887,16 @@ int launch_nt(const GemmNtParams& p, bool out_f32, hipStream_t s) {
   int cfg = g_nt_cfg;
   if (cfg == 0) {   // 256x256 tiles when they still give every CU >= 1.5 workgroups, else 128x128
     const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
-    cfg = (t256 >= 384) ? 3 : 1;
+    const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    // fewer 128x128 tiles than CUs (N=768 GEMMs at ~4k rows: per-GPU batches of 30 under strong scaling): the
+    // 64x128 tile doubles the waves (+12-15 % there, equal or worse everywhere else)
+    cfg = (t256 >= 384) ? 3 : (t128 < 256 ? 7 : 1);
   }
   if (cfg == 2) return launch_nt_cfg<Cfg<2, 4, 8, 32, 4>, EPI>(p, out_f32, s);
   if (cfg == 4) return launch_nt_cfg<Cfg<2, 4, 8, 32, 5>, EPI>(p, out_f32, s);
   if (cfg == 5) return launch_nt_cfg<Cfg<2, 2, 4, 32, 5>, EPI>(p, out_f32, s);
   if (cfg == 6) return launch_nt_cfg<Cfg<4, 2, 4, 64, 2>, EPI>(p, out_f32, s);
+  if (cfg == 7) return launch_nt_cfg<Cfg<2, 2, 2, 64, 2>, EPI>(p, out_f32, s);
   if (cfg == 3) return launch_nt_cfg<Cfg<2, 4, 8, 64, 2>, EPI>(p, out_f32, s);
   return launch_nt_cfg<Cfg<2, 2, 4, 64, 2>, EPI>(p, out_f32, s);
 }
@@ -931,7 +940,7 @@ extern "C" int unimm_gemm_set_tile(int32_t cfg) {
   cfg = cfg - ((cfg % 1000) / 100) * 100;
   g_nt_cfg = cfg % 1000;          // tile configuration
   g_nt_gn = cfg / 1000;           // tuning: n-tiles per column group (0 = default)
-  if (g_nt_cfg > 6) return UNIMM_E_ARG;
+  if (g_nt_cfg > 7) return UNIMM_E_ARG;
   return UNIMM_OK;
 }
 
