@@ -1,0 +1,25 @@
+import sys, os, time; sys.path.insert(0, os.getcwd())
+import torch
+from unimm_amd import VisualDialogEncoder, synth
+from unimm_amd.optim import FusedAdamW, WarmupLinearScheduleNonZero, default_language_weights, reference_param_groups
+dev = torch.device("cuda", 0)
+enc = VisualDialogEncoder("unimm_amd/config/bert_base_6layer_6conect.json").to(dev); enc.train()
+opt = FusedAdamW(reference_param_groups(enc, 2e-5, 2e-5, default_language_weights(enc)), enc.bert_pretrained.engine, lr=2e-5)
+sch = WarmupLinearScheduleNonZero(opt, 100, 1000)
+losses = []
+t0 = time.time()
+for it in range(40):
+    b = synth.make_batch(n_seq=240, cfg=enc.bert_pretrained.config, seed=it % 4, device=dev)   # 4 batches cycled: loss must fall
+    nw = b.pop("nsp_weight")
+    opt.zero_grad()
+    lm, img, nsp = enc(b["input_ids"], b["image_feat"], b["image_loc"], sep_indices=b["sep_indices"], sep_len=b["sep_len"],
+                       token_type_ids=b["token_type_ids"], token_position_ids=b["token_position_ids"], attention_mask=b["attention_mask"],
+                       masked_lm_labels=b["masked_lm_labels"], next_sentence_label=b["next_sentence_label"],
+                       image_attention_mask=b["image_attention_mask"], co_attention_mask=b["co_attention_mask"],
+                       image_label=b["image_label"], image_target=b["image_target"], nsp_weight=nw, lm_weight=b["lm_weight"])
+    loss = lm.mean() + nsp.mean() + img.mean()
+    loss.backward(); opt.step(); sch.step()
+    if it % 5 == 0 or it == 39:
+        torch.cuda.synchronize()
+        print(it, round(float(loss.detach()), 4), "alloc GB", round(torch.cuda.memory_allocated() / 2**30, 2), "reserved GB", round(torch.cuda.memory_reserved() / 2**30, 2), flush=True)
+print("done", round(time.time() - t0, 1), "s")
