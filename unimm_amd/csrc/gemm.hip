@@ -124,17 +124,44 @@ template <int N> __device__ __forceinline__ void lds_wait(bf16x8& a) { asm volat
 // [WPN W fragments of the next sub-step while j = v % MT is in [WP0, WP0 + 4/WPN)], all of which are
 // requested before the first X fragment of that sub-step.  pending(u) = reads requested after X(u)
 // by the time unit u waits for it.
+#ifndef UNIMM_READ_AFTER
+#define UNIMM_READ_AFTER 0     // 1: a unit requests its prefetches behind its MFMAs instead of in front of them
+#endif
 template <int MT, int KS> struct FragPipe {
-  static constexpr int WP0 = MT == 8 ? 2 : 0, WPN = MT == 8 ? 1 : 2;
+  static constexpr int U = KS * MT;
+  static constexpr bool AFTER = UNIMM_READ_AFTER != 0;
+  static constexpr int WP0 = MT == 8 ? 2 : 0, WPN = MT == 8 ? 1 : 2, WPU = 4 / WPN;   // first unit / frags per unit / units
   static constexpr int npref_w(int v) {
-    return (v >= 0 && v / MT + 1 < KS && v % MT >= WP0 && v % MT < WP0 + 4 / WPN) ? WPN : 0;
+    return (v >= 0 && v / MT + 1 < KS && v % MT >= WP0 && v % MT < WP0 + WPU) ? WPN : 0;
   }
-  static constexpr int nx(int v) { return v + 2 < KS * MT ? 1 : 0; }
-  static constexpr int pending(int u) {
-    int c = u >= 2 ? npref_w(u - 2) : (u == 0 ? 1 : 0);
-    for (int v = (u >= 2 ? u - 1 : 0); v <= u; ++v) c += nx(v) + npref_w(v);
+  static constexpr int nx(int v) { return v + 2 < U ? 1 : 0; }
+  // requests up to and including phase p (phase -1 = the 6 prologue reads)
+  static constexpr int upto(int p) {
+    int c = 6;
+    for (int v = 0; v <= p; ++v) c += nx(v) + npref_w(v);
     return c;
   }
+  static constexpr int pos_x(int u) { return u < 2 ? 4 + u : upto(u - 3); }          // X(u) is the first request of phase u-2
+  static constexpr int pos_last_w(int ks) {                                            // last W fragment of sub-step ks
+    if (ks == 0) return 3;
+    const int vl = (ks - 1) * MT + WP0 + WPU - 1;
+    return upto(vl) - 1;
+  }
+  // requests that may still be outstanding when unit u starts its MFMAs: everything requested so far minus
+  // everything up to the LAST request the unit needs (its X fragment; for the first unit of a sub-step also the
+  // sub-step's W fragments, which for small MT are requested after that X fragment)
+  static constexpr int pending(int u) {
+    const int issued = upto(AFTER ? u - 1 : u);
+    int need = pos_x(u);
+    if (u % MT == 0 && pos_last_w(u / MT) > need) need = pos_last_w(u / MT);
+    return issued - 1 - need;
+  }
+  static constexpr bool ok() {
+    for (int u = 0; u < U; ++u)
+      if (pending(u) < 0 || pending(u) > 15) return false;
+    return true;
+  }
+  static_assert(MT == 2 || MT == 4 || MT == 8, "FragPipe: unit plans exist for 2, 4 and 8 sub-tiles");
 };
 
 #ifndef UNIMM_NT_PERSIST_DEFAULT
@@ -379,18 +406,22 @@ __device__ __forceinline__ void nt_tile(const GemmNtParams& p, char* smem, int l
       fw[0][3] = lds_read_b128<3 * 16 * RB>(aw[0]);
       fx[0] = lds_read_b128<0>(ax[0]);
       fx[1] = lds_read_b128<16 * RB>(ax[0]);
+      static_assert(FragPipe<MT, KS>::ok(), "fragment pipeline: a unit would start before its fragments are certain");
+#define UNIMM_PREFETCH(u)                                                                                    \
+        if constexpr ((u) + 2 < U) fx[((u) + 2) % 3] = lds_read_b128<(((u) + 2) % MT) * 16 * RB>(ax[((u) + 2) / MT]); \
+        if constexpr (FragPipe<MT, KS>::npref_w(u) > 0) {                                                    \
+          constexpr int w_ = (((u) % MT) - WP0) * WPN, kn_ = ((u) / MT + 1 < KS) ? (u) / MT + 1 : 0;         \
+          fw[kn_ & 1][w_] = lds_read_b128<w_ * 16 * RB>(aw[kn_]);                                            \
+          if constexpr (WPN == 2) fw[kn_ & 1][w_ + 1] = lds_read_b128<(w_ + 1) * 16 * RB>(aw[kn_]);          \
+        }
 #define UNIMM_UNIT(u)                                                                                        \
       if constexpr ((u) < U) {                                                                               \
         constexpr int ks_ = (u) / MT, j_ = (u) % MT;                                                         \
-        if constexpr ((u) + 2 < U) fx[((u) + 2) % 3] = lds_read_b128<(((u) + 2) % MT) * 16 * RB>(ax[((u) + 2) / MT]); \
-        if constexpr (FragPipe<MT, KS>::npref_w(u) > 0) {                                                    \
-          constexpr int w_ = (j_ - WP0) * WPN, kn_ = (ks_ + 1 < KS) ? ks_ + 1 : 0;                           \
-          fw[kn_ & 1][w_] = lds_read_b128<w_ * 16 * RB>(aw[kn_]);                                            \
-          if constexpr (WPN == 2) fw[kn_ & 1][w_ + 1] = lds_read_b128<(w_ + 1) * 16 * RB>(aw[kn_]);          \
-        }                                                                                                    \
+        if constexpr (!FragPipe<MT, KS>::AFTER) { UNIMM_PREFETCH(u) }                                        \
         lds_wait<FragPipe<MT, KS>::pending(u)>(fx[(u) % 3]);                                                 \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                        \
           acc[i][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ks_ & 1][i], fx[(u) % 3], acc[i][j_], 0, 0, 0); \
+        if constexpr (FragPipe<MT, KS>::AFTER) { UNIMM_PREFETCH(u) }                                         \
         if constexpr (SPREAD && UNIMM_EXP != 7 && UNIMM_EXP != 3 && (u) < G) {   /* refill, one LDS-DMA per unit */ \
           if (t + 1 < nk) stage_one<C>(p, n0, m0, (t + 1) * BK, smem + ((t + 1) & 1) * C::STAGE_BYTES, wave, lane, u); \
         }                                                                                                    \
@@ -399,6 +430,7 @@ __device__ __forceinline__ void nt_tile(const GemmNtParams& p, char* smem, int l
       UNIMM_UNIT(0) UNIMM_UNIT(1) UNIMM_UNIT(2) UNIMM_UNIT(3) UNIMM_UNIT(4) UNIMM_UNIT(5) UNIMM_UNIT(6) UNIMM_UNIT(7)
       UNIMM_UNIT(8) UNIMM_UNIT(9) UNIMM_UNIT(10) UNIMM_UNIT(11) UNIMM_UNIT(12) UNIMM_UNIT(13) UNIMM_UNIT(14) UNIMM_UNIT(15)
 #undef UNIMM_UNIT
+#undef UNIMM_PREFETCH
     }
 #endif
   }
