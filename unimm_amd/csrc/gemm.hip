@@ -732,7 +732,8 @@ __global__ __launch_bounds__(64 * WN * WK, (WN * WK * (NT == 4 ? 2 : 1) + 3) / 4
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();          // step t landed everywhere; step t-1 fully read
     __builtin_amdgcn_sched_barrier(0);
-    if (t + 1 < nsteps) stage_step_tn<NW, NSUB_A, NSUB_B>(p, mt + TK, mend, n0, k0, smem + (cur ^ 1) * STAGE_BYTES, wave, lane);
+    if (UNIMM_EXP != 10 && t + 1 < nsteps)   // (experiment 10: no staging inside the loop)
+      stage_step_tn<NW, NSUB_A, NSUB_B>(p, mt + TK, mend, n0, k0, smem + (cur ^ 1) * STAGE_BYTES, wave, lane);
     const char* ta = smem + cur * STAGE_BYTES;
     const char* tb = ta + NSUB_A * TN_TILE_BYTES;
     const int valid = mend - mt;  // rows of this step that exist (>= 1); others must contribute 0
@@ -763,7 +764,7 @@ __global__ __launch_bounds__(64 * WN * WK, (WN * WK * (NT == 4 ? 2 : 1) + 3) / 4
       fb[0][0] = UNIMM_TR(sb, 0, 0); fb[0][1] = UNIMM_TR(sb, 1, 0); fb[0][2] = UNIMM_TR(sb, 2, 0); fb[0][3] = UNIMM_TR(sb, 3, 0);
       fa[0] = UNIMM_TR(sa, 0, 0);
       fa[1] = UNIMM_TR(sa, 1, 0);
-#define UNIMM_UNIT(u)                                                                                        \
+#define UNIMM_UNIT(u, WITH_BIAS)                                                                             \
       if constexpr ((u) < 2 * NT) {                                                                          \
         constexpr int ks_ = (u) / NT, i_ = (u) % NT;                                                         \
         if constexpr ((u) + 2 < 2 * NT) fa[((u) + 2) % 3] = UNIMM_TR(sa, ((u) + 2) % NT, ((u) + 2) / NT);    \
@@ -775,11 +776,18 @@ __global__ __launch_bounds__(64 * WN * WK, (WN * WK * (NT == 4 ? 2 : 1) + 3) / 4
         lds_wait<2 * FragPipe<NT, 2>::pending(u)>(fa[(u) % 3]);                                              \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
           acc[i_][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[(u) % 3], fb[ks_][j], acc[i_][j], 0, 0, 0); \
-        accb[i_] = dot_ones(fa[(u) % 3], accb[i_]);                                                          \
+        if constexpr (UNIMM_EXP != 9 && (WITH_BIAS)) accb[i_] = dot_ones(fa[(u) % 3], accb[i_]);             \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
       }
-      UNIMM_UNIT(0) UNIMM_UNIT(1) UNIMM_UNIT(2) UNIMM_UNIT(3) UNIMM_UNIT(4) UNIMM_UNIT(5) UNIMM_UNIT(6) UNIMM_UNIT(7)
-      UNIMM_UNIT(8) UNIMM_UNIT(9) UNIMM_UNIT(10) UNIMM_UNIT(11) UNIMM_UNIT(12) UNIMM_UNIT(13) UNIMM_UNIT(14) UNIMM_UNIT(15)
+#define UNIMM_UNITS(B)                                                                                       \
+      UNIMM_UNIT(0, B) UNIMM_UNIT(1, B) UNIMM_UNIT(2, B) UNIMM_UNIT(3, B) UNIMM_UNIT(4, B) UNIMM_UNIT(5, B)      \
+      UNIMM_UNIT(6, B) UNIMM_UNIT(7, B) UNIMM_UNIT(8, B) UNIMM_UNIT(9, B) UNIMM_UNIT(10, B) UNIMM_UNIT(11, B)    \
+      UNIMM_UNIT(12, B) UNIMM_UNIT(13, B) UNIMM_UNIT(14, B) UNIMM_UNIT(15, B)
+      // the column sums of DY (bias gradient) ride on the fragments of 1 wave in 4 of one tile column only; one
+      // wave-uniform branch per step picks the unit stream with or without the 4 dependent v_dot2c per unit
+      // (if-converted into every wave's stream they cost 19 % of the kernel)
+      if (do_bias) { UNIMM_UNITS(true) } else { UNIMM_UNITS(false) }
+#undef UNIMM_UNITS
 #undef UNIMM_UNIT
 #undef UNIMM_TR
     }
