@@ -164,6 +164,9 @@ template <int MT, int KS> struct FragPipe {
   static_assert(MT == 2 || MT == 4 || MT == 8, "FragPipe: unit plans exist for 2, 4 and 8 sub-tiles");
 };
 
+#ifndef UNIMM_TN_SPREAD
+#define UNIMM_TN_SPREAD 1
+#endif
 #ifndef UNIMM_NT_PERSIST_DEFAULT
 #define UNIMM_NT_PERSIST_DEFAULT 0
 #endif
@@ -619,30 +622,33 @@ __device__ __forceinline__ int tn_swz(int row) { return ((row & 3) | ((row >> 1)
 // Stage one m-step: the block's DY columns [n0, n0+TNB) and X columns [k0, k0+TKB) for rows
 // [m0, m0+64), as [64][128]-column sub-tiles of 16 KiB (4 rows x 256 B per LDS-DMA wave-instruction).
 template <int NW, int NSUB_A, int NSUB_B>
+__device__ __forceinline__ void stage_one_tn(const GemmTnParams& p, int m0, int mend, int n0, int k0, char* stage,
+                                             int wave, int lane, int r) {
+  const int q = r * NW + wave;
+  const int sub = q >> 4, rg = q & 15;
+  const int row = rg * 4 + (lane >> 4);
+  const int chunk = (lane & 15) ^ tn_swz(row);
+  const bool is_a = sub < NSUB_A;
+  const bf16_t* g = is_a ? p.dy : p.x;
+  const int ld = is_a ? p.lddy : p.ldx;
+  const int ncols = is_a ? p.N : p.K;
+  const int c0 = is_a ? n0 + sub * 128 : k0 + (sub - NSUB_A) * 128;
+  int gm = m0 + row;
+  int gc = c0 + chunk * 8;
+  // rows past the end re-read the last row (zeroed in LDS before use); columns past
+  // round_up(ncols, 8) re-read the last readable chunk (they only feed outputs that are never stored)
+  gm = gm < mend ? gm : mend - 1;
+  const int cmax = ((ncols + 7) & ~7) - 8;
+  gc = gc <= cmax ? gc : cmax;
+  const bf16_t* src = g + (size_t)gm * ld + gc;
+  __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(stage + sub * TN_TILE_BYTES + rg * 1024), 16, 0, 0);
+}
+template <int NW, int NSUB_A, int NSUB_B>
 __device__ __forceinline__ void stage_step_tn(const GemmTnParams& p, int m0, int mend, int n0, int k0, char* stage,
                                               int wave, int lane) {
   constexpr int PER_WAVE = (NSUB_A + NSUB_B) * 16 / NW;
 #pragma unroll
-  for (int r = 0; r < PER_WAVE; ++r) {
-    const int q = r * NW + wave;
-    const int sub = q >> 4, rg = q & 15;
-    const int row = rg * 4 + (lane >> 4);
-    const int chunk = (lane & 15) ^ tn_swz(row);
-    const bool is_a = sub < NSUB_A;
-    const bf16_t* g = is_a ? p.dy : p.x;
-    const int ld = is_a ? p.lddy : p.ldx;
-    const int ncols = is_a ? p.N : p.K;
-    const int c0 = is_a ? n0 + sub * 128 : k0 + (sub - NSUB_A) * 128;
-    int gm = m0 + row;
-    int gc = c0 + chunk * 8;
-    // rows past the end re-read the last row (masked to zero in the fragment); columns past
-    // round_up(ncols, 8) re-read the last readable chunk (they only feed outputs that are never stored)
-    gm = gm < mend ? gm : mend - 1;
-    const int cmax = ((ncols + 7) & ~7) - 8;
-    gc = gc <= cmax ? gc : cmax;
-    const bf16_t* src = g + (size_t)gm * ld + gc;
-    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(stage + sub * TN_TILE_BYTES + rg * 1024), 16, 0, 0);
-  }
+  for (int r = 0; r < PER_WAVE; ++r) stage_one_tn<NW, NSUB_A, NSUB_B>(p, m0, mend, n0, k0, stage, wave, lane, r);
 }
 
 // transposed fragment: 16 columns starting at c16 (tile-local, multiple of 16), reduction rows
@@ -732,7 +738,9 @@ __global__ __launch_bounds__(64 * WN * WK, (WN * WK * (NT == 4 ? 2 : 1) + 3) / 4
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();          // step t landed everywhere; step t-1 fully read
     __builtin_amdgcn_sched_barrier(0);
-    if (UNIMM_EXP != 10 && t + 1 < nsteps)   // (experiment 10: no staging inside the loop)
+    constexpr bool SPREAD = NW == 8 && UNIMM_TN_SPREAD;   // 8-wave tile: refill spread behind the units (as gemm_nt)
+    constexpr int PER_WAVE = (NSUB_A + NSUB_B) * 16 / NW;
+    if (!SPREAD && UNIMM_EXP != 10 && t + 1 < nsteps)   // (experiment 10: no staging inside the loop)
       stage_step_tn<NW, NSUB_A, NSUB_B>(p, mt + TK, mend, n0, k0, smem + (cur ^ 1) * STAGE_BYTES, wave, lane);
     const char* ta = smem + cur * STAGE_BYTES;
     const char* tb = ta + NSUB_A * TN_TILE_BYTES;
@@ -777,6 +785,10 @@ __global__ __launch_bounds__(64 * WN * WK, (WN * WK * (NT == 4 ? 2 : 1) + 3) / 4
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
           acc[i_][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[(u) % 3], fb[ks_][j], acc[i_][j], 0, 0, 0); \
         if constexpr (UNIMM_EXP != 9 && (WITH_BIAS)) accb[i_] = dot_ones(fa[(u) % 3], accb[i_]);             \
+        if constexpr (SPREAD && (u) < PER_WAVE) {                                                            \
+          if (t + 1 < nsteps)                                                                                \
+            stage_one_tn<NW, NSUB_A, NSUB_B>(p, mt + TK, mend, n0, k0, smem + (cur ^ 1) * STAGE_BYTES, wave, lane, u); \
+        }                                                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
       }
 #define UNIMM_UNITS(B)                                                                                       \
