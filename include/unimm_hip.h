@@ -62,6 +62,13 @@ typedef struct {
   uint32_t drop_key; /* dropout (UNIMM_EPI_BIAS_DROP_RESID): keep iff mix32(idx ^ key) >= thr   */
   uint32_t drop_thr; /* p * 2^32; 0 disables                                                    */
   float drop_scale;  /* 1 / (1 - p)                                                             */
+  /* UNIMM_EPI_BIAS_DROP_RESID only, all four or none: the residual operand is LayerNorm(aux) evaluated on
+   * the fly, (aux[m,n] - aux_mean[m]) * aux_rstd[m] * aux_gamma[n] + aux_beta[n] -- the fp32 output of the
+   * previous LayerNorm (models/vilbert_dialog.py:425, :468, ...) is then never written or read */
+  const float* aux_mean;
+  const float* aux_rstd;
+  const float* aux_gamma;
+  const float* aux_beta;
 } unimm_gemm_nt_args;
 
 int unimm_gemm_nt(const unimm_gemm_nt_args* args, void* stream);

@@ -27,6 +27,7 @@ struct GemmNtParams {
   int M, N, K, ldx, ldw, ldaux, ldo;
   int gn;            // n-tiles per column group of the tile order (see tile_of)
   DropoutArg drop;
+  const float* aux_mean; const float* aux_rstd; const float* aux_gamma; const float* aux_beta;  // DROP_RESID: aux = LayerNorm(aux)
 };
 
 // Tile order.  Logical ids run group by group over the n-tiles (gn tile columns per group), inside a
@@ -203,6 +204,15 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtParams& p, f32x4 (&acc)[
   float b[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) b[e] = (p.bias != nullptr && n + e < p.N) ? p.bias[n + e] : 0.f;
+  float lg[8], lb[8];                                // LayerNorm-on-the-fly residual (DROP_RESID only)
+  const bool aux_ln = EPI == UNIMM_EPI_BIAS_DROP_RESID && p.aux_mean != nullptr;
+  if (aux_ln) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      lg[e] = n + e < p.N ? p.aux_gamma[n + e] : 0.f;
+      lb[e] = n + e < p.N ? p.aux_beta[n + e] : 0.f;
+    }
+  }
   const bool vec_out = full && ((p.ldo * (OUT_F32 ? 4 : 2)) % 16 == 0);
   const bool vec_aux = full && ((p.ldaux * (EPI == UNIMM_EPI_BIAS_DROP_RESID ? 4 : 2)) % 16 == 0);
   constexpr int JP = MT < 4 ? MT : 4;               // 16-row sub-tiles per pass (a 32-row wave tile has only two)
@@ -234,6 +244,11 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtParams& p, f32x4 (&acc)[
           } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) a[e] = (n + e < p.N) ? ap[e] : 0.f;
+          }
+          if (aux_ln) {
+            const float mu = p.aux_mean[m], rs = p.aux_rstd[m];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = (a[e] - mu) * rs * lg[e] + lb[e];
           }
           if (p.drop.thr != 0u) {
             const uint32_t kb = drop_bits8(p.drop, (uint32_t)m, (uint32_t)p.N, (uint32_t)n);
@@ -970,6 +985,9 @@ extern "C" int unimm_gemm_nt(const unimm_gemm_nt_args* a, void* stream) {
   p.out = a->out; p.out2 = (bf16_t*)a->out2;
   p.M = a->M; p.N = a->N; p.K = a->K; p.ldx = a->ldx; p.ldw = a->ldw; p.ldaux = a->ldaux; p.ldo = a->ldo;
   p.drop.key = a->drop_key; p.drop.thr = a->drop_thr; p.drop.scale = a->drop_scale;
+  const int n_ln = (a->aux_mean != nullptr) + (a->aux_rstd != nullptr) + (a->aux_gamma != nullptr) + (a->aux_beta != nullptr);
+  if (n_ln != 0 && (n_ln != 4 || a->epilogue != UNIMM_EPI_BIAS_DROP_RESID)) return UNIMM_E_ARG;
+  p.aux_mean = a->aux_mean; p.aux_rstd = a->aux_rstd; p.aux_gamma = a->aux_gamma; p.aux_beta = a->aux_beta;
   p.gn = g_nt_gn > 0 ? g_nt_gn : 6;
   hipStream_t s = (hipStream_t)stream;
   const bool f32 = a->out_f32 != 0;

@@ -39,6 +39,14 @@ def _rup(x, m):
     return (x + m - 1) // m * m
 
 
+class _LazyLN:
+    """fp32 residual-stream value that is LayerNorm(x) but was never written: (x, mean, rstd, gamma, beta)."""
+    __slots__ = ("x", "mean", "rstd", "gamma", "beta")
+
+    def __init__(self, x, mean, rstd, gamma, beta):
+        self.x, self.mean, self.rstd, self.gamma, self.beta = x, mean, rstd, gamma, beta
+
+
 class _Lin:
     """One (possibly fused) linear: bf16 weight [N,K], transposed bf16 copy [K,Npad], fp32 bias + grads."""
     __slots__ = ("w", "wt", "bias", "gw", "gb", "N", "K", "gbs")
@@ -64,6 +72,7 @@ class Engine:
         self.last_seq_t = None
         self.unpad = True                # run the text stream on valid rows only (see _varlen_plan)
         self._wq = []                    # queued weight-gradient problems of the block being back-propagated
+        self.lazy_ln = os.environ.get("UNIMM_LAZY_LN", "1") == "1"   # residual epilogues evaluate the previous LayerNorm
         # Option: grouped weight-gradient launches on a side stream (UNIMM_WGRAD_STREAM=1): +1.8 % throughput in
         # interleaved runs (61.2 -> 60.1 ms) because the next block's GEMMs fill the partial last round and the
         # atomic drain.  Off by default: overlapped kernels stretch each other's durations, so per-kernel event /
@@ -228,7 +237,10 @@ class Engine:
         ldo = ldo or lin.N
         out = torch.empty((M, ldo), dtype=F32 if out_f32 else BF16, device=x.device)
         u = torch.empty((M, ldo), dtype=BF16, device=x.device) if want_u else None
-        L.gemm_nt(x, lin.w, out, bias=lin.bias, epilogue=epi, aux=aux, out2=u, drop=drop, M=M, N=lin.N, K=lin.K)
+        aux_ln = None
+        if isinstance(aux, _LazyLN):
+            aux, aux_ln = aux.x, (aux.mean, aux.rstd, aux.gamma, aux.beta)
+        L.gemm_nt(x, lin.w, out, bias=lin.bias, epilogue=epi, aux=aux, out2=u, drop=drop, M=M, N=lin.N, K=lin.K, aux_ln=aux_ln)
         return (out, u) if want_u else out
 
     def _wgrad(self, dy, x, gw, M, N, K, dbias=None):
@@ -274,16 +286,33 @@ class Engine:
         L.gemm_nt(dy, lin.wt, dx, bias=None, epilogue=epi, aux=aux, M=M, N=lin.K, K=kdim)
         return dx
 
-    def _layernorm(self, x, key, save, drop=L.NO_DROP, want32=True):
-        """x: fp32 pre-LayerNorm sum -> (y32 residual stream | None, y16 GEMM operand, mean, rstd)."""
+    def _layernorm(self, x, key, save, drop=L.NO_DROP, want32=True, lazy=False):
+        """x: fp32 pre-LayerNorm sum -> (y32 residual stream | None, y16 GEMM operand, mean, rstd).
+        lazy=True: the fp32 output is NOT written; a `_LazyLN` stands in for it and the next residual epilogue
+        evaluates LayerNorm(x) from (x, mean, rstd, gamma, beta) itself (4 of the 10 bytes per element this
+        HBM-bound kernel moved)."""
         gmm, bta, _, _ = self.ln[key]
         M, H = x.shape
-        y32 = torch.empty((M, H), dtype=F32, device=x.device) if want32 else None
+        lazy = lazy and self.lazy_ln and drop[1] == 0
+        y32 = torch.empty((M, H), dtype=F32, device=x.device) if (want32 and not lazy) else None
         y16 = torch.empty((M, H), dtype=BF16, device=x.device)
-        mean = torch.empty(M, dtype=F32, device=x.device) if save else None
-        rstd = torch.empty(M, dtype=F32, device=x.device) if save else None
+        keep = save or lazy
+        mean = torch.empty(M, dtype=F32, device=x.device) if keep else None
+        rstd = torch.empty(M, dtype=F32, device=x.device) if keep else None
         L.layernorm_fwd(x, gmm, bta, y32, y16, mean, rstd, M, H, drop=drop)
+        if lazy:
+            y32 = _LazyLN(x, mean, rstd, gmm, bta)
         return y32, y16, mean, rstd
+
+    def _dense32(self, r):
+        """fp32 tensor of a residual-stream value (materialises a lazy LayerNorm output)."""
+        if not isinstance(r, _LazyLN):
+            return r
+        M, H = r.x.shape
+        y32 = torch.empty((M, H), dtype=F32, device=r.x.device)
+        scratch = torch.empty((M, H), dtype=BF16, device=r.x.device)
+        L.layernorm_fwd(r.x, r.gamma, r.beta, y32, scratch, None, None, M, H)
+        return y32
 
     def _layernorm_bwd(self, dy, x, mean, rstd, key, dbias=None, drop=L.NO_DROP, out_drop=L.NO_DROP):
         gmm, _, gg, gb = self.ln[key]
@@ -317,12 +346,12 @@ class Engine:
         ctx, lse = self._attn(q, k, v, mask, B, heads, T, T, D, d_attn, save, qvar=var, kvar=var)
         d_so = self._drop(pname + "so", p_hid, train)
         pre1 = self._linear(ctx, so, L.EPI_BIAS_DROP_RESID, aux=x32, drop=d_so, out_f32=True)
-        x1_32, x1, m1, r1 = self._layernorm(pre1, key + ".ln1", save)
+        x1_32, x1, m1, r1 = self._layernorm(pre1, key + ".ln1", save, lazy=True)
         # training keeps GELU'(u) (not u): the backward epilogue is then a plain multiply
         h, u = self._linear(x1, ff1, L.EPI_BIAS_GELU_DG, want_u=True) if save else (self._linear(x1, ff1, L.EPI_BIAS_GELU), None)
         d_out = self._drop(pname + "out", p_hid, train)
         pre2 = self._linear(h, ff2, L.EPI_BIAS_DROP_RESID, aux=x1_32, drop=d_out, out_f32=True)
-        x2_32, x2, m2, r2 = self._layernorm(pre2, key + ".ln2", save)
+        x2_32, x2, m2, r2 = self._layernorm(pre2, key + ".ln2", save, lazy=True)
         if save:
             def bwd(dx2):
                 dpre2, dpre2d = self._layernorm_bwd(dx2, pre2, m2, r2, key + ".ln2", dbias=ff2.gb, drop=d_out)
@@ -360,9 +389,9 @@ class Engine:
         db1 = self._drop(pn + "bo1", cfg.v_hidden_dropout_prob, train)
         db2 = self._drop(pn + "bo2", cfg.hidden_dropout_prob, train)
         prev = self._linear(ctx_v, d1, L.EPI_BIAS_DROP_RESID, aux=xv32, drop=db1, out_f32=True)   # BertBiOutput (:744-754, call order :775)
-        av32, av, mv1, rv1 = self._layernorm(prev, key + ".lnb1", save)
+        av32, av, mv1, rv1 = self._layernorm(prev, key + ".lnb1", save, lazy=True)
         pret = self._linear(ctx_t, d2, L.EPI_BIAS_DROP_RESID, aux=xt32, drop=db2, out_f32=True)
-        at32, at, mt1, rt1 = self._layernorm(pret, key + ".lnb2", save)
+        at32, at, mt1, rt1 = self._layernorm(pret, key + ".lnb2", save, lazy=True)
         dvo = self._drop(pn + "vout", cfg.v_hidden_dropout_prob, train)
         dto = self._drop(pn + "tout", cfg.hidden_dropout_prob, train)
         if save:
@@ -371,9 +400,9 @@ class Engine:
         else:
             hv, uv, ht, ut = self._linear(av, vff1, L.EPI_BIAS_GELU), None, self._linear(at, tff1, L.EPI_BIAS_GELU), None
         prev2 = self._linear(hv, vff2, L.EPI_BIAS_DROP_RESID, aux=av32, drop=dvo, out_f32=True)
-        ov32, ov, mv2, rv2 = self._layernorm(prev2, key + ".lnv", save)
+        ov32, ov, mv2, rv2 = self._layernorm(prev2, key + ".lnv", save, lazy=True)
         pret2 = self._linear(ht, tff2, L.EPI_BIAS_DROP_RESID, aux=at32, drop=dto, out_f32=True)
-        ot32, ot, mt2, rt2 = self._layernorm(pret2, key + ".lnt", save)
+        ot32, ot, mt2, rt2 = self._layernorm(pret2, key + ".lnt", save, lazy=True)
         if save:
             def bwd(dov, dot):
                 sc = 1.0 / math.sqrt(D)
@@ -601,6 +630,7 @@ class Engine:
                     tape[-1] = ("c", tape[-1][0], tape[-1][1])
         seq_t, seq_v = xt, xv
 
+        xt32, xv32 = self._dense32(xt32), self._dense32(xv32)      # the final residual stream is an output
         out = dict(seq_out_t=seq_t, seq_out_v=seq_v, seq32_t=xt32, seq32_v=xv32, B=B, T=T, R=R, plan=plan, Mt=Mt)
         # ---- poolers + NSP (models/vilbert_dialog.py:946-967, 1064-1070) -------------------------
         tp, vp, nspl = self.lin["tpool"], self.lin["vpool"], self.lin["nsp"]

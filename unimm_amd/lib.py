@@ -12,7 +12,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libunimm_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROP_RESID, EPI_BIAS_RELU, EPI_DGELU, EPI_ADD, EPI_MUL, EPI_BIAS_GELU_DG = range(8)
 
@@ -29,7 +29,8 @@ class GemmNtArgs(C.Structure):
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
                 ("ldx", C.c_int32), ("ldw", C.c_int32), ("ldaux", C.c_int32), ("ldo", C.c_int32),
                 ("epilogue", C.c_int32), ("out_f32", C.c_int32),
-                ("drop_key", C.c_uint32), ("drop_thr", C.c_uint32), ("drop_scale", C.c_float)]
+                ("drop_key", C.c_uint32), ("drop_thr", C.c_uint32), ("drop_scale", C.c_float),
+                ("aux_mean", C.c_void_p), ("aux_rstd", C.c_void_p), ("aux_gamma", C.c_void_p), ("aux_beta", C.c_void_p)]
 
 
 class GemmTnArgs(C.Structure):
@@ -94,8 +95,9 @@ def _dev(*ts):
             raise UnimmHipError("unimm_amd kernels need device tensors (got a CPU tensor)")
 
 
-def gemm_nt(x, w, out, bias=None, epilogue=EPI_BIAS, aux=None, out2=None, drop=None, M=None, N=None, K=None):
-    """out[M,N] = epi(x[M,K] @ w[N,K]^T).  x/w bf16 2-D (row stride = stride(0)); out bf16 or fp32."""
+def gemm_nt(x, w, out, bias=None, epilogue=EPI_BIAS, aux=None, out2=None, drop=None, M=None, N=None, K=None, aux_ln=None):
+    """out[M,N] = epi(x[M,K] @ w[N,K]^T).  x/w bf16 2-D (row stride = stride(0)); out bf16 or fp32.
+    aux_ln = (mean[M], rstd[M], gamma[N], beta[N]): the DROP_RESID residual is LayerNorm(aux) computed on the fly."""
     _dev(x, w, out, bias, aux, out2)
     a = GemmNtArgs()
     a.x, a.w, a.bias, a.aux, a.out, a.out2 = _ptr(x), _ptr(w), _ptr(bias), _ptr(aux), _ptr(out), _ptr(out2)
@@ -108,6 +110,9 @@ def gemm_nt(x, w, out, bias=None, epilogue=EPI_BIAS, aux=None, out2=None, drop=N
     a.out_f32 = 1 if out.dtype == torch.float32 else 0
     if drop is not None:
         a.drop_key, a.drop_thr, a.drop_scale = drop
+    if aux_ln is not None:
+        _dev(*aux_ln)
+        a.aux_mean, a.aux_rstd, a.aux_gamma, a.aux_beta = (t.data_ptr() for t in aux_ln)
     _check(lib().unimm_gemm_nt(C.byref(a), _stream()), "unimm_gemm_nt")
     return out
 
