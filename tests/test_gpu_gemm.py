@@ -181,6 +181,32 @@ def test_gemm_nt_persistent_workgroups(cfg):
     assert (out2.float() - dref).abs().max().item() <= 2 ** -6
 
 
+@pytest.mark.parametrize("M,N,K", [(515, 768, 128), (4096, 1024, 1024), (300, 200, 64)])
+def test_gemm_nt_residual_from_lazy_layernorm(M, N, K):
+    """aux_mean/rstd/gamma/beta: the residual operand is LayerNorm(aux) evaluated in the epilogue; must equal
+    the same launch fed with the materialised fp32 LayerNorm output."""
+    from unimm_amd import lib
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    x, w = _rand((M, K), g), _rand((N, K), g, 0.05)
+    bias = torch.randn(N, generator=g, device="cuda")
+    ldo = (N + 7) // 8 * 8
+    h = torch.randn((M, ldo), generator=g, device="cuda") * 3 + 1
+    gamma, beta = torch.randn(N, generator=g, device="cuda"), torch.randn(N, generator=g, device="cuda")
+    mean = h[:, :N].mean(1)
+    rstd = torch.rsqrt(h[:, :N].var(1, unbiased=False) + 1e-12)
+    y = torch.zeros_like(h)
+    y[:, :N] = (h[:, :N] - mean[:, None]) * rstd[:, None] * gamma + beta
+    drop = (12345, int(0.1 * 2 ** 32), 1.0 / 0.9)
+    a = torch.full((M, ldo), float("nan"), device="cuda")
+    b = torch.full((M, ldo), float("nan"), device="cuda")
+    lib.gemm_nt(x, w, a, bias=bias, epilogue=lib.EPI_BIAS_DROP_RESID, aux=y, N=N, drop=drop)
+    lib.gemm_nt(x, w, b, bias=bias, epilogue=lib.EPI_BIAS_DROP_RESID, aux=h, N=N, drop=drop, aux_ln=(mean, rstd, gamma, beta))
+    torch.cuda.synchronize()
+    assert (a[:, :N] - b[:, :N]).abs().max().item() <= 1e-5 * max(1.0, a[:, :N].abs().max().item())
+    with pytest.raises(lib.UnimmHipError):      # only with the residual epilogue
+        lib.gemm_nt(x, w, b, bias=bias, epilogue=lib.EPI_BIAS, N=N, aux_ln=(mean, rstd, gamma, beta))
+
+
 def test_gemm_tn_grouped_matches_single_launches():
     """One grouped call over mixed problems (big-tile and small-tile classes, different M, ragged M tails,
     ragged N/K, a bias gradient on some, two problems accumulating into ONE dw as the tied decoder /
