@@ -458,19 +458,39 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
       const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qb);
       const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + qb);
       const u32x4 w4 = *reinterpret_cast<const u32x4*>(mrow + qb);
+      // dropout words: keys k and k^1 (lanes r and r^1) share the hash word of a query row, so each lane of the
+      // pair hashes two of the four queries and takes the other two from its neighbour (DPP quad_perm [1,0,3,2])
+      uint32_t dwv[4] = {0u, 0u, 0u, 0u};
+      if constexpr (D == 64) {
+        if (p.drop.thr != 0u) {
+          const uint32_t kw = (uint32_t)(wt * 32 + r) >> 1;
+          const uint32_t half = ((uint32_t)p.Tk + 1u) >> 1;
+          const uint32_t par = (uint32_t)r & 1u;
+          const uint32_t wa = drop_word(p.drop, (hbase + (uint32_t)qb + par) * half + kw);
+          const uint32_t wb = drop_word(p.drop, (hbase + (uint32_t)qb + par + 2u) * half + kw);
+          const uint32_t oa = (uint32_t)__builtin_amdgcn_mov_dpp((int)wa, 0xB1, 0xF, 0xF, true);
+          const uint32_t ob = (uint32_t)__builtin_amdgcn_mov_dpp((int)wb, 0xB1, 0xF, 0xF, true);
+          dwv[0] = par ? oa : wa; dwv[1] = par ? wa : oa; dwv[2] = par ? ob : wb; dwv[3] = par ? wb : ob;
+        }
+      }            // D = 128: the kernel is at its register limit; it hashes per element inside the loop below
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int e = 4 * g4 + i;
-        int qi = qb + i;
-        qi = qi < Tq_b ? qi : Tq_b - 1;
         float v = sacc[e] * p.scale;
         v += ((w4[i] >> r) & 1u) ? 0.0f : -10000.0f;
         const float pe = kvalid ? __builtin_amdgcn_exp2f(v * LOG2E - l4[i]) : 0.f;
         float dp = dpacc[e];
         float pdrop = pe;
         if (p.drop.thr != 0u) {
-          const uint32_t dw = drop_word(p.drop, drop_wbase(hbase + (uint32_t)qi, (uint32_t)p.Tk, (uint32_t)krow));
-          const bool keep = drop_keep(p.drop, dw, (uint32_t)krow & 1u);
+          bool keep;
+          if constexpr (D == 64) {
+            keep = drop_keep(p.drop, dwv[i], (uint32_t)r & 1u);
+          } else {
+            int qi = qb + i;
+            qi = qi < Tq_b ? qi : Tq_b - 1;
+            const uint32_t dw = drop_word(p.drop, drop_wbase(hbase + (uint32_t)qi, (uint32_t)p.Tk, (uint32_t)krow));
+            keep = drop_keep(p.drop, dw, (uint32_t)krow & 1u);
+          }
           dp = keep ? dp * p.drop.scale : 0.f;
           pdrop = keep ? pe * p.drop.scale : 0.f;
         }
