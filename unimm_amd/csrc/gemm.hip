@@ -1051,9 +1051,13 @@ int launch_tn_group(const unimm_gemm_tn_args* const* a, int count, bool big, hip
   max_s = max_s < 1 ? 1 : (max_s > 32 ? 32 : max_s);
   int splits = 1;
   double best = 1e30;
+  // cost of a split count: rounds x (steps of one workgroup + its fixed cost: pipeline fill and partial-tile
+  // drain, ~8 steps' worth); the fixed term only matters for short reductions (per-GPU batches of 30-60
+  // sequences under strong scaling), where three rounds of 17-step workgroups lose to one round of 61
+  const double steps = (double)max_m / TK;
   for (int sp = 1; sp <= max_s; ++sp) {
     const int rounds = (tiles * sp + slots - 1) / slots;
-    const double cost = (double)rounds / sp;
+    const double cost = rounds * (steps / sp + 8.0);
     if (cost < best * 0.98) { best = cost; splits = sp; }
   }
   for (int i = 0; i < count; ++i) {
