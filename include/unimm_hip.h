@@ -72,8 +72,13 @@ typedef struct {
 } unimm_gemm_nt_args;
 
 int unimm_gemm_nt(const unimm_gemm_nt_args* args, void* stream);
-/* Tuning knob: block-tile configuration of unimm_gemm_nt.  0 = automatic (default), 1 = 128x128 tile /
- * 2-stage ring / 2 workgroups per CU, 2 = 256x128 tile / 3-stage ring with counted vmcnt. */
+/* Tuning knob (tests and A/B measurements): block tile of unimm_gemm_nt.  cfg = gn * 1000 + p * 100 + tile.
+ *   tile: 0 automatic (default: 3 when >= 384 tiles of 256x256, 7 when < 256 tiles of 128x128, else 1),
+ *         1 = 128x128 / 4 waves / 2-slot ring of BK 64 / 2 workgroups per CU,   2 = 256x256 / 8 waves / 4 x BK 32,
+ *         3 = 256x256 / 8 waves / 2 x BK 64,   4, 5 = the 256x256 and 128x128 tiles behind a 5-slot ring of BK 32,
+ *         6 = 256x128 / 8 waves,   7 = 64x128 / 4 waves of 32x64 / 3 workgroups per CU
+ *   p:    0 automatic, 1 persistent workgroups (one per CU slot walks several tiles), 2 one workgroup per tile
+ *   gn:   n-tiles per column group of the tile order (0 = default 6) */
 int unimm_gemm_set_tile(int32_t cfg);
 
 /* GEMM, "TN": DW[N,K] += DY[M,N]^T . X[M,K] (fp32 atomics; caller zeroes DW once per step) and,
