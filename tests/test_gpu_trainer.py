@@ -122,3 +122,34 @@ def test_train_step_accumulation_and_checkpoint_resume(golden_dir, tmp_path):
     sd.pop(dropped)
     fresh = _encoder(golden_dir, tmp_path)
     assert trainer.load_checkpoint({"model_state_dict": sd}, fresh) == len(d["model_state_dict"]) - 1
+
+
+def test_harness_forward_evaluation_and_score_outputs(golden_dir, tmp_path):
+    """The evaluation calls of the reference (train.py:180-290, val_lm.py:104-136): no labels / targets, NSP scores
+    and dense LM scores on request, sample_size subsampling in training."""
+    from unimm_amd import synth, trainer
+    from unimm_amd.harness import forward, generative_scores
+    enc = _encoder(golden_dir, tmp_path)
+    cfg = enc.bert_pretrained.config
+    b, nsp_w = synth.make_loader_batch(n_img=2, rounds=1, samples=3, T=64, cfg=cfg, seed=7)
+    b = trainer.expand_image_fields(b)
+    params = dict(lm_loss_coeff=1.0, nsp_loss_coeff=1.0, img_loss_coeff=1.0, nsp_weight=nsp_w)
+    enc.eval()
+    with torch.no_grad():
+        out = forward(enc, b, params, output_nsp_scores=True, output_lm_scores=True, evaluation=True)
+    loss, lm, nsp, img, nsp_scores, lm_scores = out
+    assert loss is None and lm is None and nsp is None and img is None
+    assert nsp_scores.shape == (6, 2) and lm_scores.shape == (6, 64, cfg.vocab_size)
+    assert torch.isfinite(nsp_scores).all() and torch.isfinite(lm_scores[:, 0]).all()
+    ll = generative_scores(lm_scores, b["mask"].reshape(6, 64))
+    assert ll.shape == (6,) and torch.isfinite(ll).all()
+    # the fused path gives the same per-sequence log-likelihoods without the dense scores
+    flat = lambda k, keep: b[k].reshape((-1,) + tuple(b[k].shape[-keep:]))
+    s2, _ = enc.bert_pretrained.sequence_log_likelihood(
+        flat("tokens", 1), flat("image_feat", 2), flat("image_loc", 2), flat("mask", 1), token_type_ids=flat("segments", 1),
+        position_ids=flat("positions", 1), attention_mask=flat("txt_attention_mask", 2), image_attention_mask=flat("image_mask", 1),
+        co_attention_mask=flat("co_attention_mask", 2))
+    assert (ll.cpu() - s2.cpu()).abs().max() <= 2e-2 * max(1.0, float(ll.abs().max()))
+    enc.train()
+    res = forward(enc, b, params, sample_size=4)            # training call with subsampling (train.py:138-145)
+    assert len(res) == 4 and torch.isfinite(res[0])
