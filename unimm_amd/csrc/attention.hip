@@ -381,8 +381,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
 //   dV^T += dO^T . P_drop  and  dK^T += Q^T . dS  straight from the accumulators, with the
 //   transposed operands read from the Q / dO images.  No atomics, no cross-wave reduction.
 // ------------------------------------------------------------------------------------------------
-template <int D, int NQT>
-__global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
+// MAXT = 256: the variant for <= 2 key tiles (37 region keys) -- 2 compute waves + 2 staging helpers, one wave per
+// SIMD, so the D = 128 instance gets 512 registers and stops spilling (148 bytes of scratch at 256)
+template <int D, int NQT, int MAXT = 512>
+__global__ __launch_bounds__(MAXT, MAXT == 256 ? 1 : 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int QPAD = NQT * 32;
   char* qimg = smem;
@@ -571,11 +573,20 @@ int launch_bwd_dq(const AttnBwdParams& p, hipStream_t s) {
 template <int D, int NQT>
 int launch_bwd_dkv(const AttnBwdParams& p, hipStream_t s) {
   const size_t lds = (size_t)2 * NQT * 32 * 2 * D + 2 * NQT * 32 * sizeof(float) + (size_t)8 * NQT * 32 * sizeof(uint32_t);
-  auto kern = attn_bwd_dkv_kernel<D, NQT>;
-  if (set_lds(kern, lds) != UNIMM_OK) return UNIMM_E_HIP;
   AttnBwdParams q = p;
   const int tiles = (p.Tk + 31) / 32;
   q.parts = parts_for(tiles, lds);
+  if constexpr (D == 128 && NQT == 8) {   // (the 37x37 image self-attention, NQT = 2, lives on many small workgroups per CU)
+    if (tiles <= 2 && q.parts == 1 && g_attn_parts != 99) {
+      auto k4 = attn_bwd_dkv_kernel<D, NQT, 256>;
+      if (set_lds(k4, lds) != UNIMM_OK) return UNIMM_E_HIP;
+      hipLaunchKernelGGL(k4, dim3(p.B * p.H), dim3(256), lds, s, q);
+      UNIMM_CHECK_LAUNCH();
+      return UNIMM_OK;
+    }
+  }
+  auto kern = attn_bwd_dkv_kernel<D, NQT>;
+  if (set_lds(kern, lds) != UNIMM_OK) return UNIMM_E_HIP;
   hipLaunchKernelGGL(kern, dim3(p.B * p.H * q.parts), dim3(block_threads((tiles + q.parts - 1) / q.parts, NQT * 32)), lds, s, q);
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;
