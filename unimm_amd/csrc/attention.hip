@@ -116,7 +116,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnParams p) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int item = blockIdx.x / p.parts, part = blockIdx.x % p.parts;
   const int b = item / p.H, head = item % p.H;
-  const int wt = part * (blockDim.x >> 6) + wave;      // this wave's 32-query tile
+  const int nwv = blockDim.x >> 6;                     // waves of this workgroup: wave w owns query tiles w, w + nwv, ...
   const int r = lane & 31, h = lane >> 5;
 
   const int Tq_b = p.q_len ? p.q_len[b] : p.Tq, Tk_b = p.k_len ? p.k_len[b] : p.Tk;
@@ -129,26 +129,33 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnParams p) {
   stage_head<D>(kg, p.ldk, Tk_b, kpad_b, kimg, tid, blockDim.x);
   stage_head<D>(vg, p.ldv, Tk_b, kpad_b, vimg, tid, blockDim.x);
 
-  // Q fragments straight from HBM (each element is used once per key tile, by this wave only)
-  const int q0 = wt * 32;
-  int qrow = q0 + r;
-  const bool qvalid = qrow < Tq_b;
-  if (!qvalid) qrow = Tq_b - 1;
-  const bf16_t* qg = p.q + (qbase + qrow) * p.ldq + head * D;
+  // Q fragments straight from HBM (each element is used once per key tile, by this wave only) and the mask words
+  // of the query row; the first tile's are requested before the staging barrier
+  int wt = part * nwv + wave;
+  int q0, qrow;
+  bool qvalid;
   bf16x8 qf[D / 16];
-#pragma unroll
-  for (int ks = 0; ks < D / 16; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qg + 16 * ks + 8 * h);
-
-  // mask words of this query row
   uint32_t mw[NKT];
-  {
-    const uint32_t* mp = p.mask + (size_t)b * p.mask_b_stride + (size_t)qrow * p.mask_q_stride;
-#pragma unroll
-    for (int t = 0; t < NKT; ++t) mw[t] = mp[t];
+#define UNIMM_LOAD_QTILE()                                                                                    \
+  {                                                                                                          \
+    q0 = wt * 32;                                                                                            \
+    qrow = q0 + r;                                                                                           \
+    qvalid = qrow < Tq_b;                                                                                    \
+    if (!qvalid) qrow = Tq_b - 1;                                                                            \
+    const bf16_t* qg_ = p.q + (qbase + qrow) * p.ldq + head * D;                                             \
+    _Pragma("unroll") for (int ks = 0; ks < D / 16; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qg_ + 16 * ks + 8 * h); \
+    const uint32_t* mp_ = p.mask + (size_t)b * p.mask_b_stride + (size_t)qrow * p.mask_q_stride;            \
+    _Pragma("unroll") for (int t = 0; t < NKT; ++t) mw[t] = mp_[t];                                          \
   }
+  UNIMM_LOAD_QTILE()
   stage_wait();
   __syncthreads();
-  if (q0 >= Tq_b) return;          // wave-uniform: this wave's query tile is entirely padding
+  // A wave walks its query tiles one after the other.  With 8 tiles on 4 waves, two workgroups fit a CU and every
+  // resident wave has work: with one wave per tile, the tiles past a sequence's length were waves that exited at
+  // once and left the CU (one 8-wave workgroup at these register counts) half empty for the average dialog.
+  constexpr bool WALK = D == 64;     // D = 128 instances are at their register limit: one tile per wave there
+  for (bool first = true; wt * 32 < Tq_b && (WALK || first); first = false, wt += nwv * p.parts) {
+    if (WALK && !first) UNIMM_LOAD_QTILE()
 
   // ---- S^T = K . Q^T, all (non-padding) key tiles kept in registers
   f32x16 s[NKT];
@@ -246,6 +253,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnParams p) {
       }
     if (p.lse != nullptr && h == 0) p.lse[((size_t)b * p.H + head) * p.Tq + qrow] = mx + logf(sum);
   }
+  }   // query tiles of this wave
+#undef UNIMM_LOAD_QTILE
 }
 
 
@@ -600,7 +609,9 @@ int launch_fwd(const AttnParams& p, hipStream_t s) {
   if (set_lds(kern, lds) != UNIMM_OK) return UNIMM_E_HIP;
   AttnParams q = p;
   q.parts = parts_for(waves, lds);
-  hipLaunchKernelGGL(kern, dim3(p.B * p.H * q.parts), dim3(block_threads((waves + q.parts - 1) / q.parts, NKT * 32)), lds, s, q);
+  int threads = block_threads((waves + q.parts - 1) / q.parts, NKT * 32);
+  if (D == 64 && threads > 256 && g_attn_parts != 99) threads = 256;   // 4 waves walk the 8 query tiles: two workgroups per CU
+  hipLaunchKernelGGL(kern, dim3(p.B * p.H * q.parts), dim3(threads), lds, s, q);
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;
 }
