@@ -56,6 +56,9 @@ def parse():
                          "(100 sequences, nsp_loss_coeff 0, gradient accumulation: no exchange inside the step); "
                          "scoring = configs[4] (val_lm: 1 image = 10 rounds x 100 candidates in 4 chunks of 250, "
                          "forward + sequence log-likelihood + ranks)")
+    ap.add_argument("--dense-objective", choices=["ranking", "proxy"], default="ranking",
+                    help="dense workload: ranking = NeuralNDCG^T over the step's options + LM (+0 x NSP), the objective of "
+                         "dense_annotation_finetuning.py:263-293 (gradient enters through the NSP scores); proxy = LM + region-KL only")
     ap.add_argument("--with-optimizer", action="store_true",
                     help="also run the fused AdamW step (train.py:322-348 grouping and schedule) inside the timed step; "
                          "NOT the headline metric, which is fwd+bwd (the config block says which was run)")
@@ -259,6 +262,8 @@ def main():
         batch = synth.make_batch(n_seq=per_gpu, cfg=cfg, seed=1234 + rank, device=dev, modes=["dis"] * per_gpu,
                                  sequences_per_image=2)
         coeff = dict(lm=1.0, nsp=0.0, img=1.0)
+        g = torch.Generator().manual_seed(77 + rank)
+        relevance = torch.tensor([0, 0, 0, 0, 0.2, 0.4, 0.6, 1.0])[torch.randint(0, 8, (1, per_gpu), generator=g)].to(dev)
     else:
         batch = synth.make_batch(n_seq=per_gpu, cfg=cfg, seed=1234 + rank, device=dev, compact=args.compact_inputs)
         coeff = dict(lm=1.0, nsp=1.0, img=1.0)    # options.py:68-70 defaults
@@ -266,6 +271,19 @@ def main():
     n_lm_rows = int((batch["lm_weight"] != 0).sum())
 
     def fwd_bwd():
+        if args.workload == "dense" and args.dense_objective == "ranking":
+            from unimm_amd import ranking
+            lm, img, nsp, nsp_scores = net(
+                batch["input_ids"], batch["image_feat"], batch["image_loc"], sep_indices=batch["sep_indices"],
+                sep_len=batch["sep_len"], token_type_ids=batch["token_type_ids"], token_position_ids=batch["token_position_ids"],
+                attention_mask=batch["attention_mask"], masked_lm_labels=batch["masked_lm_labels"],
+                next_sentence_label=batch["next_sentence_label"], image_attention_mask=batch["image_attention_mask"],
+                co_attention_mask=batch["co_attention_mask"], image_label=batch["image_label"], image_target=batch["image_target"],
+                nsp_weight=nsp_w, lm_weight=batch["lm_weight"], output_nsp_scores=True)
+            loss, _ = ranking.dense_finetune_loss(nsp_scores, batch["next_sentence_label"], relevance, lm, coeff["nsp"],
+                                                  num_options=per_gpu)
+            loss.backward()
+            return loss
         if args.compact_inputs and args.workload == "train":
             lm, img, nsp = net(batch["input_ids"], batch["image_feat_unique"], batch["image_loc_unique"],
                                sep_indices=batch["sep_indices"], sep_len=batch["sep_len"], token_type_ids=batch["token_type_ids"],
@@ -373,7 +391,9 @@ def main():
             metric = f"dialog-sequences/sec (fwd+bwd) dense-annotation fine-tune micro-step at bs={per_gpu} seq=256 regions=36(+1 <IMG>)"
             wl = ("dense-annotation fine-tune micro-step (BASELINE configs[3]): bert_base_6layer_6conect, discriminative inputs, "
                   "sequences_per_image=2, nsp_loss_coeff=0, batch_multiply=16 (gradient exchange every 16th step), bf16, "
-                  "fwd+bwd, ranking loss and optimizer not included")
+                  "fwd+bwd, " + ("objective = NeuralNDCG^T over the step's options + LM loss (dense_annotation_finetuning.py:263-293), "
+                              "optimizer not included" if args.dense_objective == "ranking"
+                              else "LM + region-KL proxy objective, ranking loss and optimizer not included"))
         else:
             metric = "dialog-sequences/sec (fwd+bwd) at bs=240 seq=256 regions=36(+1 <IMG>)"
             wl = ("UniMM-UL sparse training step (BASELINE configs[1]): bert_base_6layer_6conect, "

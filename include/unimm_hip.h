@@ -307,6 +307,31 @@ typedef struct {
 
 int unimm_adamw_step(const unimm_adamw_args* args, void* stream);
 
+/* NeuralNDCG-transposed of `slates` independent slates of `n` answer options: value and gradient with
+ * respect to the predictions in one launch.  Replaces the deterministic branch of
+ * neuralNDCG_transposed (utils/rank_loss.py:518-581: deterministic_neural_sort :79-112, sinkhorn_scaling
+ * :55-78, dcg :18-54) as dense_annotation_finetuning.py:286-288 calls it, and its autograd backward.
+ * pred / truth fp32 [slates, n]; truth == pad_label marks a padded option.  Outputs per slate:
+ * ndcg (0 when the slate has no relevant option), alive (1 / 0: ideal DCG != 0), iters (Sinkhorn sweeps
+ * run), and dpred [slates, n] = d ndcg / d pred.  The caller forms loss = -sum(ndcg) / sum(alive). */
+#define UNIMM_NDCG_MAX_OPTIONS 128
+#define UNIMM_NDCG_MAX_ITER 64
+typedef struct {
+  const float* pred;
+  const float* truth;
+  float* ndcg;
+  float* alive;
+  float* dpred;
+  int32_t* iters;
+  int32_t slates, n;
+  int32_t k;                    /* truncation rank; <= 0 = n */
+  int32_t powered_relevancies;  /* gain 2^y - 1 (1) or y (0); the ideal DCG always uses 2^y - 1, as the reference does */
+  int32_t max_iter;             /* 1 .. UNIMM_NDCG_MAX_ITER (reference default 50) */
+  float pad_label, temperature, tol;
+} unimm_ndcg_args;
+
+int unimm_neural_ndcg(const unimm_ndcg_args* args, void* stream);
+
 /* Launch profiler for bench.py's `roofline` block: HIP events around every GEMM launch on its own
  * stream while enabled.  Variant index: 0..11 = unimm_gemm_nt (epilogue * 2 + out_f32), 12 = unimm_gemm_tn.
  * unimm_prof_collect synchronises the events and returns per-variant summed milliseconds, algorithmic

@@ -296,12 +296,68 @@ def gen_sched():
     save("sched.npz", **out)
 
 
+def gen_rankloss(vm):
+    """G8: dense fine-tune objective and evaluation metrics (utils/rank_loss.py:518-581 as called at
+    dense_annotation_finetuning.py:288; utils/visdial_metrics.py:41-193)."""
+    import utils.rank_loss as rl
+    rng = np.random.Generator(np.random.PCG64(21))
+    out, names = {}, []
+
+    def case(name, pred, true, seed=None, **kw):
+        yp = T_(pred.copy()).requires_grad_(True)
+        if seed is not None:
+            torch.manual_seed(seed)
+        loss = rl.neuralNDCG_transposed(yp, T_(true.copy()), **kw)
+        g = torch.autograd.grad(loss, yp)[0] if loss.requires_grad else torch.zeros_like(yp)
+        out[name + "_pred"], out[name + "_true"] = pred, true
+        out[name + "_loss"], out[name + "_grad"] = loss.detach().numpy(), g.numpy()
+        out[name + "_kw"] = json.dumps(dict(kw, seed=seed))
+        names.append(name)
+
+    def relevance(b, n):
+        r = rng.choice(np.array([0, 0, 0, 0.2, 0.4, 0.6, 0.8, 1.0], dtype=np.float32), size=(b, n))
+        return r.astype(np.float32)
+
+    case("one100", rng.random((1, 100), dtype=np.float32), relevance(1, 100))
+    case("three100", rng.random((3, 100), dtype=np.float32), relevance(3, 100))
+    p, t = rng.random((4, 12), dtype=np.float32), relevance(4, 12)
+    t[0, 9:] = -1
+    t[1, 4] = -1
+    t[1, 11] = -1
+    p[2, 3] = p[2, 7]
+    t[3, :] = 0                      # a slate with no relevant option: excluded from the mean
+    case("ragged", p, t)
+    case("ragged_k5_t05", p, t, k=5, temperature=0.5)
+    case("ragged_linear", p, t, powered_relevancies=False)
+    case("allzero", rng.random((2, 8), dtype=np.float32), np.zeros((2, 8), np.float32))
+    case("stoch", rng.random((1, 20), dtype=np.float32) + 0.05, relevance(1, 20), seed=3, stochastic=True, n_samples=4)
+    out["names"] = json.dumps(names)
+
+    sp = vm.SparseGTMetrics()
+    sc = rng.standard_normal((2, 2, 10, 100)).astype(np.float32)
+    gt = rng.integers(0, 100, size=(2, 2, 10))
+    for i in range(2):
+        sp.observe(T_(sc[i].copy()), T_(gt[i].copy()))
+    m = sp.retrieve()
+    out["sparse_scores"], out["sparse_gt"] = sc, gt
+    out["sparse_keys"] = json.dumps(sorted(m))
+    out["sparse_vals"] = np.array([float(m[k]) for k in sorted(m)], dtype=np.float64)
+    nd = vm.NDCG()
+    ns = rng.standard_normal((2, 3, 100)).astype(np.float32)
+    nr = np.stack([relevance(3, 100), relevance(3, 100)])
+    for i in range(2):
+        nd.observe(T_(ns[i].copy()), T_(nr[i].copy()))
+    out["ndcg_scores"], out["ndcg_rel"] = ns, nr
+    out["ndcg"] = np.array(nd.retrieve()["ndcg"], dtype=np.float64)
+    save("rankloss.npz", **out)
+
+
 if __name__ == "__main__":
-    groups = sys.argv[1:] or ["masks", "ranks", "small", "blocks", "losses", "full", "sched"]
+    groups = sys.argv[1:] or ["masks", "ranks", "small", "blocks", "losses", "full", "sched", "rankloss"]
     vd, du, vm = import_reference()
     torch.manual_seed(0)
     torch.set_num_threads(8)
     for g in groups:
         {"masks": lambda: gen_masks(du), "ranks": lambda: gen_ranks(vm), "small": lambda: gen_small(vd),
          "blocks": lambda: gen_blocks(vd), "losses": lambda: gen_losses(vd), "full": lambda: gen_full(vd),
-         "sched": gen_sched}[g]()
+         "sched": gen_sched, "rankloss": lambda: gen_rankloss(vm)}[g]()

@@ -153,3 +153,73 @@ def test_harness_forward_evaluation_and_score_outputs(golden_dir, tmp_path):
     enc.train()
     res = forward(enc, b, params, sample_size=4)            # training call with subsampling (train.py:138-145)
     assert len(res) == 4 and torch.isfinite(res[0])
+
+
+def test_dense_finetune_step_matches_oracle_objective(golden_dir, tmp_path):
+    """Row F4: one dense-annotation step (dense_annotation_finetuning.py:146-301) on the HIP path against the
+    oracle encoder + the golden-pinned ranking loss under autograd: the NeuralNDCG^T gradient has to arrive
+    through the returned NSP scores."""
+    import zlib
+    from oracle import vilbert_ref as R
+    from unimm_amd import dropout as DR, ranking, synth, trainer
+    enc = _encoder(golden_dir, tmp_path)
+    cfg = enc.bert_pretrained.config
+    sd = {k[len("bert_pretrained."):]: v.detach().float().cpu().clone() for k, v in enc.state_dict().items()}
+    opt, sch = _optim(enc)
+    n_opt = 12
+    b, nsp_w = synth.make_loader_batch(n_img=1, rounds=1, samples=n_opt, T=64, cfg=cfg, seed=31)
+    rng = np.random.Generator(np.random.PCG64(5))
+    b["gt_option"] = torch.tensor([4])
+    b["gt_relevance"] = torch.from_numpy(rng.choice(np.array([0, 0, 0.2, 0.6, 1.0], np.float32), size=(1, n_opt)))
+    b["gt_relevance"][0, 4] = 1.0
+    params = dict(lm_loss_coeff=1.0, nsp_loss_coeff=0.5, img_loss_coeff=1.0, nsp_weight=nsp_w, batch_multiply=1)
+    order = torch.tensor([4, 7, 0, 11, 2, 9, 1, 3, 10, 5, 8, 6])
+    grads = {}
+    real_step = opt.step
+    opt.step = lambda *a, **k: grads.update({n: p.grad.detach().float().cpu().clone() for n, p in enc.named_parameters()
+                                             if p.grad is not None}) or real_step(*a, **k)
+    enc.bert_pretrained.set_dropout_seed(13, step=2)
+    lr0 = [g["lr"] for g in opt.param_groups]
+    loss, parts = trainer.dense_finetune_step(enc, opt, sch, b, params, iter_id=1, num_options=n_opt, option_indices=order)
+    torch.cuda.synchronize()
+    assert grads and [g["lr"] for g in opt.param_groups] != lr0          # optimizer and scheduler both stepped
+
+    # ---- oracle replay: same option order, the fused-vector dropout mask of step 3 re-played
+    sel = trainer.expand_image_fields(trainer.select_options(b, order))
+    flat = lambda k, keep: sel[k].reshape((-1,) + tuple(sel[k].shape[-keep:])) if keep else sel[k].reshape(-1)
+
+    def drop_fn(site, x, p):
+        if site != "fuse":
+            return x
+        key = DR.make_key(13, 3, zlib.crc32(site.encode()) & 0xFFFFFFFF)
+        _, thr, scale = DR.drop_arg(p, key)
+        return x * torch.from_numpy(DR.keep_mask_nd(key, thr, tuple(x.shape))) * scale
+
+    ocfg = R.make_config(json.load(open(os.path.join(tmp_path, "small_nodrop.json"))))
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != R.TIED[0]}
+    leaves[R.TIED[0]] = leaves[R.TIED[1]]
+    out = R.forward(leaves, ocfg, flat("tokens", 1), flat("image_feat", 2), flat("image_loc", 2),
+                    token_type_ids=flat("segments", 1), position_ids=flat("positions", 1),
+                    attention_mask=flat("txt_attention_mask", 2), image_attention_mask=flat("image_mask", 1),
+                    co_attention_mask=flat("co_attention_mask", 2), masked_lm_labels=flat("mask", 1),
+                    image_label=flat("image_label", 1), image_target=flat("image_target", 2),
+                    next_sentence_label=flat("next_sentence_labels", 0), nsp_weight=nsp_w, lm_weight=flat("weights", 1),
+                    drop_fn=drop_fn)
+    want, wparts = ranking.dense_finetune_loss(out["nsp"], flat("next_sentence_labels", 0), b["gt_relevance"][:, order],
+                                               out["lm_loss"], 0.5, num_options=n_opt)
+    want.backward()
+    assert abs(float(parts["target"]) - float(wparts["target"].detach())) <= 1e-2
+    assert abs(loss - float(want)) <= 2e-2 * max(1.0, abs(float(want)))
+    bad = []
+    for n, g in grads.items():
+        ref = leaves[n[len("bert_pretrained."):]].grad
+        if ref is None:                     # image-prediction head: the masked-region loss is not in this objective
+            assert float(g.abs().max()) == 0.0, n
+            continue
+        w, got = float(ref.norm()), float(g.norm())
+        if abs(got - w) > 6e-2 * max(w, 1e-4):
+            bad.append((n, got, w))
+    assert not bad, bad[:5]
+    k = "cls.bi_seq_relationship.weight"           # reached only through the NSP scores: ranking + NSP terms
+    w_nsp = float(leaves[k].grad.norm())
+    assert w_nsp > 0 and abs(float(grads["bert_pretrained." + k].norm()) - w_nsp) <= 6e-2 * w_nsp

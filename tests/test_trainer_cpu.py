@@ -3,6 +3,7 @@ expansion of train.py:413-432, the checkpoint dict of train.py:503-505 with warm
 optimizer / scheduler cadence of train_step under batch_multiply (with a stand-in model and torch SGD)."""
 import os
 
+import pytest
 import torch
 
 from unimm_amd import synth, trainer
@@ -85,3 +86,47 @@ def test_dialog_mask_spec_dense_form_matches_the_oracle_encoders():
     import pytest
     with pytest.raises(ValueError):
         DialogMaskSpec([1], [4], [4])            # the answer cannot be the whole sequence
+
+
+class _ScoreEnc(_Enc):
+    """Also returns per-sequence NSP scores that depend on the parameters and on the option's tokens."""
+
+    def forward(self, tokens, feat, loc, output_nsp_scores=False, **kw):
+        z = self.bert_pretrained(feat.float().mean(1)[:, :4])
+        out = (z[:, 0].pow(2).mean().reshape(1), z[:, 1].pow(2).mean().reshape(1), z[:, 2].pow(2).mean().reshape(1))
+        if output_nsp_scores:
+            out = out + (z[:, :2] * (1.0 + tokens.float().mean(1, keepdim=True) / 1000.0),)
+        return out
+
+
+def test_dense_finetune_step_options_objective_and_cadence():
+    torch.manual_seed(0)
+    enc = _ScoreEnc()
+    opt = torch.optim.SGD(enc.parameters(), lr=0.1)
+    sch = WarmupLinearScheduleNonZero(opt, warmup_steps=2, t_total=10, min_lr=1e-5)
+    b, nsp_w = synth.make_loader_batch(n_img=1, rounds=1, samples=10, T=64, seed=2)
+    b["gt_option"] = torch.tensor([3])
+    b["gt_relevance"] = torch.linspace(0, 1, 10).view(1, 10)
+    params = dict(lm_loss_coeff=1.0, nsp_loss_coeff=0.7, img_loss_coeff=1.0, nsp_weight=nsp_w, batch_multiply=2)
+    seen = []
+    real = trainer.select_options
+    trainer.select_options = lambda batch, idx: (seen.append(idx.clone()), real(batch, idx))[1]
+    try:
+        w0 = enc.bert_pretrained.weight.detach().clone()
+        l0, parts = trainer.dense_finetune_step(enc, opt, sch, b, params, iter_id=0, num_options=10)
+        assert torch.equal(enc.bert_pretrained.weight, w0) and sch.last_epoch == 1      # iter 0 never steps the optimizer
+        trainer.dense_finetune_step(enc, opt, sch, b, params, iter_id=1, num_options=10)
+        assert torch.equal(enc.bert_pretrained.weight, w0)
+        trainer.dense_finetune_step(enc, opt, sch, b, params, iter_id=2, num_options=6)
+        assert not torch.equal(enc.bert_pretrained.weight, w0) and sch.last_epoch == 3
+    finally:
+        trainer.select_options = real
+    for idx, n in zip(seen, (10, 10, 6)):
+        assert int(idx[0]) == 3 and len(idx) == n and len(set(idx.tolist())) == n       # ground truth first, no repeats
+    # objective = ranking term + LM + coeff * NSP cross entropy, divided by batch_multiply
+    assert set(parts) == {"target", "nsp", "lm"} and float(parts["target"]) < 0
+    assert abs(l0 * 2 - float(parts["target"] + parts["lm"] + 0.7 * parts["nsp"])) < 1e-6
+    with pytest.raises(ValueError):
+        b2, _ = synth.make_loader_batch(n_img=2, rounds=1, samples=4, T=64, seed=2)
+        b2["gt_option"], b2["gt_relevance"] = torch.tensor([0]), torch.zeros(2, 4)
+        trainer.dense_finetune_step(enc, opt, sch, b2, params, iter_id=1, num_options=4)

@@ -73,7 +73,7 @@ SYMBOLS = ["unimm_version", "unimm_arch", "unimm_gemm_nt", "unimm_gemm_tn", "uni
            "unimm_embed_fwd", "unimm_embed_bwd", "unimm_colsum", "unimm_cast_f32_bf16", "unimm_transpose_cast",
            "unimm_pack_image", "unimm_mul_dropout", "unimm_mul_dropout_bwd", "unimm_lm_loss_fwd",
            "unimm_lm_loss_bwd", "unimm_kl_loss_fwd", "unimm_kl_loss_bwd", "unimm_nsp_loss_fwd",
-           "unimm_nsp_loss_bwd", "unimm_reduce_sum", "unimm_segment_sum", "unimm_gelu_bwd", "unimm_gather_rows", "unimm_prof_enable", "unimm_prof_collect", "unimm_gemm_set_tile", "unimm_attn_set_parts", "unimm_adamw_step", "unimm_transpose_cast_grouped", "unimm_mask_synth"]
+           "unimm_nsp_loss_bwd", "unimm_reduce_sum", "unimm_segment_sum", "unimm_gelu_bwd", "unimm_gather_rows", "unimm_prof_enable", "unimm_prof_collect", "unimm_gemm_set_tile", "unimm_attn_set_parts", "unimm_adamw_step", "unimm_transpose_cast_grouped", "unimm_mask_synth", "unimm_neural_ndcg"]
 
 
 def _check(rc, what):
@@ -455,6 +455,38 @@ def adamw_step(p, g, m, v, group, lrs, wds, step, beta1=0.9, beta2=0.999, eps=1e
     a.beta1, a.beta2, a.eps, a.grad_scale = beta1, beta2, eps, grad_scale
     a.correct_bias, a.zero_grad = int(bool(correct_bias)), int(bool(zero_grad))
     _check(lib().unimm_adamw_step(C.byref(a), _stream()), "unimm_adamw_step")
+
+
+NDCG_MAX_OPTIONS, NDCG_MAX_ITER = 128, 64
+
+
+class NdcgArgs(C.Structure):
+    _fields_ = [("pred", C.c_void_p), ("truth", C.c_void_p), ("ndcg", C.c_void_p), ("alive", C.c_void_p), ("dpred", C.c_void_p),
+                ("iters", C.c_void_p), ("slates", C.c_int32), ("n", C.c_int32), ("k", C.c_int32),
+                ("powered_relevancies", C.c_int32), ("max_iter", C.c_int32), ("pad_label", C.c_float),
+                ("temperature", C.c_float), ("tol", C.c_float)]
+
+
+def neural_ndcg(pred, truth, pad_label=-1.0, temperature=1.0, powered=True, k=None, max_iter=50, tol=1e-6):
+    """pred, truth fp32 [slates, n] on the device -> (ndcg [slates], alive [slates], dpred [slates, n], iters [slates])
+    (see include/unimm_hip.h: unimm_neural_ndcg)."""
+    _dev(pred, truth)
+    if pred.dtype != torch.float32 or truth.dtype != torch.float32 or pred.shape != truth.shape or pred.dim() != 2:
+        raise UnimmHipError("neural_ndcg: pred and truth must be fp32 [slates, n] of the same shape")
+    pred, truth = pred.contiguous(), truth.contiguous()
+    S, n = pred.shape
+    if not 1 <= n <= NDCG_MAX_OPTIONS or not 1 <= max_iter <= NDCG_MAX_ITER:
+        raise UnimmHipError(f"neural_ndcg: n <= {NDCG_MAX_OPTIONS} options and max_iter <= {NDCG_MAX_ITER} (got {n}, {max_iter})")
+    ndcg = torch.empty(S, dtype=torch.float32, device=pred.device)
+    alive = torch.empty_like(ndcg)
+    dpred = torch.empty_like(pred)
+    iters = torch.empty(S, dtype=torch.int32, device=pred.device)
+    a = NdcgArgs()
+    a.pred, a.truth, a.ndcg, a.alive, a.dpred, a.iters = (t.data_ptr() for t in (pred, truth, ndcg, alive, dpred, iters))
+    a.slates, a.n, a.k, a.powered_relevancies, a.max_iter = S, n, (0 if k is None else int(k)), int(bool(powered)), int(max_iter)
+    a.pad_label, a.temperature, a.tol = float(pad_label), float(temperature), float(tol)
+    _check(lib().unimm_neural_ndcg(C.byref(a), _stream()), "unimm_neural_ndcg")
+    return ndcg, alive, dpred, iters
 
 
 def prof_enable(on: bool):

@@ -9,7 +9,10 @@ dataloader and the checkpoint file, without the data plane.
 * `save_checkpoint`  - the dict of train.py:503-505 (`model_state_dict` with the `bert_pretrained.` prefix,
                        `scheduler_state_dict`, `optimizer_state_dict`, `iter_id`).
 * `load_checkpoint`  - warm start by key intersection (train.py:352-364) or `-continue` (train.py:366-389).
-* `expand_image_fields` - train.py:413-432 (one image's features repeated per round and per sample)."""
+* `expand_image_fields` - train.py:413-432 (one image's features repeated per round and per sample).
+* `dense_finetune_step` - one iteration of dense_annotation_finetuning.py:146-301 (row F4): one annotated
+                       round of one image against its 100 options (ground truth first, the rest permuted),
+                       NeuralNDCG^T + LM + weighted NSP objective, scheduler stepped before the optimizer."""
 from __future__ import annotations
 
 import os
@@ -17,7 +20,7 @@ from typing import Optional
 
 import torch
 
-from . import harness
+from . import harness, ranking
 
 
 def expand_image_fields(batch: dict) -> dict:
@@ -46,6 +49,51 @@ def train_step(dialog_encoder, optimizer, scheduler, batch, params, iter_id, sam
         optimizer.zero_grad()
     scheduler.step()
     return float(loss.detach()), lm_loss, nsp_loss, img_loss
+
+
+_OPTION_FIELDS = ("tokens", "segments", "positions", "weights", "sep_indices", "mask", "hist_len",
+                  "next_sentence_labels", "txt_attention_mask", "co_attention_mask")
+
+
+def select_options(batch: dict, option_indices: torch.Tensor) -> dict:
+    """Reorder / subsample the option axis (dim 2) of every per-option field
+    (dense_annotation_finetuning.py:211-220)."""
+    out = dict(batch)
+    for k in _OPTION_FIELDS:
+        out[k] = batch[k].index_select(2, option_indices.to(batch[k].device))
+    return out
+
+
+def dense_finetune_step(dialog_encoder, optimizer, scheduler, batch, params, iter_id, num_options=100, option_indices=None):
+    """One dense-annotation iteration.  `batch` holds ONE image (dense_annotation_finetuning.py:159) with
+    `tokens` [1, 1, 100, T], `gt_option` and `gt_relevance` [1, 100].  `option_indices` overrides the random
+    draw (tests).  Returns (loss, parts) with parts = target / nsp / lm tensors."""
+    if batch["image_feat"].shape[0] != 1:
+        raise ValueError("dense fine-tuning takes one image per step")
+    bm = int(params.get("batch_multiply", 1))
+    dialog_encoder.train()
+    if option_indices is None:
+        gt = int(batch["gt_option"].item())
+        n_all = batch["tokens"].shape[2]
+        rest = torch.cat([torch.arange(gt), torch.arange(gt + 1, n_all)])[torch.randperm(n_all - 1)[:num_options - 1]]
+        option_indices = torch.cat([batch["gt_option"].view(-1).cpu().long(), rest])
+    sel = expand_image_fields(select_options(batch, option_indices))
+    boundary = iter_id % bm == 0 and iter_id > 0
+    sync_ctx = dialog_encoder.no_sync() if (hasattr(dialog_encoder, "no_sync") and not boundary) else _null()
+    with sync_ctx:
+        _, lm_loss, _, _, nsp_scores = harness.forward(dialog_encoder, sel, params, output_nsp_scores=True)
+        dev = nsp_scores.device
+        relevance = batch["gt_relevance"].to(dev)[:, option_indices.to(dev)]
+        loss, parts = ranking.dense_finetune_loss(nsp_scores, sel["next_sentence_labels"].to(dev), relevance, lm_loss,
+                                                  params["nsp_loss_coeff"], num_options=len(option_indices))
+        (loss / bm).backward()
+    scheduler.step()
+    if boundary:
+        if hasattr(dialog_encoder, "sync_gradients"):
+            dialog_encoder.sync_gradients()
+        optimizer.step()
+        optimizer.zero_grad()
+    return float(loss.detach()) / bm, {k: v.detach() for k, v in parts.items()}
 
 
 class _null:
