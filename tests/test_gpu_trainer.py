@@ -223,3 +223,48 @@ def test_dense_finetune_step_matches_oracle_objective(golden_dir, tmp_path):
     k = "cls.bi_seq_relationship.weight"           # reached only through the NSP scores: ranking + NSP terms
     w_nsp = float(leaves[k].grad.norm())
     assert w_nsp > 0 and abs(float(grads["bert_pretrained." + k].norm()) - w_nsp) <= 6e-2 * w_nsp
+
+
+def test_visdial_evaluate_on_the_encoder_matches_oracle_scores(golden_dir, tmp_path):
+    """train.py:180-290 on the HIP path: chunked NSP scoring of 2 images x 2 rounds x 6 options; the probabilities
+    the metrics are computed from agree with the oracle encoder's, and chunking does not change the result."""
+    from oracle import vilbert_ref as R
+    from unimm_amd import metrics, synth, trainer
+    enc = _encoder(golden_dir, tmp_path)
+    cfg = enc.bert_pretrained.config
+    sd = {k[len("bert_pretrained."):]: v.detach().float().cpu().clone() for k, v in enc.state_dict().items()}
+    b, _ = synth.make_loader_batch(n_img=2, rounds=2, samples=6, T=64, cfg=cfg, seed=41, modes=["dis"] * 24)
+    b["gt_option_inds"] = torch.tensor([[0, 3], [5, 1]])
+    b["gt_relevance"] = torch.tensor([[1.0, 0, 0.5, 0, 0, 0], [0, 0.2, 0, 0, 1.0, 0.4]])
+    b["round_id"] = torch.tensor([[2], [1]])
+    params = dict(n_gpus=1, nsp_weight=None)
+    enc.train()
+    got = trainer.visdial_evaluate([b], params, 2, enc, chunk_size=8)
+    assert enc.training
+    again = trainer.visdial_evaluate([b], params, 2, enc, chunk_size=24)
+    assert got.keys() == again.keys() and all(abs(float(got[k]) - float(again[k])) < 1e-6 for k in got)
+    ex = trainer.expand_image_fields({k: b[k] for k in ("tokens", "image_feat", "image_loc", "image_mask")})
+    flat = lambda t, keep: t.reshape((-1,) + tuple(t.shape[-keep:]))
+    ocfg = R.make_config(json.load(open(os.path.join(tmp_path, "small_nodrop.json"))))
+    with torch.no_grad():
+        out = R.forward(sd, ocfg, flat(b["tokens"], 1), flat(ex["image_feat"], 2), flat(ex["image_loc"], 2),
+                        token_type_ids=flat(b["segments"], 1), position_ids=flat(b["positions"], 1),
+                        attention_mask=flat(b["txt_attention_mask"], 2), image_attention_mask=flat(ex["image_mask"], 1),
+                        co_attention_mask=flat(b["co_attention_mask"], 2))
+    p = torch.softmax(out["nsp"], 1)[:, 0].view(2, 2, 6)
+    sp, nd = metrics.SparseGTMetrics(), metrics.NDCG()
+    sp.observe(p, b["gt_option_inds"])
+    nd.observe(p[torch.arange(2), b["round_id"].view(-1) - 1], b["gt_relevance"])
+    want = {**sp.retrieve(), **nd.retrieve()}
+    assert set(want) == set(got) and "ndcg" in got and "mrr_round_2" in got
+    # ranks are discrete: compare the probabilities, and the metrics only where the oracle's ordering has a clear margin
+    with torch.no_grad():
+        item = {k: flat(b[k], keep) if keep else b[k].reshape(-1) for k, keep in trainer._EVAL_TEXT}
+        item.update(image_feat=flat(ex["image_feat"], 2), image_loc=flat(ex["image_loc"], 2), image_mask=flat(ex["image_mask"], 1))
+        enc.eval()
+        nsp = trainer.harness.forward(enc, item, params, output_nsp_scores=True, evaluation=True)[4]
+    pd = torch.softmax(nsp.float(), 1)[:, 0].view(2, 2, 6).cpu()
+    assert (pd - p).abs().max() <= 1e-2
+    gaps = (p.sort(-1)[0].diff(dim=-1)).abs().min()
+    if gaps > 2e-2:
+        assert all(abs(float(got[k]) - float(want[k])) < 1e-5 for k in want)

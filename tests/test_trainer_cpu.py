@@ -130,3 +130,40 @@ def test_dense_finetune_step_options_objective_and_cadence():
         b2, _ = synth.make_loader_batch(n_img=2, rounds=1, samples=4, T=64, seed=2)
         b2["gt_option"], b2["gt_relevance"] = torch.tensor([0]), torch.zeros(2, 4)
         trainer.dense_finetune_step(enc, opt, sch, b2, params, iter_id=1, num_options=4)
+
+
+def test_visdial_evaluate_chunks_scores_and_accumulates_metrics():
+    """Validation pass (train.py:180-290) with a stand-in scorer: chunking, image expansion, the metric plumbing."""
+    from unimm_amd import metrics
+
+    class _Scorer(torch.nn.Module):
+        calls = []
+
+        def forward(self, tokens, feat, loc, output_nsp_scores=False, **kw):
+            assert kw.get("next_sentence_label") is None and kw.get("image_target") is None      # evaluation call
+            _Scorer.calls.append(tokens.shape[0])
+            s = tokens[:, 1].float() / 1000.0 + feat[:, 1, 0]
+            return None, None, None, torch.stack([s, -s], 1)
+
+    assert [trainer.eval_chunk_size(n) for n in (1, 2, 8)] == [250, 500, 1000]
+    enc = _Scorer().train()
+    loader = []
+    for seed in (3, 4):
+        b, _ = synth.make_loader_batch(n_img=2, rounds=2, samples=10, T=64, seed=seed)
+        b["gt_option_inds"] = torch.randint(0, 10, (2, 2))
+        b["gt_relevance"] = torch.rand(2, 10).round()
+        b["gt_relevance"][:, 0] = 1.0
+        b["round_id"] = torch.tensor([[1], [2]])
+        loader.append(b)
+    got = trainer.visdial_evaluate(loader, dict(n_gpus=1, nsp_weight=None), 2, enc, chunk_size=8)
+    assert _Scorer.calls == [8] * 10 and enc.training                       # 40 sequences per batch in chunks of 8
+    sp, nd = metrics.SparseGTMetrics(), metrics.NDCG()
+    for b in loader:
+        s = b["tokens"][..., 1].float() / 1000.0 + b["image_feat"][:, 1, 0].view(2, 1, 1)
+        p = torch.softmax(torch.stack([s, -s], -1), -1)[..., 0]
+        sp.observe(p, b["gt_option_inds"])
+        nd.observe(p[torch.arange(2), b["round_id"].view(-1) - 1], b["gt_relevance"])
+    want = {**sp.retrieve(), **nd.retrieve()}
+    assert set(got) == set(want) and all(abs(float(got[k]) - float(want[k])) < 1e-6 for k in want)
+    with pytest.raises(ValueError):
+        trainer.visdial_evaluate(loader, dict(n_gpus=1), 2, enc, chunk_size=7)

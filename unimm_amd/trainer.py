@@ -12,7 +12,8 @@ dataloader and the checkpoint file, without the data plane.
 * `expand_image_fields` - train.py:413-432 (one image's features repeated per round and per sample).
 * `dense_finetune_step` - one iteration of dense_annotation_finetuning.py:146-301 (row F4): one annotated
                        round of one image against its 100 options (ground truth first, the rest permuted),
-                       NeuralNDCG^T + LM + weighted NSP objective, scheduler stepped before the optimizer."""
+                       NeuralNDCG^T + LM + weighted NSP objective, scheduler stepped before the optimizer.
+* `visdial_evaluate`  - the validation pass of train.py:180-290 (chunked NSP scoring -> SparseGTMetrics + NDCG)."""
 from __future__ import annotations
 
 import os
@@ -20,7 +21,7 @@ from typing import Optional
 
 import torch
 
-from . import harness, ranking
+from . import harness, metrics, ranking
 
 
 def expand_image_fields(batch: dict) -> dict:
@@ -28,6 +29,8 @@ def expand_image_fields(batch: dict) -> dict:
     rounds, samples = batch["tokens"].shape[1], batch["tokens"].shape[2]
     out = dict(batch)
     for k in ("image_feat", "image_loc", "image_target", "image_label", "image_mask"):
+        if k not in batch:
+            continue                          # evaluation batches carry no targets / labels
         v = batch[k]
         out[k] = v.unsqueeze(1).unsqueeze(1).expand(v.shape[0], rounds, samples, *v.shape[1:]).contiguous()
     return out
@@ -94,6 +97,58 @@ def dense_finetune_step(dialog_encoder, optimizer, scheduler, batch, params, ite
         optimizer.step()
         optimizer.zero_grad()
     return float(loss.detach()) / bm, {k: v.detach() for k, v in parts.items()}
+
+
+def eval_chunk_size(n_gpus: int) -> int:
+    """Sequences per evaluation forward: the largest divisor-friendly size not above 500 * n_gpus / 2 (train.py:186-190)."""
+    cap = 500 * (n_gpus / 2)
+    sizes = [1, 2, 4, 5, 100, 1000, 200, 8, 10, 40, 50, 500, 20, 25, 250, 125]
+    return min(sizes, key=lambda x: abs(x - cap) if x <= cap else float("inf"))
+
+
+_EVAL_TEXT = (("tokens", 1), ("segments", 1), ("positions", 1), ("weights", 1), ("sep_indices", 1), ("mask", 1),
+              ("hist_len", 0), ("txt_attention_mask", 2), ("co_attention_mask", 2))
+
+
+def visdial_evaluate(dataloader, params, eval_batch_size, dialog_encoder, chunk_size=None):
+    """Discriminative evaluation over a validation loader (train.py:180-290): every (round, option) sequence of
+    each image is scored in chunks with the NSP head, P(option is the answer) is ranked against the ground-truth
+    option (R@k, mean rank, MRR) and, on the densely annotated round, against the relevance scores (NDCG).
+    Batches hold `tokens` [eval_batch_size, rounds, options, T], `gt_option_inds`, `gt_relevance`, `round_id`."""
+    sparse, ndcg = metrics.SparseGTMetrics(), metrics.NDCG()
+    was_training = dialog_encoder.training
+    dialog_encoder.eval()
+    chunk = int(chunk_size or eval_chunk_size(int(params.get("n_gpus", 1))))
+    batches = 0
+    with torch.no_grad():
+        for batch in dataloader:
+            rounds, options = batch["tokens"].shape[1], batch["tokens"].shape[2]
+            total = eval_batch_size * rounds * options
+            if batch["tokens"].shape[0] != eval_batch_size or total % chunk:
+                raise ValueError(f"evaluation batch of {batch['tokens'].shape[0]} images x {rounds} x {options} sequences "
+                                 f"does not split into chunks of {chunk}")
+            flat = {k: batch[k].reshape((-1,) + tuple(batch[k].shape[-keep:])) if keep else batch[k].reshape(-1)
+                    for k, keep in _EVAL_TEXT}
+            img = expand_image_fields({k: batch[k] for k in ("tokens", "image_feat", "image_loc", "image_mask")})
+            for k in ("image_feat", "image_loc"):
+                flat[k] = img[k].reshape((-1,) + tuple(img[k].shape[-2:]))
+            flat["image_mask"] = img["image_mask"].reshape(-1, img["image_mask"].shape[-1])
+            probs = []
+            for lo in range(0, total, chunk):
+                item = {k: v[lo:lo + chunk] for k, v in flat.items()}
+                nsp_scores = harness.forward(dialog_encoder, item, params, output_nsp_scores=True, evaluation=True)[4]
+                probs.append(torch.softmax(nsp_scores.float(), dim=1)[:, 0])
+            output = torch.cat(probs).view(eval_batch_size, rounds, options)
+            dev = output.device
+            sparse.observe(output, batch["gt_option_inds"].to(dev))
+            rid = batch["round_id"].reshape(-1).to(dev).long()
+            ndcg.observe(output[torch.arange(eval_batch_size, device=dev), rid - 1, :], batch["gt_relevance"].to(dev))
+            batches += 1
+    if was_training:
+        dialog_encoder.train()
+    out = sparse.retrieve(reset=True)
+    out.update(ndcg.retrieve(reset=True))
+    return out
 
 
 class _null:
