@@ -335,7 +335,9 @@ int unimm_neural_ndcg(const unimm_ndcg_args* args, void* stream);
 /* Launch profiler for bench.py's `roofline` block: HIP events around every GEMM launch on its own
  * stream while enabled.  Variant index: 0..11 = unimm_gemm_nt (epilogue * 2 + out_f32), 12 = unimm_gemm_tn.
  * unimm_prof_collect synchronises the events and returns per-variant summed milliseconds, algorithmic
- * FLOPs (2*M*N*K per launch) and launch counts; arrays of >= 20 entries. */
+ * FLOPs (2*M*N*K per launch) and launch counts; arrays of >= 20 entries.  on = 1: every GEMM launch;
+ * on = 2: unimm_gemm_tn launches only (the two event records per launch are host time, which a
+ * launch-rate-bound step should not pay for all ~340 GEMM launches); 0 = off. */
 int unimm_prof_enable(int32_t on);
 int unimm_prof_collect(double* ms, double* flops, int32_t* count, int32_t nvar);
 

@@ -867,11 +867,13 @@ struct ProfRec { hipEvent_t a, b; int variant; double flops; };
 constexpr int PROF_MAX = 1 << 16;
 constexpr int PROF_VARIANTS = 20;   // 0..15: gemm_nt epi*2+out_f32 ; 16: gemm_tn
 bool g_prof_on = false;
+bool g_prof_tn_only = false;        // unimm_prof_enable(2): only the weight-gradient launches (2 event records per launch
+                                    // are host time; a rank whose step is launch-rate-bound should not pay them 340 times)
 ProfRec* g_prof = nullptr;
 int g_prof_n = 0;
 
 inline ProfRec* prof_begin(int variant, double flops, hipStream_t s) {
-  if (!g_prof_on || g_prof_n >= PROF_MAX) return nullptr;
+  if (!g_prof_on || g_prof_n >= PROF_MAX || (g_prof_tn_only && variant != 16)) return nullptr;
   ProfRec* r = &g_prof[g_prof_n];
   if (r->a == nullptr) {
     if (hipEventCreate(&r->a) != hipSuccess || hipEventCreate(&r->b) != hipSuccess) return nullptr;
@@ -1123,6 +1125,7 @@ extern "C" int unimm_prof_enable(int32_t on) {
     if (g_prof == nullptr) return UNIMM_E_HIP;
   }
   g_prof_on = on != 0;
+  g_prof_tn_only = on == 2;
   g_prof_n = 0;
   return UNIMM_OK;
 }

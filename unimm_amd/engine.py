@@ -17,6 +17,7 @@ from __future__ import annotations
 import math
 import os
 import zlib
+from contextlib import contextmanager
 from typing import Dict, List, Optional
 
 import torch
@@ -79,6 +80,12 @@ class Engine:
         # rocprof timings (bench.py's roofline block) would no longer be exclusive.
         self.wgrad_stream = os.environ.get("UNIMM_WGRAD_STREAM", "0") == "1"
         self._side = None
+        # Image-stream blocks on their own HIP stream (UNIMM_DUAL_STREAM): between two connection layers the
+        # image layer and the text layer are independent (models/vilbert_dialog.py:842-929), and the image side's
+        # kernels are too small to fill 256 CUs (M = B*37 rows), so they run beside the text layer's and fill its
+        # partial rounds.  Same kernels, same order within each stream; streams meet at every connection layer.
+        self.dual_stream = os.environ.get("UNIMM_DUAL_STREAM", "1") == "1"
+        self._vside = None
         self.last_plan = None
 
     # ------------------------------------------------------------------------------------------
@@ -262,7 +269,7 @@ class Engine:
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.arena.flat.device)
         self._side.wait_stream(main)
-        with torch.cuda.stream(self._side):
+        with torch.cuda.stream(self._side), L.stream_scope(self._side):
             L.gemm_tn_grouped(self._wq)
         for dy, x, *_ in self._wq:              # keep the caching allocator from recycling them early
             dy.record_stream(self._side)
@@ -313,6 +320,54 @@ class Engine:
         scratch = torch.empty((M, H), dtype=BF16, device=r.x.device)
         L.layernorm_fwd(r.x, r.gamma, r.beta, y32, scratch, None, None, M, H)
         return y32
+
+    # ------------------------------------------------------------------------------------------
+    # image-side stream
+    # ------------------------------------------------------------------------------------------
+    def _dual(self):
+        return self.dual_stream and self.arena.flat.is_cuda and not self.wgrad_stream
+
+    @staticmethod
+    def _touch(obj, stream):
+        """Tell the caching allocator that `obj` (allocated on another stream) is read on `stream`."""
+        if obj is None:
+            return
+        if isinstance(obj, _LazyLN):
+            for t in (obj.x, obj.mean, obj.rstd):
+                t.record_stream(stream)
+        elif torch.is_tensor(obj) and obj.is_cuda:
+            obj.record_stream(stream)
+
+    @contextmanager
+    def _image_side(self, after, reads=()):
+        """Run the enclosed launches on the image-side stream once event `after` (recorded on the main stream)
+        has completed.  No-op when the dual-stream schedule is off."""
+        if not self._dual():
+            yield
+            return
+        if self._vside is None:
+            self._vside = torch.cuda.Stream(device=self.arena.flat.device)
+        side = self._vside
+        side.wait_event(after)
+        for t in reads:
+            self._touch(t, side)
+        with torch.cuda.stream(side), L.stream_scope(side):
+            yield
+
+    def _mark(self):
+        """Event on the current (main) stream: everything enqueued so far."""
+        if not self._dual():
+            return None
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        return ev
+
+    def _join_image_side(self, *reads):
+        if self._dual() and self._vside is not None:
+            main = torch.cuda.current_stream()
+            main.wait_stream(self._vside)
+            for t in reads:                      # produced on the image-side stream, read on the main one from here on
+                self._touch(t, main)
 
     def _layernorm_bwd(self, dy, x, mean, rstd, key, dbias=None, drop=L.NO_DROP, out_drop=L.NO_DROP):
         gmm, _, gg, gb = self.ln[key]
@@ -497,6 +552,18 @@ class Engine:
     # forward
     # ------------------------------------------------------------------------------------------
     def forward(self, inp: dict, train: bool, save: bool, lm_rows: str, want_pred_v: bool):
+        if not self.arena.flat.is_cuda:
+            return self._forward(inp, train, save, lm_rows, want_pred_v)
+        with L.stream_scope(torch.cuda.current_stream()):
+            return self._forward(inp, train, save, lm_rows, want_pred_v)
+
+    def backward(self, out, g_lm, g_img, g_nsp, g_nsp_scores=None):
+        if not self.arena.flat.is_cuda:
+            return self._backward(out, g_lm, g_img, g_nsp, g_nsp_scores)
+        with L.stream_scope(torch.cuda.current_stream()):
+            return self._backward(out, g_lm, g_img, g_nsp, g_nsp_scores)
+
+    def _forward(self, inp: dict, train: bool, save: bool, lm_rows: str, want_pred_v: bool):
         """Runs the trunk + heads.  Returns a dict of outputs and (when save) the tape for backward.
         lm_rows: 'labelled' (decode only rows that carry a label / weight), 'all', or 'none'."""
         cfg = self.cfg
@@ -590,44 +657,64 @@ class Engine:
                             cfg.type_vocab_size, drop=d_embt)
 
         F = cfg.v_feature_size
-        featd = feat.to(dev, dtype=F32, non_blocking=True)
-        locd = inp["image_loc"].to(dev, dtype=F32, non_blocking=True)
-        if img_idx is not None:             # one entry per image on the wire, expanded on the device (train.py:413-432)
-            featd, locd = featd.index_select(0, img_idx), locd.index_select(0, img_idx)
-        featd, locd = featd.contiguous().view(B * R, F), locd.contiguous().view(B * R, 5)
-        packed = torch.empty((B * R, self.vemb_k), dtype=BF16, device=dev)
-        L.pack_image(featd, locd, packed, B * R, F, self.vemb_k)
-        prev = torch.empty((B * R, Hv), dtype=F32, device=dev)
-        L.gemm_nt(packed, self.vemb_w, prev, bias=self.vemb_b, M=B * R, N=Hv, K=self.vemb_k)
-        d_embv = self._drop("emb_v", cfg.hidden_dropout_prob, train)
-        xv32, xv, mv, rv = self._layernorm(prev, "emb_v", save, drop=d_embv)
-        if save:
-            v = "bert.v_embeddings."
+        mark = self._mark()                   # masks and text embeddings are enqueued; the image side may start
+        with self._image_side(mark):          # image embedding: beside the first text layers
+            featd = feat.to(dev, dtype=F32, non_blocking=True)
+            locd = inp["image_loc"].to(dev, dtype=F32, non_blocking=True)
+            if img_idx is not None:             # one entry per image on the wire, expanded on the device (train.py:413-432)
+                featd, locd = featd.index_select(0, img_idx), locd.index_select(0, img_idx)
+            featd, locd = featd.contiguous().view(B * R, F), locd.contiguous().view(B * R, 5)
+            packed = torch.empty((B * R, self.vemb_k), dtype=BF16, device=dev)
+            L.pack_image(featd, locd, packed, B * R, F, self.vemb_k)
+            prev = torch.empty((B * R, Hv), dtype=F32, device=dev)
+            L.gemm_nt(packed, self.vemb_w, prev, bias=self.vemb_b, M=B * R, N=Hv, K=self.vemb_k)
+            d_embv = self._drop("emb_v", cfg.hidden_dropout_prob, train)
+            xv32, xv, mv, rv = self._layernorm(prev, "emb_v", save, drop=d_embv)
+            if save:
+                v = "bert.v_embeddings."
 
-            def bwd_embv(dxv):
-                dbias = A.grad(v + "image_embeddings.bias")
-                before = dbias.clone()
-                dpre, _ = self._layernorm_bwd(dxv, prev, mv, rv, "emb_v", dbias=dbias, out_drop=d_embv)
-                A.grad(v + "image_location_embeddings.bias").add_(dbias - before)
-                self._wgrad(dpre, packed, A.grad(v + "image_embeddings.weight"), B * R, Hv, F)
-                self._wgrad(dpre, packed[:, F:], A.grad(v + "image_location_embeddings.weight"), B * R, Hv, 5)
+                def bwd_embv(dxv):
+                    dbias = A.grad(v + "image_embeddings.bias")
+                    before = dbias.clone()
+                    dpre, _ = self._layernorm_bwd(dxv, prev, mv, rv, "emb_v", dbias=dbias, out_drop=d_embv)
+                    A.grad(v + "image_location_embeddings.bias").add_(dbias - before)
+                    self._wgrad(dpre, packed, A.grad(v + "image_embeddings.weight"), B * R, Hv, F)
+                    self._wgrad(dpre, packed[:, F:], A.grad(v + "image_location_embeddings.weight"), B * R, Hv, 5)
 
         # ---- encoder (schedule of models/vilbert_dialog.py:842-929) ------------------------------
-        for kind, i in PM.encoder_schedule(cfg):
-            if kind == "t":
-                xt32, xt = self._self_block(f"t{i}", xt32, xt, tmask, B, T, cfg.num_attention_heads, f"bert.encoder.layer.{i}.",
-                                      cfg.attention_probs_dropout_prob, cfg.hidden_dropout_prob, st, var=var)
-                if save:
-                    tape[-1] = ("t", tape[-1][0], tape[-1][1])
-            elif kind == "v":
-                xv32, xv = self._self_block(f"v{i}", xv32, xv, vmask, B, R, cfg.v_num_attention_heads, f"bert.encoder.v_layer.{i}.",
-                                      cfg.v_attention_probs_dropout_prob, cfg.v_hidden_dropout_prob, st)
-                if save:
-                    tape[-1] = ("v", tape[-1][0], tape[-1][1])
-            else:
+        # Between two connection layers the image layers and the text layers do not depend on each other: the image
+        # ones go to the image-side stream first, the text ones follow on the main stream, and both meet at the
+        # connection layer.  The tape keeps the per-stream order, so backward mirrors it.
+        sched = PM.encoder_schedule(cfg)
+        pos = 0
+        while pos < len(sched):
+            seg = []
+            while pos < len(sched) and sched[pos][0] != "c":
+                seg.append(sched[pos])
+                pos += 1
+            v_ids = [i for kind, i in seg if kind == "v"]
+            if v_ids:
+                with self._image_side(mark, reads=(xv32, xv)):
+                    for i in v_ids:
+                        xv32, xv = self._self_block(f"v{i}", xv32, xv, vmask, B, R, cfg.v_num_attention_heads,
+                                                    f"bert.encoder.v_layer.{i}.", cfg.v_attention_probs_dropout_prob,
+                                                    cfg.v_hidden_dropout_prob, st)
+                        if save:
+                            tape[-1] = ("v", tape[-1][0], tape[-1][1])
+            for kind, i in seg:
+                if kind == "t":
+                    xt32, xt = self._self_block(f"t{i}", xt32, xt, tmask, B, T, cfg.num_attention_heads, f"bert.encoder.layer.{i}.",
+                                                cfg.attention_probs_dropout_prob, cfg.hidden_dropout_prob, st, var=var)
+                    if save:
+                        tape[-1] = ("t", tape[-1][0], tape[-1][1])
+            self._join_image_side(xv32, xv)
+            if pos < len(sched):
+                i = sched[pos][1]
+                pos += 1
                 xv32, xv, xt32, xt = self._conn_block(f"c{i}", i, xv32, xv, xt32, xt, B, R, T, vmask, comask, st, var=var)
                 if save:
                     tape[-1] = ("c", tape[-1][0], tape[-1][1])
+                mark = self._mark()
         seq_t, seq_v = xt, xv
 
         xt32, xv32 = self._dense32(xt32), self._dense32(xv32)      # the final residual stream is an output
@@ -777,7 +864,7 @@ class Engine:
         res["nsp_loss"] = nsp_loss
         return res
 
-    def backward(self, out, g_lm, g_img, g_nsp, g_nsp_scores=None):
+    def _backward(self, out, g_lm, g_img, g_nsp, g_nsp_scores=None):
         """Accumulates every parameter gradient into the arena (+=)."""
         cfg = self.cfg
         dev = self.arena.device
@@ -836,17 +923,36 @@ class Engine:
         self._bucket_done("heads")
         # ---- encoder blocks in reverse -------------------------------------------------------------
         gt, gv = dseq_t, dseq_v
-        for kind, key, fn in reversed(bw["tape"]):
-            if kind == "t":
-                gt = fn(gt)
-            elif kind == "v":
-                gv = fn(gv)
-            else:
+        entries = list(reversed(bw["tape"]))
+        mark = self._mark()
+        pos = 0
+        while pos < len(entries):
+            seg = []
+            while pos < len(entries) and entries[pos][0] != "c":
+                seg.append(entries[pos])
+                pos += 1
+            v_fns = [(key, fn) for kind, key, fn in seg if kind == "v"]
+            if v_fns:                                        # image layers of this segment beside its text layers
+                with self._image_side(mark, reads=(gv,)):
+                    for key, fn in v_fns:
+                        gv = fn(gv)
+                        self._bucket_done(key)
+            for kind, key, fn in seg:
+                if kind == "t":
+                    gt = fn(gt)
+                    self._bucket_done(key)
+            if pos < len(entries):
+                self._join_image_side(gv)
+                _, key, fn = entries[pos]
+                pos += 1
                 gv, gt = fn(gv, gt)
-            self._bucket_done(key)
-        bw["embv"](gv)
-        self._bucket_done("image_embeddings")
+                self._bucket_done(key)
+                mark = self._mark()
+        with self._image_side(mark, reads=(gv,)):
+            bw["embv"](gv)
+            self._bucket_done("image_embeddings")
         bw["embt"](gt)
+        self._join_image_side()
         self._bucket_done("text_embeddings")
 
     def _bucket_done(self, group):
