@@ -305,3 +305,41 @@ def test_compact_inputs_equal_dense_inputs(golden_dir):
     (l0, n0, g0), (l1, n1, g1) = outs
     assert l0 == l1 and torch.equal(n0, n1)                           # same kernels on the same words: bit-identical
     assert (g0 - g1).abs().max() <= 1e-5 * g0.abs().max()             # (atomics order)
+
+
+def test_image_side_stream_schedule_equals_single_stream(golden_dir):
+    """The image layers on their own HIP stream (engine.dual_stream) give the same losses bit for bit and the same
+    gradients up to the order of the weight-gradient atomics as everything on one stream, in train mode with
+    dropout (counter-based masks do not depend on launch order), over several steps back to back."""
+    from unimm_amd import synth
+    model, _, _ = build_small(golden_dir)
+    model.train()
+    eng = model.engine
+    b = synth.make_batch(n_seq=12, T=64, R=37, cfg=model.config, seed=33, sequences_per_image=6, device="cuda")
+    nsp_w = b.pop("nsp_weight")
+    kw = dict(token_type_ids=b["token_type_ids"], position_ids=b["token_position_ids"], attention_mask=b["attention_mask"],
+              co_attention_mask=b["co_attention_mask"], image_attention_mask=b["image_attention_mask"],
+              masked_lm_labels=b["masked_lm_labels"], image_label=b["image_label"], image_target=b["image_target"],
+              next_sentence_label=b["next_sentence_label"], nsp_weight=nsp_w, lm_weight=b["lm_weight"], _want_lm_scores=False)
+    runs = {}
+    was = eng.dual_stream
+    try:
+        for dual in (False, True, True, False):
+            eng.dual_stream = dual
+            model.set_dropout_seed(5, step=0)
+            seq = []
+            for _ in range(3):                      # consecutive steps: stream hand-over across iterations too
+                model.zero_grad(set_to_none=True)
+                r = model(b["input_ids"], b["image_feat"], b["image_loc"], **kw)
+                (r[0] + r[1] + r[2]).sum().backward()
+                torch.cuda.synchronize()
+                seq.append(([float(x.detach()) for x in r[:3]], r[5].detach().clone(), eng.arena.grad_flat.clone()))
+            runs.setdefault(dual, []).append(seq)
+    finally:
+        eng.dual_stream = was
+    assert eng._vside is not None                    # the side stream was really used
+    ref = runs[False][0]
+    for seq in runs[True] + runs[False][1:]:
+        for (l0, n0, g0), (l1, n1, g1) in zip(ref, seq):
+            assert l0 == l1 and torch.equal(n0, n1)
+            assert torch.isfinite(g1).all() and (g0 - g1).abs().max() <= 1e-5 * g0.abs().max()

@@ -42,10 +42,23 @@ print(f"B={B}: enqueue {1e3 * (t1 - t0) / K:.2f} ms/step, complete {1e3 * (t2 - 
       f"(dual_stream={model.engine.dual_stream})")
 import cProfile, pstats
 pr = cProfile.Profile()
-pr.enable()
+eng = model.engine
+orig_b, orig_f = eng._backward, eng._forward
+
+
+def prof_call(fn):
+    def w(*a, **k):
+        pr.enable()
+        try:
+            return fn(*a, **k)
+        finally:
+            pr.disable()
+    return w
+
+
+eng._backward, eng._forward = prof_call(orig_b), prof_call(orig_f)
 for _ in range(5):
     step()
-pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(45)
+st.sort_stats("tottime").print_stats(40)
