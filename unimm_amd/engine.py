@@ -83,9 +83,12 @@ class Engine:
         # Image-stream blocks on their own HIP stream (UNIMM_DUAL_STREAM): between two connection layers the
         # image layer and the text layer are independent (models/vilbert_dialog.py:842-929), and the image side's
         # kernels are too small to fill 256 CUs (M = B*37 rows), so they run beside the text layer's and fill its
-        # partial rounds.  Same kernels, same order within each stream; streams meet at every connection layer.
+        # partial rounds; the same holds for the image half of a connection layer once the two co-attention
+        # directions have exchanged their K/V.  Same kernels, same order within each stream.
         self.dual_stream = os.environ.get("UNIMM_DUAL_STREAM", "1") == "1"
         self._vside = None
+        self._on_side = False            # inside `_img()`: launches (and queued weight gradients) belong to the image side
+        self._wq_img = []
         self.last_plan = None
 
     # ------------------------------------------------------------------------------------------
@@ -254,9 +257,13 @@ class Engine:
         """dW += dy^T x (+ bias gradient).  Nothing downstream in the backward chain reads a weight gradient,
         so the call is only queued; `_flush_wgrad` (end of each encoder block = one gradient bucket) hands
         the block's whole list to one grouped launch.  dy / x stay referenced by the queue until then."""
-        self._wq.append((dy, x, gw, M, N, K, dbias))
+        (self._wq_img if self._on_side else self._wq).append((dy, x, gw, M, N, K, dbias))
 
     def _flush_wgrad(self):
+        if self._wq_img:                          # image-side problems: operands were produced on that stream
+            with self._img():
+                L.gemm_tn_grouped(self._wq_img)
+            self._wq_img = []
         if not self._wq:
             return
         if not self.wgrad_stream:
@@ -338,36 +345,48 @@ class Engine:
         elif torch.is_tensor(obj) and obj.is_cuda:
             obj.record_stream(stream)
 
+    def _side_stream(self):
+        if self._vside is None:
+            self._vside = torch.cuda.Stream(device=self.arena.flat.device)
+        return self._vside
+
     @contextmanager
-    def _image_side(self, after, reads=()):
-        """Run the enclosed launches on the image-side stream once event `after` (recorded on the main stream)
-        has completed.  No-op when the dual-stream schedule is off."""
+    def _img(self):
+        """Launches inside the block go to the image-side stream, in that stream's order (no waits: use
+        `_to_img` / `_to_txt` where the two streams exchange data).  No-op when the dual-stream schedule is off."""
         if not self._dual():
             yield
             return
-        if self._vside is None:
-            self._vside = torch.cuda.Stream(device=self.arena.flat.device)
-        side = self._vside
-        side.wait_event(after)
-        for t in reads:
-            self._touch(t, side)
-        with torch.cuda.stream(side), L.stream_scope(side):
-            yield
+        side = self._side_stream()
+        was, self._on_side = self._on_side, True
+        try:
+            with torch.cuda.stream(side), L.stream_scope(side):
+                yield
+        finally:
+            self._on_side = was
 
-    def _mark(self):
-        """Event on the current (main) stream: everything enqueued so far."""
+    def _to_img(self, *reads):
+        """Everything enqueued on the main (text) stream so far happens before whatever the image-side stream is
+        given next; `reads` are main-stream tensors the image side is about to use."""
         if not self._dual():
-            return None
+            return
+        side = self._side_stream()
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
-        return ev
+        side.wait_event(ev)
+        for t in reads:
+            self._touch(t, side)
 
-    def _join_image_side(self, *reads):
-        if self._dual() and self._vside is not None:
-            main = torch.cuda.current_stream()
-            main.wait_stream(self._vside)
-            for t in reads:                      # produced on the image-side stream, read on the main one from here on
-                self._touch(t, main)
+    def _to_txt(self, *reads):
+        """The mirror image: the main stream waits for what the image-side stream has been given so far."""
+        if not self._dual() or self._vside is None:
+            return
+        main = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(self._vside)
+        main.wait_event(ev)
+        for t in reads:
+            self._touch(t, main)
 
     def _layernorm_bwd(self, dy, x, mean, rstd, key, dbias=None, drop=L.NO_DROP, out_drop=L.NO_DROP):
         gmm, _, gg, gb = self.ln[key]
@@ -433,56 +452,73 @@ class Engine:
         D = Hb // nh
         lq1, lq2, d1, d2 = (self.lin[key + s] for s in (".qkv1", ".qkv2", ".d1", ".d2"))
         vff1, vff2, tff1, tff2 = (self.lin[key + s] for s in (".vff1", ".vff2", ".tff1", ".tff2"))
-        qkv1 = self._linear(xv, lq1)      # image side  [B*R, 3Hb]
-        qkv2 = self._linear(xt, lq2)      # text side   [B*T, 3Hb]
+        # The two halves run on their own streams (`_img()` = image side, otherwise the text side); the only
+        # exchanges are the other side's K/V for the two co-attention directions.
+        with self._img():
+            qkv1 = self._linear(xv, lq1)      # image side  [B*R, 3Hb]
+        qkv2 = self._linear(xt, lq2)          # text side   [B*T, 3Hb]
+        self._to_txt(qkv1)
+        self._to_img(qkv2)
         q1, k1, v1 = qkv1[:, :Hb], qkv1[:, Hb:2 * Hb], qkv1[:, 2 * Hb:]
         q2, k2, v2 = qkv2[:, :Hb], qkv2[:, Hb:2 * Hb], qkv2[:, 2 * Hb:]
         da1 = self._drop(pn + "attn1", cfg.v_attention_probs_dropout_prob, train)
         da2 = self._drop(pn + "attn2", cfg.attention_probs_dropout_prob, train)
-        ctx_t, lse_t = self._attn(q2, k1, v1, vmask, B, nh, T, R, D, da1, save, qvar=var)     # text attends regions (:681-698)
-        ctx_v, lse_v = self._attn(q1, k2, v2, comask, B, nh, R, T, D, da2, save, kvar=var)    # regions attend text (:701-721)
         db1 = self._drop(pn + "bo1", cfg.v_hidden_dropout_prob, train)
         db2 = self._drop(pn + "bo2", cfg.hidden_dropout_prob, train)
-        prev = self._linear(ctx_v, d1, L.EPI_BIAS_DROP_RESID, aux=xv32, drop=db1, out_f32=True)   # BertBiOutput (:744-754, call order :775)
-        av32, av, mv1, rv1 = self._layernorm(prev, key + ".lnb1", save, lazy=True)
-        pret = self._linear(ctx_t, d2, L.EPI_BIAS_DROP_RESID, aux=xt32, drop=db2, out_f32=True)
-        at32, at, mt1, rt1 = self._layernorm(pret, key + ".lnb2", save, lazy=True)
         dvo = self._drop(pn + "vout", cfg.v_hidden_dropout_prob, train)
         dto = self._drop(pn + "tout", cfg.hidden_dropout_prob, train)
+        with self._img():
+            ctx_v, lse_v = self._attn(q1, k2, v2, comask, B, nh, R, T, D, da2, save, kvar=var)    # regions attend text (:701-721)
+            prev = self._linear(ctx_v, d1, L.EPI_BIAS_DROP_RESID, aux=xv32, drop=db1, out_f32=True)   # BertBiOutput (:744-754, call order :775)
+            av32, av, mv1, rv1 = self._layernorm(prev, key + ".lnb1", save, lazy=True)
+            if save:
+                hv, uv = self._linear(av, vff1, L.EPI_BIAS_GELU_DG, want_u=True)
+            else:
+                hv, uv = self._linear(av, vff1, L.EPI_BIAS_GELU), None
+            prev2 = self._linear(hv, vff2, L.EPI_BIAS_DROP_RESID, aux=av32, drop=dvo, out_f32=True)
+            ov32, ov, mv2, rv2 = self._layernorm(prev2, key + ".lnv", save, lazy=True)
+        ctx_t, lse_t = self._attn(q2, k1, v1, vmask, B, nh, T, R, D, da1, save, qvar=var)     # text attends regions (:681-698)
+        pret = self._linear(ctx_t, d2, L.EPI_BIAS_DROP_RESID, aux=xt32, drop=db2, out_f32=True)
+        at32, at, mt1, rt1 = self._layernorm(pret, key + ".lnb2", save, lazy=True)
         if save:
-            hv, uv = self._linear(av, vff1, L.EPI_BIAS_GELU_DG, want_u=True)
             ht, ut = self._linear(at, tff1, L.EPI_BIAS_GELU_DG, want_u=True)
         else:
-            hv, uv, ht, ut = self._linear(av, vff1, L.EPI_BIAS_GELU), None, self._linear(at, tff1, L.EPI_BIAS_GELU), None
-        prev2 = self._linear(hv, vff2, L.EPI_BIAS_DROP_RESID, aux=av32, drop=dvo, out_f32=True)
-        ov32, ov, mv2, rv2 = self._layernorm(prev2, key + ".lnv", save, lazy=True)
+            ht, ut = self._linear(at, tff1, L.EPI_BIAS_GELU), None
         pret2 = self._linear(ht, tff2, L.EPI_BIAS_DROP_RESID, aux=at32, drop=dto, out_f32=True)
         ot32, ot, mt2, rt2 = self._layernorm(pret2, key + ".lnt", save, lazy=True)
         if save:
             def bwd(dov, dot):
                 sc = 1.0 / math.sqrt(D)
-                # FFNs
-                dp, dpd = self._layernorm_bwd(dov, prev2, mv2, rv2, key + ".lnv", dbias=vff2.gb, drop=dvo)
-                duv = self._linear_bwd(dpd, hv, vff2, L.EPI_MUL, aux=uv, bias_grad=False)
-                dav = self._linear_bwd(duv, av, vff1, L.EPI_ADD, aux=dp)
-                dp, dpd = self._layernorm_bwd(dot, pret2, mt2, rt2, key + ".lnt", dbias=tff2.gb, drop=dto)
+                # gradient buffers of the two projections: each is written by BOTH attention backward kernels (every
+                # slice exactly once), i.e. from both streams -> allocate first and let each stream see the other's
+                with self._img():
+                    dqkv1 = torch.empty_like(qkv1)
+                dqkv2 = torch.empty_like(qkv2)
+                self._to_txt(dqkv1)
+                self._to_img(dqkv2)
+                with self._img():                                   # image half: FFN, bi-output
+                    dp, dpd = self._layernorm_bwd(dov, prev2, mv2, rv2, key + ".lnv", dbias=vff2.gb, drop=dvo)
+                    duv = self._linear_bwd(dpd, hv, vff2, L.EPI_MUL, aux=uv, bias_grad=False)
+                    dav = self._linear_bwd(duv, av, vff1, L.EPI_ADD, aux=dp)
+                    dprev, dprevd = self._layernorm_bwd(dav, prev, mv1, rv1, key + ".lnb1", dbias=d1.gb, drop=db1)
+                    dctx_v = self._linear_bwd(dprevd, ctx_v, d1, bias_grad=False)
+                    delta_v = torch.empty_like(lse_v)
+                    w, mq, mb = comask
+                    L.attn_bwd(q1, k2, v2, ctx_v, dctx_v, lse_v, delta_v, dqkv1[:, :Hb], dqkv2[:, Hb:2 * Hb], dqkv2[:, 2 * Hb:],
+                               w, B, nh, R, T, D, sc, mq, mb, da2, kvar=var)
+                dp, dpd = self._layernorm_bwd(dot, pret2, mt2, rt2, key + ".lnt", dbias=tff2.gb, drop=dto)   # text half
                 dut = self._linear_bwd(dpd, ht, tff2, L.EPI_MUL, aux=ut, bias_grad=False)
                 dat = self._linear_bwd(dut, at, tff1, L.EPI_ADD, aux=dp)
-                # bi-output
-                dprev, dprevd = self._layernorm_bwd(dav, prev, mv1, rv1, key + ".lnb1", dbias=d1.gb, drop=db1)
-                dctx_v = self._linear_bwd(dprevd, ctx_v, d1, bias_grad=False)
                 dpret, dpretd = self._layernorm_bwd(dat, pret, mt1, rt1, key + ".lnb2", dbias=d2.gb, drop=db2)
                 dctx_t = self._linear_bwd(dpretd, ctx_t, d2, bias_grad=False)
-                # attention cores: every slice of dqkv1 / dqkv2 is written exactly once
-                dqkv1, dqkv2 = torch.empty_like(qkv1), torch.empty_like(qkv2)
-                delta_t, delta_v = torch.empty_like(lse_t), torch.empty_like(lse_v)
+                delta_t = torch.empty_like(lse_t)
                 w, mq, mb = vmask
                 L.attn_bwd(q2, k1, v1, ctx_t, dctx_t, lse_t, delta_t, dqkv2[:, :Hb], dqkv1[:, Hb:2 * Hb], dqkv1[:, 2 * Hb:],
                            w, B, nh, T, R, D, sc, mq, mb, da1, qvar=var)
-                w, mq, mb = comask
-                L.attn_bwd(q1, k2, v2, ctx_v, dctx_v, lse_v, delta_v, dqkv1[:, :Hb], dqkv2[:, Hb:2 * Hb], dqkv2[:, 2 * Hb:],
-                           w, B, nh, R, T, D, sc, mq, mb, da2, kvar=var)
-                dxv = self._linear_bwd(dqkv1, xv, lq1, L.EPI_ADD, aux=dprev)
+                self._to_img()                                      # dK1/dV1 written by the text side
+                self._to_txt()                                      # dK2/dV2 written by the image side
+                with self._img():
+                    dxv = self._linear_bwd(dqkv1, xv, lq1, L.EPI_ADD, aux=dprev)
                 dxt = self._linear_bwd(dqkv2, xt, lq2, L.EPI_ADD, aux=dpret)
                 return dxv, dxt
             tape.append((key, bwd))
@@ -657,8 +693,8 @@ class Engine:
                             cfg.type_vocab_size, drop=d_embt)
 
         F = cfg.v_feature_size
-        mark = self._mark()                   # masks and text embeddings are enqueued; the image side may start
-        with self._image_side(mark):          # image embedding: beside the first text layers
+        self._to_img()                        # masks are packed (and the previous step is behind us): the image side may start
+        with self._img():                     # image embedding: beside the first text layers
             featd = feat.to(dev, dtype=F32, non_blocking=True)
             locd = inp["image_loc"].to(dev, dtype=F32, non_blocking=True)
             if img_idx is not None:             # one entry per image on the wire, expanded on the device (train.py:413-432)
@@ -682,9 +718,10 @@ class Engine:
                     self._wgrad(dpre, packed[:, F:], A.grad(v + "image_location_embeddings.weight"), B * R, Hv, 5)
 
         # ---- encoder (schedule of models/vilbert_dialog.py:842-929) ------------------------------
-        # Between two connection layers the image layers and the text layers do not depend on each other: the image
-        # ones go to the image-side stream first, the text ones follow on the main stream, and both meet at the
-        # connection layer.  The tape keeps the per-stream order, so backward mirrors it.
+        # Two streams: the image stream (embedding, image layers, the image half of every connection layer) and the
+        # text stream (= the caller's current stream).  They exchange data only inside the connection layers (the
+        # co-attention needs the other side's K/V) and meet again before the heads.  Within a segment the image
+        # layers are enqueued first so that both queues are fed; the tape keeps each stream's order for backward.
         sched = PM.encoder_schedule(cfg)
         pos = 0
         while pos < len(sched):
@@ -692,29 +729,27 @@ class Engine:
             while pos < len(sched) and sched[pos][0] != "c":
                 seg.append(sched[pos])
                 pos += 1
-            v_ids = [i for kind, i in seg if kind == "v"]
-            if v_ids:
-                with self._image_side(mark, reads=(xv32, xv)):
-                    for i in v_ids:
+            for kind, i in seg:
+                if kind == "v":
+                    with self._img():
                         xv32, xv = self._self_block(f"v{i}", xv32, xv, vmask, B, R, cfg.v_num_attention_heads,
                                                     f"bert.encoder.v_layer.{i}.", cfg.v_attention_probs_dropout_prob,
                                                     cfg.v_hidden_dropout_prob, st)
-                        if save:
-                            tape[-1] = ("v", tape[-1][0], tape[-1][1])
+                    if save:
+                        tape[-1] = ("v", tape[-1][0], tape[-1][1])
             for kind, i in seg:
                 if kind == "t":
                     xt32, xt = self._self_block(f"t{i}", xt32, xt, tmask, B, T, cfg.num_attention_heads, f"bert.encoder.layer.{i}.",
                                                 cfg.attention_probs_dropout_prob, cfg.hidden_dropout_prob, st, var=var)
                     if save:
                         tape[-1] = ("t", tape[-1][0], tape[-1][1])
-            self._join_image_side(xv32, xv)
             if pos < len(sched):
                 i = sched[pos][1]
                 pos += 1
                 xv32, xv, xt32, xt = self._conn_block(f"c{i}", i, xv32, xv, xt32, xt, B, R, T, vmask, comask, st, var=var)
                 if save:
                     tape[-1] = ("c", tape[-1][0], tape[-1][1])
-                mark = self._mark()
+        self._to_txt(xv32, xv)                # the heads read both streams
         seq_t, seq_v = xt, xv
 
         xt32, xv32 = self._dense32(xt32), self._dense32(xv32)      # the final residual stream is an output
@@ -924,17 +959,16 @@ class Engine:
         # ---- encoder blocks in reverse -------------------------------------------------------------
         gt, gv = dseq_t, dseq_v
         entries = list(reversed(bw["tape"]))
-        mark = self._mark()
+        self._to_img(gv)                         # the heads' gradient of the image stream was produced on the main stream
         pos = 0
         while pos < len(entries):
             seg = []
             while pos < len(entries) and entries[pos][0] != "c":
                 seg.append(entries[pos])
                 pos += 1
-            v_fns = [(key, fn) for kind, key, fn in seg if kind == "v"]
-            if v_fns:                                        # image layers of this segment beside its text layers
-                with self._image_side(mark, reads=(gv,)):
-                    for key, fn in v_fns:
+            for kind, key, fn in seg:                        # image layers of this segment beside its text layers
+                if kind == "v":
+                    with self._img():
                         gv = fn(gv)
                         self._bucket_done(key)
             for kind, key, fn in seg:
@@ -942,23 +976,23 @@ class Engine:
                     gt = fn(gt)
                     self._bucket_done(key)
             if pos < len(entries):
-                self._join_image_side(gv)
                 _, key, fn = entries[pos]
                 pos += 1
-                gv, gt = fn(gv, gt)
+                gv, gt = fn(gv, gt)                          # exchanges between the streams happen inside
                 self._bucket_done(key)
-                mark = self._mark()
-        with self._image_side(mark, reads=(gv,)):
+        with self._img():
             bw["embv"](gv)
             self._bucket_done("image_embeddings")
         bw["embt"](gt)
-        self._join_image_side()
+        self._to_txt()                                       # everything joined before the caller continues
         self._bucket_done("text_embeddings")
 
     def _bucket_done(self, group):
         self._flush_wgrad()                       # the bucket's queued weight gradients
         if self.grad_bucket_hook is not None:
             self._join_wgrad()                    # the exchange reads them
+            if not self._on_side:
+                self._to_txt()                    # ... including the ones the image side produced for this bucket
             self.grad_bucket_hook(group)
         elif group == "text_embeddings":          # last bucket: everything joined before the caller continues
             self._join_wgrad()
