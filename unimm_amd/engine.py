@@ -332,7 +332,7 @@ class Engine:
     # image-side stream
     # ------------------------------------------------------------------------------------------
     def _dual(self):
-        return self.dual_stream and self.arena.flat.is_cuda and not self.wgrad_stream
+        return self.dual_stream and self.arena.flat.is_cuda
 
     @staticmethod
     def _touch(obj, stream):
