@@ -369,3 +369,69 @@ def test_mask_synth_matches_the_oracle_encoders_bit_for_bit():
         assert torch.equal(tw, want_t) and torch.equal(cw, want_c)
         dt, dc = spec.dense(T)                                   # the host-side dense form agrees too
         assert torch.equal(dt, torch.from_numpy(np.stack(txt))) and torch.equal(dc, torch.from_numpy(np.stack(co)))
+
+
+def test_plan_kernels_match_the_dense_formulation():
+    """unimm_plan_lengths / unimm_plan_build against the definition on the dense masks (what the engine used to compute
+    with eager ops): valid prefix lengths, row maps, and the decoded rows in torch.nonzero order."""
+    import struct
+    from unimm_amd import lib as L
+    g = torch.Generator().manual_seed(5)
+    for B, T, R, two_d, use_w in [(7, 256, 37, False, True), (5, 64, 37, False, False), (6, 100, 9, True, True), (3, 256, 256, False, True)]:
+        lens_true = torch.randint(1, T + 1, (B,), generator=g)
+        if two_d:
+            am = (torch.arange(T)[None, :] < lens_true[:, None]).to(torch.uint8)
+        else:
+            am = torch.zeros(B, T, T, dtype=torch.uint8)
+            for b in range(B):
+                n = int(lens_true[b])
+                am[b, :n, :n] = (torch.rand(n, n, generator=g) < 0.5).to(torch.uint8)
+                am[b, torch.randint(0, n, (1,), generator=g), n - 1] = 1       # someone attends the last valid token
+        cm = torch.zeros(B, R, T, dtype=torch.uint8)
+        for b in range(B):
+            cm[b, :, :max(1, int(lens_true[b]) - 3)] = (torch.rand(R, max(1, int(lens_true[b]) - 3), generator=g) < 0.3).to(torch.uint8)
+        labels = torch.full((B, T), -1, dtype=torch.int64)
+        weights = torch.zeros(B, T, dtype=torch.int64)
+        for b in range(B):
+            pos = torch.randperm(T, generator=g)[:5]
+            labels[b, pos] = torch.randint(0, 1000, (5,), generator=g)
+            weights[b, pos[:4]] = torch.tensor([1, -1, 1, -1])                  # one labelled row with weight 0 (context mask of a negative)
+        labels[0, T - 1] = 7
+        weights[0, T - 1] = 1                                                   # a label past every mask extends the prefix
+        nspw = torch.tensor([[5.0, 1.0]], device="cuda")
+        amd, cmd = am.cuda(), cm.cuda()
+        tw, cw = L.mask_pack(amd), L.mask_pack(cmd)
+        nw = tw.shape[-1]
+        tmask = (tw, 0, nw) if two_d else (tw, nw, T * nw)
+        lab32, w32 = labels.cuda().int(), (weights.cuda().int() if use_w else None)
+        header = L.plan_lengths(tmask, (cw, nw, R * nw), R, lab32, w32, nspw.reshape(-1), B, T)
+        hh = header.tolist()
+        # definition on the dense tensors
+        valid = am.ne(0) if two_d else (am.ne(0).any(1) | am.ne(0).any(2))
+        valid = valid | cm.ne(0).any(1) | labels.ne(-1)
+        if use_w:
+            valid = valid | weights.ne(0)
+        want_len = (valid.int() * torch.arange(1, T + 1)).amax(1).clamp_min(1)
+        assert hh[:B] == want_len.tolist()
+        selm = weights.ne(0) if use_w else labels.ne(-1)
+        assert hh[B:2 * B] == selm.sum(1).tolist()
+        assert struct.unpack("<2f", struct.pack("<2i", hh[2 * B], hh[2 * B + 1])) == (5.0, 1.0)
+        Mv, n = sum(hh[:B]), sum(hh[B:2 * B])
+        built = L.plan_build(header, lab32, w32, B, T, Mv, n)
+        off = torch.cat([torch.zeros(1, dtype=torch.int64), want_len.cumsum(0)[:-1]])
+        assert built["off"].cpu().tolist() == off.tolist() and built["lens"].cpu().tolist() == want_len.tolist()
+        rows = torch.cat([torch.arange(b * T, b * T + int(l)) for b, l in enumerate(want_len)])
+        assert torch.equal(built["rows"].cpu(), rows)
+        inv = torch.full((B * T,), -1, dtype=torch.int64)
+        inv[rows] = torch.arange(Mv)
+        assert torch.equal(built["inv"].cpu(), inv)
+        pos = torch.nonzero(selm.reshape(-1))[:, 0]
+        assert built["lm_pos"].cpu().tolist() == pos.tolist()
+        assert built["lm_idx"].cpu().tolist() == inv[pos].tolist()
+        assert built["lm_label"].cpu().tolist() == labels.reshape(-1)[pos].tolist()
+        assert built["lm_weight"].cpu().tolist() == (weights.reshape(-1)[pos].tolist() if use_w else [1] * n)
+    # nothing labelled, no masks beyond labels=None: counts are zero and the lm group may be omitted
+    header = L.plan_lengths((tw, nw, T * nw), None, 0, None, None, None, B, T)
+    assert sum(header.tolist()[B:2 * B]) == 0
+    b2 = L.plan_build(header, None, None, B, T, sum(header.tolist()[:B]), 0)
+    assert b2["lm_pos"] is None and b2["rows"].numel() == sum(header.tolist()[:B])

@@ -101,6 +101,113 @@ int mask_pack_impl(const void* m, uint32_t* out, size_t rows, int t, hipStream_t
 }
 
 // ------------------------------------------------------------------------------------------------
+// Unpadded-schedule plan on the device.  The engine runs the text stream on the valid prefix of every sequence and
+// decodes only the labelled rows; both need counts on the host (allocation sizes, grid sizes), which used to cost ~25
+// eager torch kernels over the dense [B,T,T] masks, two device->host round trips at the start of forward and a
+// third in the middle of it (torch.nonzero for the labelled rows, which drained the whole encoder forward first).
+//   plan_lengths: one workgroup per sequence, lane = token.  header[b] = valid prefix length (a token is valid when it
+//     attends something, is attended by a token or a region, carries a label or a weight; >= 1), header[B+b] = number of
+//     rows the MLM head decodes (weight != 0 when weights are given, else label != -1), header[2B..2B+1] = the bits of the
+//     two NSP class weights when they live on the device.  ONE device->host copy of the header follows.
+//   plan_build: from the header, everything else without the host: offsets, the packed-row -> padded-row map and its
+//     inverse, and the decoded rows' positions / packed indices / labels / weights in row order.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void plan_lengths_kernel(const uint32_t* __restrict__ tw, int t_qs, int t_bs,
+                                                           const uint32_t* __restrict__ cw, int c_qs, int c_bs, int R,
+                                                           const int32_t* __restrict__ labels,
+                                                           const int32_t* __restrict__ weights, const float* __restrict__ nspw,
+                                                           int B, int T, int nw, int32_t* __restrict__ header) {
+  __shared__ uint32_t col[8];
+  __shared__ int red_len[4], red_cnt[4];
+  const int b = blockIdx.x, t = threadIdx.x;
+  if (t < 8) col[t] = 0u;
+  __syncthreads();
+  bool valid = false;
+  if (tw != nullptr && t < T) {
+    if (t_qs == 0) {
+      valid = (tw[(size_t)b * t_bs + (t >> 5)] >> (t & 31)) & 1u;           // key-padding mask: the bit itself
+    } else {
+      for (int w = 0; w < nw; ++w) {
+        const uint32_t x = tw[(size_t)b * t_bs + (size_t)t * t_qs + w];
+        if (x != 0u) { valid = true; atomicOr(&col[w], x); }                // attends something | marks attended keys
+      }
+    }
+  }
+  if (cw != nullptr) {
+    if (c_qs == 0) {
+      if (t < nw) atomicOr(&col[t], cw[(size_t)b * c_bs + t]);
+    } else if (t < R) {
+      for (int w = 0; w < nw; ++w) {
+        const uint32_t x = cw[(size_t)b * c_bs + (size_t)t * c_qs + w];
+        if (x != 0u) atomicOr(&col[w], x);
+      }
+    }
+  }
+  __syncthreads();
+  bool sel = false;
+  if (t < T) {
+    valid = valid || ((col[t >> 5] >> (t & 31)) & 1u);
+    const int lab = labels != nullptr ? labels[(size_t)b * T + t] : -1;
+    const int wt = weights != nullptr ? weights[(size_t)b * T + t] : 0;
+    valid = valid || lab != -1 || wt != 0;
+    sel = labels != nullptr && (weights != nullptr ? wt != 0 : lab != -1);
+  }
+  int len = valid ? t + 1 : 0;
+  int cnt = sel ? 1 : 0;
+  for (int o = 32; o > 0; o >>= 1) { len = max(len, __shfl_xor(len, o, 64)); cnt += __shfl_xor(cnt, o, 64); }
+  if ((t & 63) == 0) { red_len[t >> 6] = len; red_cnt[t >> 6] = cnt; }
+  __syncthreads();
+  if (t == 0) {
+    header[b] = max(1, max(max(red_len[0], red_len[1]), max(red_len[2], red_len[3])));
+    header[B + b] = red_cnt[0] + red_cnt[1] + red_cnt[2] + red_cnt[3];
+  }
+  if (b == 0 && t < 2 && nspw != nullptr) header[2 * B + t] = __float_as_int(nspw[t]);
+}
+
+__global__ __launch_bounds__(256) void plan_build_kernel(const int32_t* __restrict__ header, const int32_t* __restrict__ labels,
+                                                         const int32_t* __restrict__ weights, int B, int T,
+                                                         int32_t* __restrict__ off, int32_t* __restrict__ lens,
+                                                         int64_t* __restrict__ rows, int64_t* __restrict__ inv,
+                                                         int32_t* __restrict__ lm_pos, int32_t* __restrict__ lm_idx,
+                                                         int32_t* __restrict__ lm_lab, int32_t* __restrict__ lm_w) {
+  __shared__ int s_off, s_lmoff, wave_cnt[4];
+  const int b = blockIdx.x, t = threadIdx.x;
+  // exclusive prefix sums over the sequences before this one (B is a few hundred: one strided pass)
+  int a = 0, c = 0;
+  for (int i = t; i < b; i += 256) { a += header[i]; c += header[B + i]; }
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); }
+  __shared__ int pa[4], pc[4];
+  if ((t & 63) == 0) { pa[t >> 6] = a; pc[t >> 6] = c; }
+  __syncthreads();
+  if (t == 0) { s_off = pa[0] + pa[1] + pa[2] + pa[3]; s_lmoff = pc[0] + pc[1] + pc[2] + pc[3]; }
+  __syncthreads();
+  const int len = header[b], o0 = s_off;
+  if (t == 0) { off[b] = o0; lens[b] = len; }
+  if (t < T) {
+    const bool in = t < len;
+    if (in && rows != nullptr) rows[o0 + t] = (int64_t)b * T + t;
+    if (inv != nullptr) inv[(size_t)b * T + t] = in ? (int64_t)(o0 + t) : (int64_t)-1;
+  }
+  if (labels == nullptr || lm_pos == nullptr) return;
+  const int lab = t < T ? labels[(size_t)b * T + t] : -1;
+  const int wt = (weights != nullptr && t < T) ? weights[(size_t)b * T + t] : 0;
+  const bool sel = t < T && (weights != nullptr ? wt != 0 : lab != -1);
+  const unsigned long long bal = __ballot(sel);
+  const int lane = t & 63, wv = t >> 6;
+  if (lane == 0) wave_cnt[wv] = __popcll(bal);
+  __syncthreads();
+  if (sel) {
+    int r = __popcll(bal & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wv; ++w) r += wave_cnt[w];
+    const int dst = s_lmoff + r;                    // row order: by sequence, then by position (what torch.nonzero gave)
+    lm_pos[dst] = b * T + t;
+    lm_idx[dst] = o0 + t;                           // a decoded row is valid by construction (t < len)
+    lm_lab[dst] = lab;
+    lm_w[dst] = weights != nullptr ? wt : 1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // row helpers: a wave owns one row of H elements as 8-element (16-byte) chunks, chunk c = lane + 64*i
 // ------------------------------------------------------------------------------------------------
 struct Row8 { float v[MAXC][8]; };
@@ -738,6 +845,29 @@ extern "C" int unimm_embed_bwd(const unimm_embed_args* a, const void* dy, float*
   UNIMM_CHECK_LAUNCH();
   hipLaunchKernelGGL(colpartials_finish_kernel, dim3((a->H + 63) / 64, 4), dim3(1024), 0, s, partials, blocks, 4, a->H,
                      dgamma, dbeta, dtype, dtype + a->H);
+  UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
+}
+
+extern "C" int unimm_plan_lengths(const uint32_t* text_words, int32_t t_q_stride, int32_t t_b_stride, const uint32_t* co_words,
+                                  int32_t c_q_stride, int32_t c_b_stride, int32_t R, const int32_t* labels, const int32_t* weights,
+                                  const float* nsp_weight, int32_t B, int32_t T, int32_t* header, void* stream) {
+  if (header == nullptr || (text_words == nullptr && co_words == nullptr && labels == nullptr)) return UNIMM_E_ARG;
+  if (B <= 0 || T <= 0 || T > 256 || R < 0 || R > 256) return UNIMM_E_SHAPE;
+  hipLaunchKernelGGL(plan_lengths_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, text_words, t_q_stride, t_b_stride,
+                     co_words, c_q_stride, c_b_stride, R, labels, weights, nsp_weight, B, T, (T + 31) / 32, header);
+  UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
+}
+
+extern "C" int unimm_plan_build(const int32_t* header, const int32_t* labels, const int32_t* weights, int32_t B, int32_t T,
+                                int32_t* off, int32_t* lens, int64_t* rows, int64_t* inv, int32_t* lm_pos, int32_t* lm_idx,
+                                int32_t* lm_label, int32_t* lm_weight, void* stream) {
+  if (header == nullptr || off == nullptr || lens == nullptr) return UNIMM_E_ARG;
+  if (lm_pos != nullptr && (lm_idx == nullptr || lm_label == nullptr || lm_weight == nullptr || labels == nullptr)) return UNIMM_E_ARG;
+  if (B <= 0 || T <= 0 || T > 256) return UNIMM_E_SHAPE;
+  hipLaunchKernelGGL(plan_build_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, header, labels, weights, B, T, off, lens, rows,
+                     inv, lm_pos, lm_idx, lm_label, lm_weight);
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;
 }

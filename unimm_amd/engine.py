@@ -71,7 +71,7 @@ class Engine:
         self.grad_bucket_hook = None     # set by the data-parallel wrapper: f(group_name, lo, hi)
         self._anchor = None
         self.last_seq_t = None
-        self.unpad = True                # run the text stream on valid rows only (see _varlen_plan)
+        self.unpad = True                # run the text stream on valid rows only (see the plan step of _forward)
         self._wq = []                    # queued weight-gradient problems of the block being back-propagated
         self.lazy_ln = os.environ.get("UNIMM_LAZY_LN", "1") == "1"   # residual epilogues evaluate the previous LayerNorm
         # Option: grouped weight-gradient launches on a side stream (UNIMM_WGRAD_STREAM=1): +1.8 % throughput in
@@ -545,44 +545,12 @@ class Engine:
             return (words, 0, nw)
         return (words, nw, m.shape[1] * nw)
 
-    def _varlen_plan(self, am, cm, labels, weights, B, T, device):
-        """Valid prefix length of every sequence.  A text row is INERT when no valid row ever attends it
-        (its column of the text mask and of the co-attention mask is empty), it carries no label and it
-        is not the pooled first token: whatever it computes never reaches a loss or a valid row, and its
-        gradient is exactly zero (the reference still spends ~45 % of its token FLOPs there: rows past
-        each dialog's length, models/vilbert_dialog.py:1418 / utils/data_utils.py:207).  The engine runs
-        the text stream on rows [0, len_b) only; returns None when nothing can be dropped."""
-        if am.dim() == 3:
-            valid = am.ne(0).any(dim=1) | am.ne(0).any(dim=2)      # attended as key | attends something
-        else:
-            valid = am.ne(0)
-        valid = valid | cm.ne(0).any(dim=1)
-        if labels is not None:
-            valid = valid | labels.to(device).ne(-1)
-        if weights is not None:
-            valid = valid | weights.to(device).ne(0)
-        idx = torch.arange(1, T + 1, device=device, dtype=torch.int32)
-        lens = (valid.to(torch.int32) * idx).amax(dim=1).clamp_min(1)
-        lens_h = lens.tolist()                                         # one host sync per step
-        return self._plan_from_lengths(lens_h, lens, B, T, device)
-
-    @staticmethod
-    def _plan_from_lengths(lens_h, lens, B, T, device):
-        """Row maps of the unpadded schedule from the per-sequence valid lengths (host list [+ device copy])."""
-        Mv = int(sum(lens_h))
-        if Mv == B * T:
-            return None
-        import numpy as np
-        ln = np.asarray(lens_h, dtype=np.int64)
-        off = np.concatenate([[0], np.cumsum(ln)[:-1]])
-        rows = np.concatenate([np.arange(b * T, b * T + l) for b, l in enumerate(lens_h)])
-        inv = np.full(B * T, -1, dtype=np.int64)
-        inv[rows] = np.arange(Mv)
-        if lens is None:
-            lens = torch.from_numpy(ln.astype(np.int32)).to(device)
-        return dict(Mv=Mv, lens_h=lens_h, rows=torch.from_numpy(rows).to(device),
-                    inv=torch.from_numpy(inv).to(device), inv_h=inv,
-                    var=(torch.from_numpy(off.astype(np.int32)).to(device), lens.contiguous()))
+    # Unpadded schedule: a text row is INERT when no valid row ever attends it (its column of the text mask and of
+    # the co-attention mask is empty), it attends nothing, carries no label / weight and is not the pooled first
+    # token: whatever it computes never reaches a loss or a valid row, and its gradient is exactly zero (the
+    # reference still spends ~45 % of its token FLOPs there: rows past each dialog's length,
+    # models/vilbert_dialog.py:1418 / utils/data_utils.py:207).  The engine runs the text stream on rows
+    # [0, len_b) of every sequence only; len_b comes from `unimm_plan_lengths` (see `_forward`).
 
     # ------------------------------------------------------------------------------------------
     # forward
@@ -642,16 +610,12 @@ class Engine:
         if im.dim() not in (2, 3):
             raise ValueError(f"Wrong shape for img input_ids (shape {tuple(feat.shape)}) or attention_mask (shape {tuple(im.shape)})")
         self._dev_masks = []
-        plan = None
         if spec is not None:
-            # masks synthesised on the device from (mode, L, n); valid lengths known on the host: no sync
+            # masks synthesised on the device from (mode, L, n)
             tw, cw = L.mask_synth(*spec.to_device(dev), T)
             nw = tw.shape[-1]
             tmask, comask = (tw, nw, T * nw), (cw, 0, nw)
             vmask = self._pack_mask(im, dev, R)
-            if self.unpad:
-                lens_h = spec.valid_lengths(T).tolist()
-                plan = self._plan_from_lengths(lens_h, None, B, T, dev)
         else:
             cm = inp.get("co_attention_mask")
             if cm is None:
@@ -660,38 +624,10 @@ class Engine:
             tmask = self._pack_mask(am, dev, T)
             vmask = self._pack_mask(im, dev, R)
             comask = self._pack_mask(cm, dev, R)
-            if self.unpad:
-                plan = self._varlen_plan(self._dev_masks[0], self._dev_masks[2], inp.get("masked_lm_labels"),
-                                         inp.get("lm_weight"), B, T, dev)
         self._dev_masks = []
-        self.last_plan = plan
-        var = plan["var"] if plan is not None else None
-        Mt = plan["Mv"] if plan is not None else B * T      # text rows actually computed
-
-        # ---- embeddings --------------------------------------------------------------------------
-        tt = inp.get("token_type_ids")
-        ids32 = self._i32(ids.reshape(-1), dev)
-        typ32 = self._i32(tt.reshape(-1), dev) if tt is not None else torch.zeros(B * T, dtype=torch.int32, device=dev)
-        pos = inp.get("position_ids")
-        pos32 = self._i32(pos.reshape(-1), dev) if pos is not None else \
-            torch.arange(T, dtype=torch.int32, device=dev).repeat(B)
-        if plan is not None:
-            ids32, typ32, pos32 = (t.index_select(0, plan["rows"]) for t in (ids32, typ32, pos32))
-        gmm, bta, ggm, gbt = self.ln["emb_t"]
-        d_embt = self._drop("emb_t", cfg.hidden_dropout_prob, train)
-        xt = torch.empty((Mt, H), dtype=BF16, device=dev)
-        xt32 = torch.empty((Mt, H), dtype=F32, device=dev)
-        tabs = (self.tab["word"], self.tab["pos"], self.tab["type"], self.tab["ext"])
-        L.embed_fwd(ids32, pos32, typ32, *tabs, gmm, bta, xt32, xt, Mt, H, cfg.type_vocab_size, drop=d_embt)
+        # ---- image embedding first: it does not depend on the plan, so the image stream already has work while the
+        # host waits for the header below (models/vilbert_dialog.py:360-383)
         A = self.arena
-        e = "bert.embeddings."
-        if save:
-            def bwd_embt(dxt):
-                L.embed_bwd(ids32, pos32, typ32, *tabs, gmm, bta, dxt, A.grad(e + "word_embeddings.weight"),
-                            A.grad(e + "position_embeddings.weight"), A.grad(e + "token_type_embeddings.weight"),
-                            A.grad(e + "token_type_embeddings_extension.weight"), ggm, gbt, self.part[H], Mt, H,
-                            cfg.type_vocab_size, drop=d_embt)
-
         F = cfg.v_feature_size
         self._to_img()                        # masks are packed (and the previous step is behind us): the image side may start
         with self._img():                     # image embedding: beside the first text layers
@@ -716,6 +652,64 @@ class Engine:
                     A.grad(v + "image_location_embeddings.bias").add_(dbias - before)
                     self._wgrad(dpre, packed, A.grad(v + "image_embeddings.weight"), B * R, Hv, F)
                     self._wgrad(dpre, packed[:, F:], A.grad(v + "image_location_embeddings.weight"), B * R, Hv, 5)
+
+        # ---- plan of the step: everything the host has to know, in ONE device->host copy ------------------
+        # (valid prefix lengths for the unpadded schedule, the number of rows the MLM head decodes, the NSP class
+        # weights when they live on the device); row maps and the decoded rows' index lists are then built on the
+        # device.  See csrc/rowops.hip: plan_lengths / plan_build.
+        tt = inp.get("token_type_ids")                       # (input conversions go in front of the sync as well)
+        ids32 = self._i32(ids.reshape(-1), dev)
+        typ32 = self._i32(tt.reshape(-1), dev) if tt is not None else torch.zeros(B * T, dtype=torch.int32, device=dev)
+        pos = inp.get("position_ids")
+        pos32 = self._i32(pos.reshape(-1), dev) if pos is not None else \
+            torch.arange(T, dtype=torch.int32, device=dev).repeat(B)
+        labels, weights = inp.get("masked_lm_labels"), inp.get("lm_weight")
+        want_sel = lm_rows == "labelled" and labels is not None
+        lab32 = self._i32(labels.reshape(B, T), dev) if labels is not None else None
+        w32 = self._i32(weights.reshape(B, T), dev) if (weights is not None and labels is not None) else None
+        nw_in = inp.get("nsp_weight")
+        nw_dev = nw_in.reshape(-1)[:2].to(F32).contiguous() if (torch.is_tensor(nw_in) and nw_in.is_cuda) else None
+        plan, sel = None, None
+        if self.unpad or want_sel or nw_dev is not None:
+            header = L.plan_lengths(tmask, comask, R, lab32, w32, nw_dev, B, T)
+            hh = header.tolist()                                          # the step's one host sync
+            lens_h, n_lm = hh[:B], (sum(hh[B:2 * B]) if want_sel else 0)
+            Mv = sum(lens_h)
+            unpadded = self.unpad and Mv < B * T
+            built = L.plan_build(header, lab32 if want_sel else None, w32 if want_sel else None, B, T, Mv, n_lm, want_rows=unpadded)
+            if unpadded:
+                plan = dict(Mv=Mv, lens_h=lens_h, rows=built["rows"], inv=built["inv"], var=(built["off"], built["lens"]))
+            if want_sel:
+                sel = dict(n=n_lm, pos=built["lm_pos"], idx=built["lm_idx"] if unpadded else built["lm_pos"],
+                           label=built["lm_label"], weight=built["lm_weight"])
+            if nw_dev is not None:
+                import struct
+                st_nspw = struct.unpack("<2f", struct.pack("<2i", hh[2 * B], hh[2 * B + 1]))
+            else:
+                st_nspw = None
+        else:
+            st_nspw = None
+        self.last_plan = plan
+        var = plan["var"] if plan is not None else None
+        Mt = plan["Mv"] if plan is not None else B * T      # text rows actually computed
+
+        # ---- embeddings --------------------------------------------------------------------------
+        if plan is not None:
+            ids32, typ32, pos32 = (t.index_select(0, plan["rows"]) for t in (ids32, typ32, pos32))
+        gmm, bta, ggm, gbt = self.ln["emb_t"]
+        d_embt = self._drop("emb_t", cfg.hidden_dropout_prob, train)
+        xt = torch.empty((Mt, H), dtype=BF16, device=dev)
+        xt32 = torch.empty((Mt, H), dtype=F32, device=dev)
+        tabs = (self.tab["word"], self.tab["pos"], self.tab["type"], self.tab["ext"])
+        L.embed_fwd(ids32, pos32, typ32, *tabs, gmm, bta, xt32, xt, Mt, H, cfg.type_vocab_size, drop=d_embt)
+        A = self.arena
+        e = "bert.embeddings."
+        if save:
+            def bwd_embt(dxt):
+                L.embed_bwd(ids32, pos32, typ32, *tabs, gmm, bta, dxt, A.grad(e + "word_embeddings.weight"),
+                            A.grad(e + "position_embeddings.weight"), A.grad(e + "token_type_embeddings.weight"),
+                            A.grad(e + "token_type_embeddings_extension.weight"), ggm, gbt, self.part[H], Mt, H,
+                            cfg.type_vocab_size, drop=d_embt)
 
         # ---- encoder (schedule of models/vilbert_dialog.py:842-929) ------------------------------
         # Two streams: the image stream (embedding, image layers, the image half of every connection layer) and the
@@ -753,7 +747,8 @@ class Engine:
         seq_t, seq_v = xt, xv
 
         xt32, xv32 = self._dense32(xt32), self._dense32(xv32)      # the final residual stream is an output
-        out = dict(seq_out_t=seq_t, seq_out_v=seq_v, seq32_t=xt32, seq32_v=xv32, B=B, T=T, R=R, plan=plan, Mt=Mt)
+        out = dict(seq_out_t=seq_t, seq_out_v=seq_v, seq32_t=xt32, seq32_v=xv32, B=B, T=T, R=R, plan=plan, Mt=Mt,
+                   nsp_weight_host=st_nspw)
         # ---- poolers + NSP (models/vilbert_dialog.py:946-967, 1064-1070) -------------------------
         tp, vp, nspl = self.lin["tpool"], self.lin["vpool"], self.lin["nsp"]
         cls_idx_t = var[0] if var is not None else torch.arange(0, B * T, T, dtype=torch.int32, device=dev)
@@ -771,30 +766,17 @@ class Engine:
         out["nsp"] = nsp[:, :2]
 
         # ---- MLM head: transform + tied decoder on the selected rows (:982-986, :1023-1026) -------
-        labels, weights = inp.get("masked_lm_labels"), inp.get("lm_weight")
         V = cfg.vocab_size
         Vp = _rup(V, 64)
         lmtr, dec = self.lin["lmtr"], self.lin["dec"]
         lm = None
         if lm_rows == "labelled" and labels is not None:
-            lab_flat = labels.reshape(-1)
-            if weights is not None:
-                w_flat = weights.reshape(-1)
-                sel = torch.nonzero(w_flat != 0)[:, 0]
-                w_sel = w_flat[sel]
-            else:
-                sel = torch.nonzero(lab_flat != -1)[:, 0]
-                w_sel = torch.ones_like(sel)
-            n = int(sel.numel())
+            n = sel["n"]                                          # rows chosen by the plan kernels at the start of forward
             if n > 0:
-                pos_idx = self._i32(sel, dev)                     # position in the padded [B*T] layout
-                idx = self._i32(plan["inv"][sel.to(dev)], dev) if plan is not None else pos_idx
-                lab_sel = self._i32(lab_flat[sel], dev)
-                w_sel = self._i32(w_sel, dev)
                 xs = torch.empty((n, H), dtype=BF16, device=dev)
-                L.gather_rows(seq_t, idx, xs, n, H)
-                lm = self._lm_head(xs, n, lab_sel, w_sel, save)
-                lm.update(idx=idx, pos_idx=pos_idx, n=n)
+                L.gather_rows(seq_t, sel["idx"], xs, n, H)
+                lm = self._lm_head(xs, n, sel["label"], sel["weight"], save)
+                lm.update(idx=sel["idx"], pos_idx=sel["pos"], n=n)
             out["lm"] = lm
         elif lm_rows == "all":
             out["pred_t"] = self.decode_rows(self.padded(out, seq_t), B * T).view(B, T, Vp)[:, :, :V]
@@ -890,7 +872,8 @@ class Engine:
         if nw is None:
             w0, w1 = 1.0, 1.0
         else:
-            w = [float(x) for x in nw.reshape(-1, 2)[0].tolist()]
+            w = out["nsp_weight_host"] if out.get("nsp_weight_host") is not None else \
+                [float(x) for x in nw.reshape(-1, 2)[0].tolist()]          # host tensor: no device round trip
             w0, w1 = 1.0, w[1] / w[0]
         nlab = self._i32(inp["next_sentence_label"].reshape(-1), dev)
         nsp_loss = torch.empty(1, dtype=F32, device=dev)

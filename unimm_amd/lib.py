@@ -73,7 +73,7 @@ SYMBOLS = ["unimm_version", "unimm_arch", "unimm_gemm_nt", "unimm_gemm_tn", "uni
            "unimm_embed_fwd", "unimm_embed_bwd", "unimm_colsum", "unimm_cast_f32_bf16", "unimm_transpose_cast",
            "unimm_pack_image", "unimm_mul_dropout", "unimm_mul_dropout_bwd", "unimm_lm_loss_fwd",
            "unimm_lm_loss_bwd", "unimm_kl_loss_fwd", "unimm_kl_loss_bwd", "unimm_nsp_loss_fwd",
-           "unimm_nsp_loss_bwd", "unimm_reduce_sum", "unimm_segment_sum", "unimm_gelu_bwd", "unimm_gather_rows", "unimm_prof_enable", "unimm_prof_collect", "unimm_gemm_set_tile", "unimm_attn_set_parts", "unimm_adamw_step", "unimm_transpose_cast_grouped", "unimm_mask_synth", "unimm_neural_ndcg"]
+           "unimm_nsp_loss_bwd", "unimm_reduce_sum", "unimm_segment_sum", "unimm_gelu_bwd", "unimm_gather_rows", "unimm_prof_enable", "unimm_prof_collect", "unimm_gemm_set_tile", "unimm_attn_set_parts", "unimm_adamw_step", "unimm_transpose_cast_grouped", "unimm_mask_synth", "unimm_neural_ndcg", "unimm_plan_lengths", "unimm_plan_build"]
 
 
 def _check(rc, what):
@@ -332,6 +332,33 @@ def mask_synth(mode, length, nans, T):
     _check(lib().unimm_mask_synth(_ptr(mode), _ptr(length), _ptr(nans), _ptr(text), _ptr(co), C.c_int32(B), C.c_int32(T),
                                   _stream()), "unimm_mask_synth")
     return text, co
+
+
+def plan_lengths(text_mask, co_mask, R, labels, weights, nsp_weight, B, T):
+    """-> int32 header [2B+2] on the device (see include/unimm_hip.h: unimm_plan_lengths).  text_mask / co_mask are
+    (words, q_stride, b_stride) tuples or None."""
+    tw, tq, tb = text_mask if text_mask is not None else (None, 0, 0)
+    cw, cq, cb = co_mask if co_mask is not None else (None, 0, 0)
+    ref = tw if tw is not None else (cw if cw is not None else labels)
+    header = torch.zeros(2 * B + 2, dtype=torch.int32, device=ref.device)
+    _dev(tw, cw, labels, weights, nsp_weight)
+    _check(lib().unimm_plan_lengths(_ptr(tw), C.c_int32(tq), C.c_int32(tb), _ptr(cw), C.c_int32(cq), C.c_int32(cb), C.c_int32(R),
+                                    _ptr(labels), _ptr(weights), _ptr(nsp_weight), C.c_int32(B), C.c_int32(T), _ptr(header),
+                                    _stream()), "unimm_plan_lengths")
+    return header
+
+
+def plan_build(header, labels, weights, B, T, Mv, n_lm, want_rows=True):
+    """-> dict(off, lens, rows, inv, lm_pos, lm_idx, lm_label, lm_weight) built on the device from the header."""
+    dev = header.device
+    i32 = lambda n: torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    off, lens = i32(B), i32(B)
+    rows = torch.empty(Mv, dtype=torch.int64, device=dev) if want_rows else None
+    inv = torch.empty(B * T, dtype=torch.int64, device=dev) if want_rows else None
+    lm = [i32(n_lm) for _ in range(4)] if (n_lm > 0 and labels is not None) else [None] * 4
+    _check(lib().unimm_plan_build(_ptr(header), _ptr(labels), _ptr(weights), C.c_int32(B), C.c_int32(T), _ptr(off), _ptr(lens),
+                                  _ptr(rows), _ptr(inv), *[_ptr(t) for t in lm], _stream()), "unimm_plan_build")
+    return dict(off=off, lens=lens, rows=rows, inv=inv, lm_pos=lm[0], lm_idx=lm[1], lm_label=lm[2], lm_weight=lm[3])
 
 
 def transpose_cast(src, dst, R, C_, ldd):
