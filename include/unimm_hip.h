@@ -208,6 +208,22 @@ int unimm_layernorm_bwd(const void* dy, const float* x, const float* mean, const
                         void* dx, void* dx_drop, float* dgamma, float* dbeta, float* dbias, float* partials,
                         int32_t M, int32_t H, uint32_t drop_key, uint32_t drop_thr, float drop_scale,
                         uint32_t odrop_key, uint32_t odrop_thr, float odrop_scale, void* stream);
+/* The same row kernel without the reduction of its column partials: `partials` (unimm_colpartials_bytes(H), private to
+ * this call until it is reduced) holds [blocks][3][H] = per-block sums for dgamma, dbeta, dbias; *blocks_out (host)
+ * receives the block count.  unimm_colpartials_finish_grouped then adds the column sums of up to many pending calls
+ * into their destinations in one launch (dst[q] == NULL skips quantity q): the engine reduces a block's LayerNorm
+ * partials once at the end of the block instead of between two dependent kernels each time. */
+int unimm_layernorm_bwd_partials(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                 void* dx, void* dx_drop, float* partials, int32_t M, int32_t H, uint32_t drop_key,
+                                 uint32_t drop_thr, float drop_scale, uint32_t odrop_key, uint32_t odrop_thr,
+                                 float odrop_scale, int32_t* blocks_out, void* stream);
+#define UNIMM_FINISH_MAX 8
+typedef struct {
+  const float* partials;
+  float* dst[4];
+  int32_t blocks, nq, H, pad_;
+} unimm_finish_desc;
+int unimm_colpartials_finish_grouped(const unimm_finish_desc* descs, int32_t count, void* stream);
 
 /* Text embeddings: y = dropout(LN(word[ids] + pos[position] + type)) with token-type ids >= type_vocab
  * routed to the 10-row extension table (BertEmbeddingsDialog.forward, models/vilbert_dialog.py:326-356).

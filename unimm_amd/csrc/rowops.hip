@@ -443,6 +443,43 @@ __global__ __launch_bounds__(1024) void colpartials_finish_kernel(const float* _
   }
 }
 
+// The same reduction for up to UNIMM_FINISH_MAX pending row kernels in one launch (blockIdx.z = which): the engine
+// defers the column-partials reductions of a block's LayerNorm backward calls to the end of the block, where nothing
+// waits for them (94 launches of ~4 us per step otherwise, each between two dependent kernels of the critical path).
+struct FinishGroup { unimm_finish_desc d[UNIMM_FINISH_MAX]; };
+
+__global__ __launch_bounds__(1024) void colpartials_finish_grouped_kernel(FinishGroup g) {
+  __shared__ float red[16][64];
+  const unimm_finish_desc& d = g.d[blockIdx.z];
+  const int H = d.H, nq = d.nq, nblocks = d.blocks;
+  const int qn = blockIdx.y;
+  if (blockIdx.x * 64 >= H || qn >= nq) return;                 // block-uniform
+  const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cl;
+  float* dst = d.dst[qn];
+  float s = 0.f;
+  if (col < H && dst != nullptr) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
+    int b = sl;
+    const size_t st = (size_t)16 * nq * H;
+    const float* pp = d.partials + ((size_t)b * nq + qn) * H + col;
+    for (; b + 7 * 16 < nblocks; b += 8 * 16, pp += 8 * st) {
+      s0 += pp[0]; s1 += pp[st]; s2 += pp[2 * st]; s3 += pp[3 * st];
+      s4 += pp[4 * st]; s5 += pp[5 * st]; s6 += pp[6 * st]; s7 += pp[7 * st];
+    }
+    for (; b < nblocks; b += 16, pp += st) s0 += pp[0];
+    s = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));       // same order as colpartials_finish_kernel
+  }
+  red[sl][cl] = s;
+  __syncthreads();
+  if (sl == 0 && col < H && dst != nullptr) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][cl];
+    dst[col] += t;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // text embeddings: LN(word[id] + pos[pid] + type) with type ids >= tv routed to the 10-row extension
 // table (models/vilbert_dialog.py:326-356), dropout after the LayerNorm.
@@ -807,6 +844,41 @@ extern "C" int unimm_layernorm_bwd(const void* dy, const float* x, const float* 
   hipLaunchKernelGGL(colpartials_finish_kernel, dim3((H + 63) / 64, 3), dim3(1024), 0, s, partials, blocks, 3, H, dgamma,
                      dbeta, dbias, (float*)nullptr);
   UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
+}
+
+extern "C" int unimm_layernorm_bwd_partials(const void* dy, const float* x, const float* mean, const float* rstd,
+                                            const float* gamma, void* dx, void* dx_drop, float* partials, int32_t M, int32_t H,
+                                            uint32_t drop_key, uint32_t drop_thr, float drop_scale, uint32_t odrop_key,
+                                            uint32_t odrop_thr, float odrop_scale, int32_t* blocks_out, void* stream) {
+  if (!dy || !x || !mean || !rstd || !gamma || !dx || !partials || !blocks_out) return UNIMM_E_ARG;
+  if (M <= 0 || H <= 0 || H > MAXC * 512 || (H % 8)) return UNIMM_E_SHAPE;
+  int blocks = (M + 3) / 4;
+  blocks = blocks > RED_BLOCKS ? RED_BLOCKS : blocks;
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, x, mean, rstd,
+                     gamma, (bf16_t*)dx, (bf16_t*)dx_drop, partials, M, H, mk_drop(drop_key, drop_thr, drop_scale),
+                     mk_drop(odrop_key, odrop_thr, odrop_scale));
+  UNIMM_CHECK_LAUNCH();
+  *blocks_out = blocks;
+  return UNIMM_OK;
+}
+
+extern "C" int unimm_colpartials_finish_grouped(const unimm_finish_desc* descs, int32_t count, void* stream) {
+  if (descs == nullptr || count < 1) return UNIMM_E_ARG;
+  for (int base = 0; base < count; base += UNIMM_FINISH_MAX) {
+    const int n = count - base < UNIMM_FINISH_MAX ? count - base : UNIMM_FINISH_MAX;
+    FinishGroup g;
+    int hmax = 0, qmax = 0;
+    for (int i = 0; i < n; ++i) {
+      const unimm_finish_desc& d = descs[base + i];
+      if (d.partials == nullptr || d.blocks < 1 || d.nq < 1 || d.nq > 4 || d.H < 1) return UNIMM_E_ARG;
+      g.d[i] = d;
+      hmax = d.H > hmax ? d.H : hmax;
+      qmax = d.nq > qmax ? d.nq : qmax;
+    }
+    hipLaunchKernelGGL(colpartials_finish_grouped_kernel, dim3((hmax + 63) / 64, qmax, n), dim3(1024), 0, (hipStream_t)stream, g);
+    UNIMM_CHECK_LAUNCH();
+  }
   return UNIMM_OK;
 }
 

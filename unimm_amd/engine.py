@@ -89,6 +89,7 @@ class Engine:
         self._vside = None
         self._on_side = False            # inside `_img()`: launches (and queued weight gradients) belong to the image side
         self._wq_img = []
+        self._fq, self._fq_img = [], []  # pending column-partials reductions of LayerNorm backward calls, per stream
         self.last_plan = None
 
     # ------------------------------------------------------------------------------------------
@@ -260,10 +261,15 @@ class Engine:
         (self._wq_img if self._on_side else self._wq).append((dy, x, gw, M, N, K, dbias))
 
     def _flush_wgrad(self):
-        if self._wq_img:                          # image-side problems: operands were produced on that stream
+        if self._wq_img or self._fq_img:          # image-side problems: operands were produced on that stream
             with self._img():
                 L.gemm_tn_grouped(self._wq_img)
-            self._wq_img = []
+                L.colpartials_finish_grouped(self._fq_img)
+            self._wq_img, self._fq_img = [], []
+        if self._on_side:
+            return                                # the text side's queues are flushed from the text side
+        L.colpartials_finish_grouped(self._fq)
+        self._fq = []
         if not self._wq:
             return
         if not self.wgrad_stream:
@@ -388,12 +394,19 @@ class Engine:
         for t in reads:
             self._touch(t, main)
 
-    def _layernorm_bwd(self, dy, x, mean, rstd, key, dbias=None, drop=L.NO_DROP, out_drop=L.NO_DROP):
+    def _layernorm_bwd(self, dy, x, mean, rstd, key, dbias=None, drop=L.NO_DROP, out_drop=L.NO_DROP, defer=True):
+        """Row kernel now; the column sums (dgamma, dbeta, dbias) of all the calls of a block are reduced by one grouped
+        launch at the end of the block (`_flush_wgrad`), where nothing waits for them.  defer=False: reduce right away."""
         gmm, _, gg, gb = self.ln[key]
         M, H = x.shape
         dx = torch.empty((M, H), dtype=BF16, device=x.device)
         dxd = torch.empty((M, H), dtype=BF16, device=x.device) if drop[1] != 0 else None
-        L.layernorm_bwd(dy, x, mean, rstd, gmm, dx, dxd, gg, gb, dbias, self.part[H], M, H, drop=drop, out_drop=out_drop)
+        if not defer:
+            L.layernorm_bwd(dy, x, mean, rstd, gmm, dx, dxd, gg, gb, dbias, self.part[H], M, H, drop=drop, out_drop=out_drop)
+            return dx, (dxd if dxd is not None else dx)
+        part = torch.empty(self.part[H].numel(), dtype=F32, device=x.device)      # private until the grouped reduction
+        blocks = L.layernorm_bwd_partials(dy, x, mean, rstd, gmm, dx, dxd, part, M, H, drop=drop, out_drop=out_drop)
+        (self._fq_img if self._on_side else self._fq).append((part, blocks, H, [gg, gb, dbias]))
         return dx, (dxd if dxd is not None else dx)
 
     # ------------------------------------------------------------------------------------------
@@ -648,7 +661,7 @@ class Engine:
                 def bwd_embv(dxv):
                     dbias = A.grad(v + "image_embeddings.bias")
                     before = dbias.clone()
-                    dpre, _ = self._layernorm_bwd(dxv, prev, mv, rv, "emb_v", dbias=dbias, out_drop=d_embv)
+                    dpre, _ = self._layernorm_bwd(dxv, prev, mv, rv, "emb_v", dbias=dbias, out_drop=d_embv, defer=False)
                     A.grad(v + "image_location_embeddings.bias").add_(dbias - before)
                     self._wgrad(dpre, packed, A.grad(v + "image_embeddings.weight"), B * R, Hv, F)
                     self._wgrad(dpre, packed[:, F:], A.grad(v + "image_location_embeddings.weight"), B * R, Hv, 5)

@@ -73,7 +73,8 @@ SYMBOLS = ["unimm_version", "unimm_arch", "unimm_gemm_nt", "unimm_gemm_tn", "uni
            "unimm_embed_fwd", "unimm_embed_bwd", "unimm_colsum", "unimm_cast_f32_bf16", "unimm_transpose_cast",
            "unimm_pack_image", "unimm_mul_dropout", "unimm_mul_dropout_bwd", "unimm_lm_loss_fwd",
            "unimm_lm_loss_bwd", "unimm_kl_loss_fwd", "unimm_kl_loss_bwd", "unimm_nsp_loss_fwd",
-           "unimm_nsp_loss_bwd", "unimm_reduce_sum", "unimm_segment_sum", "unimm_gelu_bwd", "unimm_gather_rows", "unimm_prof_enable", "unimm_prof_collect", "unimm_gemm_set_tile", "unimm_attn_set_parts", "unimm_adamw_step", "unimm_transpose_cast_grouped", "unimm_mask_synth", "unimm_neural_ndcg", "unimm_plan_lengths", "unimm_plan_build"]
+           "unimm_nsp_loss_bwd", "unimm_reduce_sum", "unimm_segment_sum", "unimm_gelu_bwd", "unimm_gather_rows", "unimm_prof_enable", "unimm_prof_collect", "unimm_gemm_set_tile", "unimm_attn_set_parts", "unimm_adamw_step", "unimm_transpose_cast_grouped", "unimm_mask_synth", "unimm_neural_ndcg", "unimm_plan_lengths", "unimm_plan_build", "unimm_layernorm_bwd_partials",
+           "unimm_colpartials_finish_grouped"]
 
 
 def _check(rc, what):
@@ -259,6 +260,37 @@ def mask_pack(mask, out=None):
 
 def colpartials_bytes(H):
     return int(lib().unimm_colpartials_bytes(C.c_int32(H)))
+
+
+class FinishDesc(C.Structure):
+    _fields_ = [("partials", C.c_void_p), ("dst", C.c_void_p * 4), ("blocks", C.c_int32), ("nq", C.c_int32), ("H", C.c_int32),
+                ("pad_", C.c_int32)]
+
+
+def layernorm_bwd_partials(dy, x, mean, rstd, gamma, dx, dx_drop, partials, M, H, drop=None, out_drop=None):
+    """LayerNorm backward row kernel only; returns the number of partial blocks (see unimm_layernorm_bwd_partials)."""
+    drop = drop or NO_DROP
+    out_drop = out_drop or NO_DROP
+    _dev(dy, x, mean, rstd, gamma, dx, dx_drop, partials)
+    blocks = C.c_int32(0)
+    _check(lib().unimm_layernorm_bwd_partials(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(dx), _ptr(dx_drop),
+                                              _ptr(partials), C.c_int32(M), C.c_int32(H), C.c_uint32(drop[0]), C.c_uint32(drop[1]),
+                                              C.c_float(drop[2]), C.c_uint32(out_drop[0]), C.c_uint32(out_drop[1]),
+                                              C.c_float(out_drop[2]), C.byref(blocks), _stream()), "unimm_layernorm_bwd_partials")
+    return blocks.value
+
+
+def colpartials_finish_grouped(pending):
+    """pending: list of (partials, blocks, H, [dst tensors or None, up to 4]) -> their column sums added in one launch."""
+    n = len(pending)
+    if n == 0:
+        return
+    arr = (FinishDesc * n)()
+    for d, (part, blocks, H, dsts) in zip(arr, pending):
+        d.partials, d.blocks, d.nq, d.H = part.data_ptr(), blocks, len(dsts), H
+        for q, t in enumerate(dsts):
+            d.dst[q] = t.data_ptr() if t is not None else None
+    _check(lib().unimm_colpartials_finish_grouped(arr, C.c_int32(n), _stream()), "unimm_colpartials_finish_grouped")
 
 
 def layernorm_fwd(x, gamma, beta, y32, y16, mean, rstd, M, H, eps=1e-12, drop=NO_DROP):
