@@ -29,16 +29,31 @@ def step():
     (lm.mean() + nsp.mean() + img.mean()).backward()
 
 
+_wait = [0.0]
+_orig_tolist = torch.Tensor.tolist
+
+
+def _timed_tolist(self):
+    a = time.perf_counter()
+    r = _orig_tolist(self)
+    if self.is_cuda:
+        _wait[0] += time.perf_counter() - a
+    return r
+
+
+torch.Tensor.tolist = _timed_tolist
 for _ in range(5):
     step()
 torch.cuda.synchronize()
+_wait[0] = 0.0
 t0 = time.perf_counter()
 for _ in range(K):
     step()
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
-print(f"B={B}: enqueue {1e3 * (t1 - t0) / K:.2f} ms/step, complete {1e3 * (t2 - t0) / K:.2f} ms/step "
+print(f"B={B}: enqueue {1e3 * (t1 - t0) / K:.2f} ms/step of which {1e3 * _wait[0] / K:.2f} ms waiting in the plan's device->host copy, "
+      f"complete {1e3 * (t2 - t0) / K:.2f} ms/step "
       f"(dual_stream={model.engine.dual_stream})")
 import cProfile, pstats
 pr = cProfile.Profile()
