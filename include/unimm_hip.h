@@ -176,7 +176,8 @@ int unimm_mask_synth(const int32_t* mode, const int32_t* len, const int32_t* nan
  * device->host round trips of a step).  unimm_plan_lengths: header[b] = valid prefix length of sequence b (>= 1; a token
  * is valid when it attends something, is attended by a token or a region, or carries a label / weight), header[B+b] =
  * rows the MLM head decodes (weight != 0 when weights are given, else label != -1), header[2B..2B+1] = bit patterns of
- * the two NSP class weights when nsp_weight != NULL; header has 2B+2 entries.  Masks are the packed words of
+ * the two NSP class weights when nsp_weight != NULL, header[2B+2+b] = regions of sequence b with image_label == 1
+ * (int32 [B, R] or NULL: the divisor of the masked-region loss); header has 3B+2 entries.  Masks are the packed words of
  * unimm_mask_pack / unimm_mask_synth with their (query, batch) word strides (query stride 0 = one key-padding row per
  * sequence); text_words or co_words may be NULL, labels / weights int32 [B, T] or NULL.
  * unimm_plan_build (after the host has read the header and allocated): off[B] / lens[B], rows[sum len] = padded row of
@@ -184,7 +185,8 @@ int unimm_mask_synth(const int32_t* mode, const int32_t* len, const int32_t* nan
  * (packed row), lm_label, lm_weight (1 when weights == NULL); rows / inv / the lm_* group may be NULL. */
 int unimm_plan_lengths(const uint32_t* text_words, int32_t t_q_stride, int32_t t_b_stride, const uint32_t* co_words,
                        int32_t c_q_stride, int32_t c_b_stride, int32_t R, const int32_t* labels, const int32_t* weights,
-                       const float* nsp_weight, int32_t B, int32_t T, int32_t* header, void* stream);
+                       const float* nsp_weight, const int32_t* image_label, int32_t B, int32_t T, int32_t* header,
+                       void* stream);
 int unimm_plan_build(const int32_t* header, const int32_t* labels, const int32_t* weights, int32_t B, int32_t T,
                      int32_t* off, int32_t* lens, int64_t* rows, int64_t* inv, int32_t* lm_pos, int32_t* lm_idx,
                      int32_t* lm_label, int32_t* lm_weight, void* stream);

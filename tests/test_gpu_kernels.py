@@ -404,8 +404,10 @@ def test_plan_kernels_match_the_dense_formulation():
         nw = tw.shape[-1]
         tmask = (tw, 0, nw) if two_d else (tw, nw, T * nw)
         lab32, w32 = labels.cuda().int(), (weights.cuda().int() if use_w else None)
-        header = L.plan_lengths(tmask, (cw, nw, R * nw), R, lab32, w32, nspw.reshape(-1), B, T)
+        il = torch.randint(-1, 2, (B, R), generator=g)
+        header = L.plan_lengths(tmask, (cw, nw, R * nw), R, lab32, w32, nspw.reshape(-1), B, T, image_label=il.cuda().int())
         hh = header.tolist()
+        assert hh[2 * B + 2:3 * B + 2] == il.eq(1).sum(1).tolist()
         # definition on the dense tensors
         valid = am.ne(0) if two_d else (am.ne(0).any(1) | am.ne(0).any(2))
         valid = valid | cm.ne(0).any(1) | labels.ne(-1)

@@ -116,9 +116,10 @@ __global__ __launch_bounds__(256) void plan_lengths_kernel(const uint32_t* __res
                                                            const uint32_t* __restrict__ cw, int c_qs, int c_bs, int R,
                                                            const int32_t* __restrict__ labels,
                                                            const int32_t* __restrict__ weights, const float* __restrict__ nspw,
+                                                           const int32_t* __restrict__ img_label,
                                                            int B, int T, int nw, int32_t* __restrict__ header) {
   __shared__ uint32_t col[8];
-  __shared__ int red_len[4], red_cnt[4];
+  __shared__ int red_len[4], red_cnt[4], red_img[4];
   const int b = blockIdx.x, t = threadIdx.x;
   if (t < 8) col[t] = 0u;
   __syncthreads();
@@ -154,12 +155,16 @@ __global__ __launch_bounds__(256) void plan_lengths_kernel(const uint32_t* __res
   }
   int len = valid ? t + 1 : 0;
   int cnt = sel ? 1 : 0;
-  for (int o = 32; o > 0; o >>= 1) { len = max(len, __shfl_xor(len, o, 64)); cnt += __shfl_xor(cnt, o, 64); }
-  if ((t & 63) == 0) { red_len[t >> 6] = len; red_cnt[t >> 6] = cnt; }
+  int nim = (img_label != nullptr && t < R && img_label[(size_t)b * R + t] == 1) ? 1 : 0;   // regions in the masked-region loss
+  for (int o = 32; o > 0; o >>= 1) {
+    len = max(len, __shfl_xor(len, o, 64)); cnt += __shfl_xor(cnt, o, 64); nim += __shfl_xor(nim, o, 64);
+  }
+  if ((t & 63) == 0) { red_len[t >> 6] = len; red_cnt[t >> 6] = cnt; red_img[t >> 6] = nim; }
   __syncthreads();
   if (t == 0) {
     header[b] = max(1, max(max(red_len[0], red_len[1]), max(red_len[2], red_len[3])));
     header[B + b] = red_cnt[0] + red_cnt[1] + red_cnt[2] + red_cnt[3];
+    header[2 * B + 2 + b] = red_img[0] + red_img[1] + red_img[2] + red_img[3];
   }
   if (b == 0 && t < 2 && nspw != nullptr) header[2 * B + t] = __float_as_int(nspw[t]);
 }
@@ -923,11 +928,12 @@ extern "C" int unimm_embed_bwd(const unimm_embed_args* a, const void* dy, float*
 
 extern "C" int unimm_plan_lengths(const uint32_t* text_words, int32_t t_q_stride, int32_t t_b_stride, const uint32_t* co_words,
                                   int32_t c_q_stride, int32_t c_b_stride, int32_t R, const int32_t* labels, const int32_t* weights,
-                                  const float* nsp_weight, int32_t B, int32_t T, int32_t* header, void* stream) {
+                                  const float* nsp_weight, const int32_t* image_label, int32_t B, int32_t T, int32_t* header,
+                                  void* stream) {
   if (header == nullptr || (text_words == nullptr && co_words == nullptr && labels == nullptr)) return UNIMM_E_ARG;
   if (B <= 0 || T <= 0 || T > 256 || R < 0 || R > 256) return UNIMM_E_SHAPE;
   hipLaunchKernelGGL(plan_lengths_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, text_words, t_q_stride, t_b_stride,
-                     co_words, c_q_stride, c_b_stride, R, labels, weights, nsp_weight, B, T, (T + 31) / 32, header);
+                     co_words, c_q_stride, c_b_stride, R, labels, weights, nsp_weight, image_label, B, T, (T + 31) / 32, header);
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;
 }

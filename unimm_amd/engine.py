@@ -682,10 +682,13 @@ class Engine:
         w32 = self._i32(weights.reshape(B, T), dev) if (weights is not None and labels is not None) else None
         nw_in = inp.get("nsp_weight")
         nw_dev = nw_in.reshape(-1)[:2].to(F32).contiguous() if (torch.is_tensor(nw_in) and nw_in.is_cuda) else None
-        plan, sel = None, None
-        if self.unpad or want_sel or nw_dev is not None:
-            header = L.plan_lengths(tmask, comask, R, lab32, w32, nw_dev, B, T)
+        il = inp.get("image_label")
+        il32 = self._i32(il.reshape(B, R), dev) if (il is not None and inp.get("image_target") is not None) else None
+        plan, sel, n_img = None, None, None
+        if self.unpad or want_sel or nw_dev is not None or il32 is not None:
+            header = L.plan_lengths(tmask, comask, R, lab32, w32, nw_dev, B, T, image_label=il32)
             hh = header.tolist()                                          # the step's one host sync
+            n_img = sum(hh[2 * B + 2:3 * B + 2]) if il32 is not None else None
             lens_h, n_lm = hh[:B], (sum(hh[B:2 * B]) if want_sel else 0)
             Mv = sum(lens_h)
             unpadded = self.unpad and Mv < B * T
@@ -761,7 +764,7 @@ class Engine:
 
         xt32, xv32 = self._dense32(xt32), self._dense32(xv32)      # the final residual stream is an output
         out = dict(seq_out_t=seq_t, seq_out_v=seq_v, seq32_t=xt32, seq32_v=xv32, B=B, T=T, R=R, plan=plan, Mt=Mt,
-                   nsp_weight_host=st_nspw)
+                   nsp_weight_host=st_nspw, n_img=n_img, img_label32=il32)
         # ---- poolers + NSP (models/vilbert_dialog.py:946-967, 1064-1070) -------------------------
         tp, vp, nspl = self.lin["tpool"], self.lin["vpool"], self.lin["nsp"]
         cls_idx_t = var[0] if var is not None else torch.arange(0, B * T, T, dtype=torch.int32, device=dev)
@@ -867,12 +870,12 @@ class Engine:
         img = out["img"]
         C = cfg.v_target_size
         label = inp["image_label"]
-        n_img = int((label == 1).sum())
+        n_img = out["n_img"] if out.get("n_img") is not None else int((label == 1).sum())     # counted by the step plan
         tgt = inp["image_target"].to(dev, dtype=F32, non_blocking=True)
         if inp.get("image_index") is not None and tgt.shape[0] != B:
             tgt = tgt.index_select(0, inp["image_index"].to(dev, dtype=torch.int64).reshape(-1))
         tgt = tgt.contiguous().view(B * R, C)
-        lab32 = self._i32(label.reshape(-1), dev)
+        lab32 = out["img_label32"].reshape(-1) if out.get("img_label32") is not None else self._i32(label.reshape(-1), dev)
         rl, lse = torch.empty(B * R, dtype=F32, device=dev), torch.empty(B * R, dtype=F32, device=dev)
         L.kl_loss_fwd(img["pred"], tgt, lab32, rl, lse, B * R, C)
         img_loss = torch.empty(1, dtype=F32, device=dev)

@@ -366,16 +366,17 @@ def mask_synth(mode, length, nans, T):
     return text, co
 
 
-def plan_lengths(text_mask, co_mask, R, labels, weights, nsp_weight, B, T):
-    """-> int32 header [2B+2] on the device (see include/unimm_hip.h: unimm_plan_lengths).  text_mask / co_mask are
+def plan_lengths(text_mask, co_mask, R, labels, weights, nsp_weight, B, T, image_label=None):
+    """-> int32 header [3B+2] on the device (see include/unimm_hip.h: unimm_plan_lengths).  text_mask / co_mask are
     (words, q_stride, b_stride) tuples or None."""
     tw, tq, tb = text_mask if text_mask is not None else (None, 0, 0)
     cw, cq, cb = co_mask if co_mask is not None else (None, 0, 0)
     ref = tw if tw is not None else (cw if cw is not None else labels)
-    header = torch.zeros(2 * B + 2, dtype=torch.int32, device=ref.device)
-    _dev(tw, cw, labels, weights, nsp_weight)
+    header = torch.zeros(3 * B + 2, dtype=torch.int32, device=ref.device)
+    _dev(tw, cw, labels, weights, nsp_weight, image_label)
     _check(lib().unimm_plan_lengths(_ptr(tw), C.c_int32(tq), C.c_int32(tb), _ptr(cw), C.c_int32(cq), C.c_int32(cb), C.c_int32(R),
-                                    _ptr(labels), _ptr(weights), _ptr(nsp_weight), C.c_int32(B), C.c_int32(T), _ptr(header),
+                                    _ptr(labels), _ptr(weights), _ptr(nsp_weight), _ptr(image_label), C.c_int32(B), C.c_int32(T),
+                                    _ptr(header),
                                     _stream()), "unimm_plan_lengths")
     return header
 
