@@ -104,11 +104,13 @@ int mask_pack_impl(const void* m, uint32_t* out, size_t rows, int t, hipStream_t
 // Unpadded-schedule plan on the device.  The engine runs the text stream on the valid prefix of every sequence and
 // decodes only the labelled rows; both need counts on the host (allocation sizes, grid sizes), which used to cost ~25
 // eager torch kernels over the dense [B,T,T] masks, two device->host round trips at the start of forward and a
-// third in the middle of it (torch.nonzero for the labelled rows, which drained the whole encoder forward first).
+// third and fourth in the middle of it (torch.nonzero for the labelled rows and the count of masked regions, each of which
+// drained the whole encoder forward before the host could go on).
 //   plan_lengths: one workgroup per sequence, lane = token.  header[b] = valid prefix length (a token is valid when it
 //     attends something, is attended by a token or a region, carries a label or a weight; >= 1), header[B+b] = number of
 //     rows the MLM head decodes (weight != 0 when weights are given, else label != -1), header[2B..2B+1] = the bits of the
-//     two NSP class weights when they live on the device.  ONE device->host copy of the header follows.
+//     two NSP class weights when they live on the device, header[2B+2+b] = regions of the sequence that enter the
+//     masked-region loss (image_label == 1).  ONE device->host copy of the header follows: the step's only host sync.
 //   plan_build: from the header, everything else without the host: offsets, the packed-row -> padded-row map and its
 //     inverse, and the decoded rows' positions / packed indices / labels / weights in row order.
 // ------------------------------------------------------------------------------------------------
