@@ -268,3 +268,48 @@ def test_visdial_evaluate_on_the_encoder_matches_oracle_scores(golden_dir, tmp_p
     gaps = (p.sort(-1)[0].diff(dim=-1)).abs().min()
     if gaps > 2e-2:
         assert all(abs(float(got[k]) - float(want[k])) < 1e-5 for k in want)
+
+
+def test_generative_evaluate_matches_oracle_log_likelihood_ranks(golden_dir, tmp_path):
+    """val_lm.py:38-150 on the HIP path: candidates ranked by the summed log-likelihood of their answer tokens; the
+    scores agree with the oracle's dense-logits formulation (CE over all 256 rows, ignore_index=-1), chunking does not
+    change them, and the metrics / rank tensors come out of the same accumulators."""
+    from oracle import vilbert_ref as R
+    from unimm_amd import metrics, synth, trainer
+    enc = _encoder(golden_dir, tmp_path)
+    cfg = enc.bert_pretrained.config
+    sd = {k[len("bert_pretrained."):]: v.detach().float().cpu().clone() for k, v in enc.state_dict().items()}
+    b, _ = synth.make_loader_batch(n_img=2, rounds=2, samples=6, T=64, cfg=cfg, seed=43, modes=["gen"] * 24, mask_prob=0.0)
+    b["gt_option_inds"] = torch.tensor([[2, 0], [4, 5]])
+    b["gt_relevance"] = torch.tensor([[0, 0.5, 1.0, 0, 0, 0], [0.4, 0, 0, 0, 1.0, 0]])
+    b["round_id"] = torch.tensor([[1], [2]])
+    params = dict(n_gpus=1, nsp_weight=None)
+    ranks = []
+    got = trainer.generative_evaluate([b], params, 2, enc, chunk_size=8, ranks_out=ranks)
+    again = trainer.generative_evaluate([b], params, 2, enc, chunk_size=24)
+    assert got.keys() == again.keys() and all(abs(float(got[k]) - float(again[k])) < 1e-6 for k in got)
+    assert len(ranks) == 1 and ranks[0].shape == (2, 2, 6) and sorted(ranks[0][0, 0].tolist()) == [1, 2, 3, 4, 5, 6]
+    # oracle scores
+    ex = trainer.expand_image_fields({k: b[k] for k in ("tokens", "image_feat", "image_loc", "image_mask")})
+    flat = lambda t, keep: t.reshape((-1,) + tuple(t.shape[-keep:]))
+    ocfg = R.make_config(json.load(open(os.path.join(tmp_path, "small_nodrop.json"))))
+    with torch.no_grad():
+        out = R.forward(sd, ocfg, flat(b["tokens"], 1), flat(ex["image_feat"], 2), flat(ex["image_loc"], 2),
+                        token_type_ids=flat(b["segments"], 1), position_ids=flat(b["positions"], 1),
+                        attention_mask=flat(b["txt_attention_mask"], 2), image_attention_mask=flat(ex["image_mask"], 1),
+                        co_attention_mask=flat(b["co_attention_mask"], 2))
+        want = R.sequence_log_likelihood(out["pred_t"], flat(b["mask"], 1)).view(2, 2, 6)
+    model = enc.bert_pretrained
+    enc.eval()
+    with torch.no_grad():
+        s, _ = model.sequence_log_likelihood(flat(b["tokens"], 1), flat(ex["image_feat"], 2), flat(ex["image_loc"], 2), flat(b["mask"], 1),
+                                             token_type_ids=flat(b["segments"], 1), position_ids=flat(b["positions"], 1),
+                                             attention_mask=flat(b["txt_attention_mask"], 2), image_attention_mask=flat(ex["image_mask"], 1),
+                                             co_attention_mask=flat(b["co_attention_mask"], 2))
+    s = s.view(2, 2, 6).cpu()
+    assert (s - want).abs().max() <= 2e-2 * max(1.0, float(want.abs().max()))
+    sp, nd = metrics.SparseGTMetrics(), metrics.NDCG()
+    sp.observe(s, b["gt_option_inds"])
+    nd.observe(s[torch.arange(2), b["round_id"].view(-1) - 1], b["gt_relevance"])
+    mine = {**sp.retrieve(), **nd.retrieve()}
+    assert all(abs(float(got[k]) - float(mine[k])) < 1e-6 for k in mine)      # the loop adds nothing to the scorer

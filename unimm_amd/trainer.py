@@ -13,7 +13,8 @@ dataloader and the checkpoint file, without the data plane.
 * `dense_finetune_step` - one iteration of dense_annotation_finetuning.py:146-301 (row F4): one annotated
                        round of one image against its 100 options (ground truth first, the rest permuted),
                        NeuralNDCG^T + LM + weighted NSP objective, scheduler stepped before the optimizer.
-* `visdial_evaluate`  - the validation pass of train.py:180-290 (chunked NSP scoring -> SparseGTMetrics + NDCG)."""
+* `visdial_evaluate`  - the validation pass of train.py:180-290 (chunked NSP scoring -> SparseGTMetrics + NDCG).
+* `generative_evaluate` - the validation pass of val_lm.py:38-150 (candidates ranked by sequence log-likelihood)."""
 from __future__ import annotations
 
 import os
@@ -110,16 +111,12 @@ _EVAL_TEXT = (("tokens", 1), ("segments", 1), ("positions", 1), ("weights", 1), 
               ("hist_len", 0), ("txt_attention_mask", 2), ("co_attention_mask", 2))
 
 
-def visdial_evaluate(dataloader, params, eval_batch_size, dialog_encoder, chunk_size=None):
-    """Discriminative evaluation over a validation loader (train.py:180-290): every (round, option) sequence of
-    each image is scored in chunks with the NSP head, P(option is the answer) is ranked against the ground-truth
-    option (R@k, mean rank, MRR) and, on the densely annotated round, against the relevance scores (NDCG).
-    Batches hold `tokens` [eval_batch_size, rounds, options, T], `gt_option_inds`, `gt_relevance`, `round_id`."""
+def _evaluate(dataloader, params, eval_batch_size, dialog_encoder, chunk, score_chunk, collect_ranks=None):
+    """Shared loop of the two validation passes: flatten an image's (round, option) sequences, score them chunk by
+    chunk with `score_chunk(item) -> [chunk] scores (higher = better answer)`, accumulate the retrieval metrics."""
     sparse, ndcg = metrics.SparseGTMetrics(), metrics.NDCG()
     was_training = dialog_encoder.training
     dialog_encoder.eval()
-    chunk = int(chunk_size or eval_chunk_size(int(params.get("n_gpus", 1))))
-    batches = 0
     with torch.no_grad():
         for batch in dataloader:
             rounds, options = batch["tokens"].shape[1], batch["tokens"].shape[2]
@@ -133,22 +130,56 @@ def visdial_evaluate(dataloader, params, eval_batch_size, dialog_encoder, chunk_
             for k in ("image_feat", "image_loc"):
                 flat[k] = img[k].reshape((-1,) + tuple(img[k].shape[-2:]))
             flat["image_mask"] = img["image_mask"].reshape(-1, img["image_mask"].shape[-1])
-            probs = []
-            for lo in range(0, total, chunk):
-                item = {k: v[lo:lo + chunk] for k, v in flat.items()}
-                nsp_scores = harness.forward(dialog_encoder, item, params, output_nsp_scores=True, evaluation=True)[4]
-                probs.append(torch.softmax(nsp_scores.float(), dim=1)[:, 0])
-            output = torch.cat(probs).view(eval_batch_size, rounds, options)
+            scores = [score_chunk({k: v[lo:lo + chunk] for k, v in flat.items()}) for lo in range(0, total, chunk)]
+            output = torch.cat(scores).view(eval_batch_size, rounds, options)
             dev = output.device
             sparse.observe(output, batch["gt_option_inds"].to(dev))
             rid = batch["round_id"].reshape(-1).to(dev).long()
             ndcg.observe(output[torch.arange(eval_batch_size, device=dev), rid - 1, :], batch["gt_relevance"].to(dev))
-            batches += 1
+            if collect_ranks is not None:
+                collect_ranks.append(harness.scores_to_ranks(output).cpu())
     if was_training:
         dialog_encoder.train()
     out = sparse.retrieve(reset=True)
     out.update(ndcg.retrieve(reset=True))
     return out
+
+
+def visdial_evaluate(dataloader, params, eval_batch_size, dialog_encoder, chunk_size=None):
+    """Discriminative evaluation over a validation loader (train.py:180-290): every (round, option) sequence of
+    each image is scored in chunks with the NSP head, P(option is the answer) is ranked against the ground-truth
+    option (R@k, mean rank, MRR) and, on the densely annotated round, against the relevance scores (NDCG).
+    Batches hold `tokens` [eval_batch_size, rounds, options, T], `gt_option_inds`, `gt_relevance`, `round_id`."""
+    chunk = int(chunk_size or eval_chunk_size(int(params.get("n_gpus", 1))))
+
+    def score(item):
+        nsp_scores = harness.forward(dialog_encoder, item, params, output_nsp_scores=True, evaluation=True)[4]
+        return torch.softmax(nsp_scores.float(), dim=1)[:, 0]
+
+    return _evaluate(dataloader, params, eval_batch_size, dialog_encoder, chunk, score)
+
+
+def generative_evaluate(dataloader, params, eval_batch_size, dialog_encoder, chunk_size=None, average=False, ranks_out=None):
+    """Generative evaluation (val_lm.py:38-150; token-mean variant val_avg_lm.py:135 with average=True): every
+    candidate answer is scored by the sum of its tokens' log-likelihoods under the masked-LM head, the candidates of a
+    round are ranked by that score.  The reference decodes all 256 rows of every sequence into [chunk, 256, 30522]
+    logits and cross-entropies them; here only the labelled rows are decoded (`sequence_log_likelihood`).  Chunks of
+    `250 * n_gpus / 2` rounded down to the reference's size table (val_lm.py:47-49).  `ranks_out`: optional list that
+    receives the [eval_batch_size, rounds, options] rank tensors (what val_lm.py:139-149 writes to its json)."""
+    if chunk_size is None:
+        cap = 250 * (int(params.get("n_gpus", 1)) / 2)
+        sizes = [1, 2, 4, 5, 100, 1000, 200, 8, 10, 40, 50, 500, 20, 25, 250, 125]
+        chunk_size = min(sizes, key=lambda x: abs(x - cap) if x <= cap else float("inf"))
+    model = _unwrap(dialog_encoder).bert_pretrained
+
+    def score(item):
+        s, _ = model.sequence_log_likelihood(
+            item["tokens"], item["image_feat"], item["image_loc"], item["mask"], average=average,
+            token_type_ids=item["segments"], position_ids=item["positions"], attention_mask=item["txt_attention_mask"],
+            image_attention_mask=item["image_mask"], co_attention_mask=item["co_attention_mask"])
+        return s
+
+    return _evaluate(dataloader, params, eval_batch_size, dialog_encoder, int(chunk_size), score, collect_ranks=ranks_out)
 
 
 class _null:
