@@ -1,0 +1,32 @@
+"""bench.py prints ONE JSON line with the fields the driver reads (a small batch, one step; run as a child process the way
+the driver runs it)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_prints_one_json_line_with_the_contract_fields():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "12",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["higher_is_better"] is True
+    assert j["unit"] == "dialog-sequences/sec" and j["dtype"] == "bf16" and j["data"] == "synthetic" and j["vs_baseline"] is None
+    assert abs(j["value"] - 12 / (j["ms_per_step"] * 1e-3)) <= 0.01 * j["value"]
+    assert "workload" in j["config"] and "model" not in j["config"]
+    rf = j["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert rf["exclusive"] is None or rf["exclusive"]["achieved"] > 0
