@@ -26,7 +26,19 @@ __device__ __forceinline__ float row_lse(const float* __restrict__ z, int V, boo
   float m = -INFINITY, s = 0.f;
   if (vec) {
     const int nv = V >> 2;
-    for (int i = threadIdx.x; i < nv; i += 256) {
+    int i = threadIdx.x;
+    for (; i + 768 < nv; i += 1024) {        // four 16-byte loads in flight per lane (the row is read once, from HBM)
+      f32x4 a[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const f32x4*>(z + 4 * (i + 256 * u));
+      float mm = -INFINITY;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) mm = fmaxf(mm, fmaxf(fmaxf(a[u][0], a[u][1]), fmaxf(a[u][2], a[u][3])));
+      if (mm > m) { s *= __expf(m - mm); m = mm; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s += __expf(a[u][0] - m) + __expf(a[u][1] - m) + __expf(a[u][2] - m) + __expf(a[u][3] - m);
+    }
+    for (; i < nv; i += 256) {
       const f32x4 a = *reinterpret_cast<const f32x4*>(z + 4 * i);
       const float mm = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
       if (mm > m) { s *= __expf(m - mm); m = mm; }
@@ -93,15 +105,27 @@ __global__ __launch_bounds__(256) void lm_loss_bwd_kernel(const float* __restric
       coef = om >= clamp_min ? -gs * py / om : 0.f;   // d/dz of -log(clamp(1-p_y)): zero once clamped
     }
   }
-  const int nv = ldd >> 2;   // ldd % 8 == 0; columns >= V are written as zeros (K padding of the dgrad GEMM)
-  for (int i = threadIdx.x; i < nv; i += 256) {
-    float v[4];
+  // 8 columns per lane and iteration: two 16-byte loads, one 16-byte store (ldd % 8 == 0; columns >= V are written as
+  // zeros: K padding of the dgrad GEMM).  Rows of the logits are 16-byte aligned when ld % 4 == 0.
+  const int n8 = ldd >> 3;
+  const bool vec = (ld & 3) == 0;
+  for (int i = threadIdx.x; i < n8; i += 256) {
+    const int c0 = 8 * i;
+    float v[8];
+    if (vec && c0 + 8 <= V) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(z + c0), b2 = *reinterpret_cast<const f32x4*>(z + c0 + 4);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int c = 4 * i + e;
-      v[e] = (c < V) ? coef * (__expf(z[c] - lse) - (c == y ? 1.0f : 0.0f)) : 0.f;
+      for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b2[e]; }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = coef * (__expf(v[e] - lse) - (c0 + e == y ? 1.0f : 0.0f));
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = c0 + e;
+        v[e] = (c < V) ? coef * (__expf(z[c] - lse) - (c == y ? 1.0f : 0.0f)) : 0.f;
+      }
     }
-    *reinterpret_cast<u32x2*>(dz + 4 * i) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+    *reinterpret_cast<u32x4*>(dz + c0) = u32x4{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
   }
 }
 
