@@ -41,7 +41,9 @@ class DataParallelRCCL(nn.Module):
             self.arena = eng.arena
             eng.grad_bucket_hook = self._on_bucket
             if self.arena.flat.is_cuda:
-                self._comm_stream = torch.cuda.Stream(device=self.arena.flat.device)
+                # high priority: the exchange's workgroups take CUs as they free up instead of queueing behind the
+                # backward kernels that fill the chip (the point of issuing buckets early is to finish them under backward)
+                self._comm_stream = torch.cuda.Stream(device=self.arena.flat.device, priority=-1)
         else:
             named = dict(module.named_parameters())
             groups = [("all", [(n, tuple(p.shape)) for n, p in named.items()])]
