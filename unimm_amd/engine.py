@@ -87,6 +87,8 @@ class Engine:
         # directions have exchanged their K/V.  Same kernels, same order within each stream.
         self.dual_stream = os.environ.get("UNIMM_DUAL_STREAM", "1") == "1"
         self._vside = None
+        self.text_priority = os.environ.get("UNIMM_TEXT_PRIORITY", "0") == "1"
+        self._tstream = None
         self._on_side = False            # inside `_img()`: launches (and queued weight gradients) belong to the image side
         self._wq_img = []
         self._fq, self._fq_img = [], []  # pending column-partials reductions of LayerNorm backward calls, per stream
@@ -568,17 +570,34 @@ class Engine:
     # ------------------------------------------------------------------------------------------
     # forward
     # ------------------------------------------------------------------------------------------
-    def forward(self, inp: dict, train: bool, save: bool, lm_rows: str, want_pred_v: bool):
+    def _on_text_stream(self, fn, *args):
+        """Run one engine entry on the text stream.  Normally that is the caller's current stream.  With
+        UNIMM_TEXT_PRIORITY=1 (and two streams) it is an internal HIGH-priority stream bracketed by waits in both
+        directions, so that the text kernels - the critical path - are placed before the image side's."""
         if not self.arena.flat.is_cuda:
-            return self._forward(inp, train, save, lm_rows, want_pred_v)
-        with L.stream_scope(torch.cuda.current_stream()):
-            return self._forward(inp, train, save, lm_rows, want_pred_v)
+            return fn(*args)
+        caller = torch.cuda.current_stream()
+        if not (self.text_priority and self._dual()):
+            with L.stream_scope(caller):
+                return fn(*args)
+        if self._tstream is None:
+            self._tstream = torch.cuda.Stream(device=self.arena.flat.device, priority=-1)
+        hp = self._tstream
+        hp.wait_stream(caller)
+        try:
+            with torch.cuda.stream(hp), L.stream_scope(hp):
+                return fn(*args)
+        finally:
+            caller.wait_stream(hp)
+
+    def forward(self, inp: dict, train: bool, save: bool, lm_rows: str, want_pred_v: bool):
+        return self._on_text_stream(self._forward, inp, train, save, lm_rows, want_pred_v)
 
     def backward(self, out, g_lm, g_img, g_nsp, g_nsp_scores=None):
-        if not self.arena.flat.is_cuda:
-            return self._backward(out, g_lm, g_img, g_nsp, g_nsp_scores)
-        with L.stream_scope(torch.cuda.current_stream()):
-            return self._backward(out, g_lm, g_img, g_nsp, g_nsp_scores)
+        return self._on_text_stream(self._backward, out, g_lm, g_img, g_nsp, g_nsp_scores)
+
+    def losses(self, out, inp):
+        return self._on_text_stream(self._losses, out, inp)
 
     def _forward(self, inp: dict, train: bool, save: bool, lm_rows: str, want_pred_v: bool):
         """Runs the trunk + heads.  Returns a dict of outputs and (when save) the tape for backward.
@@ -853,7 +872,7 @@ class Engine:
     # ------------------------------------------------------------------------------------------
     # losses + backward
     # ------------------------------------------------------------------------------------------
-    def losses(self, out, inp):
+    def _losses(self, out, inp):
         """Three shape-[1] fp32 losses from the forward state (models/vilbert_dialog.py:1559-1621)."""
         cfg = self.cfg
         dev = self.arena.device
