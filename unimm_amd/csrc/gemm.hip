@@ -169,7 +169,7 @@ template <int MT, int KS> struct FragPipe {
 #define UNIMM_TN_SPREAD 1
 #endif
 #ifndef UNIMM_NT_PERSIST_DEFAULT
-#define UNIMM_NT_PERSIST_DEFAULT 0
+#define UNIMM_NT_PERSIST_DEFAULT 1
 #endif
 #ifndef UNIMM_EXP
 #define UNIMM_EXP 0   // bottleneck experiments of tools/exp_gemm.cpp; 0 in the product build
@@ -922,7 +922,7 @@ int launch_nt_cfg(const GemmNtParams& p, bool out_f32, hipStream_t s) {
   bool persist = false;
   if constexpr (C::STAGES != 5) {
     const int slots = (cu_count() & ~7) * C::WG_PER_CU;
-    persist = (g_nt_persist < 0 ? (UNIMM_NT_PERSIST_DEFAULT && C::NW == 4) : g_nt_persist != 0) && nwg > slots && slots > 0;
+    persist = (g_nt_persist < 0 ? UNIMM_NT_PERSIST_DEFAULT != 0 : g_nt_persist != 0) && nwg > slots && slots > 0;
     if (persist) {
       auto p32 = gemm_ntp_kernel<C, EPI, true>;
       auto p16 = gemm_ntp_kernel<C, EPI, false>;
