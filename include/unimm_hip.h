@@ -367,6 +367,11 @@ typedef struct {
 
 int unimm_neural_ndcg(const unimm_ndcg_args* args, void* stream);
 
+/* Hint for the split heuristic of unimm_gemm_tn(_grouped): on = the launches share the chip with kernels of another
+ * stream (the engine's two-stream schedule), so an under-filled last round is not idle time and fewer, longer
+ * workgroups with fewer partial tiles to drain are preferred; off (default) = the launch has the chip to itself. */
+int unimm_gemm_tn_set_shared(int32_t on);
+
 /* Launch profiler for bench.py's `roofline` block: HIP events around every GEMM launch on its own
  * stream while enabled.  Variant index: 0..11 = unimm_gemm_nt (epilogue * 2 + out_f32), 12 = unimm_gemm_tn.
  * unimm_prof_collect synchronises the events and returns per-variant summed milliseconds, algorithmic

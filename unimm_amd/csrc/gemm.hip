@@ -885,6 +885,7 @@ inline ProfRec* prof_begin(int variant, double flops, hipStream_t s) {
 }
 inline void prof_end(ProfRec* r, hipStream_t s) { if (r) hipEventRecord(r->b, s); }
 
+bool g_tn_shared = false;   // unimm_gemm_tn_set_shared
 int g_nt_gn = 0;    // 0 = automatic
 int g_nt_cfg = 0;   // 0 = auto, 1 = 128x128 BK64 x2, 2 = 256x256 BK32 x4, 3 = 256x256 BK64 x2  (unimm_gemm_set_tile)
 
@@ -1054,12 +1055,14 @@ int launch_tn_group(const unimm_gemm_tn_args* const* a, int count, bool big, hip
   int splits = 1;
   double best = 1e30;
   // cost of a split count: rounds x (steps of one workgroup + its fixed cost: pipeline fill and partial-tile
-  // drain, ~8 steps' worth); the fixed term only matters for short reductions (per-GPU batches of 30-60
+  // drain, ~8 steps' worth; 40 when the caller says the launch shares the chip with another stream's kernels
+  // (unimm_gemm_tn_set_shared): an under-filled round is then not idle time, so fewer, longer workgroups and fewer
+  // partial tiles win: 51.5 -> 50.9 ms per step at 240 sequences, neutral at 30-120; alone on the chip it costs 10 %); the fixed term only matters for short reductions (per-GPU batches of 30-60
   // sequences under strong scaling), where three rounds of 17-step workgroups lose to one round of 61
   const double steps = (double)max_m / TK;
   for (int sp = 1; sp <= max_s; ++sp) {
     const int rounds = (tiles * sp + slots - 1) / slots;
-    const double cost = rounds * (steps / sp + 8.0);
+    const double cost = rounds * (steps / sp + (g_tn_shared ? 40.0 : 8.0));
     if (cost < best * 0.98) { best = cost; splits = sp; }
   }
   for (int i = 0; i < count; ++i) {
@@ -1117,6 +1120,11 @@ extern "C" int unimm_gemm_tn_grouped(const unimm_gemm_tn_args* a, int32_t count,
 extern "C" int unimm_gemm_tn(const unimm_gemm_tn_args* a, void* stream) {
   if (a == nullptr) return UNIMM_E_ARG;
   return unimm_gemm_tn_grouped(a, 1, stream);
+}
+
+extern "C" int unimm_gemm_tn_set_shared(int32_t on) {
+  g_tn_shared = on != 0;
+  return UNIMM_OK;
 }
 
 extern "C" int unimm_prof_enable(int32_t on) {

@@ -926,6 +926,7 @@ class Engine:
         H, Hv = cfg.hidden_size, cfg.v_hidden_size
         seq_t, seq_v = out["seq_out_t"], out["seq_out_v"]
         self.arena.attach_grads()
+        L.gemm_tn_set_shared(self._dual())       # the weight-gradient launches of this backward share the chip or not
 
         def gvec(g):
             return torch.zeros(1, dtype=F32, device=dev) if g is None else g.detach().to(F32).reshape(1).contiguous()

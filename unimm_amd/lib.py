@@ -74,7 +74,7 @@ SYMBOLS = ["unimm_version", "unimm_arch", "unimm_gemm_nt", "unimm_gemm_tn", "uni
            "unimm_pack_image", "unimm_mul_dropout", "unimm_mul_dropout_bwd", "unimm_lm_loss_fwd",
            "unimm_lm_loss_bwd", "unimm_kl_loss_fwd", "unimm_kl_loss_bwd", "unimm_nsp_loss_fwd",
            "unimm_nsp_loss_bwd", "unimm_reduce_sum", "unimm_segment_sum", "unimm_gelu_bwd", "unimm_gather_rows", "unimm_prof_enable", "unimm_prof_collect", "unimm_gemm_set_tile", "unimm_attn_set_parts", "unimm_adamw_step", "unimm_transpose_cast_grouped", "unimm_mask_synth", "unimm_neural_ndcg", "unimm_plan_lengths", "unimm_plan_build", "unimm_layernorm_bwd_partials",
-           "unimm_colpartials_finish_grouped"]
+           "unimm_colpartials_finish_grouped", "unimm_gemm_tn_set_shared"]
 
 
 def _check(rc, what):
@@ -584,6 +584,10 @@ def prof_collect():
     ms, fl, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_int32 * n)()
     _check(lib().unimm_prof_collect(ms, fl, cnt, C.c_int32(n)), "unimm_prof_collect")
     return {GEMM_VARIANTS.get(i, f"variant{i}"): (ms[i], fl[i], cnt[i]) for i in range(n) if cnt[i] > 0}
+
+
+def gemm_tn_set_shared(on: bool):
+    _check(lib().unimm_gemm_tn_set_shared(C.c_int32(1 if on else 0)), "unimm_gemm_tn_set_shared")
 
 
 def gemm_set_tile(cfg: int):
