@@ -104,3 +104,12 @@ def loss_inputs(seed=21, V=30522, Vi=1601, B=2, T=24, Rg=37):
     nsl[0] = 0
     return dict(pred_t=pred_t, labels=labels, weights=weights, pred_v=pred_v, image_target=tgt,
                 image_label=img_label, nsp=nsp, next_sentence_label=nsl)
+
+
+def grad_sample_index(shape):
+    """Sampling rule of the full-size gradient fixture (tests/golden/full_b6_grads.npz): 16 evenly spaced rows x
+    every 4th column of a matrix, every 4th element of a vector."""
+    if len(shape) == 1:
+        return (slice(None, None, 4),)
+    rows = np.unique(np.linspace(0, shape[0] - 1, 16).astype(np.int64))
+    return (rows, slice(None, None, 4))

@@ -27,7 +27,7 @@ OUT = os.path.join(ROOT, "tests", "golden")
 sys.path.insert(0, ROOT)
 
 from oracle import masks as OM          # noqa: E402
-from oracle.cases import make_batch, block_inputs, embedding_inputs, loss_inputs  # noqa: E402
+from oracle.cases import make_batch, block_inputs, embedding_inputs, loss_inputs, grad_sample_index  # noqa: E402
 from oracle import vilbert_ref as R     # noqa: E402
 
 
@@ -238,6 +238,46 @@ def gen_full(vd):
          seq_out_t_rows=seq_t.reshape(-1, 768)[rows], seq_loglik=ll)
 
 
+FULLGRAD_SAMPLED = ("bert.encoder.layer.3.", "bert.encoder.layer.11.", "bert.encoder.v_layer.2.", "bert.encoder.c_layer.1.",
+                    "bert.encoder.c_layer.5.", "bert.embeddings.", "bert.v_embeddings.", "bert.t_pooler.", "bert.v_pooler.",
+                    "cls.")
+
+
+def gen_fullgrad(vd):
+    """G9: full config, B=6 (the batch of G4): gradients of (lm + img + nsp) in eval mode through the REFERENCE
+    (models/vilbert_dialog.py:1519-1624 + autograd).  Norms of all 535 tensors, sampled slices of one block of
+    every type, the embeddings and the heads (`grad_sample_index`)."""
+    cfg = R.make_config(FULL_CFG)
+    sd = R.init_state_dict(cfg, seed=5)
+    model = build_reference_model(vd, FULL_CFG, sd)
+    rng = np.random.Generator(np.random.PCG64(55))
+    modes = ["gen", "dis", "gen", "dis", "gen", "gen"]
+    negs = [0, 1, 1, 1, 1, 1]
+    b = make_batch(rng, FULL_CFG, 6, 256, 37, modes, negs, share_image=True)
+    model.zero_grad()
+    lm, img, nsp_l, seq_t, pred_t, nsp = run_reference(model, b, train=True)
+    (lm + img + nsp_l).sum().backward()
+    out = dict(lm_loss=lm, img_loss=img, nsp_loss=nsp_l)
+    names = [n for n, _ in model.named_parameters()]
+    out["grad_names"] = np.array(names)
+    out["grad_norms"] = np.array([float(p.grad.double().norm()) if p.grad is not None else -1.0
+                                  for _, p in model.named_parameters()], dtype=np.float64)
+    out["grad_absmax"] = np.array([float(p.grad.abs().max()) if p.grad is not None else -1.0
+                                   for _, p in model.named_parameters()], dtype=np.float64)
+    for n, p in model.named_parameters():
+        if p.grad is None or not n.startswith(FULLGRAD_SAMPLED):
+            continue
+        g = p.grad
+        if n.endswith("word_embeddings.weight"):          # rows that carry gradient: the batch's token ids + labels
+            ids = np.unique(np.concatenate([b["input_ids"].reshape(-1), b["masked_lm_labels"].reshape(-1)]))
+            ids = ids[ids >= 0][:: max(1, len(ids) // 48)]
+            out["grad_rowidx::" + n] = ids
+            out["grad::" + n] = g[T_(ids)][:, ::4]
+            continue
+        out["grad::" + n] = g[grad_sample_index(tuple(g.shape))] if g.dim() == 1 else g[grad_sample_index(tuple(g.shape))[0]][:, ::4]
+    save("full_b6_grads.npz", **out)
+
+
 def gen_masks(du):
     """G5: the reference's own encode_input_gen / encode_input_dis on scripted token lists."""
     out = {}
@@ -353,11 +393,11 @@ def gen_rankloss(vm):
 
 
 if __name__ == "__main__":
-    groups = sys.argv[1:] or ["masks", "ranks", "small", "blocks", "losses", "full", "sched", "rankloss"]
+    groups = sys.argv[1:] or ["masks", "ranks", "small", "blocks", "losses", "full", "sched", "rankloss", "fullgrad"]
     vd, du, vm = import_reference()
     torch.manual_seed(0)
     torch.set_num_threads(8)
     for g in groups:
         {"masks": lambda: gen_masks(du), "ranks": lambda: gen_ranks(vm), "small": lambda: gen_small(vd),
          "blocks": lambda: gen_blocks(vd), "losses": lambda: gen_losses(vd), "full": lambda: gen_full(vd),
-         "sched": gen_sched, "rankloss": lambda: gen_rankloss(vm)}[g]()
+         "sched": gen_sched, "rankloss": lambda: gen_rankloss(vm), "fullgrad": lambda: gen_fullgrad(vd)}[g]()

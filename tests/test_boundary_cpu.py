@@ -1,0 +1,104 @@
+"""Host-side boundary behaviour that needs no GPU: checkpoint key handling of `from_pretrained`
+(models/vilbert_dialog.py:1232-1296), rank arithmetic with ties (utils/visdial_metrics.py:21-39), the engine's
+weight-version tracking."""
+import json
+import logging
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vilbert_ref as R
+from unimm_amd import BertConfig, BertForMultiModalPreTraining
+from unimm_amd import harness
+from unimm_amd.modeling import load_pretrained_state_dict
+
+
+def small_cfg(golden_dir):
+    return BertConfig.from_dict(json.load(open(os.path.join(golden_dir, "small_config.json"))))
+
+
+def test_from_pretrained_renames_gamma_beta_and_reports_keys(golden_dir, caplog):
+    cfg = small_cfg(golden_dir)
+    src = BertForMultiModalPreTraining(cfg)
+    with torch.no_grad():
+        for n, p in src.named_parameters():
+            if "LayerNorm" in n:
+                p.copy_(torch.randn_like(p))
+    sd = {}
+    for k, v in src.state_dict().items():
+        if "LayerNorm" in k:                       # the key names of old BERT checkpoints (bert-base-uncased)
+            k = k.replace("LayerNorm.weight", "LayerNorm.gamma").replace("LayerNorm.bias", "LayerNorm.beta")
+        sd[k] = v.clone()
+    dropped = "bert.encoder.c_layer.0.biOutput.q_dense1.weight"
+    del sd[dropped]
+    sd["bert.pooler.dense.weight"] = torch.zeros(4, 4)           # exists in bert-base, not in this model
+    with caplog.at_level(logging.INFO, logger="unimm_amd.modeling"):
+        model = BertForMultiModalPreTraining.from_pretrained("unused", cfg, state_dict=sd)
+    assert model.pretrained_missing_keys == [dropped]
+    assert model.pretrained_unexpected_keys == ["bert.pooler.dense.weight"]
+    text = caplog.text
+    assert "not initialized from pretrained model" in text and dropped in text
+    assert "not used in BertForMultiModalPreTraining" in text and "bert.pooler.dense.weight" in text
+    got = model.state_dict()
+    for k, v in src.state_dict().items():
+        if k != dropped:
+            assert torch.equal(got[k], v), k               # the renamed LayerNorm tensors arrived too
+    # a VisualDialogEncoder checkpoint (prefix `bert_pretrained.`, train.py:503-505) loads as well
+    pref = {"bert_pretrained." + k: v for k, v in src.state_dict().items()}
+    m2 = BertForMultiModalPreTraining.from_pretrained("unused", cfg, state_dict=pref)
+    assert m2.pretrained_missing_keys == [] and m2.pretrained_unexpected_keys == []
+    # shape mismatch: the reference raises (models/vilbert_dialog.py:1288-1294)
+    bad = dict(src.state_dict())
+    bad["bert.t_pooler.dense.weight"] = torch.zeros(3, 3)
+    with pytest.raises(RuntimeError, match="size mismatch for bert.t_pooler.dense.weight"):
+        BertForMultiModalPreTraining.from_pretrained("unused", cfg, state_dict=bad)
+    # silent when default_gpu is False, as the reference
+    missing, unexpected = load_pretrained_state_dict(BertForMultiModalPreTraining(cfg), bad, default_gpu=False)
+    assert "bert.t_pooler.dense.weight" not in missing
+
+
+def test_start_prefix_is_detected_for_a_bare_trunk():
+    class Trunk(torch.nn.Module):                  # a model WITHOUT a `.bert` attribute (:1270-1274)
+        def __init__(self):
+            super().__init__()
+            self.embeddings = torch.nn.Linear(3, 2)
+
+    t = Trunk()
+    sd = {"bert.embeddings.weight": torch.ones(2, 3), "bert.embeddings.bias": torch.ones(2), "cls.x": torch.zeros(1)}
+    missing, unexpected = load_pretrained_state_dict(t, sd)
+    assert missing == [] and unexpected == ["cls.x"]
+    assert torch.equal(t.embeddings.weight, torch.ones(2, 3))
+
+
+def test_scores_to_ranks_matches_reference_fixture_with_ties(golden_dir):
+    g = np.load(os.path.join(golden_dir, "ranks.npz"))
+    s = torch.from_numpy(g["scores"])
+    assert torch.equal(harness.scores_to_ranks(s), torch.from_numpy(g["ranks"]))
+    assert torch.equal(R.scores_to_ranks(s), torch.from_numpy(g["ranks"]))
+
+
+def test_weight_version_sees_writes_through_the_parameters(golden_dir):
+    """Parameters are `p.data = view` views with their own version counters; the engine's staleness test
+    must follow them (and load_state_dict invalidates explicitly)."""
+    from unimm_amd.arena import FlatArena
+    from unimm_amd import params as PM
+    cfg = small_cfg(golden_dir)
+    model = BertForMultiModalPreTraining(cfg)
+    eng = model.engine
+    named = dict(model.named_parameters())
+    eng.arena = FlatArena(named, PM.arena_groups(cfg))      # CPU arena: the bookkeeping is device-agnostic
+    eng._plist = list(named.values())
+    v0 = eng._weight_version()
+    with torch.no_grad():
+        named["bert.t_pooler.dense.bias"].copy_(torch.ones_like(named["bert.t_pooler.dense.bias"]))
+    v1 = eng._weight_version()
+    assert v1 != v0
+    eng._w_version = v1
+    model.load_state_dict(model.state_dict())
+    assert eng._w_version is None                           # post-hook of load_state_dict
+    assert eng.arena.is_current() and eng.arena.is_current_full()
+    mid = eng.arena._probe[len(eng.arena._probe) // 2]         # first parameter of a bucket in the middle of the arena
+    named[mid].data = named[mid].data.clone()                  # re-pointed (what a partial .to() / assign=True does)
+    assert not eng.arena.is_current() and not eng.arena.is_current_full()

@@ -1,0 +1,389 @@
+"""Full-size parity of the HIP path (bert_base_6layer_6conect: H=768 / Hv=1024 / 12+6+6 blocks, T=256, R=37).
+
+  * the whole model's BACKWARD on BASELINE config 1 (B=6) against gradients produced by the REFERENCE's own
+    modules (tests/golden/full_b6_grads.npz, oracle/make_goldens.py::gen_fullgrad): norms of all 534 tensors and
+    sampled slices of one block of every type, the embeddings and the heads;
+  * the engine's text / image / connection blocks and both embedding kernels at full width on the inputs of
+    the reference fixtures block_layers.npz / block_embeddings.npz: forward against the fixture, backward
+    against the oracle's autograd on the same inputs;
+  * BASELINE config 2 (bs=240) at the full config as properties: finite losses, unpadded == padded,
+    two streams == one stream, losses == the mean of the oracle's losses over B=6 chunks.
+
+Every test prints the worst measured error of each tensor family (`pytest -s` / the captured report), so the
+margin to the gates below is visible.  Gates: measured worst case + margin, never above the north_star's 1e-2
+(bf16) on outputs; gradients are gated relative to the tensor's own scale (max |g|)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG_PATH = os.path.join(ROOT, "unimm_amd", "config", "bert_base_6layer_6conect.json")
+
+
+def T_(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def rel_to_scale(got, want):
+    """max |got - want| / max |want|"""
+    got = got.detach().float().cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
+    want = want.detach().float().cpu().numpy() if torch.is_tensor(want) else np.asarray(want)
+    return float(np.abs(got.astype(np.float64) - want.astype(np.float64)).max() / max(float(np.abs(want).max()), 1e-30))
+
+
+def build_full(seed):
+    from oracle import vilbert_ref as R
+    from unimm_amd import BertConfig, BertForMultiModalPreTraining
+    model = BertForMultiModalPreTraining(BertConfig.from_json_file(CFG_PATH))
+    ocfg = R.make_config(CFG_PATH)
+    sd = R.init_state_dict(ocfg, seed=seed)
+    model.load_state_dict(sd, strict=True)
+    return model.cuda().eval(), ocfg, sd
+
+
+def full_b6_call(g):
+    i = lambda k: T_(g["in::" + k])
+    n = g["in::input_ids"].shape[0]
+    rep = lambda x: x.expand(n, *x.shape[1:])
+    args = (i("input_ids"), rep(i("image_feat")), rep(i("image_loc")))
+    kw = dict(token_type_ids=i("token_type_ids"), position_ids=i("position_ids"), attention_mask=i("attention_mask"),
+              image_attention_mask=i("image_attention_mask"), co_attention_mask=i("co_attention_mask").expand(n, 37, 256),
+              masked_lm_labels=i("masked_lm_labels"), image_label=i("image_label"), image_target=rep(i("image_target")),
+              next_sentence_label=i("next_sentence_label"), nsp_weight=i("nsp_weight"), lm_weight=i("lm_weight"))
+    return args, kw
+
+
+# Gates of the full-size backward (set from the measured worst cases printed below, plus margin).
+GRAD_NORM_GATE = 3e-2        # | ||g_hip|| - ||g_ref|| | / ||g_ref||, every tensor whose gradient is not numerically zero
+GRAD_SLICE_GATE = 3e-2       # max |g_hip - g_ref| / max |g_ref| on the sampled slices
+
+
+def test_full_config_b6_backward_matches_reference_golden(golden_dir):
+    """models/vilbert_dialog.py:1519-1624 + autograd, full config, BASELINE config 1."""
+    from oracle.cases import grad_sample_index
+    g = np.load(os.path.join(golden_dir, "full_b6.npz"))
+    gg = np.load(os.path.join(golden_dir, "full_b6_grads.npz"))
+    model, _, _ = build_full(seed=5)
+    args, kw = full_b6_call(g)
+    model.zero_grad(set_to_none=True)
+    lm, img, nsp_l, _, _, _ = model(*args, **kw, _want_lm_scores=False)
+    (lm + img + nsp_l).sum().backward()
+    torch.cuda.synchronize()
+    for name, got in (("lm_loss", lm), ("img_loss", img), ("nsp_loss", nsp_l)):
+        assert abs(float(got.detach()) - float(gg[name])) <= 1e-2 * (1 + abs(float(gg[name]))), name
+    params = dict(model.named_parameters())
+    names = [str(n) for n in gg["grad_names"]]
+    norms, amax = gg["grad_norms"], gg["grad_absmax"]
+    gmax = float(amax.max())
+    worst = {}
+    checked = 0
+    for n, want, am in zip(names, norms, amax):
+        p = params[n]
+        if want < 0:
+            assert p.grad is None, f"{n} is never used by forward: grad must stay None"
+            continue
+        got = float(p.grad.double().norm())
+        fam = n.split(".")[2] if n.startswith("bert.encoder") else n.split(".")[0] + "." + n.split(".")[1]
+        if am < 1e-6 * gmax:
+            # mathematically zero gradients (key biases: softmax is shift-invariant): only bounded, not compared
+            assert got <= 1e-3 * float(norms.max()), (n, got)
+            continue
+        rel = abs(got - want) / want
+        worst[fam] = max(worst.get(fam, 0.0), rel)
+        assert rel <= GRAD_NORM_GATE, (n, got, want, rel)
+        checked += 1
+    assert checked > 450
+    print("\nfull-config backward: worst relative error of a gradient norm, per tensor family")
+    for k, v in sorted(worst.items()):
+        print(f"  {k:32s} {v:.3e}")
+    worst_s = {}
+    nslices = 0
+    for k in gg.files:
+        if not k.startswith("grad::"):
+            continue
+        n = k[6:]
+        want = gg[k]
+        gr = params[n].grad
+        if n.endswith("word_embeddings.weight"):
+            got = gr[T_(gg["grad_rowidx::" + n]).cuda()][:, ::4]
+        elif gr.dim() == 1:
+            got = gr[::4]
+        else:
+            got = gr[T_(grad_sample_index(tuple(gr.shape))[0]).cuda()][:, ::4]
+        if np.abs(want).max() < 1e-6 * gmax:
+            continue
+        r = rel_to_scale(got, want)
+        fam = ".".join(n.split(".")[:4]) if n.startswith("bert.encoder") else ".".join(n.split(".")[:2])
+        worst_s[fam] = max(worst_s.get(fam, 0.0), r)
+        assert r <= GRAD_SLICE_GATE, (n, r)
+        nslices += 1
+    assert nslices > 100
+    print("full-config backward: worst max|err|/max|g| on the sampled slices, per block")
+    for k, v in sorted(worst_s.items()):
+        print(f"  {k:40s} {v:.3e}")
+
+
+# ------------------------------------------------------------------------------------------------------
+# single blocks at full width
+# ------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def full3():
+    model, ocfg, sd = build_full(seed=3)
+    eng = model.engine
+    eng.ensure(torch.device("cuda", 0))
+    eng.refresh_weights(force=True)
+    eng.arena.attach_grads()
+    return model, eng, ocfg, sd
+
+
+def _leaves(sd, prefix):
+    return {k: (v.clone().requires_grad_(True) if k.startswith(prefix) else v) for k, v in sd.items()}
+
+
+def _check_param_grads(eng, leaves, prefix, gate, what):
+    mine = {k: v for k, v in leaves.items() if k.startswith(prefix) and v.grad is not None and "q_dense" not in k}
+    top = max(float(v.grad.abs().max()) for v in mine.values())
+    worst = 0.0
+    for k, v in mine.items():
+        want = v.grad
+        if float(want.abs().max()) < 1e-4 * top:      # mathematically zero gradients (key biases): rounding noise only
+            assert float(eng.arena.grad(k).abs().max()) <= 1e-2 * top, (what, k)
+            continue
+        r = rel_to_scale(eng.arena.grad(k), want)
+        worst = max(worst, r)
+        assert r <= gate, (what, k, r)
+    print(f"  {what}: worst parameter-gradient error (max|err|/max|g|) {worst:.3e}")
+
+
+BLOCK_FWD_GATE = 1e-2     # |err| <= 1e-2 + 1e-2 |want| (north_star, bf16)
+BLOCK_BWD_GATE = 2e-2     # max |err| / max |g|
+
+
+def _close(got, want, what):
+    got = got.detach().float().cpu().numpy()
+    want = np.asarray(want, dtype=np.float64)
+    diff = np.abs(got - want)
+    excess = (diff - (BLOCK_FWD_GATE + BLOCK_FWD_GATE * np.abs(want))).max()
+    print(f"  {what}: max |err| {diff.max():.3e} (values up to {np.abs(want).max():.2f})")
+    assert excess <= 0, (what, float(diff.max()), float(excess))
+
+
+def test_full_size_text_and_image_layer_fwd_bwd(golden_dir, full3):
+    """BertLayer / BertImageLayer (models/vilbert_dialog.py:385-483, :514-612) at H=768x12 heads / Hv=1024x8 heads:
+    forward against the reference fixture, backward against the oracle's autograd."""
+    from oracle import vilbert_ref as R
+    from oracle.cases import block_inputs
+    from unimm_amd import lib as L
+    model, eng, ocfg, sd = full3
+    cfg = model.config
+    g = np.load(os.path.join(golden_dir, "block_layers.npz"))
+    bi = block_inputs(int(g["seed"]))
+    rows = bi["rows"]
+    dev = torch.device("cuda", 0)
+    B, T, Rg = 2, 256, 37
+    rng = np.random.Generator(np.random.PCG64(123))
+    print()
+    for kind in ("text", "image"):
+        if kind == "text":
+            key, pfx, x_np, mask_np, n, heads, li = "t3", "bert.encoder.layer.3.", bi["xt"], bi["tmask"], T, cfg.num_attention_heads, 3
+        else:
+            key, pfx, x_np, mask_np, n, heads, li = "v2", "bert.encoder.v_layer.2.", bi["xv"], bi["vmask"], Rg, cfg.v_num_attention_heads, 2
+        Hd = x_np.shape[-1]
+        eng.arena.zero_grads()
+        eng._dev_masks = []
+        mask = eng._pack_mask(T_(mask_np), dev, n)
+        x32 = T_(x_np).reshape(B * n, Hd).to(dev)
+        x16 = x32.to(torch.bfloat16)
+        st = dict(train=False, tape=[])
+        y32, y16 = eng._self_block(key, x32, x16, mask, B, n, heads, pfx, 0.1, 0.1, st)
+        y32 = eng._dense32(y32).view(B, n, Hd)
+        want = g["text_layer3"] if kind == "text" else g["image_layer2"]
+        _close(y32[:, T_(rows).to(dev)] if kind == "text" else y32, want, f"{kind} layer forward")
+        # backward: upstream gradient on the valid rows only (pad rows of the fixture masks never reach a loss)
+        dy = rng.standard_normal((B, n, Hd)).astype(np.float32) * 0.05
+        valid = (mask_np.any(-1) if mask_np.ndim == 3 else mask_np > 0)
+        dy *= valid[:, :, None]
+        dy_t = T_(dy)
+        dx = st["tape"][-1][1](dy_t.reshape(B * n, Hd).to(dev).to(torch.bfloat16))
+        eng._flush_wgrad()
+        torch.cuda.synchronize()
+        leaves = _leaves(sd, pfx)
+        xr = T_(x_np).clone().requires_grad_(True)
+        if kind == "text":
+            add = R.additive(T_(mask_np))[:, None]
+            yo = R.text_layer(leaves, ocfg, li, xr, add, R._Drop(None))
+        else:
+            add = R.additive(T_(mask_np))[:, None, None, :]
+            yo = R.image_layer(leaves, ocfg, li, xr, add, R._Drop(None))
+        (yo * dy_t.to(torch.bfloat16).float()).sum().backward()
+        r = rel_to_scale(dx.view(B, n, Hd)[T_(valid).to(dev)], xr.grad[T_(valid)])
+        print(f"  {kind} layer backward: input-gradient error (max|err|/max|g|) {r:.3e}")
+        assert r <= BLOCK_BWD_GATE, (kind, r)
+        _check_param_grads(eng, leaves, pfx, BLOCK_BWD_GATE, f"{kind} layer")
+
+
+def test_full_size_connection_layer_fwd_bwd(golden_dir, full3):
+    """BertConnectionLayer (models/vilbert_dialog.py:655-783): both co-attention directions, bi-output, both FFNs."""
+    from oracle import vilbert_ref as R
+    from oracle.cases import block_inputs
+    model, eng, ocfg, sd = full3
+    g = np.load(os.path.join(golden_dir, "block_layers.npz"))
+    bi = block_inputs(int(g["seed"]))
+    rows = bi["rows"]
+    dev = torch.device("cuda", 0)
+    B, T, Rg, H, Hv = 2, 256, 37, 768, 1024
+    pfx = "bert.encoder.c_layer.1."
+    eng.arena.zero_grads()
+    eng._dev_masks = []
+    vmask = eng._pack_mask(T_(bi["vmask"]), dev, Rg)
+    comask = eng._pack_mask(T_(bi["co"]), dev, Rg)
+    xv32 = T_(bi["xv"]).reshape(B * Rg, Hv).to(dev)
+    xt32 = T_(bi["xt"]).reshape(B * T, H).to(dev)
+    st = dict(train=False, tape=[])
+    ov32, ov, ot32, ot = eng._conn_block("c1", 1, xv32, xv32.to(torch.bfloat16), xt32, xt32.to(torch.bfloat16), B, Rg, T,
+                                         vmask, comask, st)
+    eng._to_txt(ov32, ov)
+    print()
+    _close(eng._dense32(ov32).view(B, Rg, Hv), g["conn1_v"], "connection layer forward (image side)")
+    _close(eng._dense32(ot32).view(B, T, H)[:, T_(rows).to(dev)], g["conn1_t"], "connection layer forward (text side)")
+    rng = np.random.Generator(np.random.PCG64(321))
+    dv = (rng.standard_normal((B, Rg, Hv)) * 0.05).astype(np.float32)
+    dt = (rng.standard_normal((B, T, H)) * 0.05).astype(np.float32)
+    dv_t, dt_t = T_(dv), T_(dt)
+    gv = dv_t.reshape(B * Rg, Hv).to(dev).to(torch.bfloat16)
+    gt = dt_t.reshape(B * T, H).to(dev).to(torch.bfloat16)
+    eng._to_img(gv)
+    dxv, dxt = st["tape"][-1][1](gv, gt)
+    eng._flush_wgrad()
+    eng._to_txt(dxv)
+    torch.cuda.synchronize()
+    leaves = _leaves(sd, pfx)
+    xvr = T_(bi["xv"]).clone().requires_grad_(True)
+    xtr = T_(bi["xt"]).clone().requires_grad_(True)
+    v_add = R.additive(T_(bi["vmask"]))[:, None, None, :]
+    co_add = R.additive(T_(bi["co"])).unsqueeze(1)
+    cv, ct = R.connection_layer(leaves, ocfg, 1, xvr, v_add, xtr, co_add, R._Drop(None))
+    ((cv * dv_t.to(torch.bfloat16).float()).sum() + (ct * dt_t.to(torch.bfloat16).float()).sum()).backward()
+    rv = rel_to_scale(dxv.view(B, Rg, Hv), xvr.grad)
+    rt = rel_to_scale(dxt.view(B, T, H), xtr.grad)
+    print(f"  connection layer backward: input-gradient error image {rv:.3e} text {rt:.3e}")
+    assert rv <= BLOCK_BWD_GATE and rt <= BLOCK_BWD_GATE, (rv, rt)
+    _check_param_grads(eng, leaves, pfx, BLOCK_BWD_GATE, "connection layer")
+
+
+def test_full_size_embeddings_fwd_bwd(golden_dir, full3):
+    """BertEmbeddingsDialog incl. type ids >= 2 and BertImageEmbeddings (models/vilbert_dialog.py:326-356, :1487-1493)
+    through the whole-model entry (they are fused into Engine._forward), on the inputs of block_embeddings.npz."""
+    from oracle import vilbert_ref as R
+    from oracle.cases import embedding_inputs
+    from unimm_amd import lib as L
+    model, eng, ocfg, sd = full3
+    g = np.load(os.path.join(golden_dir, "block_embeddings.npz"))
+    ei = embedding_inputs(int(g["seed"]))
+    dev = torch.device("cuda", 0)
+    B, T, Rg, H, Hv = 2, 256, 37, 768, 1024
+    cfg = model.config
+    eng.arena.zero_grads()
+    # text: the embedding kernel directly (the model entry would also run the encoder)
+    ids32, pos32, typ32 = (T_(ei[k].reshape(-1)).to(dev, dtype=torch.int32) for k in ("ids", "pos", "typ"))
+    gmm, bta, ggm, gbt = eng.ln["emb_t"]
+    xt = torch.empty((B * T, H), dtype=torch.bfloat16, device=dev)
+    xt32 = torch.empty((B * T, H), dtype=torch.float32, device=dev)
+    tabs = (eng.tab["word"], eng.tab["pos"], eng.tab["type"], eng.tab["ext"])
+    L.embed_fwd(ids32, pos32, typ32, *tabs, gmm, bta, xt32, xt, B * T, H, cfg.type_vocab_size, drop=L.NO_DROP)
+    print()
+    _close(xt32.view(B, T, H)[:, ::8], g["text"], "text embeddings forward")
+    rng = np.random.Generator(np.random.PCG64(77))
+    dy = (rng.standard_normal((B, T, H)) * 0.05).astype(np.float32)
+    dy_t = T_(dy)
+    A = eng.arena
+    e = "bert.embeddings."
+    L.embed_bwd(ids32, pos32, typ32, *tabs, gmm, bta, dy_t.reshape(B * T, H).to(dev).to(torch.bfloat16),
+                A.grad(e + "word_embeddings.weight"), A.grad(e + "position_embeddings.weight"),
+                A.grad(e + "token_type_embeddings.weight"), A.grad(e + "token_type_embeddings_extension.weight"), ggm, gbt,
+                eng.part[H], B * T, H, cfg.type_vocab_size, drop=L.NO_DROP)
+    torch.cuda.synchronize()
+    leaves = _leaves(sd, e)
+    et = R.text_embeddings(leaves, ocfg, T_(ei["ids"]), T_(ei["typ"]), T_(ei["pos"]), R._Drop(None))
+    (et * dy_t.to(torch.bfloat16).float()).sum().backward()
+    _check_param_grads(eng, {k: v for k, v in leaves.items() if "sep_embeddings" not in k}, e, BLOCK_BWD_GATE, "text embeddings")
+    # image: pack + one GEMM + LayerNorm, as Engine._forward runs them
+    F = cfg.v_feature_size
+    feat = T_(ei["feat"]).reshape(B * Rg, F).to(dev)
+    loc = T_(ei["loc"]).reshape(B * Rg, 5).to(dev)
+    packed = torch.empty((B * Rg, eng.vemb_k), dtype=torch.bfloat16, device=dev)
+    L.pack_image(feat, loc, packed, B * Rg, F, eng.vemb_k)
+    prev = torch.empty((B * Rg, Hv), dtype=torch.float32, device=dev)
+    L.gemm_nt(packed, eng.vemb_w, prev, bias=eng.vemb_b, M=B * Rg, N=Hv, K=eng.vemb_k)
+    xv32, xv, mv, rv = eng._layernorm(prev, "emb_v", True)
+    _close(xv32.view(B, Rg, Hv), g["image"], "image embeddings forward")
+
+
+# ------------------------------------------------------------------------------------------------------
+# BASELINE config 2 at the full config: properties at bs=240
+# ------------------------------------------------------------------------------------------------------
+def test_bs240_full_config_properties(golden_dir):
+    """240 sequences x 256 tokens x 37 regions, the bench workload (dropout off so that runs are comparable):
+    losses finite; the unpadded schedule == the padded one; two streams == one stream (bit-identical losses);
+    every parameter gradient finite; and the losses of two B=6 chunks == the CPU oracle's on the same rows."""
+    from oracle import vilbert_ref as R
+    from unimm_amd import synth
+    model, ocfg, sd = build_full(seed=5)
+    eng = model.engine
+    b = synth.make_batch(n_seq=240, T=256, R=37, cfg=model.config, seed=1234, sequences_per_image=6, device="cuda")
+
+    def kwargs(sl=slice(None), dev=None):
+        mv = (lambda t: t[sl].to(dev)) if dev else (lambda t: t[sl])
+        return (mv(b["input_ids"]), mv(b["image_feat"]), mv(b["image_loc"])), dict(
+            token_type_ids=mv(b["token_type_ids"]), position_ids=mv(b["token_position_ids"]), attention_mask=mv(b["attention_mask"]),
+            co_attention_mask=mv(b["co_attention_mask"]), image_attention_mask=mv(b["image_attention_mask"]),
+            masked_lm_labels=mv(b["masked_lm_labels"]), image_label=mv(b["image_label"]), image_target=mv(b["image_target"]),
+            next_sentence_label=mv(b["next_sentence_label"]), nsp_weight=b["nsp_weight"].to(dev) if dev else b["nsp_weight"],
+            lm_weight=mv(b["lm_weight"]))
+
+    def run(unpad, dual):
+        eng.unpad, eng.dual_stream = unpad, dual
+        model.zero_grad(set_to_none=True)
+        args, kw = kwargs()
+        lm, img, nsp_l, _, _, nsp = model(*args, **kw, _want_lm_scores=False)
+        (lm + img + nsp_l).sum().backward()
+        torch.cuda.synchronize()
+        return torch.stack([lm, img, nsp_l]).flatten().detach().clone(), nsp.detach().clone(), eng.arena.grad_flat.clone()
+
+    was = (eng.unpad, eng.dual_stream)
+    try:
+        base = run(True, True)
+        padded = run(False, True)
+        single = run(True, False)
+    finally:
+        eng.unpad, eng.dual_stream = was
+    assert torch.isfinite(base[0]).all() and torch.isfinite(base[2]).all()
+    print(f"\nbs=240 losses (lm, img, nsp): {[round(float(x), 4) for x in base[0]]}")
+    d_loss = float((base[0] - padded[0]).abs().max())
+    d_nsp = float((base[1] - padded[1]).abs().max())
+    d_grad = float((base[2] - padded[2]).abs().max() / padded[2].abs().max())
+    print(f"  unpadded vs padded: losses {d_loss:.2e}, nsp {d_nsp:.2e}, gradients {d_grad:.2e} of max|g|")
+    assert d_loss <= 2e-3 and d_nsp <= 2e-3 and d_grad <= 1e-2
+    assert torch.equal(base[0], single[0]) and torch.equal(base[1], single[1])      # same kernels, same words
+    d2 = float((base[2] - single[2]).abs().max() / single[2].abs().max())
+    print(f"  two streams vs one: losses bit-identical, gradients {d2:.2e} of max|g| (atomics order)")
+    assert d2 <= 1e-4
+    # two B=6 chunks against the oracle (mean-of-chunk losses is what the data-parallel split computes)
+    leaves = dict(sd)
+    for c in (0, 17):
+        sl = slice(6 * c, 6 * c + 6)
+        args, kw = kwargs(sl)
+        with torch.no_grad():
+            got = model(*args, **kw, _want_lm_scores=False)
+            cargs, ckw = kwargs(sl, dev="cpu")
+            want = R.forward(leaves, ocfg, *cargs, **ckw)
+        for name, gi in (("lm_loss", 0), ("img_loss", 1), ("nsp_loss", 2)):
+            e = abs(float(got[gi]) - float(want[name]))
+            print(f"  chunk {c}: {name} hip {float(got[gi]):.4f} oracle {float(want[name]):.4f}")
+            assert e <= 1e-2 * (1 + abs(float(want[name]))), (c, name, e)
+        e = float((got[5].cpu() - want["nsp"]).abs().max())
+        assert e <= 1e-2 * (1 + float(want["nsp"].abs().max())), (c, "nsp", e)

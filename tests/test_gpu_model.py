@@ -343,3 +343,83 @@ def test_image_side_stream_schedule_equals_single_stream(golden_dir):
         for (l0, n0, g0), (l1, n1, g1) in zip(ref, seq):
             assert l0 == l1 and torch.equal(n0, n1)
             assert torch.isfinite(g1).all() and (g0 - g1).abs().max() <= 1e-5 * g0.abs().max()
+
+
+def test_weights_loaded_after_a_forward_reach_the_kernels(golden_dir):
+    """forward, then load_state_dict (a second checkpoint in one process, a warm start after a sanity
+    forward), then forward: the kernels must compute with the NEW weights (bf16 copies, transposed copies, the fused
+    image-embedding operand), i.e. match a fresh model that loaded them before its first forward.  The same through
+    writes to the Parameters (`p.copy_`)."""
+    from oracle import vilbert_ref as R
+    model, ocfg, sd = build_small(golden_dir)
+    model.eval()
+    g = np.load(os.path.join(golden_dir, "small_mixed.npz"))
+    args, kw = kwargs_from(g)
+    with torch.no_grad():
+        first = [float(x) for x in model(*args, **kw, _want_lm_scores=False)[:3]]
+    sd2 = R.init_state_dict(ocfg, seed=29)
+    model.load_state_dict(sd2, strict=True)
+    fresh, _, _ = build_small(golden_dir)
+    fresh.eval()
+    fresh.load_state_dict(sd2, strict=True)
+    with torch.no_grad():
+        got = model(*args, **kw, _want_lm_scores=False)
+        want = fresh(*args, **kw, _want_lm_scores=False)
+    assert [float(x) for x in got[:3]] == [float(x) for x in want[:3]] and torch.equal(got[5], want[5])
+    assert [float(x) for x in got[:3]] != first
+    with torch.no_grad():                             # a write through one Parameter
+        p = dict(model.named_parameters())["cls.bi_seq_relationship.weight"]
+        p.copy_(p * 2.0)
+        q = dict(fresh.named_parameters())["cls.bi_seq_relationship.weight"]
+        q.copy_(q * 2.0)
+        got = model(*args, **kw, _want_lm_scores=False)
+        want = fresh(*args, **kw, _want_lm_scores=False)
+    assert torch.equal(got[5], want[5]) and float(got[2]) == float(want[2])
+
+
+def test_equal_hidden_sizes_two_streams_equal_one_stream(golden_dir):
+    """hidden_size == v_hidden_size (the BertConfig default 768/768): the image stream's embedding backward
+    and the text stream's must not share one column-partials scratch buffer.  Gradients of the embedding LayerNorms,
+    the image-embedding biases and the token-type rows equal the one-stream run, repeatedly."""
+    from oracle import vilbert_ref as R
+    from unimm_amd import BertConfig, BertForMultiModalPreTraining, synth
+    cfgd = json.load(open(os.path.join(golden_dir, "small_config.json")))
+    cfgd.update(v_hidden_size=128, bi_hidden_size=128, v_intermediate_size=128)
+    model = BertForMultiModalPreTraining(BertConfig.from_dict(cfgd))
+    model.load_state_dict(R.init_state_dict(R.make_config(cfgd), seed=13), strict=True)
+    model = model.cuda().eval()
+    eng = model.engine
+    b = synth.make_batch(n_seq=24, T=64, R=37, cfg=model.config, seed=5, sequences_per_image=6, device="cuda")
+    kw = dict(token_type_ids=b["token_type_ids"], position_ids=b["token_position_ids"], attention_mask=b["attention_mask"],
+              co_attention_mask=b["co_attention_mask"], image_attention_mask=b["image_attention_mask"],
+              masked_lm_labels=b["masked_lm_labels"], image_label=b["image_label"], image_target=b["image_target"],
+              next_sentence_label=b["next_sentence_label"], nsp_weight=b["nsp_weight"], lm_weight=b["lm_weight"], _want_lm_scores=False)
+    names = ["bert.embeddings.LayerNorm.weight", "bert.embeddings.LayerNorm.bias", "bert.v_embeddings.LayerNorm.weight",
+             "bert.v_embeddings.LayerNorm.bias", "bert.v_embeddings.image_embeddings.bias",
+             "bert.v_embeddings.image_location_embeddings.bias", "bert.embeddings.token_type_embeddings.weight"]
+    was = eng.dual_stream
+    try:
+        res = {}
+        for dual in (False, True, True, True):
+            eng.dual_stream = dual
+            model.zero_grad(set_to_none=True)
+            r = model(b["input_ids"], b["image_feat"], b["image_loc"], **kw)
+            (r[0] + r[1] + r[2]).sum().backward()
+            torch.cuda.synchronize()
+            cur = {n: eng.arena.grad(n).clone() for n in names}
+            if not dual:
+                res = cur
+                continue
+            for n in names:
+                assert torch.isfinite(cur[n]).all()
+                assert (cur[n] - res[n]).abs().max() <= 1e-5 * res[n].abs().max() + 1e-12, n
+    finally:
+        eng.dual_stream = was
+
+
+def test_scores_to_ranks_on_the_device_matches_reference_fixture_with_ties(golden_dir):
+    """utils/visdial_metrics.py:21-39 incl. the tie cases of tests/golden/ranks.npz (produced by the reference)."""
+    from unimm_amd.harness import scores_to_ranks
+    g = np.load(os.path.join(golden_dir, "ranks.npz"))
+    got = scores_to_ranks(T_(g["scores"]).cuda())
+    assert got.is_cuda and torch.equal(got.cpu(), T_(g["ranks"]))

@@ -172,3 +172,55 @@ def test_full_config_b6(golden_dir):
     close(out["seq_out_t"].reshape(-1, 768)[rows], g["seq_out_t_rows"], tol=5e-5, what="seq_out_t")
     ll = R.sequence_log_likelihood(out["pred_t"], i("masked_lm_labels"))
     close(ll, g["seq_loglik"], tol=5e-5, what="sequence log-likelihood")
+
+
+def test_full_config_b6_gradients(golden_dir):
+    """G9: the oracle's autograd at the full config against the gradients the REFERENCE produced on the same batch
+    (norms of every tensor + the sampled slices): pins the oracle as the checker of the full-size GPU backward tests."""
+    from oracle.cases import grad_sample_index
+    g = np.load(os.path.join(golden_dir, "full_b6.npz"))
+    gg = np.load(os.path.join(golden_dir, "full_b6_grads.npz"))
+    cfg = R.make_config(os.path.join(os.path.dirname(os.path.dirname(__file__)), "unimm_amd", "config",
+                                     "bert_base_6layer_6conect.json"))
+    sd = R.init_state_dict(cfg, seed=5)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != R.TIED[0]}
+    leaves[R.TIED[0]] = leaves[R.TIED[1]]
+    i = lambda k: T_(g["in::" + k])
+    n = g["in::input_ids"].shape[0]
+    rep = lambda x: x.expand(n, *x.shape[1:])
+    out = R.forward(leaves, cfg, i("input_ids"), rep(i("image_feat")), rep(i("image_loc")),
+                    token_type_ids=i("token_type_ids"), position_ids=i("position_ids"),
+                    attention_mask=i("attention_mask"), image_attention_mask=i("image_attention_mask"),
+                    co_attention_mask=i("co_attention_mask").expand(n, 37, 256),
+                    masked_lm_labels=i("masked_lm_labels"), image_label=i("image_label"),
+                    image_target=rep(i("image_target")), next_sentence_label=i("next_sentence_label"),
+                    nsp_weight=i("nsp_weight"), lm_weight=i("lm_weight"))
+    (out["lm_loss"] + out["img_loss"] + out["nsp_loss"]).sum().backward()
+    gmax = float(gg["grad_absmax"].max())
+    checked = 0
+    for name, want, am in zip(gg["grad_names"], gg["grad_norms"], gg["grad_absmax"]):
+        name = str(name)
+        got = leaves[name].grad
+        if want < 0:
+            assert got is None or float(got.abs().max()) == 0.0, name
+            continue
+        if am < 1e-6 * gmax:      # mathematically zero (key biases): both sides hold rounding noise only
+            continue
+        assert abs(float(got.double().norm()) - want) <= 2e-4 * want, (name, float(got.norm()), want)
+        checked += 1
+    assert checked > 450
+    for k in gg.files:
+        if not k.startswith("grad::"):
+            continue
+        name = k[6:]
+        gr = leaves[name].grad
+        if name.endswith("word_embeddings.weight"):
+            got = gr[T_(gg["grad_rowidx::" + name])][:, ::4]
+        elif gr.dim() == 1:
+            got = gr[::4]
+        else:
+            got = gr[T_(grad_sample_index(tuple(gr.shape))[0])][:, ::4]
+        if np.abs(gg[k]).max() < 1e-6 * gmax:
+            continue
+        err = np.abs(got.numpy() - gg[k]).max()
+        assert err <= 2e-4 * np.abs(gg[k]).max(), (k, err)

@@ -46,6 +46,14 @@ class FlatArena:
                 view.copy_(p.data.to(self.device))
                 p.data = view
         self._grads_attached = False
+        probe = []
+        for _, items in groups:
+            for name, _ in items:
+                if name in named_params:
+                    probe.append(name)
+                    break
+        last = [n for n in self.offsets if n in named_params][-1:]
+        self._probe = list(dict.fromkeys(probe + last))
 
     # -- views ---------------------------------------------------------------------------------
     def view(self, name, buf=None):
@@ -60,10 +68,18 @@ class FlatArena:
 
     def is_current(self) -> bool:
         """False once something (module.to(), load of new Parameters) re-pointed the parameters."""
-        for name, p in self.params.items():
-            o, _ = self.offsets[name]
-            return p.data_ptr() == self.flat.data_ptr() + 4 * o and p.device == self.flat.device
+        base = self.flat.data_ptr()
+        for name in self._probe:                      # first parameter of every bucket + the last parameter
+            p = self.params[name]
+            if p.device != self.flat.device or p.data_ptr() != base + 4 * self.offsets[name][0]:
+                return False
         return True
+
+    def is_current_full(self) -> bool:
+        """Every parameter checked (used before an optimizer / data-parallel wrapper caches the arena)."""
+        base = self.flat.data_ptr()
+        return all(p.device == self.flat.device and p.data_ptr() == base + 4 * self.offsets[n][0]
+                   for n, p in self.params.items())
 
     # -- gradients -----------------------------------------------------------------------------
     def attach_grads(self):

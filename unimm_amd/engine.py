@@ -93,6 +93,12 @@ class Engine:
         self._wq_img = []
         self._fq, self._fq_img = [], []  # pending column-partials reductions of LayerNorm backward calls, per stream
         self.last_plan = None
+        self._arena_users = []           # weakrefs of objects that cache `self.arena` (FusedAdamW, DataParallelRCCL)
+        self._plist = []
+
+    def register_arena_user(self, obj):
+        import weakref
+        self._arena_users.append(weakref.ref(obj))
 
     # ------------------------------------------------------------------------------------------
     # arenas + bf16 weight copies
@@ -104,15 +110,39 @@ class Engine:
         L.lib()
         if self.arena is not None and self.arena.is_current() and self.arena.device == device:
             return
+        if self.arena is not None:
+            users = [u() for u in self._arena_users]
+            users = [type(u).__name__ for u in users if u is not None]
+            if users:
+                raise L.UnimmHipError(
+                    "the model's parameters were re-pointed (module.to(), load_state_dict(assign=True), a replaced "
+                    f"Parameter) while {', '.join(users)} still hold the engine's flat arena: build the optimizer / "
+                    "data-parallel wrapper after the model has reached its final device")
         self.cfg.validate_for_hip()
         named = {n: p for n, p in self.model.named_parameters()}   # tied decoder alias is deduplicated
         self.arena = FlatArena(named, PM.arena_groups(self.cfg), device=device)
         A = self.arena
         self.w16 = torch.zeros(A.numel, dtype=BF16, device=device)
         self._anchor = torch.zeros(1, device=device, requires_grad=True)
+        self._plist = list(named.values())
         self._build_tables(device)
         self._w_version = None
         self._wt_table = None
+
+    def invalidate_weights(self):
+        """The fp32 master weights changed behind the engine's back (load_state_dict, a broadcast, a raw-pointer
+        write): the next forward re-casts the bf16 copies and rebuilds the transposed ones."""
+        self._w_version = None
+
+    def _weight_version(self):
+        """Changes whenever a parameter (or the flat arena) was written through torch.  The Parameters are views
+        created with `p.data = view`, so each has its OWN version counter: `p.copy_()`, `load_state_dict` and eager
+        optimizers bump those, not `flat._version`.  Writes torch cannot see (`p.data.mul_()`, kernels taking raw
+        pointers) need `invalidate_weights()`; the fused AdamW step refreshes the copies itself."""
+        v = self.arena.flat._version
+        for p in self._plist:
+            v += p._version
+        return v
 
     def _fused(self, names):
         """bf16 / fp32 / grad views spanning several consecutive arena entries (fused QKV)."""
@@ -207,14 +237,19 @@ class Engine:
         self.tab = {k: A.view(e + n + ".weight") for k, n in
                     (("word", "word_embeddings"), ("pos", "position_embeddings"), ("type", "token_type_embeddings"),
                      ("ext", "token_type_embeddings_extension"))}
+        # column-partials scratch of the non-deferred LayerNorm / embedding backward calls: one set per stream (with
+        # hidden_size == v_hidden_size the image stream's `bwd_embv` and the text stream's `bwd_embt` would otherwise
+        # share one buffer without any ordering between them)
         self.part = {h: torch.empty(L.colpartials_bytes(h) // 4, dtype=F32, device=device)
                      for h in {cfg.hidden_size, cfg.v_hidden_size}}
+        self.part_side = {h: torch.empty(L.colpartials_bytes(h) // 4, dtype=F32, device=device)
+                          for h in {cfg.hidden_size, cfg.v_hidden_size}}
 
     def refresh_weights(self, force=False, cast=True):
         """fp32 arena -> bf16 copies (one cast kernel) + transposed copies for the dgrad GEMMs.
         cast=False: the caller (the fused AdamW step) has already written the bf16 copy."""
         A = self.arena
-        ver = A.flat._version
+        ver = self._weight_version()
         if not force and ver == self._w_version:
             return
         if cast:
@@ -404,7 +439,8 @@ class Engine:
         dx = torch.empty((M, H), dtype=BF16, device=x.device)
         dxd = torch.empty((M, H), dtype=BF16, device=x.device) if drop[1] != 0 else None
         if not defer:
-            L.layernorm_bwd(dy, x, mean, rstd, gmm, dx, dxd, gg, gb, dbias, self.part[H], M, H, drop=drop, out_drop=out_drop)
+            scratch = (self.part_side if self._on_side else self.part)[H]
+            L.layernorm_bwd(dy, x, mean, rstd, gmm, dx, dxd, gg, gb, dbias, scratch, M, H, drop=drop, out_drop=out_drop)
             return dx, (dxd if dxd is not None else dx)
         part = torch.empty(self.part[H].numel(), dtype=F32, device=x.device)      # private until the grouped reduction
         blocks = L.layernorm_bwd_partials(dy, x, mean, rstd, gmm, dx, dxd, part, M, H, drop=drop, out_drop=out_drop)

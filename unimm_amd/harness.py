@@ -55,9 +55,15 @@ def generative_scores(lm_scores, masked_lm_labels, average=False):
 
 
 def scores_to_ranks(scores: torch.Tensor):
-    """[batch, rounds, options] scores -> 1-based ranks (descending, ties in sort order)."""
+    """[batch, rounds, options] scores -> 1-based ranks (descending; utils/visdial_metrics.py:21-39).
+    Index parity with the reference's CPU path includes TIES: the reference calls `scores.sort(1, descending=True)`,
+    whose tie order is a property of torch's CPU sort (tests/golden/ranks.npz holds a 10-way tie: neither index
+    order nor reverse index order).  A device sort orders ties differently (and unspecified), so device scores are
+    ranked on the host with that same call - a few KB at evaluation time, never on the training path - and the
+    ranks are returned on the scores' device."""
     b, r, o = scores.shape
-    order = scores.reshape(-1, o).sort(1, descending=True)[1]
+    dev = scores.device
+    order = scores.detach().reshape(-1, o).cpu().sort(1, descending=True)[1]
     ranks = torch.empty_like(order)
-    ranks.scatter_(1, order, torch.arange(1, o + 1, device=scores.device).expand_as(order))
-    return ranks.view(b, r, o)
+    ranks.scatter_(1, order, torch.arange(1, o + 1).expand_as(order))
+    return ranks.view(b, r, o).to(dev)

@@ -5,6 +5,7 @@ engine (unimm_amd.engine).  The modules below only own parameters; all arithmeti
 """
 from __future__ import annotations
 
+import logging
 import os
 import warnings
 
@@ -14,6 +15,8 @@ from torch import nn
 from . import params as PM
 from .config import BertConfig
 from .engine import Engine
+
+logger = logging.getLogger(__name__)
 
 
 def _build_param_tree(root: nn.Module, cfg) -> None:
@@ -40,6 +43,44 @@ def _build_param_tree(root: nn.Module, cfg) -> None:
     # tie the decoder to the word embeddings (models/vilbert_dialog.py:1020, :1504-1506)
     root.cls.predictions.add_module("decoder", nn.Module())
     root.cls.predictions.decoder.register_parameter("weight", root.bert.embeddings.word_embeddings.weight)
+
+
+def load_pretrained_state_dict(model: nn.Module, state_dict, default_gpu=True):
+    """models/vilbert_dialog.py:1232-1296 on a plain key -> tensor mapping.  Returns (missing_keys, unexpected_keys)."""
+    sd = {}
+    for key, v in state_dict.items():
+        new_key = key
+        if "gamma" in new_key:
+            new_key = new_key.replace("gamma", "weight")
+        if "beta" in new_key:
+            new_key = new_key.replace("beta", "bias")
+        if new_key.startswith("bert_pretrained."):          # a VisualDialogEncoder checkpoint (train.py:503-505)
+            new_key = new_key[len("bert_pretrained."):]
+        sd[new_key] = v
+    start_prefix = ""
+    if not hasattr(model, "bert") and any(k.startswith("bert.") for k in sd):
+        start_prefix = "bert."
+    own = model.state_dict()
+    missing, errors, usable = [], [], {}
+    for k, t in own.items():
+        src = sd.get(start_prefix + k)
+        if src is None:
+            missing.append(k)
+        elif tuple(src.shape) != tuple(t.shape):
+            errors.append(f"size mismatch for {k}: copying a param with shape {tuple(src.shape)} from checkpoint, "
+                          f"the shape in current model is {tuple(t.shape)}.")
+        else:
+            usable[k] = src
+    expected = {start_prefix + k for k in own}
+    unexpected = [k for k in sd if k not in expected]
+    if errors and default_gpu:
+        raise RuntimeError("Error(s) in loading state_dict for {}:\n\t{}".format(model.__class__.__name__, "\n\t".join(errors)))
+    model.load_state_dict(usable, strict=False)
+    if missing and default_gpu:
+        logger.info("Weights of {} not initialized from pretrained model: {}".format(model.__class__.__name__, missing))
+    if unexpected and default_gpu:
+        logger.info("Weights from pretrained model not used in {}: {}".format(model.__class__.__name__, unexpected))
+    return missing, unexpected
 
 
 class _HotPath(torch.autograd.Function):
@@ -79,13 +120,19 @@ class BertForMultiModalPreTraining(nn.Module):
         _build_param_tree(self, config)
         self.predict_feature = config.predict_feature
         self._engine = Engine(self, config)
+        # values loaded into the Parameters must reach the engine's bf16 / transposed weight copies
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._engine.invalidate_weights())
 
     # -- construction helpers -----------------------------------------------------------------
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path, config, default_gpu=True, state_dict=None, *inputs, **kwargs):
-        """The reference downloads 'bert-base-uncased' here (models/vilbert_dialog.py:1123-1296); there is
-        no network in this build, so weights come from `state_dict` or a local checkpoint file/dir when
-        one exists at the given path, otherwise the model keeps its fresh init (with a warning)."""
+        """Key handling of models/vilbert_dialog.py:1232-1296.  The reference downloads 'bert-base-uncased' here
+        (:1123-1231); there is no network in this build, so weights come from `state_dict` or from a local
+        checkpoint file / directory at the given path, otherwise the model keeps its fresh init (with a warning).
+        A found state dict is loaded as the reference loads it: old LayerNorm names (`gamma` / `beta`) are renamed to
+        `weight` / `bias` (:1233-1245), the `bert.` start prefix is detected (:1270-1274), every key of the model that
+        the checkpoint lacks is reported as missing and every checkpoint key the model lacks as unexpected
+        (:1276-1287, logged when `default_gpu`), and a shape mismatch raises (:1288-1294)."""
         model = cls(config, *inputs, **kwargs)
         if state_dict is None and isinstance(pretrained_model_name_or_path, str):
             path = pretrained_model_name_or_path
@@ -97,11 +144,8 @@ class BertForMultiModalPreTraining(nn.Module):
             warnings.warn(f"from_pretrained({pretrained_model_name_or_path!r}): no local weights found, "
                           "keeping random initialisation (no network access)")
             return model
-        state_dict = {k[len("bert_pretrained."):] if k.startswith("bert_pretrained.") else k: v
-                      for k, v in state_dict.items()}
-        own = model.state_dict()
-        usable = {k: v for k, v in state_dict.items() if k in own and tuple(v.shape) == tuple(own[k].shape)}
-        model.load_state_dict(usable, strict=False)   # key-intersection warm start, as train.py:355-364
+        missing, unexpected = load_pretrained_state_dict(model, state_dict, default_gpu=default_gpu)
+        model.pretrained_missing_keys, model.pretrained_unexpected_keys = missing, unexpected
         return model
 
     @property

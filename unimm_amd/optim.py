@@ -75,6 +75,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self.engine = engine
         engine.ensure(first.device)         # (re)builds the arena if the model was moved since
         self.arena = A = engine.arena
+        engine.register_arena_user(self)
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, correct_bias=correct_bias))
         # every parameter -> its chunk range in the arena
         by_ptr = {A.flat.data_ptr() + 4 * o: (name, o, shape) for name, (o, shape) in A.offsets.items()}
