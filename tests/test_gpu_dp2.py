@@ -65,7 +65,7 @@ def single_rank(golden_dir):
         (lm + img + nsp_l).sum().backward()
         torch.cuda.synchronize()
         grads.append(model.engine.arena.grad_flat.clone().cpu())
-        losses.append([float(lm), float(img), float(nsp_l)])
+        losses.append([float(lm.detach()), float(img.detach()), float(nsp_l.detach())])
     return dict(grads=grads, losses=losses, flat=model.engine.arena.flat.detach().cpu().clone())
 
 

@@ -256,3 +256,46 @@ def test_gemm_rejects_bad_arguments():
         lib.gemm_nt(x, w, out)
     with pytest.raises(lib.UnimmHipError):
         lib.gemm_nt(x.cpu(), w, out)
+
+
+@pytest.mark.parametrize("cfg", [1, 3, 7])
+@pytest.mark.parametrize("epi", ["add", "mul", "bias16", "resid_drop"])
+def test_gemm_nt_epilogue_layout_against_torch(cfg, epi):
+    """Every epilogue family on ragged M / N with strides that allow and forbid the 16-byte path (and the epilogue-operand
+    prefetch clamped at the edges), against torch on the same bf16 inputs; the dropout mask against the host mirror
+    of the counter-based generator."""
+    from unimm_amd import lib
+    from unimm_amd import dropout as DR
+    g = torch.Generator(device="cuda").manual_seed(cfg * 10 + len(epi))
+    for (M, N, K, ldo) in [(777, 1000, 192, 1000), (777, 1000, 192, 1004), (300, 250, 64, 256)]:
+        x, w = _rand((M, K), g), _rand((N, K), g, 0.05)
+        base = x.float() @ w.float().t()
+        bias = torch.randn(N, generator=g, device="cuda")
+        lib.gemm_set_tile(cfg)
+        try:
+            if epi in ("add", "mul"):
+                aux = torch.zeros((M, ldo), device="cuda", dtype=torch.bfloat16)
+                aux[:, :N] = _rand((M, N), g)
+                out = torch.full((M, ldo), 7.0, device="cuda", dtype=torch.bfloat16)
+                lib.gemm_nt(x, w, out, epilogue=lib.EPI_ADD if epi == "add" else lib.EPI_MUL, aux=aux, N=N)
+                ref = base + aux[:, :N].float() if epi == "add" else base * aux[:, :N].float()
+                tol = 2 ** -7
+            elif epi == "bias16":
+                out = torch.full((M, ldo), 7.0, device="cuda", dtype=torch.bfloat16)
+                lib.gemm_nt(x, w, out, bias=bias, N=N)
+                ref, tol = base + bias, 2 ** -7
+            else:
+                aux = torch.randn((M, ldo), generator=g, device="cuda")
+                out = torch.full((M, ldo), 7.0, device="cuda")
+                key = DR.make_key(3, 9, 77)
+                drop = DR.drop_arg(0.1, key)
+                lib.gemm_nt(x, w, out, bias=bias, epilogue=lib.EPI_BIAS_DROP_RESID, aux=aux, N=N, drop=drop)
+                keep = torch.from_numpy(DR.keep_mask2d(key, drop[1], M, N)).cuda()
+                ref, tol = (base + bias) * keep * drop[2] + aux[:, :N], 2e-3
+            torch.cuda.synchronize()
+        finally:
+            lib.gemm_set_tile(0)
+        err = (out[:, :N].float() - ref).abs().max().item()
+        assert err <= tol * max(1.0, ref.abs().max().item()), (M, N, K, ldo, err)
+        if ldo > N:
+            assert (out[:, N:].float() == 7.0).all()                 # pad columns untouched

@@ -194,6 +194,11 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtParams& p, f32x4 (&acc)[
   // 64 rows at a time, through its own fp32 LDS slab (the ring is dead by now) and walks it
   // row-contiguously: a lane owns 8 consecutive columns of one row -> 16-byte bias/residual loads and
   // 16-byte stores, 8 full 128-byte row segments per wave-instruction.
+  // Outputs (and the once-read residual / multiplier operand) use the NON-TEMPORAL cache policy: the workgroups of a
+  // launch reach their epilogues together and a round's 33 MB of output is the size of the eight L2s, so with the
+  // default write-back policy the stores of every round waited for evictions (N=3072, K=768, "x aux" epilogue: 215 us
+  // -> 187 us with nt stores + nt operand loads, 167 -> 155 us for the 128x128 tile at K=3072; 200-launch averages of
+  // alternating builds in one gpurun call).  Nothing re-reads these lines before the next kernel does.
   constexpr int SLAB_LD = 68;                       // floats per slab row (64 + 4 pad)
   __builtin_amdgcn_s_barrier();                      // all waves finished reading the ring
   float* slab = reinterpret_cast<float*>(smem) + wave * (C::SLAB_ROWS * SLAB_LD);
@@ -238,7 +243,8 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtParams& p, f32x4 (&acc)[
         if constexpr (EPI == UNIMM_EPI_BIAS_DROP_RESID) {   // fp32 residual stream
           const float* ap = reinterpret_cast<const float*>(p.aux) + (size_t)m * p.ldaux + n;
           if (vec_aux) {
-            const f32x4 r0 = *reinterpret_cast<const f32x4*>(ap), r1 = *reinterpret_cast<const f32x4*>(ap + 4);
+            const f32x4 r0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ap));
+            const f32x4 r1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ap + 4));
 #pragma unroll
             for (int e = 0; e < 4; ++e) { a[e] = r0[e]; a[4 + e] = r1[e]; }
           } else {
@@ -259,8 +265,12 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtParams& p, f32x4 (&acc)[
           for (int e = 0; e < 8; ++e) v[e] += a[e];
         } else {
           const bf16_t* ap = reinterpret_cast<const bf16_t*>(p.aux) + (size_t)m * p.ldaux + n;
-          if (vec_aux) {
-            const u32x4 raw = *reinterpret_cast<const u32x4*>(ap);
+          if (UNIMM_EXP == 12 || UNIMM_EXP == 14) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = 1.0f + (float)(lane & 1);
+          } else if (vec_aux) {
+            const u32x4 raw = UNIMM_EXP == 18 ? *reinterpret_cast<const u32x4*>(ap)
+                                                : __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ap));
 #pragma unroll
             for (int e = 0; e < 4; ++e) { a[2 * e] = __uint_as_float(raw[e] << 16); a[2 * e + 1] = __uint_as_float(raw[e] & 0xffff0000u); }
           } else {
@@ -290,7 +300,8 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtParams& p, f32x4 (&acc)[
         if (p.out2 != nullptr) {
           bf16_t* up = p.out2 + (size_t)m * p.ldo + n;
           if (full && (p.ldo % 8) == 0)
-            *reinterpret_cast<u32x4*>(up) = u32x4{pack2bf(u[0], u[1]), pack2bf(u[2], u[3]), pack2bf(u[4], u[5]), pack2bf(u[6], u[7])};
+            __builtin_nontemporal_store(u32x4{pack2bf(u[0], u[1]), pack2bf(u[2], u[3]), pack2bf(u[4], u[5]), pack2bf(u[6], u[7])},
+                                        reinterpret_cast<u32x4*>(up));
           else
             for (int e = 0; e < 8; ++e) if (n + e < p.N) up[e] = f2bf(u[e]);
         }
@@ -302,16 +313,20 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtParams& p, f32x4 (&acc)[
       if constexpr (OUT_F32) {
         float* op = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n;
         if (vec_out) {
-          *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
-          *reinterpret_cast<f32x4*>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
+          __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(op));
+          __builtin_nontemporal_store(f32x4{v[4], v[5], v[6], v[7]}, reinterpret_cast<f32x4*>(op + 4));
         } else {
           for (int e = 0; e < 8; ++e) if (n + e < p.N) op[e] = v[e];
         }
       } else {
         bf16_t* op = reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldo + n;
-        if (vec_out)
-          *reinterpret_cast<u32x4*>(op) = u32x4{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
-        else
+        if (UNIMM_EXP == 13 || UNIMM_EXP == 14) {
+          if (v[0] + v[3] + v[5] == 12345.678f) op[0] = f2bf(v[1]);     // keeps the values live, never true
+        } else if (vec_out) {
+          const u32x4 pk = u32x4{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+          if (UNIMM_EXP == 18) *reinterpret_cast<u32x4*>(op) = pk;
+          else __builtin_nontemporal_store(pk, reinterpret_cast<u32x4*>(op));
+        } else
           for (int e = 0; e < 8; ++e) if (n + e < p.N) op[e] = f2bf(v[e]);
       }
     }
