@@ -100,6 +100,18 @@ int unimm_gemm_tn(const unimm_gemm_tn_args* args, void* stream);
  * Same result as `count` calls of unimm_gemm_tn; the problems must not alias each other's dw / dbias
  * unless they are meant to accumulate (fp32 atomics make that safe). */
 int unimm_gemm_tn_grouped(const unimm_gemm_tn_args* args, int32_t count, void* stream);
+/* The same with (a) the "launches share the chip with another stream's kernels" hint of the split heuristic as a
+ * per-call argument instead of the process-wide unimm_gemm_tn_set_shared, and (b) a caller-owned WORKSPACE: when the
+ * reduction is split, every split stores its fp32 partial tile to a slab of the workspace (plain coalesced stores) and
+ * the split that arrives last at the tile's counter sums the slabs and adds the tile into dw once, instead of every
+ * split adding 256 KiB with memory-side atomics (8x the algorithmic write traffic, a ~43 us drain per launch).
+ * ws: 256-byte aligned device memory, ZERO-FILLED ONCE by the caller before its first use and then private to launches
+ * of ONE stream (the kernels leave the counters zero); ws_bytes >= 16 KiB + tiles * splits * tile bytes
+ * (512 MiB covers every launch of the full config at 240 sequences); too small or NULL = the atomic path.
+ * The result equals the atomic path's up to the order of the fp32 sums (the last arriver adds the other splits'
+ * partials to its own in index order). */
+int unimm_gemm_tn_grouped_ws(const unimm_gemm_tn_args* args, int32_t count, int32_t shared_chip, void* ws, int64_t ws_bytes,
+                             void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused attention core: out = dropout(softmax(Q K^T * scale + additive(mask))) V per (sequence,

@@ -299,3 +299,42 @@ def test_gemm_nt_epilogue_layout_against_torch(cfg, epi):
         assert err <= tol * max(1.0, ref.abs().max().item()), (M, N, K, ldo, err)
         if ldo > N:
             assert (out[:, N:].float() == 7.0).all()                 # pad columns untouched
+
+
+def test_gemm_tn_workspace_reducer_matches_atomic_path():
+    """unimm_gemm_tn_grouped_ws: partial tiles through slabs + one last-arriver reducer per tile == the fp32-atomic path,
+    on a group that mixes tile classes and ragged shapes, accumulating (+=) over repeated launches (the arrival counters
+    must be back at zero after every launch), with the chip-sharing hint on and off, and with a workspace that is too
+    small (falls back to atomics)."""
+    from unimm_amd import lib
+    g = torch.Generator(device="cuda").manual_seed(31)
+    M = 9000
+    shapes = [(768, 768), (2304, 768), (768, 3072), (1000, 520), (200, 72)]
+    probs_a, probs_b, refs = [], [], []
+    for (N, K) in shapes:
+        ldy, ldx = (N + 7) // 8 * 8, (K + 7) // 8 * 8
+        dy = torch.zeros((M, ldy), device="cuda", dtype=torch.bfloat16)
+        x = torch.zeros((M, ldx), device="cuda", dtype=torch.bfloat16)
+        dy[:, :N] = _rand((M, N), g)
+        x[:, :K] = _rand((M, K), g)
+        dwa, dwb = torch.zeros((N, K), device="cuda"), torch.zeros((N, K), device="cuda")
+        dba, dbb = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")
+        probs_a.append((dy, x, dwa, M, N, K, dba))
+        probs_b.append((dy, x, dwb, M, N, K, dbb))
+        refs.append(dy[:, :N].float().t() @ x[:, :K].float())
+    ws = torch.zeros(256 << 20, dtype=torch.uint8, device="cuda")
+    for rep, shared in enumerate((True, False, True)):
+        lib.gemm_tn_grouped(probs_a, shared=shared, ws=None)
+        lib.gemm_tn_grouped(probs_b, shared=shared, ws=ws)
+        torch.cuda.synchronize()
+        for (dy, x, dwa, _, N, K, dba), (_, _, dwb, _, _, _, dbb), ref in zip(probs_a, probs_b, refs):
+            scale = max(1.0, ref.abs().max().item()) * (rep + 1)
+            assert (dwa - dwb).abs().max().item() <= 1e-4 * scale, (N, K, rep)
+            assert (dwb - (rep + 1) * ref).abs().max().item() <= 3e-3 * scale, (N, K, rep)
+            assert (dba - dbb).abs().max().item() <= 1e-3 * max(1.0, dba.abs().max().item())
+        # the arrival counters (the first bytes of the workspace) are zero again
+        assert int(ws[:16384].view(torch.int32).abs().sum()) == 0
+    small = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda")          # too small for the slabs: atomic fallback
+    lib.gemm_tn_grouped(probs_b, shared=True, ws=small)
+    torch.cuda.synchronize()
+    assert (probs_b[0][2] - 4 * refs[0]).abs().max().item() <= 3e-3 * 4 * max(1.0, refs[0].abs().max().item())

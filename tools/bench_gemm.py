@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from unimm_amd import lib
 
-def timeit(fn, iters=10, warm=3):
+def timeit(fn, iters=100, warm=5):
     for _ in range(warm): fn()
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -35,8 +35,6 @@ for (N, K, epi) in [(2304, 768, lib.EPI_BIAS), (768, 768, lib.EPI_BIAS_DROP_RESI
         t = timeit(lambda: lib.gemm_nt(x, w, o, bias=b, epilogue=epi, aux=ax, out2=out2 if epi == lib.EPI_BIAS_GELU_DG else None))
         print(f"NT  N={N:5d} K={K:5d} epi={epi} cfg={cfg}: {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TFLOP/s")
     lib.gemm_set_tile(0)
-    tt = timeit(lambda: torch.matmul(x, w.t()))
-    print(f"    torch(hipBLASLt) matmul          : {tt*1e6:8.1f} us  {fl/tt/1e12:7.1f} TFLOP/s")
 for (N, K) in [(2304, 768), (768, 768), (3072, 768), (768, 3072)]:
     dy = torch.randn((M, N), generator=g, device="cuda").to(torch.bfloat16)
     x = torch.randn((M, K), generator=g, device="cuda").to(torch.bfloat16)
@@ -46,5 +44,7 @@ for (N, K) in [(2304, 768), (768, 768), (3072, 768), (768, 3072)]:
     db = torch.zeros(N, device="cuda")
     tb = timeit(lambda: lib.gemm_tn(dy, x, dw, dbias=db))
     print(f"TN  N={N:5d} K={K:5d}: {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TFLOP/s   with dbias: {tb*1e6:8.1f} us {fl/tb/1e12:7.1f} TFLOP/s")
-    tt = timeit(lambda: torch.matmul(dy.t(), x))
-    print(f"    torch matmul         : {tt*1e6:8.1f} us  {fl/tt/1e12:7.1f} TFLOP/s")
+    if hasattr(lib.lib(), "unimm_gemm_tn_grouped_ws"):
+        ws = torch.zeros(256 << 20, dtype=torch.uint8, device="cuda")
+        tw = timeit(lambda: lib.gemm_tn_grouped([(dy, x, dw, None, None, None, db)], shared=False, ws=ws))
+        print(f"    slab reducer (workspace): {tw*1e6:8.1f} us  {fl/tw/1e12:7.1f} TFLOP/s")

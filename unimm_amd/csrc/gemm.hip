@@ -221,13 +221,43 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtParams& p, f32x4 (&acc)[
   const bool vec_out = full && ((p.ldo * (OUT_F32 ? 4 : 2)) % 16 == 0);
   const bool vec_aux = full && ((p.ldaux * (EPI == UNIMM_EPI_BIAS_DROP_RESID ? 4 : 2)) % 16 == 0);
   constexpr int JP = MT < 4 ? MT : 4;               // 16-row sub-tiles per pass (a 32-row wave tile has only two)
+  // GELU epilogues with bf16 outputs do their arithmetic BEFORE the transposition, on the accumulator registers:
+  // elementwise math does not care about the layout, and there every lane has 16 x JP independent values in flight
+  // (the row-walk below has 8 behind an LDS read per iteration: the erf + exp + rcp chains of the fused GELU / GELU'
+  // ran at ~10 cycles per instruction and cost 90 us of the 234 us ff1 GEMM at 240 sequences).  The two results of an
+  // element travel through the slab as ONE 32-bit word (bf16 pair: low = output, high = second output).
+  constexpr bool PRE = (EPI == UNIMM_EPI_BIAS_GELU || EPI == UNIMM_EPI_BIAS_GELU_DG) && !OUT_F32;
+  f32x4 bq[4];                                       // bias of the lane's accumulator columns 16 i + 4 (lane >> 4) + e
+  if constexpr (PRE) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int na = n0 + wn * 64 + i * 16 + 4 * (lane >> 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bq[i][e] = (p.bias != nullptr && na + e < p.N) ? p.bias[na + e] : 0.f;
+    }
+  }
 #pragma unroll
   for (int pass = 0; pass < MT / JP; ++pass) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < JP; ++j)
-        *reinterpret_cast<f32x4*>(slab + (j * 16 + (lane & 15)) * SLAB_LD + i * 16 + 4 * (lane >> 4)) = acc[i][pass * JP + j];
+      for (int j = 0; j < JP; ++j) {
+        float* dst = slab + (j * 16 + (lane & 15)) * SLAB_LD + i * 16 + 4 * (lane >> 4);
+        if constexpr (PRE) {
+          u32x4 w;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float x = acc[i][pass * JP + j][e] + bq[i][e];
+            float y, d;
+            if constexpr (EPI == UNIMM_EPI_BIAS_GELU) { y = gelu_erf(x); d = x; }
+            else gelu_and_grad(x, y, d);
+            w[e] = pack2bf(y, d);
+          }
+          *reinterpret_cast<u32x4*>(dst) = w;
+        } else {
+          *reinterpret_cast<f32x4*>(dst) = acc[i][pass * JP + j];
+        }
+      }
 #pragma unroll
     for (int it = 0; it < 2 * JP; ++it) {
       const int row = it * 8 + (lane >> 3);
@@ -235,6 +265,30 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtParams& p, f32x4 (&acc)[
       const f32x4 lo = *reinterpret_cast<const f32x4*>(slab + row * SLAB_LD + c0);
       const f32x4 hi = *reinterpret_cast<const f32x4*>(slab + row * SLAB_LD + c0 + 4);
       if (m >= p.M || !ncols_ok) continue;
+      if constexpr (PRE) {
+        uint32_t pw[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { pw[e] = __float_as_uint(lo[e]); pw[4 + e] = __float_as_uint(hi[e]); }
+        bf16_t* op = reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldo + n;
+        bf16_t* up = p.out2 != nullptr ? p.out2 + (size_t)m * p.ldo + n : nullptr;
+        if (vec_out) {
+          u32x4 ow, uw;
+#pragma unroll
+          for (int k2 = 0; k2 < 4; ++k2) {
+            ow[k2] = __builtin_amdgcn_perm(pw[2 * k2 + 1], pw[2 * k2], 0x05040100u);   // low halves of two words
+            uw[k2] = __builtin_amdgcn_perm(pw[2 * k2 + 1], pw[2 * k2], 0x07060302u);   // high halves
+          }
+          __builtin_nontemporal_store(ow, reinterpret_cast<u32x4*>(op));
+          if (up != nullptr) __builtin_nontemporal_store(uw, reinterpret_cast<u32x4*>(up));
+        } else {
+          for (int e = 0; e < 8; ++e)
+            if (n + e < p.N) {
+              op[e] = (bf16_t)(pw[e] & 0xffffu);
+              if (up != nullptr) up[e] = (bf16_t)(pw[e] >> 16);
+            }
+        }
+        continue;
+      }
       float v[8], u[8];
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[e] = lo[e] + b[e]; v[4 + e] = hi[e] + b[4 + e]; }
@@ -633,6 +687,7 @@ struct GemmTnParams {
   const bf16_t* dy; const bf16_t* x; float* dw; float* dbias;
   int M, N, K, lddy, ldx, lddw, rows_per_split;
   int tile0;   // first tile index of this problem inside a grouped launch
+  int nsplit;  // splits of this problem that own rows (the others leave at once and never arrive at the tile's counter)
 };
 // A grouped launch: the weight gradients of one encoder block in ONE grid.  Every launch ends with a
 // drain of one fp32 partial tile per resident workgroup (256 x 256 KiB = 67 MB of memory-side atomics,
@@ -641,6 +696,9 @@ struct GemmTnParams {
 constexpr int TN_MAXG = 12;
 struct GemmTnGroup {
   int count, total_tiles;
+  int splits;            // reduction ranges per tile
+  float* slabs;          // workspace: [total_tiles][splits] partial tiles, or NULL = every split adds with fp32 atomics
+  int* counters;         // workspace: arrival counter per tile (zero between launches: the last arriver resets it)
   GemmTnParams pr[TN_MAXG];
 };
 
@@ -723,6 +781,7 @@ __global__ __launch_bounds__(64 * WN * WK, (WN * WK * (NT == 4 ? 2 : 1) + 3) / 4
   for (int i = 1; i < grp.count; ++i) gi = (tile >= grp.pr[i].tile0) ? i : gi;
   gi = __builtin_amdgcn_readfirstlane(gi);   // wave-uniform: the descriptor is fetched once, into SGPRs
   const GemmTnParams p = grp.pr[gi];
+  const int gtile = tile;                    // tile index inside the grouped launch (slab / counter index)
   tile -= p.tile0;
   const int nbk = (p.K + TKB - 1) / TKB;
   const int tn = tile / nbk, tk = tile - tn * nbk;
@@ -857,6 +916,65 @@ __global__ __launch_bounds__(64 * WN * WK, (WN * WK * (NT == 4 ? 2 : 1) + 3) / 4
     return;
   }
 #endif
+  // ---- partial tile -> gradient.  Without a workspace every split adds its fp32 partial with memory-side atomics:
+  // one 256 KiB tile per resident workgroup at the END of every round, 67 MB at ~1.3 TB/s = ~43 us in which the chip
+  // only drains (and 8x the algorithmic write traffic: 222 MB per text-block launch against 28 MB of gradients).
+  // With a workspace the splits of a tile meet at a counter instead: each stores its partial to its own SLAB with plain,
+  // fully coalesced 16-byte stores (register order: the reducer has the same layout), and whoever arrives LAST reads
+  // the other slabs on top of the partial it still holds in registers and adds the sum into the gradient exactly once
+  // (plain read-modify-write: nobody else touches these elements in this launch).  Placement-independent hand-off (guide,
+  // "in-launch split-K reduction"): slab stores -> every wave's vmcnt(0) -> workgroup barrier -> lane 0: agent-scope
+  // release, vmcnt(0), relaxed agent-scope ticket; the last arriver: agent-scope acquire, vmcnt(0), barrier, plain loads.
+  if (grp.slabs != nullptr && p.nsplit > 1) {
+    constexpr int TILE_F4 = NW * NT * 4 * 64;                      // f32x4 per partial tile
+    f32x4* mine = reinterpret_cast<f32x4*>(grp.slabs) + ((size_t)gtile * grp.splits + split) * TILE_F4;
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mine[((wave * NT + i) * 4 + j) * 64 + lane] = acc[i][j];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                               // (the ring is dead: smem[0..3] carries the ticket)
+    int* flag = reinterpret_cast<int*>(smem);
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int ticket = __hip_atomic_fetch_add(grp.counters + gtile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (ticket == p.nsplit - 1) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(grp.counters + gtile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+      }
+      *flag = ticket;
+    }
+    __syncthreads();
+    if (*flag != p.nsplit - 1) return;                             // block-uniform
+    const f32x4* base = reinterpret_cast<const f32x4*>(grp.slabs) + (size_t)gtile * grp.splits * TILE_F4;
+    for (int sp = 0; sp < p.nsplit; ++sp) {
+      if (sp == split) continue;
+      const f32x4* other = base + (size_t)sp * TILE_F4;
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 o = other[((wave * NT + i) * 4 + j) * 64 + lane];
+          acc[i][j][0] += o[0]; acc[i][j][1] += o[1]; acc[i][j][2] += o[2]; acc[i][j][3] += o[3];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = n0 + wn * 16 * NT + i * 16 + 4 * (lane >> 4) + e;
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = k0 + wk * 64 + j * 16 + (lane & 15);
+          if (k < p.K) p.dw[(size_t)n * p.lddw + k] += acc[i][j][e];
+        }
+      }
+    }
+    return;
+  }
   // D[n][k]: lane holds k = .. + (lane&15) (column), n = .. + 4*(lane>>4) + e (rows)
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
@@ -1045,7 +1163,8 @@ int check_tn(const unimm_gemm_tn_args* a) {
 inline bool tn_is_big(const unimm_gemm_tn_args* a) { return a->N >= 256 && a->K >= 256 && a->M >= 4096; }
 
 // One launch of `count` (<= TN_MAXG) problems that all use the same tile size.
-int launch_tn_group(const unimm_gemm_tn_args* const* a, int count, bool big, hipStream_t s) {
+int launch_tn_group(const unimm_gemm_tn_args* const* a, int count, bool big, bool shared, void* ws, int64_t ws_bytes,
+                    hipStream_t s) {
   GemmTnGroup g;
   const int tb = big ? 256 : 128;
   int tiles = 0, max_m = 0;
@@ -1077,12 +1196,27 @@ int launch_tn_group(const unimm_gemm_tn_args* const* a, int count, bool big, hip
   const double steps = (double)max_m / TK;
   for (int sp = 1; sp <= max_s; ++sp) {
     const int rounds = (tiles * sp + slots - 1) / slots;
-    const double cost = rounds * (steps / sp + (g_tn_shared ? 40.0 : 8.0));
+    const double cost = rounds * (steps / sp + (shared ? 40.0 : 8.0));
     if (cost < best * 0.98) { best = cost; splits = sp; }
   }
   for (int i = 0; i < count; ++i) {
     int rps = (g.pr[i].M + splits - 1) / splits;
     g.pr[i].rows_per_split = ((rps + TK - 1) / TK) * TK;
+    g.pr[i].nsplit = (g.pr[i].M + g.pr[i].rows_per_split - 1) / g.pr[i].rows_per_split;
+  }
+  // workspace layout: [counters: one int per tile in a FIXED 16 KiB region: launches with different tile counts share
+  // the workspace, and the slabs of one must never cover the (zero-between-launches) counters of another]
+  // [slabs: tiles x splits partial tiles of tb x tb floats]
+  g.splits = splits;
+  g.slabs = nullptr;
+  g.counters = nullptr;
+  if (ws != nullptr && splits > 1) {
+    const int64_t cbytes = 16384;
+    const int64_t need = cbytes + (int64_t)tiles * splits * tb * tb * 4;
+    if (need <= ws_bytes && tiles <= 4096) {
+      g.counters = reinterpret_cast<int*>(ws);
+      g.slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + cbytes);
+    }
   }
   ProfRec* pr = prof_begin(16, flops, s);
   if (big) {
@@ -1104,8 +1238,10 @@ int launch_tn_group(const unimm_gemm_tn_args* const* a, int count, bool big, hip
 
 }  // namespace
 
-extern "C" int unimm_gemm_tn_grouped(const unimm_gemm_tn_args* a, int32_t count, void* stream) {
-  if (a == nullptr || count <= 0) return UNIMM_E_ARG;
+extern "C" int unimm_gemm_tn_grouped_ws(const unimm_gemm_tn_args* a, int32_t count, int32_t shared_chip, void* ws,
+                                        int64_t ws_bytes, void* stream) {
+  if (a == nullptr || count <= 0 || (ws != nullptr && (ws_bytes < 0 || ((uintptr_t)ws & 255)))) return UNIMM_E_ARG;
+  const bool shared = shared_chip != 0;
   for (int i = 0; i < count; ++i) {
     const int rc = check_tn(a + i);
     if (rc != UNIMM_OK) return rc;
@@ -1119,17 +1255,21 @@ extern "C" int unimm_gemm_tn_grouped(const unimm_gemm_tn_args* a, int32_t count,
       if (tn_is_big(a + i) != big) continue;
       sel[n++] = a + i;
       if (n == TN_MAXG) {
-        const int rc = launch_tn_group(sel, n, big, s);
+        const int rc = launch_tn_group(sel, n, big, shared, ws, ws_bytes, s);
         if (rc != UNIMM_OK) return rc;
         n = 0;
       }
     }
     if (n > 0) {
-      const int rc = launch_tn_group(sel, n, big, s);
+      const int rc = launch_tn_group(sel, n, big, shared, ws, ws_bytes, s);
       if (rc != UNIMM_OK) return rc;
     }
   }
   return UNIMM_OK;
+}
+
+extern "C" int unimm_gemm_tn_grouped(const unimm_gemm_tn_args* a, int32_t count, void* stream) {
+  return unimm_gemm_tn_grouped_ws(a, count, g_tn_shared ? 1 : 0, nullptr, 0, stream);
 }
 
 extern "C" int unimm_gemm_tn(const unimm_gemm_tn_args* a, void* stream) {

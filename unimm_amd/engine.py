@@ -94,6 +94,13 @@ class Engine:
         self._fq, self._fq_img = [], []  # pending column-partials reductions of LayerNorm backward calls, per stream
         self.last_plan = None
         self._arena_users = []           # weakrefs of objects that cache `self.arena` (FusedAdamW, DataParallelRCCL)
+        # Partial-tile workspaces of the weight-gradient launches, one per launch stream (text / image / optional side).
+        # OFF by default (0 MB = every split adds its partial tile with fp32 atomics): the slab + last-arriver reducer
+        # of unimm_gemm_tn_grouped_ws measured SLOWER at 240 sequences (4,797 against 4,949 sequences/s, interleaved
+        # runs on one box; single problems 220 against 128 us): the last round's ~108 reducers each read 1.5 MB of
+        # slabs serially and every split's agent-scope release writes back its XCD's L2.  UNIMM_WGRAD_WS_MB=512 enables it.
+        self.wgrad_ws_bytes = int(os.environ.get("UNIMM_WGRAD_WS_MB", "0")) << 20
+        self._wgrad_ws = {}
         self._plist = []
 
     def register_arena_user(self, obj):
@@ -297,10 +304,20 @@ class Engine:
         the block's whole list to one grouped launch.  dy / x stay referenced by the queue until then."""
         (self._wq_img if self._on_side else self._wq).append((dy, x, gw, M, N, K, dbias))
 
+    def _ws(self, which):
+        """Zero-initialised workspace of the weight-gradient launches of one stream (0 bytes = fp32-atomic path)."""
+        if self.wgrad_ws_bytes <= 0:
+            return None
+        t = self._wgrad_ws.get(which)
+        if t is None:
+            t = self._wgrad_ws[which] = torch.zeros(self.wgrad_ws_bytes, dtype=torch.uint8, device=self.arena.flat.device)
+        return t
+
     def _flush_wgrad(self):
+        shared = self._dual()                     # the launches of this backward share the chip with the other stream's
         if self._wq_img or self._fq_img:          # image-side problems: operands were produced on that stream
             with self._img():
-                L.gemm_tn_grouped(self._wq_img)
+                L.gemm_tn_grouped(self._wq_img, shared=shared, ws=self._ws("img"))
                 L.colpartials_finish_grouped(self._fq_img)
             self._wq_img, self._fq_img = [], []
         if self._on_side:
@@ -310,7 +327,7 @@ class Engine:
         if not self._wq:
             return
         if not self.wgrad_stream:
-            L.gemm_tn_grouped(self._wq)
+            L.gemm_tn_grouped(self._wq, shared=shared, ws=self._ws("txt"))
             self._wq = []
             return
         # side stream: the grouped launch ends with a partial last round and a memory-side atomic drain during
@@ -320,7 +337,7 @@ class Engine:
             self._side = torch.cuda.Stream(device=self.arena.flat.device)
         self._side.wait_stream(main)
         with torch.cuda.stream(self._side), L.stream_scope(self._side):
-            L.gemm_tn_grouped(self._wq)
+            L.gemm_tn_grouped(self._wq, shared=shared, ws=self._ws("side"))
         for dy, x, *_ in self._wq:              # keep the caching allocator from recycling them early
             dy.record_stream(self._side)
             x.record_stream(self._side)
@@ -962,7 +979,6 @@ class Engine:
         H, Hv = cfg.hidden_size, cfg.v_hidden_size
         seq_t, seq_v = out["seq_out_t"], out["seq_out_v"]
         self.arena.attach_grads()
-        L.gemm_tn_set_shared(self._dual())       # the weight-gradient launches of this backward share the chip or not
 
         def gvec(g):
             return torch.zeros(1, dtype=F32, device=dev) if g is None else g.detach().to(F32).reshape(1).contiguous()

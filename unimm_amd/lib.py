@@ -12,7 +12,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libunimm_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROP_RESID, EPI_BIAS_RELU, EPI_DGELU, EPI_ADD, EPI_MUL, EPI_BIAS_GELU_DG = range(8)
 
@@ -74,7 +74,7 @@ SYMBOLS = ["unimm_version", "unimm_arch", "unimm_gemm_nt", "unimm_gemm_tn", "uni
            "unimm_pack_image", "unimm_mul_dropout", "unimm_mul_dropout_bwd", "unimm_lm_loss_fwd",
            "unimm_lm_loss_bwd", "unimm_kl_loss_fwd", "unimm_kl_loss_bwd", "unimm_nsp_loss_fwd",
            "unimm_nsp_loss_bwd", "unimm_reduce_sum", "unimm_segment_sum", "unimm_gelu_bwd", "unimm_gather_rows", "unimm_prof_enable", "unimm_prof_collect", "unimm_gemm_set_tile", "unimm_attn_set_parts", "unimm_adamw_step", "unimm_transpose_cast_grouped", "unimm_mask_synth", "unimm_neural_ndcg", "unimm_plan_lengths", "unimm_plan_build", "unimm_layernorm_bwd_partials",
-           "unimm_colpartials_finish_grouped", "unimm_gemm_tn_set_shared"]
+           "unimm_colpartials_finish_grouped", "unimm_gemm_tn_set_shared", "unimm_gemm_tn_grouped_ws"]
 
 
 def _check(rc, what):
@@ -155,9 +155,12 @@ def gemm_tn(dy, x, dw, M=None, N=None, K=None, dbias=None):
     return dw
 
 
-def gemm_tn_grouped(problems):
+def gemm_tn_grouped(problems, shared=None, ws=None):
     """problems: list of (dy, x, dw, M, N, K, dbias) -- every dw[N,K] += dy[:M,:N]^T @ x[:M,:K] in as few
-    launches as possible (one per <= 12 problems of the same tile class)."""
+    launches as possible (one per <= 12 problems of the same tile class).
+    shared: the launches run beside another stream's kernels (split heuristic hint; None = the process-wide default).
+    ws: zero-initialised uint8 device tensor private to the launch stream (partial-tile slabs + arrival counters);
+    None = every split adds its partial tile with fp32 atomics."""
     n = len(problems)
     if n == 0:
         return
@@ -169,7 +172,11 @@ def gemm_tn_grouped(problems):
         a.N = dy.shape[1] if N is None else N
         a.K = x.shape[1] if K is None else K
         a.lddy, a.ldx, a.lddw = dy.stride(0), x.stride(0), dw.stride(0)
-    _check(lib().unimm_gemm_tn_grouped(arr, C.c_int32(n), _stream()), "unimm_gemm_tn_grouped")
+    if shared is None and ws is None:
+        _check(lib().unimm_gemm_tn_grouped(arr, C.c_int32(n), _stream()), "unimm_gemm_tn_grouped")
+        return
+    _check(lib().unimm_gemm_tn_grouped_ws(arr, C.c_int32(n), C.c_int32(1 if shared else 0), _ptr(ws),
+                                          C.c_int64(ws.numel() if ws is not None else 0), _stream()), "unimm_gemm_tn_grouped_ws")
 
 
 # ---------------------------------------------------------------------------------------------
