@@ -30,3 +30,8 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
         assert k in rf, k
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert rf["exclusive"] is None or rf["exclusive"]["achieved"] > 0
+    # executed work, whole-step fraction, measured kernel ranking and the padded schedule are always in the line
+    assert j["config"]["gemm_gflop_per_seq_executed_fwd_bwd"] > 0
+    assert 0 < rf["whole_step_frac"] < 1 and abs(rf["whole_step_frac"] - rf["whole_step_executed_gemm_tflops"] / rf["peak"]) < 1e-3
+    assert rf["gemm_kernels_by_time"] and rf["gemm_kernels_by_time"][0]["kernel"] == rf["kernel"]
+    assert j["config"]["padded_schedule_value"] > 0
