@@ -50,6 +50,8 @@ __device__ __forceinline__ void tile_of(int lid, int nbm, int nbn, int gn, int& 
 //   Cfg<2,2,4,64,2>: 128x128, 4 waves, 68 KiB LDS -> 2 workgroups per CU
 //   Cfg<2,4,8,32,4>: 256x256, 8 waves, BK=32, 4-slot ring (128 KiB): 3 K-steps in flight across barriers
 //   Cfg<2,4,8,64,2>: 256x256, 8 waves, BK=64, 2-slot ring (128 KiB)
+//   Cfg<2,4,6,64,2>: 192x256, 8 waves of 96x64, 2-slot ring (112 KiB): the tile for N = 768 at ~31k rows (489 tiles = 1.91
+//                     rounds of 256 CUs, where 256x256 gives 366 tiles = 1.43 rounds and 128x128 is staging-bound)
 //   Cfg<2,2,2,64,2>:  64x128, 4 waves of 32x64 (48 KiB, 3 workgroups per CU): twice the waves of the 128x128 tile
 //                     for grids that do not fill the chip (per-GPU batches of 30-60 sequences under strong scaling)
 template <int WM_, int WN_, int MT_, int BK_, int STAGES_>
@@ -60,7 +62,8 @@ struct Cfg {
   static constexpr int RPI = 1024 / ROWB;                     // rows per LDS-DMA wave-instruction
   static constexpr int STAGE_BYTES = (BM + BN) * ROWB;
   static constexpr int G = (BM + BN) / RPI / NW;              // LDS-DMA wave-instructions per wave per K-step
-  static constexpr int SLAB_ROWS = 16 * (MT < 4 ? MT : 4);    // rows of a wave's tile per epilogue pass
+  static constexpr int JP = MT == 6 ? 3 : (MT < 4 ? MT : 4);  // 16-row sub-tiles of a wave's tile per epilogue pass
+  static constexpr int SLAB_ROWS = 16 * JP;                   // rows per pass
   static constexpr int SLAB_BYTES = NW * SLAB_ROWS * 68 * 4;  // epilogue transpose slabs
   static constexpr int LDS = STAGES * STAGE_BYTES > SLAB_BYTES ? STAGES * STAGE_BYTES : SLAB_BYTES;
   static constexpr int WG_PER_CU = LDS <= 53 * 1024 ? 3 : (LDS <= 80 * 1024 ? 2 : 1);
@@ -131,7 +134,7 @@ template <int N> __device__ __forceinline__ void lds_wait(bf16x8& a) { asm volat
 template <int MT, int KS> struct FragPipe {
   static constexpr int U = KS * MT;
   static constexpr bool AFTER = UNIMM_READ_AFTER != 0;
-  static constexpr int WP0 = MT == 8 ? 2 : 0, WPN = MT == 8 ? 1 : 2, WPU = 4 / WPN;   // first unit / frags per unit / units
+  static constexpr int WP0 = MT >= 6 ? 2 : 0, WPN = MT >= 6 ? 1 : 2, WPU = 4 / WPN;   // first unit / frags per unit / units
   static constexpr int npref_w(int v) {
     return (v >= 0 && v / MT + 1 < KS && v % MT >= WP0 && v % MT < WP0 + WPU) ? WPN : 0;
   }
@@ -162,7 +165,7 @@ template <int MT, int KS> struct FragPipe {
       if (pending(u) < 0 || pending(u) > 15) return false;
     return true;
   }
-  static_assert(MT == 2 || MT == 4 || MT == 8, "FragPipe: unit plans exist for 2, 4 and 8 sub-tiles");
+  static_assert(MT == 2 || MT == 4 || MT == 6 || MT == 8, "FragPipe: unit plans exist for 2, 4, 6 and 8 sub-tiles");
 };
 
 #ifndef UNIMM_TN_SPREAD
@@ -220,7 +223,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtParams& p, f32x4 (&acc)[
   }
   const bool vec_out = full && ((p.ldo * (OUT_F32 ? 4 : 2)) % 16 == 0);
   const bool vec_aux = full && ((p.ldaux * (EPI == UNIMM_EPI_BIAS_DROP_RESID ? 4 : 2)) % 16 == 0);
-  constexpr int JP = MT < 4 ? MT : 4;               // 16-row sub-tiles per pass (a 32-row wave tile has only two)
+  constexpr int JP = C::JP;                          // 16-row sub-tiles per pass (a 32-row wave tile has only two)
   // GELU epilogues with bf16 outputs do their arithmetic BEFORE the transposition, on the accumulator registers:
   // elementwise math does not care about the layout, and there every lane has 16 x JP independent values in flight
   // (the row-walk below has 8 behind an LDS read per iteration: the erf + exp + rcp chains of the fused GELU / GELU'
@@ -1088,17 +1091,29 @@ int launch_nt_cfg(const GemmNtParams& p, bool out_f32, hipStream_t s) {
 template <int EPI>
 int launch_nt(const GemmNtParams& p, bool out_f32, hipStream_t s) {
   int cfg = g_nt_cfg;
-  if (cfg == 0) {   // 256x256 tiles when they still give every CU >= 1.5 workgroups, else 128x128
-    const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+  if (cfg == 0) {
+    // One-workgroup-per-CU tiles (256x256, 192x256) when they still fill the chip: the one that wastes less of its last
+    // round of 256 CUs (the 192x256 tile pays ~3 % per flop for its smaller wave tile: N = 3072 at 31k rows stays on
+    // 256x256 with 5.72 rounds, N = 2304 (4.29 rounds) and N = 768 (1.43 rounds) go to 192x256 with 5.73 / 1.91 rounds:
+    // measured 112 vs 116 us and 135 vs 151 us (vs 141 us for two 128x128 workgroups per CU)); else 128x128, or 64x128
+    // for grids that do not even give every CU one 128x128 workgroup (per-GPU batches of 30 under strong scaling).
+    const long nn = (p.N + 255) / 256;
+    const long t256 = (long)((p.M + 255) / 256) * nn, t192 = (long)((p.M + 191) / 192) * nn;
     const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-    // fewer 128x128 tiles than CUs (N=768 GEMMs at ~4k rows: per-GPU batches of 30 under strong scaling): the
-    // 64x128 tile doubles the waves (+12-15 % there, equal or worse everywhere else)
-    cfg = (t256 >= 384) ? 3 : (t128 < 256 ? 7 : 1);
+    const int cus = cu_count() & ~7;
+    if (UNIMM_EXP == 19) cfg = (t256 >= 384) ? 3 : (t128 < 256 ? 7 : 1);      // (the round-1 rule, for A/B builds)
+    else if (t256 >= 384 || t192 >= 300) {
+      const double e256 = (double)t256 / (double)(((t256 + cus - 1) / cus) * cus);
+      const double e192 = 0.97 * (double)t192 / (double)(((t192 + cus - 1) / cus) * cus);
+      cfg = e192 > e256 ? 6 : 3;
+    } else {
+      cfg = t128 < 256 ? 7 : 1;
+    }
   }
   if (cfg == 2) return launch_nt_cfg<Cfg<2, 4, 8, 32, 4>, EPI>(p, out_f32, s);
   if (cfg == 4) return launch_nt_cfg<Cfg<2, 4, 8, 32, 5>, EPI>(p, out_f32, s);
   if (cfg == 5) return launch_nt_cfg<Cfg<2, 2, 4, 32, 5>, EPI>(p, out_f32, s);
-  if (cfg == 6) return launch_nt_cfg<Cfg<4, 2, 4, 64, 2>, EPI>(p, out_f32, s);
+  if (cfg == 6) return launch_nt_cfg<Cfg<2, 4, 6, 64, 2>, EPI>(p, out_f32, s);
   if (cfg == 7) return launch_nt_cfg<Cfg<2, 2, 2, 64, 2>, EPI>(p, out_f32, s);
   if (cfg == 3) return launch_nt_cfg<Cfg<2, 4, 8, 64, 2>, EPI>(p, out_f32, s);
   return launch_nt_cfg<Cfg<2, 2, 4, 64, 2>, EPI>(p, out_f32, s);
