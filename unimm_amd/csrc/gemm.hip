@@ -1092,22 +1092,32 @@ template <int EPI>
 int launch_nt(const GemmNtParams& p, bool out_f32, hipStream_t s) {
   int cfg = g_nt_cfg;
   if (cfg == 0) {
-    // One-workgroup-per-CU tiles (256x256, 192x256) when they still fill the chip: the one that wastes less of its last
-    // round of 256 CUs (the 192x256 tile pays ~3 % per flop for its smaller wave tile: N = 3072 at 31k rows stays on
-    // 256x256 with 5.72 rounds, N = 2304 (4.29 rounds) and N = 768 (1.43 rounds) go to 192x256 with 5.73 / 1.91 rounds:
-    // measured 112 vs 116 us and 135 vs 151 us (vs 141 us for two 128x128 workgroups per CU)); else 128x128, or 64x128
-    // for grids that do not even give every CU one 128x128 workgroup (per-GPU batches of 30 under strong scaling).
-    const long nn = (p.N + 255) / 256;
-    const long t256 = (long)((p.M + 255) / 256) * nn, t192 = (long)((p.M + 191) / 192) * nn;
-    const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    // Tile choice = the configuration with the smallest modelled time: rounds of `slots` workgroups, a round of a tile
+    // with W workgroups per CU costs area x W / eff, the last (partial) round only the workgroups per CU it really
+    // has.  eff (per-flop efficiency against the 256x256 tile, from interleaved micro-benchmarks at K = 768..3072):
+    // 192x256 0.95, 128x128 0.85.  At ~31k rows: N = 3072 -> 256x256 (5.72 rounds), N = 2304 / 768 -> 192x256 (5.73 /
+    // 1.91 rounds instead of 4.29 / 1.43; 112 vs 116 us, 135 vs 151 us and vs 141 us for 128x128); the image side at
+    // 8,880 rows: N = 1024 -> 192x256 (30.6 vs 37.3 us), N = 3072 -> 256x256 (58.5 vs 65.9 us).  Grids too small to
+    // give every CU 1.5 workgroups of 128x128 take the 64x128 tile (three workgroups per CU: per-GPU batches of 30).
     const int cus = cu_count() & ~7;
-    if (UNIMM_EXP == 19) cfg = (t256 >= 384) ? 3 : (t128 < 256 ? 7 : 1);      // (the round-1 rule, for A/B builds)
-    else if (t256 >= 384 || t192 >= 300) {
-      const double e256 = (double)t256 / (double)(((t256 + cus - 1) / cus) * cus);
-      const double e192 = 0.97 * (double)t192 / (double)(((t192 + cus - 1) / cus) * cus);
-      cfg = e192 > e256 ? 6 : 3;
+    const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    if (UNIMM_EXP == 19) {                                  // (the round-1 rule, for A/B builds)
+      const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+      cfg = (t256 >= 384) ? 3 : (t128 < 256 ? 7 : 1);
+    } else if (t128 < 384) {
+      cfg = 7;
     } else {
-      cfg = t128 < 256 ? 7 : 1;
+      struct Cand { int cfg, bm, bn, w; double eff; };
+      const Cand cand[3] = {{3, 256, 256, 1, 1.0}, {6, 192, 256, 1, 0.95}, {1, 128, 128, 2, 0.85}};
+      double best = 1e30;
+      for (const Cand& c : cand) {
+        const long tiles = (long)((p.M + c.bm - 1) / c.bm) * ((p.N + c.bn - 1) / c.bn);
+        const long slots = (long)cus * c.w;
+        const double area = (double)c.bm * c.bn / 65536.0;
+        const long rem = tiles % slots;
+        const double cost = ((double)(tiles / slots) * c.w + (rem ? (double)((rem + cus - 1) / cus) : 0.0)) * area / c.eff;
+        if (cost < best) { best = cost; cfg = c.cfg; }
+      }
     }
   }
   if (cfg == 2) return launch_nt_cfg<Cfg<2, 4, 8, 32, 4>, EPI>(p, out_f32, s);
