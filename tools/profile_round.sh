@@ -1,0 +1,19 @@
+# All the judged measurement artefacts of one state of the tree, in ONE gpurun call:  bash tools/profile_round.sh <tag>
+# -> gpurun_out/<tag>/...; copy what is to be kept into profiles/ (see profiles/README.md).
+tag=$1
+out=gpurun_out/$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+python bench.py > $out/bench_b240.json 2> $out/bench_b240.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o run -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-padded > $out/bench_b240_under_rocprof.json 2> $out/stats.err
+UNIMM_DUAL_STREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats1 -o run -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-padded > $out/bench_b240_single_stream_under_rocprof.json 2> $out/stats1.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o run -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-padded > /dev/null 2> $out/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_write -o run -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-padded > /dev/null 2> $out/pmc_write.err
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $out/pmc_sq -o run -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-padded > /dev/null 2> $out/pmc_sq.err
+python tools/pmc_report.py $out/pmc_fetch $out/pmc_write $out/pmc_sq $out/traffic_dominant_kernel.json "profiles/${tag}_pmc_bench.txt (rocprofv3 --pmc, separate passes: FETCH_SIZE | WRITE_SIZE GRBM_GUI_ACTIVE | SQ_VALU_MFMA_BUSY_CYCLES; python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-padded)" > $out/pmc_bench.txt 2> $out/pmc_report.err
+python bench.py --batch 30 --steps 30 --no-cpu-baseline --no-padded > $out/bench_b30.json 2> $out/bench_b30.err
+python bench.py --workload dense --steps 16 --warmup 16 --no-cpu-baseline > $out/bench_dense_b100.json 2> $out/bench_dense.err
+python bench.py --workload scoring --no-cpu-baseline > $out/bench_scoring.json 2> $out/bench_scoring.err
+rm -rf $out/pmc_fetch $out/pmc_write $out/pmc_sq
+find $out -name "*kernel_trace.csv" -size +20M -delete
+ls -la $out | head -30

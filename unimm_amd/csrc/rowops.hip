@@ -126,6 +126,7 @@ __global__ __launch_bounds__(256) void plan_lengths_kernel(const uint32_t* __res
   if (t < 8) col[t] = 0u;
   __syncthreads();
   bool valid = false;
+  bool empty_row = false;        // dense mask: this token's own mask row has no bit set
   if (tw != nullptr && t < T) {
     if (t_qs == 0) {
       valid = (tw[(size_t)b * t_bs + (t >> 5)] >> (t & 31)) & 1u;           // key-padding mask: the bit itself
@@ -134,6 +135,7 @@ __global__ __launch_bounds__(256) void plan_lengths_kernel(const uint32_t* __res
         const uint32_t x = tw[(size_t)b * t_bs + (size_t)t * t_qs + w];
         if (x != 0u) { valid = true; atomicOr(&col[w], x); }                // attends something | marks attended keys
       }
+      empty_row = !valid;
     }
   }
   if (cw != nullptr) {
@@ -155,7 +157,11 @@ __global__ __launch_bounds__(256) void plan_lengths_kernel(const uint32_t* __res
     valid = valid || lab != -1 || wt != 0;
     sel = labels != nullptr && (weights != nullptr ? wt != 0 : lab != -1);
   }
-  int len = valid ? t + 1 : 0;
+  // A token that is valid (labelled, weighted or attended) although its OWN mask row is empty attends, in the
+  // reference, every one of the T keys uniformly (softmax of raw scores - 10000, models/vilbert_dialog.py:1418), the
+  // padding rows' K / V included: such a sequence must run at its full length (the reference's own encoders never
+  // produce one: utils/data_utils.py:199-210, :354; only user-supplied masks can).
+  int len = valid ? (empty_row ? T : t + 1) : 0;
   int cnt = sel ? 1 : 0;
   int nim = (img_label != nullptr && t < R && img_label[(size_t)b * R + t] == 1) ? 1 : 0;   // regions in the masked-region loss
   for (int o = 32; o > 0; o >>= 1) {
