@@ -130,7 +130,7 @@ def test_gemm_tn(M, N, K):
     assert (db - ref_b).abs().max().item() <= 2e-3 * max(1.0, ref_b.abs().max().item())
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("M,N,K", [(300, 200, 64), (1000, 1000, 768), (515, 2304, 128), (4096, 768, 3072), (257, 257 * 3, 320)])
 def test_gemm_nt_every_tile_configuration(cfg, M, N, K):
     """All block-tile / ring configurations of unimm_gemm_nt give the same result (the automatic choice only
@@ -155,7 +155,7 @@ def test_gemm_nt_every_tile_configuration(cfg, M, N, K):
         assert torch.isnan(out[:, N:]).all()
 
 
-@pytest.mark.parametrize("cfg", [101, 103, 201, 203])
+@pytest.mark.parametrize("cfg", [101, 103, 108, 201, 203, 208])
 def test_gemm_nt_persistent_workgroups(cfg):
     """x1xx = persistent workgroups (one per CU slot walking several tiles), x2xx = one workgroup per tile: same
     result on a grid of several rounds, ragged M edge, GELU epilogue with its second output."""
@@ -179,6 +179,31 @@ def test_gemm_nt_persistent_workgroups(cfg):
     cdf = 0.5 * (1 + torch.erf(u / math.sqrt(2.0)))
     dref = cdf + u * torch.exp(-0.5 * u * u) / math.sqrt(2 * math.pi)
     assert (out2.float() - dref).abs().max().item() <= 2 ** -6
+
+
+@pytest.mark.parametrize("K", [64, 192, 768, 3072])
+def test_gemm_nt_ping_pong_loop_is_race_free_and_bit_equal_to_the_ring_loop(K):
+    """Tile configuration 8 (two half-workgroups one barrier apart, hand-counted LDS-DMA completion) accumulates every
+    output element in the same K order as configuration 3 (lock-step ring): the results must be bit-identical, on a
+    grid of several persistent rounds, every one of 8 repetitions (a staging race shows up as a sporadic mismatch)."""
+    from unimm_amd import lib
+    M, N = 31162, 768
+    g = torch.Generator(device="cuda").manual_seed(K)
+    x, w = _rand((M, K), g), _rand((N, K), g, 0.05)
+    bias = torch.randn(N, generator=g, device="cuda")
+    ref = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+    lib.gemm_set_tile(3)
+    try:
+        lib.gemm_nt(x, w, ref, bias=bias, epilogue=lib.EPI_BIAS)
+        lib.gemm_set_tile(8)
+        for rep in range(8):
+            out = torch.zeros_like(ref)
+            lib.gemm_nt(x, w, out, bias=bias, epilogue=lib.EPI_BIAS)
+            torch.cuda.synchronize()
+            bad = (out.view(torch.int16) != ref.view(torch.int16)).sum().item()
+            assert bad == 0, (rep, bad)
+    finally:
+        lib.gemm_set_tile(0)
 
 
 @pytest.mark.parametrize("M,N,K", [(515, 768, 128), (4096, 1024, 1024), (300, 200, 64)])

@@ -54,9 +54,10 @@ __device__ __forceinline__ void tile_of(int lid, int nbm, int nbn, int gn, int& 
 //                     rounds of 256 CUs, where 256x256 gives 366 tiles = 1.43 rounds and 128x128 is staging-bound)
 //   Cfg<2,2,2,64,2>:  64x128, 4 waves of 32x64 (48 KiB, 3 workgroups per CU): twice the waves of the 128x128 tile
 //                     for grids that do not fill the chip (per-GPU batches of 30-60 sequences under strong scaling)
-template <int WM_, int WN_, int MT_, int BK_, int STAGES_>
+template <int WM_, int WN_, int MT_, int BK_, int STAGES_, int PP_ = 0>
 struct Cfg {
   static constexpr int WM = WM_, WN = WN_, MT = MT_, BK = BK_, STAGES = STAGES_;
+  static constexpr bool PP = PP_ != 0;                        // ping-pong main loop (nt_mainloop_pp)
   static constexpr int BM = 16 * MT * WM, BN = 64 * WN, NW = WM * WN, THREADS = 64 * NW;
   static constexpr int ROWB = BK * 2;                         // bytes per staged row
   static constexpr int RPI = 1024 / ROWB;                     // rows per LDS-DMA wave-instruction
@@ -390,6 +391,188 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtParams& p, f32x4 (&acc)[
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Ping-pong main loop of the 256x256x64 tile (Cfg<2,4,8,64,2,1>).
+//
+// The loop above runs all 8 waves through the same fragment stream in lock-step: the two waves of a SIMD want the
+// LDS, the LDS-DMA issue slots and the matrix pipe at the same moments, and the step-top vmcnt(0) + barrier drains the
+// whole pipeline once per K-step.  Here the waves form two groups, G0 = waves 0-3 (rows 0-127 of the tile) and
+// G1 = waves 4-7 (rows 128-255) - one wave of each per SIMD - that run the SAME program one barrier apart (G1 passes
+// one extra barrier first), so that in every barrier interval one group issues nothing but its 16 MFMAs (one
+// quadrant of its 128x64 accumulator tile x the whole 64-deep K-tile) while the other requests the fragments of its
+// next quadrant and issues its share of the LDS-DMA staging (the 8-phase structure of the CDNA guide's 256^2 GEMM).
+// Per K-tile and wave: 4 phases = 8 barriers,
+//   phase 0: read X(m-half 0: 8 fragments) + W(n-half 0: 4)  | MFMA quadrant (m0, n0)
+//   phase 1: read W(n-half 1: 4)                              | MFMA quadrant (m0, n1)
+//   phase 2: read X(m-half 1: 8, same registers)              | MFMA quadrant (m1, n1)
+//   phase 3: no reads (W(n-half 0) stays in registers)        | MFMA quadrant (m1, n0)
+// Staging: the K-tile's 64 KiB are four 16 KiB half-tiles [W rows 0-127 | W 128-255 | X 0-127 | X 128-255]; every phase
+// stages ONE half-tile (each wave 2 LDS-DMA instructions, in its read interval), phase P the half-tile (P+1) % 4 of
+// K-tile (P+1) / 4 + 1.  Two buffers; a half-tile is restaged at least two barrier intervals after the lgkmcnt(0) that
+// retired its last fragment read in BOTH groups (WAR), and a K-tile is certified by ONE counted wait per K-tile: in
+// phase 3 every wave, after issuing that phase's 2 DMAs, waits vmcnt(2) - all DMAs of the next K-tile are older - and
+// the barrier that follows orders them before the first reads of the next K-tile in either group (RAW).  Proof sketch
+// with I_k = the interval before barrier k; G0 reads phase P in I_2P and computes it in I_2P+1, G1 one interval later:
+//   buffer b of K-tile t: last W reads in phase 4t+1 (G1: I_8t+3, retired at the start of I_8t+4), last X reads in phase
+//   4t+2 (G0 I_8t+4 / G1 I_8t+5, retired at the start of I_8t+5 / I_8t+6); restaged by phases 4t+3 (W0: I_8t+6, I_8t+7),
+//   4t+4 (W1), 4t+5 (X0: I_8t+10, I_8t+11), 4t+6 (X1); certified in phase 4t+7 (I_8t+14 / I_8t+15), first read of K-tile
+//   t+2 in I_8t+16.
+// ------------------------------------------------------------------------------------------------
+// Staging addresses of one wave: half-tile ht (0,1 = W rows 0-127 / 128-255; 2,3 = X) is 16 wave-instructions of 8 rows
+// x 128 B; this wave issues two of them, inst = group * 8 + (wave & 3) * 2 + r.  Sources are a 32-bit byte offset per
+// lane (row * ld + swizzled 16-B chunk, constant over K) on top of a scalar base that advances 128 B per K-tile.
+struct PpStage {
+  uint32_t so[4][2];       // per-lane source byte offsets
+  uint32_t lds;            // LDS byte address of this wave's first instruction slot in half-tile 0 of buffer 0 (uniform)
+};
+
+template <class C>
+__device__ __forceinline__ void pp_stage_init(PpStage& st, const GemmNtParams& p, int n0, int m0, uint32_t lds0, int wave, int lane) {
+  const int inst0 = (wave >> 2) * 8 + (wave & 3) * 2;
+  st.lds = __builtin_amdgcn_readfirstlane(lds0 + inst0 * 1024);
+#pragma unroll
+  for (int ht = 0; ht < 4; ++ht)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int rl = (inst0 + r) * 8 + (lane >> 3);            // row inside the half-tile
+      const int chunk = (lane & 7) ^ kswz<64>(rl);
+      const int rr = (ht & 1) * 128 + rl;                      // row inside the W (or X) tile
+      int g = (ht < 2 ? n0 : m0) + rr;
+      const int lim = ht < 2 ? p.N : p.M;
+      g = g < lim ? g : lim - 1;                               // edge rows re-read a valid row; their outputs are never stored
+      st.so[ht][r] = (uint32_t)g * (uint32_t)((ht < 2 ? p.ldw : p.ldx) * 2) + chunk * 16;
+    }
+}
+
+// Issued through inline asm: the compiler must not know that LDS-DMA is in flight.  With the builtin it tracks the pending
+// "VMEM write to LDS" across the loop's back edge and puts an s_waitcnt vmcnt(0) in front of the first MFMA cluster of every
+// K-tile (seen in the .s), which drains the half-tile that was just requested and serialises staging with compute once
+// per K-tile.  Completion is counted by hand (wait_vmcnt in nt_mainloop_pp).
+template <class C>
+__device__ __forceinline__ void pp_stage(const PpStage& st, const GemmNtParams& p, int kt, int ht) {
+  const char* base = (const char*)(ht < 2 ? p.w : p.x) + (size_t)kt * 128;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const uint32_t dst = st.lds + (kt & 1) * 65536 + ht * 16384 + r * 1024;
+    uint32_t keep;                                             // m0 is the compiler's: hand it back as found
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(st.so[ht][r]), "s"(dst), "s"(base) : "memory");
+  }
+}
+
+template <class C>
+__device__ __forceinline__ void nt_mainloop_pp(const GemmNtParams& p, char* smem, int m0, int n0, f32x4 (&acc)[4][C::MT]) {
+  static_assert(C::WM == 2 && C::WN == 4 && C::MT == 8 && C::BK == 64 && C::STAGES == 2, "ping-pong loop: 256x256x64, 8 waves");
+  constexpr int RB = 128;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nk = p.K / 64;
+  // fragment addresses in buffer 0 (second 32-deep sub-step = a second base: the swizzle is an XOR)
+  uint32_t aw0[2], ax0[2];
+  PpStage st;
+  {
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)LDS_PTR(smem);
+    pp_stage_init<C>(st, p, n0, m0, lds0, wave, lane);
+    const int rw = wn * 64 + (lane & 15), rx = wm * 128 + (lane & 15), cq = lane >> 4;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      aw0[ks] = lds0 + rw * RB + (((ks * 4 + cq) ^ kswz<64>(rw)) << 4);
+      ax0[ks] = lds0 + (256 + rx) * RB + (((ks * 4 + cq) ^ kswz<64>(rx)) << 4);
+    }
+  }
+  // prologue: K-tile 0 (4 half-tiles) and half-tile 0 of K-tile 1
+#pragma unroll
+  for (int ht = 0; ht < 4; ++ht) pp_stage<C>(st, p, 0, ht);
+  // vmcnt(0) through the builtin, not asm and not vmcnt(2): a full wait the compiler can SEE retires the stores it still
+  // tracks from the previous tile's epilogue (persistent kernel); with anything less it protects their data registers
+  // with a vmcnt(0) of its own in front of the first MFMA cluster of every K-tile, which drains the staging pipeline.
+  if (nk > 1) pp_stage<C>(st, p, 1, 0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __builtin_amdgcn_s_barrier();                        // K-tile 0 has landed for every wave
+  if (wm == 1) __builtin_amdgcn_s_barrier();           // G1 runs one barrier behind G0 (matched by G0's first loop barrier)
+  __builtin_amdgcn_sched_barrier(0);
+
+  bf16x8 fx[2][4], fw[2][4];
+  // phase P stages half-tile (P + 1) % 4 of K-tile (P + 1) / 4 + 1
+#define UNIMM_PP_STAGE(P_)                                                                       \
+  {                                                                                              \
+    const int u_ = (P_) + 1, kt_ = (u_ >> 2) + 1;                                                \
+    if (kt_ < nk) pp_stage<C>(st, p, kt_, u_ & 3);                                               \
+  }
+#define UNIMM_PP_MFMA(JH, IH)                                                                    \
+  {                                                                                              \
+    __builtin_amdgcn_s_setprio(1);                                                               \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                             \
+      _Pragma("unroll") for (int jj = 0; jj < 4; ++jj)                                           \
+        _Pragma("unroll") for (int ii = 0; ii < 2; ++ii)                                         \
+          acc[2 * (IH) + ii][4 * (JH) + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(           \
+              fw[ks][2 * (IH) + ii], fx[ks][jj], acc[2 * (IH) + ii][4 * (JH) + jj], 0, 0, 0);    \
+    __builtin_amdgcn_s_setprio(0);                                                               \
+  }
+#define UNIMM_PP_READ_X(JH)                                                                      \
+  {                                                                                              \
+    fx[0][0] = lds_read_b128<((JH) * 4 + 0) * 16 * RB>(ax[0]); fx[0][1] = lds_read_b128<((JH) * 4 + 1) * 16 * RB>(ax[0]); \
+    fx[0][2] = lds_read_b128<((JH) * 4 + 2) * 16 * RB>(ax[0]); fx[0][3] = lds_read_b128<((JH) * 4 + 3) * 16 * RB>(ax[0]); \
+    fx[1][0] = lds_read_b128<((JH) * 4 + 0) * 16 * RB>(ax[1]); fx[1][1] = lds_read_b128<((JH) * 4 + 1) * 16 * RB>(ax[1]); \
+    fx[1][2] = lds_read_b128<((JH) * 4 + 2) * 16 * RB>(ax[1]); fx[1][3] = lds_read_b128<((JH) * 4 + 3) * 16 * RB>(ax[1]); \
+  }
+#define UNIMM_PP_READ_W(IH)                                                                      \
+  {                                                                                              \
+    fw[0][2 * (IH)] = lds_read_b128<(2 * (IH)) * 16 * RB>(aw[0]); fw[0][2 * (IH) + 1] = lds_read_b128<(2 * (IH) + 1) * 16 * RB>(aw[0]); \
+    fw[1][2 * (IH)] = lds_read_b128<(2 * (IH)) * 16 * RB>(aw[1]); fw[1][2 * (IH) + 1] = lds_read_b128<(2 * (IH) + 1) * 16 * RB>(aw[1]); \
+  }
+#define UNIMM_PP_SYNC_READS()                                                                    \
+  __builtin_amdgcn_s_barrier();                                                                  \
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fx[0][0]), "+v"(fx[0][1]), "+v"(fx[0][2]), "+v"(fx[0][3]), "+v"(fx[1][0]), \
+               "+v"(fx[1][1]), "+v"(fx[1][2]), "+v"(fx[1][3]), "+v"(fw[0][0]), "+v"(fw[0][1]), "+v"(fw[0][2]), "+v"(fw[0][3]), \
+               "+v"(fw[1][0]), "+v"(fw[1][1]), "+v"(fw[1][2]), "+v"(fw[1][3]));                 \
+  __builtin_amdgcn_sched_barrier(0);
+
+  for (int t = 0; t < nk; ++t) {
+    const uint32_t off = (uint32_t)((t & 1) * 65536);
+    const uint32_t aw[2] = {aw0[0] + off, aw0[1] + off}, ax[2] = {ax0[0] + off, ax0[1] + off};
+    const int P = 4 * t;
+    // ---- phase 0
+    UNIMM_PP_READ_W(0)
+    UNIMM_PP_READ_X(0)
+    UNIMM_PP_STAGE(P)
+    UNIMM_PP_SYNC_READS()
+    UNIMM_PP_MFMA(0, 0)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase 1
+    UNIMM_PP_READ_W(1)
+    UNIMM_PP_STAGE(P + 1)
+    UNIMM_PP_SYNC_READS()
+    UNIMM_PP_MFMA(0, 1)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase 2
+    UNIMM_PP_READ_X(1)
+    UNIMM_PP_STAGE(P + 2)
+    UNIMM_PP_SYNC_READS()
+    UNIMM_PP_MFMA(1, 1)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase 3: no fragment reads; certify K-tile t+1 (every DMA older than this phase's two has landed)
+    {
+      const int u_ = P + 4, kt_ = (u_ >> 2) + 1;
+      if (kt_ < nk) { pp_stage<C>(st, p, kt_, 0); wait_vmcnt<2>(); } else wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    UNIMM_PP_MFMA(1, 0)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();           // G0 waits for G1's last phase (barrier counts match again)
+#undef UNIMM_PP_STAGE
+#undef UNIMM_PP_MFMA
+#undef UNIMM_PP_READ_X
+#undef UNIMM_PP_READ_W
+#undef UNIMM_PP_SYNC_READS
+}
+
 // One output tile (logical tile id `lid`, already XCD-remapped): ring-staged main loop + epilogue.
 template <class C, int EPI, bool OUT_F32>
 __device__ __forceinline__ void nt_tile(const GemmNtParams& p, char* smem, int lid) {
@@ -418,6 +601,11 @@ __device__ __forceinline__ void nt_tile(const GemmNtParams& p, char* smem, int l
       aw0[ks] = lds0 + rw * C::ROWB + (((ks * 4 + cq) ^ kswz<BK>(rw)) << 4);
       ax0[ks] = lds0 + (BN + rx) * C::ROWB + (((ks * 4 + cq) ^ kswz<BK>(rx)) << 4);
     }
+  }
+  if constexpr (C::PP) {
+    nt_mainloop_pp<C>(p, smem, m0, n0, acc);
+    nt_epilogue<C, EPI, OUT_F32>(p, acc, smem, m0, n0, wm, wn, wave, lane);
+    return;
   }
   const int nk = p.K / BK;
   // One 8-wave workgroup per CU: spread the ring refill over the MFMA units (see the main loop).  With two
@@ -1108,7 +1296,8 @@ int launch_nt(const GemmNtParams& p, bool out_f32, hipStream_t s) {
       cfg = 7;
     } else {
       struct Cand { int cfg, bm, bn, w; double eff; };
-      const Cand cand[3] = {{3, 256, 256, 1, 1.0}, {6, 192, 256, 1, 0.95}, {1, 128, 128, 2, 0.85}};
+      // 256x256 = the ping-pong loop (configuration 8; 3 = the lock-step ring, kept for A/B builds with UNIMM_EXP == 20)
+      const Cand cand[3] = {{UNIMM_EXP == 20 ? 3 : 8, 256, 256, 1, 1.0}, {6, 192, 256, 1, 0.95}, {1, 128, 128, 2, 0.85}};
       double best = 1e30;
       for (const Cand& c : cand) {
         const long tiles = (long)((p.M + c.bm - 1) / c.bm) * ((p.N + c.bn - 1) / c.bn);
@@ -1120,6 +1309,7 @@ int launch_nt(const GemmNtParams& p, bool out_f32, hipStream_t s) {
       }
     }
   }
+  if (cfg == 8) return launch_nt_cfg<Cfg<2, 4, 8, 64, 2, 1>, EPI>(p, out_f32, s);
   if (cfg == 2) return launch_nt_cfg<Cfg<2, 4, 8, 32, 4>, EPI>(p, out_f32, s);
   if (cfg == 4) return launch_nt_cfg<Cfg<2, 4, 8, 32, 5>, EPI>(p, out_f32, s);
   if (cfg == 5) return launch_nt_cfg<Cfg<2, 2, 4, 32, 5>, EPI>(p, out_f32, s);
@@ -1171,7 +1361,7 @@ extern "C" int unimm_gemm_set_tile(int32_t cfg) {
   cfg = cfg - ((cfg % 1000) / 100) * 100;
   g_nt_cfg = cfg % 1000;          // tile configuration
   g_nt_gn = cfg / 1000;           // tuning: n-tiles per column group (0 = default)
-  if (g_nt_cfg > 7) return UNIMM_E_ARG;
+  if (g_nt_cfg > 8) return UNIMM_E_ARG;
   return UNIMM_OK;
 }
 
