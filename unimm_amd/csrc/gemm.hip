@@ -16,6 +16,7 @@
 // 16-byte fp32 stores and vector loads of bias / residual in the epilogue.  Grid order is
 // XCD-aware: each XCD walks a contiguous run of tiles with the N index fastest, so an X row panel is
 // fetched from HBM once per XCD and W stays L2/MALL resident.
+#include <type_traits>
 #include "common.h"
 #include <stdlib.h>
 
@@ -204,12 +205,50 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtParams& p, f32x4 (&acc)[
   // -> 187 us with nt stores + nt operand loads, 167 -> 155 us for the 128x128 tile at K=3072; 200-launch averages of
   // alternating builds in one gpurun call).  Nothing re-reads these lines before the next kernel does.
   constexpr int SLAB_LD = 68;                       // floats per slab row (64 + 4 pad)
-  __builtin_amdgcn_s_barrier();                      // all waves finished reading the ring
   float* slab = reinterpret_cast<float*>(smem) + wave * (C::SLAB_ROWS * SLAB_LD);
   const int c0 = (lane & 7) * 8;
   const int n = n0 + wn * 64 + c0;
-  const bool ncols_ok = n < p.N;
-  const bool full = (n + 7 < p.N);
+  const bool ncols_ok_ = n < p.N;
+  const bool full_ = (n + 7 < p.N);
+  // Residual / multiplier operand: loaded in batches of PF row-walk iterations, one batch ahead of its use (the first
+  // before the barrier below; registers: the main loop's fragment registers are dead).  In program order the walk used
+  // to reach each load only after the slab reads of its iteration, and because loads and stores share vmcnt (and may
+  // retire out of order with respect to each other) the compiler can only wait vmcnt(0): every one of the 16 iterations
+  // paid a full load round trip plus the acknowledgement of the previous iteration's stores.  Batched, there is one
+  // such drain per batch, and the loads it waits for were requested a whole batch earlier.
+  constexpr bool AUX32 = EPI == UNIMM_EPI_BIAS_DROP_RESID;
+  constexpr bool AUX16 = EPI == UNIMM_EPI_DGELU || EPI == UNIMM_EPI_ADD || EPI == UNIMM_EPI_MUL;
+  constexpr int NIT = 2 * C::JP, NWALK = (MT / C::JP) * NIT;
+  constexpr int PF = (AUX32 || AUX16) ? (UNIMM_EXP == 21 ? 0 : (AUX32 && NIT % 2 == 0 ? NIT / 2 : NIT)) : 0;
+  constexpr int PFN = PF > 0 ? PF : 1;
+  const bool pf_on = PF > 0 && p.aux != nullptr && ((p.ldaux * (AUX32 ? 4 : 2)) % 16 == 0);   // uniform
+  const int pf_n = full_ ? n : 0;                     // lanes at the ragged N edge take the scalar path; their prefetch is ignored
+  f32x4 pf0[2][PFN], pf1[2][PFN];
+  float pfmu[2][PFN], pfrs[2][PFN];
+  auto aux_prefetch = [&](int batch, auto sure) {    // requests walk iterations [batch * PF, (batch + 1) * PF)
+    if constexpr (PF > 0) {
+      if (batch * PF < NWALK && (decltype(sure)::value || pf_on)) {
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+          const int g = batch * PF + k;
+          const int row = (g % NIT) * 8 + (lane >> 3);
+          int m = m0 + wm * 16 * MT + (g / NIT) * 16 * C::JP + row;
+          m = m < p.M ? m : p.M - 1;
+          if constexpr (AUX32) {
+            const float* ap = reinterpret_cast<const float*>(p.aux) + (size_t)m * p.ldaux + pf_n;
+            pf0[batch & 1][k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ap));
+            pf1[batch & 1][k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ap + 4));
+            if (p.aux_mean != nullptr) { pfmu[batch & 1][k] = p.aux_mean[m]; pfrs[batch & 1][k] = p.aux_rstd[m]; }
+          } else {
+            const bf16_t* ap = reinterpret_cast<const bf16_t*>(p.aux) + (size_t)m * p.ldaux + pf_n;
+            pf0[batch & 1][k] = __builtin_bit_cast(f32x4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ap)));
+          }
+        }
+      }
+    }
+  };
+  aux_prefetch(0, std::false_type{});
+  __builtin_amdgcn_s_barrier();                      // all waves finished reading the ring
   float b[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) b[e] = (p.bias != nullptr && n + e < p.N) ? p.bias[n + e] : 0.f;
@@ -222,8 +261,8 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtParams& p, f32x4 (&acc)[
       lb[e] = n + e < p.N ? p.aux_beta[n + e] : 0.f;
     }
   }
-  const bool vec_out = full && ((p.ldo * (OUT_F32 ? 4 : 2)) % 16 == 0);
-  const bool vec_aux = full && ((p.ldaux * (EPI == UNIMM_EPI_BIAS_DROP_RESID ? 4 : 2)) % 16 == 0);
+  const bool vec_out_ = full_ && ((p.ldo * (OUT_F32 ? 4 : 2)) % 16 == 0);
+  const bool vec_aux_ = full_ && ((p.ldaux * (EPI == UNIMM_EPI_BIAS_DROP_RESID ? 4 : 2)) % 16 == 0);
   constexpr int JP = C::JP;                          // 16-row sub-tiles per pass (a 32-row wave tile has only two)
   // GELU epilogues with bf16 outputs do their arithmetic BEFORE the transposition, on the accumulator registers:
   // elementwise math does not care about the layout, and there every lane has 16 x JP independent values in flight
@@ -240,6 +279,18 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtParams& p, f32x4 (&acc)[
       for (int e = 0; e < 4; ++e) bq[i][e] = (p.bias != nullptr && na + e < p.N) ? p.bias[na + e] : 0.f;
     }
   }
+  // The walk exists twice: FAST = the wave's 64 columns are all inside N and every row pointer is 16-byte aligned (wave-
+  // uniform), so no lane ever takes an element-wise path.  Keeping the element-wise loads out of that instance is what
+  // lets the batched operand loads above work: with divergent load paths at every join the compiler's conservative
+  // vmcnt(0)s also waited for the batch that had just been requested.
+  const bool fastw = (n0 + wn * 64 + 64 <= p.N) && ((p.ldo * (OUT_F32 ? 4 : 2)) % 16 == 0) &&
+                     (!(AUX32 || AUX16) || (p.ldaux * (AUX32 ? 4 : 2)) % 16 == 0) && UNIMM_EXP != 22;
+  auto walk = [&](auto fast_tag) {
+  constexpr bool FAST = decltype(fast_tag)::value;
+  const bool ncols_ok = FAST ? true : ncols_ok_;
+  const bool full = FAST ? true : full_;
+  const bool vec_out = FAST ? true : vec_out_;
+  const bool vec_aux = FAST ? true : vec_aux_;
 #pragma unroll
   for (int pass = 0; pass < MT / JP; ++pass) {
 #pragma unroll
@@ -268,6 +319,16 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtParams& p, f32x4 (&acc)[
       const int m = m0 + wm * 16 * MT + pass * 16 * JP + row;
       const f32x4 lo = *reinterpret_cast<const f32x4*>(slab + row * SLAB_LD + c0);
       const f32x4 hi = *reinterpret_cast<const f32x4*>(slab + row * SLAB_LD + c0 + 4);
+      const int gw = pass * NIT + it;                  // walk index; at the start of a batch request the next one
+      if (PF > 0 && gw % PFN == 0) {
+        // drain first (this batch's operands, requested a batch ago), THEN request: with the order reversed the
+        // compiler's vmcnt(0) in front of the first use would also wait for the loads just issued
+        if (FAST || pf_on) __builtin_amdgcn_s_waitcnt(0x0F70);
+        aux_prefetch(gw / PFN + 1, fast_tag);
+      }
+      const f32x4 pfa0 = pf0[(gw / PFN) & 1][gw % PFN], pfa1 = pf1[(gw / PFN) & 1][gw % PFN];
+      const float pfamu = pfmu[(gw / PFN) & 1][gw % PFN], pfars = pfrs[(gw / PFN) & 1][gw % PFN];
+      (void)pfa1; (void)pfamu; (void)pfars;
       if (m >= p.M || !ncols_ok) continue;
       if constexpr (PRE) {
         uint32_t pw[8];
@@ -301,8 +362,12 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtParams& p, f32x4 (&acc)[
         if constexpr (EPI == UNIMM_EPI_BIAS_DROP_RESID) {   // fp32 residual stream
           const float* ap = reinterpret_cast<const float*>(p.aux) + (size_t)m * p.ldaux + n;
           if (vec_aux) {
-            const f32x4 r0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ap));
-            const f32x4 r1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ap + 4));
+            f32x4 r0, r1;
+            if (PF > 0) { r0 = pfa0; r1 = pfa1; }
+            else {
+              r0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ap));
+              r1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ap + 4));
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) { a[e] = r0[e]; a[4 + e] = r1[e]; }
           } else {
@@ -310,7 +375,8 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtParams& p, f32x4 (&acc)[
             for (int e = 0; e < 8; ++e) a[e] = (n + e < p.N) ? ap[e] : 0.f;
           }
           if (aux_ln) {
-            const float mu = p.aux_mean[m], rs = p.aux_rstd[m];
+            const bool pfd = PF > 0 && (FAST || pf_on);
+            const float mu = pfd ? pfamu : p.aux_mean[m], rs = pfd ? pfars : p.aux_rstd[m];
 #pragma unroll
             for (int e = 0; e < 8; ++e) a[e] = (a[e] - mu) * rs * lg[e] + lb[e];
           }
@@ -327,8 +393,9 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtParams& p, f32x4 (&acc)[
 #pragma unroll
             for (int e = 0; e < 8; ++e) a[e] = 1.0f + (float)(lane & 1);
           } else if (vec_aux) {
-            const u32x4 raw = UNIMM_EXP == 18 ? *reinterpret_cast<const u32x4*>(ap)
-                                                : __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ap));
+            const u32x4 raw = PF > 0 ? __builtin_bit_cast(u32x4, pfa0)
+                                     : (UNIMM_EXP == 18 ? *reinterpret_cast<const u32x4*>(ap)
+                                                        : __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ap)));
 #pragma unroll
             for (int e = 0; e < 4; ++e) { a[2 * e] = __uint_as_float(raw[e] << 16); a[2 * e + 1] = __uint_as_float(raw[e] & 0xffff0000u); }
           } else {
@@ -389,6 +456,8 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtParams& p, f32x4 (&acc)[
       }
     }
   }
+  };  // walk
+  if (fastw) walk(std::true_type{}); else walk(std::false_type{});
 }
 
 // ------------------------------------------------------------------------------------------------
