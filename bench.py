@@ -71,6 +71,8 @@ def parse():
                          "around each of ~340 GEMM launches are not free: measured 1.3 ms of a 56 ms step at bs=240 (drain + "
                          "timestamp between back-to-back kernels) and 2 ms of 16 ms at 30 sequences per GPU (host launch rate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-profile", default=None, metavar="FILE",
+                    help="after warm-up, cProfile 5 untimed steps of host-side enqueue work into FILE (text, by own time)")
     ap.add_argument("--no-padded", action="store_true", help="skip the 3 extra steps that time the padded schedule beside the default")
     ap.add_argument("--wire", choices=["fp32", "bf16"], default="fp32", help="N > 1: dtype of the gradient exchange")
     ap.add_argument("--exchange", choices=["allreduce", "rs_ag"], default="allreduce",
@@ -354,6 +356,18 @@ def main():
     for _ in range(args.warmup):
         step()
     log("warm-up done")
+    if args.host_profile and rank == 0:
+        import cProfile, io, pstats
+        torch.cuda.synchronize()
+        pr = cProfile.Profile()
+        pr.enable()
+        for _ in range(5):
+            step()
+        pr.disable()
+        torch.cuda.synchronize()
+        buf = io.StringIO()
+        pstats.Stats(pr, stream=buf).sort_stats("tottime").print_stats(45)
+        open(args.host_profile, "w").write(buf.getvalue())
 
     def fence():
         torch.cuda.synchronize()

@@ -16,6 +16,7 @@
 //     softmax(raw scores) exactly as models/vilbert_dialog.py:1418 does.
 //   * P (bf16) feeds O^T = V^T . P^T directly from the accumulator registers (its key index is the
 //     MFMA's reduction index); V^T fragments come from ds_read_b64_tr_b16.
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -172,38 +173,49 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnParams p) {
     s[t] = acc;
   }
 
-  // ---- mask + softmax over the lane's 16*NKT keys and its partner's (lane ^ 32)
+  // ---- mask + softmax over the lane's 16*NKT keys and its partner's (lane ^ 32), in the log2 domain:
+  // v = s * (scale * log2 e) + (masked ? -10000 * log2 e : 0) is ONE fma per score -- the additive mask (reference
+  // :1418) is the sign-extended inverted mask bit ANDed with the constant's bit pattern (v_bfe_i32 + v_and) instead of
+  // shift / and / compare / select / add -- and the "key exists" test runs only on the sequence's last, partial tile.
+  const float c1 = p.scale * LOG2E;
+  constexpr float MOFF = -10000.0f * LOG2E;
+  // (opaque copy: the 128 "key exists" compares are invariant over this wave's query tiles, and hoisted out of the walk
+  // the compiler parked their lane masks in SGPRs, spilled them to VGPR lanes and read two lanes back per score)
+  int tk_here = Tk_b;
+  asm volatile("" : "+v"(tk_here));
   float mx = -INFINITY;
 #pragma unroll
   for (int t = 0; t < NKT; ++t) {
     if (32 * t >= Tk_b) continue;                          // (wave-uniform) tile holds padding keys only
-    const uint32_t w = mw[t] >> (4 * h);
+    const uint32_t wn = ~(mw[t] >> (4 * h));               // bit kk set = key kk (+ 4h folded in) is masked
+    auto scores = [&](auto partial) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int kk = (e & 3) + 8 * (e >> 2);              // + 4h folded into w
-      const int key = 32 * t + kk + 4 * h;
-      float v = s[t][e] * p.scale;
-      v += ((w >> kk) & 1u) ? 0.0f : -10000.0f;            // additive mask, fp32 (reference :1418)
-      v = key < Tk_b ? v : -INFINITY;                      // padded keys do not exist
-      s[t][e] = v;
-      mx = fmaxf(mx, v);
-    }
+      for (int e = 0; e < 16; ++e) {
+        const int kk = (e & 3) + 8 * (e >> 2);
+        const uint32_t madd = (uint32_t)__builtin_amdgcn_sbfe((int)wn, kk, 1) & __builtin_bit_cast(uint32_t, MOFF);
+        float v = fmaf(s[t][e], c1, __uint_as_float(madd));
+        if constexpr (decltype(partial)::value) v = (32 * t + kk + 4 * h) < tk_here ? v : -INFINITY;   // padded keys do not exist
+        s[t][e] = v;
+        mx = fmaxf(mx, v);
+      }
+    };
+    if (32 * (t + 1) > Tk_b) scores(std::true_type{}); else scores(std::false_type{});
   }
   mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-  const float mxl = mx * LOG2E;
   float sum = 0.f;
 #pragma unroll
   for (int t = 0; t < NKT; ++t) {
     if (32 * t >= Tk_b) continue;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const float pe = __builtin_amdgcn_exp2f(s[t][e] * LOG2E - mxl);
+      const float pe = __builtin_amdgcn_exp2f(s[t][e] - mx);
       s[t][e] = pe;
       sum += pe;
     }
   }
   sum += __shfl_xor(sum, 32, 64);
-  const float inv = 1.0f / sum;
+  // the dropout scale 1 / (1 - p) rides on the normalisation: the keep test below is a plain select
+  const float inv = (p.drop.thr != 0u ? p.drop.scale : 1.0f) / sum;
 
   if (p.drop.thr != 0u) {
     // one hash per two neighbouring keys (registers e, e+1 with e even hold keys k, k+1 with k even)
@@ -214,8 +226,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
       for (int e = 0; e < 16; e += 2) {
         const uint32_t w = drop_word(p.drop, wb + (uint32_t)((32 * t + key_of_reg(e, h)) >> 1));
-        s[t][e] = drop_sel(p.drop, w, 0u, s[t][e]);
-        s[t][e + 1] = drop_sel(p.drop, w, 1u, s[t][e + 1]);
+        s[t][e] = drop_keep(p.drop, w, 0u) ? s[t][e] : 0.0f;
+        s[t][e + 1] = drop_keep(p.drop, w, 1u) ? s[t][e + 1] : 0.0f;
       }
     }
   }
@@ -251,7 +263,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnParams p) {
         *reinterpret_cast<u32x2*>(og + d) = u32x2{pack2bf(o[dt][4 * qd] * inv, o[dt][4 * qd + 1] * inv),
                                                   pack2bf(o[dt][4 * qd + 2] * inv, o[dt][4 * qd + 3] * inv)};
       }
-    if (p.lse != nullptr && h == 0) p.lse[((size_t)b * p.H + head) * p.Tq + qrow] = mx + logf(sum);
+    if (p.lse != nullptr && h == 0) p.lse[((size_t)b * p.H + head) * p.Tq + qrow] = (mx + __log2f(sum)) * LN2;
   }
   }   // query tiles of this wave
 #undef UNIMM_LOAD_QTILE
@@ -333,10 +345,21 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
   for (int dt = 0; dt < D / 32; ++dt) dq[dt] = f32x16{};
   const uint32_t dwb = drop_wbase(((uint32_t)b * p.H + head) * p.Tq + (uint32_t)qrow, (uint32_t)p.Tk, 0u);
 
+  // Per score (same log2-domain form as the forward): arg = s * c1 + (masked ? -10000 log2 e : 0) - lse log2 e is one
+  // fma, because -lse / scale is what the S accumulator STARTS from; the dropout select carries 1 / (1 - p) and feeds an
+  // fma with -delta; the softmax scale is applied once to dQ at the end instead of to every dS.
+  const float c1 = p.scale * LOG2E;
+  constexpr float MOFF = -10000.0f * LOG2E;
+  const float s0 = -lse_l / c1;
+  const bool dropping = p.drop.thr != 0u;
+  const uint32_t thr16 = dropping ? (p.drop.thr >> 16) : 0u;
+  const float dsc = dropping ? p.drop.scale : 1.0f;
 #pragma unroll
   for (int t = 0; t < NKT; ++t) {
     if (32 * t >= Tk_b) break;
-    f32x16 sacc = {}, dpacc = {};
+    f32x16 sacc, dpacc = {};
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sacc[e] = s0;
 #pragma unroll
     for (int ks = 0; ks < D / 16; ++ks) {
       const bf16x8 kf = read_row_frag<D>(kimg, 32 * t + r, 2 * ks + h);
@@ -344,23 +367,29 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
       const bf16x8 vf = read_row_frag<D>(vimg, 32 * t + r, 2 * ks + h);
       dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dpacc, 0, 0, 0);
     }
-    const uint32_t w = mw[t] >> (4 * h);
+    const uint32_t wn = ~(mw[t] >> (4 * h));
     float ds[16];
     uint32_t dw[8];   // dropout words: one hash per two neighbouring keys
-    if (p.drop.thr != 0u) {
+    if (dropping) {
 #pragma unroll
       for (int e2 = 0; e2 < 8; ++e2) dw[e2] = drop_word(p.drop, dwb + (uint32_t)((32 * t + key_of_reg(2 * e2, h)) >> 1));
+    } else {
+#pragma unroll
+      for (int e2 = 0; e2 < 8; ++e2) dw[e2] = 0u;          // with thr16 = 0 every field "keeps", at scale 1
     }
+    // Straight-line per score (no per-element branch: without dropout the keep test is simply always true), one
+    // instance with the "key exists" select on every tile: the unrolled tile loop is 8 copies of this already, and a
+    // second, select-free copy per tile made the D = 128 instances slower (code size and registers).
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int kk = (e & 3) + 8 * (e >> 2);
-      const int key = 32 * t + kk + 4 * h;
-      float v = sacc[e] * p.scale;
-      v += ((w >> kk) & 1u) ? 0.0f : -10000.0f;
-      const float pe = key < Tk_b ? __builtin_amdgcn_exp2f(v * LOG2E - lse_l) : 0.f;
-      float dp = dpacc[e];
-      if (p.drop.thr != 0u) dp = drop_sel(p.drop, dw[e >> 1], (uint32_t)(e & 1), dp);
-      ds[e] = pe * (dp - delta) * p.scale;
+      const uint32_t madd = (uint32_t)__builtin_amdgcn_sbfe((int)wn, kk, 1) & __builtin_bit_cast(uint32_t, MOFF);
+      float arg = fmaf(sacc[e], c1, __uint_as_float(madd));
+      arg = (32 * t + kk + 4 * h) < Tk_b ? arg : -INFINITY;  // padded keys: P = 0
+      const float pe = __builtin_amdgcn_exp2f(arg);
+      const uint32_t field = (e & 1) ? (dw[e >> 1] >> 16) : (dw[e >> 1] & 0xffffu);
+      const float dpm = fmaf(dpacc[e], field >= thr16 ? dsc : 0.0f, -delta);
+      ds[e] = pe * dpm;
     }
 #pragma unroll
     for (int ss = 0; ss < 2; ++ss) {
@@ -372,6 +401,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
       }
     }
   }
+#pragma unroll
+  for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dq[dt][e] *= p.scale;
 
   if (qvalid) {
     bf16_t* dqg = p.dq + grow * p.lddq + head * D;
@@ -416,7 +449,7 @@ __global__ __launch_bounds__(MAXT, MAXT == 256 ? 1 : 2) void attn_bwd_dkv_kernel
   stage_head<D>(p.dout + qbase * p.lddo + head * D, p.lddo, Tq_b, qpad_b, doimg, tid, blockDim.x);
   for (int i = tid; i < qpad_b; i += blockDim.x) {
     const size_t stat = ((size_t)b * p.H + head) * p.Tq + i;
-    lse_s[i] = i < Tq_b ? p.lse[stat] * LOG2E : INFINITY;   // +inf => P = 0 for padded queries
+    lse_s[i] = i < Tq_b ? -p.lse[stat] * LOG2E : -INFINITY;   // NEGATED; -inf => P = 0 for padded queries
     del_s[i] = i < Tq_b ? p.delta[stat] : 0.f;
   }
   {
@@ -425,7 +458,7 @@ __global__ __launch_bounds__(MAXT, MAXT == 256 ? 1 : 2) void attn_bwd_dkv_kernel
     for (int i = tid; i < nkt_b * qpad_b; i += blockDim.x) {
       const int kt = i / qpad_b, qi = i - kt * qpad_b;
       const int qc = qi < Tq_b ? qi : Tq_b - 1;
-      mw_s[kt * QPAD + qi] = mb[(size_t)qc * p.mask_q_stride + kt];
+      mw_s[kt * QPAD + qi] = ~mb[(size_t)qc * p.mask_q_stride + kt];   // INVERTED: bit set = masked
     }
   }
 
@@ -450,6 +483,11 @@ __global__ __launch_bounds__(MAXT, MAXT == 256 ? 1 : 2) void attn_bwd_dkv_kernel
   for (int dt = 0; dt < D / 32; ++dt) { dk[dt] = f32x16{}; dv[dt] = f32x16{}; }
   const uint32_t* mrow = mw_s + wt * QPAD;
   const uint32_t hbase = ((uint32_t)b * p.H + head) * (uint32_t)p.Tq;
+  const float c1 = p.scale * LOG2E;
+  constexpr float MOFF = -10000.0f * LOG2E;
+  const bool dropping = p.drop.thr != 0u;
+  const uint32_t thr16 = dropping ? (p.drop.thr >> 16) : 0u;
+  const float dsc = dropping ? p.drop.scale : 1.0f;
 
 #pragma unroll 1
   for (int qt = 0; qt < NQT; ++qt) {
@@ -471,9 +509,11 @@ __global__ __launch_bounds__(MAXT, MAXT == 256 ? 1 : 2) void attn_bwd_dkv_kernel
       const u32x4 w4 = *reinterpret_cast<const u32x4*>(mrow + qb);
       // dropout words: keys k and k^1 (lanes r and r^1) share the hash word of a query row, so each lane of the
       // pair hashes two of the four queries and takes the other two from its neighbour (DPP quad_perm [1,0,3,2])
-      uint32_t dwv[4] = {0u, 0u, 0u, 0u};
+      uint32_t dwv[4] = {0u, 0u, 0u, 0u};               // without dropout: thr16 = 0, every field "keeps" at scale 1
+      uint32_t odd;
       if constexpr (D == 64) {
-        if (p.drop.thr != 0u) {
+        odd = (uint32_t)r & 1u;
+        if (dropping) {
           const uint32_t kw = (uint32_t)(wt * 32 + r) >> 1;
           const uint32_t half = ((uint32_t)p.Tk + 1u) >> 1;
           const uint32_t par = (uint32_t)r & 1u;
@@ -483,30 +523,27 @@ __global__ __launch_bounds__(MAXT, MAXT == 256 ? 1 : 2) void attn_bwd_dkv_kernel
           const uint32_t ob = (uint32_t)__builtin_amdgcn_mov_dpp((int)wb, 0xB1, 0xF, 0xF, true);
           dwv[0] = par ? oa : wa; dwv[1] = par ? wa : oa; dwv[2] = par ? ob : wb; dwv[3] = par ? wb : ob;
         }
-      }            // D = 128: the kernel is at its register limit; it hashes per element inside the loop below
+      } else {      // D = 128: at its register limit -- one hash per element, inside the loop below, unconditionally
+        odd = (uint32_t)krow & 1u;
+      }
+      // log2-domain score: one fma on top of (-lse log2 e) + (masked ? -10000 log2 e : 0); lanes past the last key need
+      // no select -- a key is a lane here, nothing of an invalid lane reaches a valid one and its dK / dV are not stored.
+      // Straight-line per element: the dropout select always runs (see dwv above).
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int e = 4 * g4 + i;
-        float v = sacc[e] * p.scale;
-        v += ((w4[i] >> r) & 1u) ? 0.0f : -10000.0f;
-        const float pe = kvalid ? __builtin_amdgcn_exp2f(v * LOG2E - l4[i]) : 0.f;
-        float dp = dpacc[e];
-        float pdrop = pe;
-        if (p.drop.thr != 0u) {
-          bool keep;
-          if constexpr (D == 64) {
-            keep = drop_keep(p.drop, dwv[i], (uint32_t)r & 1u);
-          } else {
-            int qi = qb + i;
-            qi = qi < Tq_b ? qi : Tq_b - 1;
-            const uint32_t dw = drop_word(p.drop, drop_wbase(hbase + (uint32_t)qi, (uint32_t)p.Tk, (uint32_t)krow));
-            keep = drop_keep(p.drop, dw, (uint32_t)krow & 1u);
-          }
-          dp = keep ? dp * p.drop.scale : 0.f;
-          pdrop = keep ? pe * p.drop.scale : 0.f;
+        const uint32_t madd = (uint32_t)__builtin_amdgcn_sbfe((int)w4[i], (uint32_t)r, 1) & __builtin_bit_cast(uint32_t, MOFF);
+        const float pe = __builtin_amdgcn_exp2f(fmaf(sacc[e], c1, l4[i] + __uint_as_float(madd)));
+        uint32_t dwe = dwv[i];
+        if constexpr (D != 64) {
+          int qi = qb + i;
+          qi = qi < Tq_b ? qi : Tq_b - 1;
+          dwe = drop_word(p.drop, drop_wbase(hbase + (uint32_t)qi, (uint32_t)p.Tk, (uint32_t)krow));
         }
-        pd[e] = pdrop;
-        ds[e] = pe * (dp - d4[i]) * p.scale;
+        const uint32_t field = odd ? (dwe >> 16) : (dwe & 0xffffu);
+        const float tk = field >= thr16 ? dsc : 0.0f;
+        pd[e] = pe * tk;
+        ds[e] = pe * fmaf(dpacc[e], tk, -d4[i]);           // the softmax scale is applied once to dK at the end
       }
     }
 #pragma unroll
@@ -523,6 +560,10 @@ __global__ __launch_bounds__(MAXT, MAXT == 256 ? 1 : 2) void attn_bwd_dkv_kernel
     }
   }
 
+#pragma unroll
+  for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dk[dt][e] *= p.scale;
   if (kvalid) {
     bf16_t* dkg = p.dk + grow * p.lddk + head * D;
     bf16_t* dvg = p.dv + grow * p.lddv + head * D;
