@@ -78,6 +78,30 @@ __device__ __forceinline__ void gelu_and_grad(float x, float& y, float& dy) {
   dy = fmaf(x * 0.3989422804014327f, e, cdf);
 }
 
+// Two elements at a time: the multiplies / fmas become v_pk_mul_f32 / v_pk_fma_f32 (two fp32 lanes per instruction slot);
+// only |x|, exp2, rcp and the sign select stay per element.  Same formulas as gelu_and_grad (erfc(|t|) = p(r) r e^{-t^2}).
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_and_grad2(f32x2v x, f32x2v& y, f32x2v& dy) {
+  const f32x2v t = x * 0.70710678118654752f;
+  f32x2v ax;
+  ax.x = fabsf(t.x); ax.y = fabsf(t.y);
+  const f32x2v arg = (ax * ax) * -1.4426950408889634f;
+  f32x2v e, r;
+  e.x = __builtin_amdgcn_exp2f(arg.x); e.y = __builtin_amdgcn_exp2f(arg.y);
+  const f32x2v den = ax * 0.3275911f + 1.0f;
+  r.x = __builtin_amdgcn_rcpf(den.x); r.y = __builtin_amdgcn_rcpf(den.y);
+  f32x2v p = r * 1.061405429f + -1.453152027f;
+  p = p * r + 1.421413741f;
+  p = p * r + -0.284496736f;
+  p = p * r + 0.254829592f;
+  const f32x2v hq = (p * r) * (e * 0.5f);                // erfc(|t|) / 2 = Phi(-|x|)
+  const f32x2v om = 1.0f - hq;
+  f32x2v cdf;
+  cdf.x = t.x < 0.f ? hq.x : om.x; cdf.y = t.y < 0.f ? hq.y : om.y;
+  y = x * cdf;
+  dy = (x * 0.3989422804014327f) * e + cdf;
+}
+
 // Counter-based dropout.  Element (row, col) of a [rows, ncols] activation is kept iff the 16-bit field
 // (col & 1) of  mix32((row * ceil(ncols / 2) + (col >> 1)) ^ key)  is >= thr >> 16, key = per-(step, site)
 // word built on the host (unimm_amd/dropout.py mirrors this bit for bit so the oracle can replay the

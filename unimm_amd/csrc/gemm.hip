@@ -300,13 +300,22 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtParams& p, f32x4 (&acc)[
         float* dst = slab + (j * 16 + (lane & 15)) * SLAB_LD + i * 16 + 4 * (lane >> 4);
         if constexpr (PRE) {
           u32x4 w;
+          if constexpr (EPI == UNIMM_EPI_BIAS_GELU) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float x = acc[i][pass * JP + j][e] + bq[i][e];
-            float y, d;
-            if constexpr (EPI == UNIMM_EPI_BIAS_GELU) { y = gelu_erf(x); d = x; }
-            else gelu_and_grad(x, y, d);
-            w[e] = pack2bf(y, d);
+            for (int e = 0; e < 4; ++e) {
+              const float x = acc[i][pass * JP + j][e] + bq[i][e];
+              w[e] = pack2bf(gelu_erf(x), x);
+            }
+          } else {                                           // GELU and GELU', packed fp32 math on element pairs
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+              const f32x4 a4 = acc[i][pass * JP + j];
+              const f32x2v x = f32x2v{a4[e], a4[e + 1]} + f32x2v{bq[i][e], bq[i][e + 1]};
+              f32x2v y, d;
+              gelu_and_grad2(x, y, d);
+              w[e] = pack2bf(y.x, d.x);
+              w[e + 1] = pack2bf(y.y, d.y);
+            }
           }
           *reinterpret_cast<u32x4*>(dst) = w;
         } else {
