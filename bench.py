@@ -422,6 +422,7 @@ def main():
 
     # the padded schedule (every sequence computed on all 256 token rows, as the reference does) beside the default one
     padded_value = None
+    plan_default = model.engine.last_plan          # (the padded steps below replace engine.last_plan)
     if world == 1 and args.workload == "train" and not args.no_padded:
         model.engine.unpad = False
         step()
@@ -490,7 +491,7 @@ def main():
                 traffic, traffic_src = round(tj["bytes_per_launch_corrected"]), tj["source"]
                 traffic_commit = tj.get("commit")      # the commit the PMC passes were taken at
         f_fwd = F_FWD_BASE_GF + F_DEC_ROW_GF * n_lm_rows / per_gpu     # reference-equivalent (padded to 256 tokens)
-        plan = model.engine.last_plan
+        plan = plan_default
         valid_rows = plan["Mv"] if plan is not None else per_gpu * 256
         exec_gf_seq = exec_fl_step / per_gpu / 1e9          # GEMM FLOPs actually executed per sequence, fwd+bwd
         if args.workload == "dense":
