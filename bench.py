@@ -360,13 +360,15 @@ def main():
         import cProfile, io, pstats
         torch.cuda.synchronize()
         pr = cProfile.Profile()
-        pr.enable()
-        for _ in range(5):
-            step()
-        pr.disable()
+        # backward in the calling thread, so that the profile sees the engine's backward too
+        with torch.autograd.set_multithreading_enabled(False):
+            pr.enable()
+            for _ in range(5):
+                step()
+            pr.disable()
         torch.cuda.synchronize()
         buf = io.StringIO()
-        pstats.Stats(pr, stream=buf).sort_stats("tottime").print_stats(45)
+        pstats.Stats(pr, stream=buf).sort_stats("tottime").print_stats(60)
         open(args.host_profile, "w").write(buf.getvalue())
 
     def fence():

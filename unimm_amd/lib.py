@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 
 import torch
 
@@ -63,6 +64,16 @@ def lib():
             fn.restype = C.c_int64
         elif name != "unimm_arch":
             fn.restype = C.c_int
+    VP, I32, U32, F32, I64 = C.c_void_p, C.c_int32, C.c_uint32, C.c_float, C.c_int64
+    L.unimm_gemm_nt.argtypes = [VP, VP]
+    L.unimm_attn_fwd.argtypes = [VP, VP]
+    L.unimm_attn_bwd.argtypes = [VP, VP]
+    L.unimm_gemm_tn_grouped.argtypes = [VP, I32, VP]
+    L.unimm_gemm_tn_grouped_ws.argtypes = [VP, I32, I32, VP, I64, VP]
+    L.unimm_colpartials_finish_grouped.argtypes = [VP, I32, VP]
+    L.unimm_layernorm_fwd.argtypes = [VP] * 7 + [I32, I32, F32, U32, U32, F32, VP]
+    L.unimm_layernorm_bwd_partials.argtypes = [VP] * 8 + [I32, I32, U32, U32, F32, U32, U32, F32, VP, VP]
+    L.unimm_layernorm_bwd.argtypes = [VP] * 11 + [I32, I32, U32, U32, F32, U32, U32, F32, VP]
     _lib = L
     return L
 
@@ -114,6 +125,14 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+def _P(t):
+    """raw device address for an entry point with declared argtypes / a c_void_p struct field (None = NULL)"""
+    return t.data_ptr() if t is not None else None
+
+
+_tls = threading.local()      # per-thread argument structs of the hot wrappers (the C side reads them before it returns)
+
+
 def _dev(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -123,22 +142,35 @@ def _dev(*ts):
 def gemm_nt(x, w, out, bias=None, epilogue=EPI_BIAS, aux=None, out2=None, drop=None, M=None, N=None, K=None, aux_ln=None):
     """out[M,N] = epi(x[M,K] @ w[N,K]^T).  x/w bf16 2-D (row stride = stride(0)); out bf16 or fp32.
     aux_ln = (mean[M], rstd[M], gamma[N], beta[N]): the DROP_RESID residual is LayerNorm(aux) computed on the fly."""
-    _dev(x, w, out, bias, aux, out2)
-    a = GemmNtArgs()
-    a.x, a.w, a.bias, a.aux, a.out, a.out2 = _ptr(x), _ptr(w), _ptr(bias), _ptr(aux), _ptr(out), _ptr(out2)
+    if not (x.is_cuda and w.is_cuda and out.is_cuda):
+        _dev(x, w, out)
+    st = getattr(_tls, "nt", None)
+    if st is None:
+        a = GemmNtArgs()
+        st = _tls.nt = (a, C.addressof(a), lib().unimm_gemm_nt)
+    a, addr, fn = st
+    a.x, a.w, a.out = x.data_ptr(), w.data_ptr(), out.data_ptr()
+    a.bias = bias.data_ptr() if bias is not None else None
+    a.out2 = out2.data_ptr() if out2 is not None else None
+    if aux is not None:
+        a.aux, a.ldaux = aux.data_ptr(), aux.stride(0)
+    else:
+        a.aux, a.ldaux = None, 0
     a.M = x.shape[0] if M is None else M
     a.N = w.shape[0] if N is None else N
     a.K = x.shape[1] if K is None else K
     a.ldx, a.ldw, a.ldo = x.stride(0), w.stride(0), out.stride(0)
-    a.ldaux = aux.stride(0) if aux is not None else 0
     a.epilogue = epilogue
     a.out_f32 = 1 if out.dtype == torch.float32 else 0
-    if drop is not None:
-        a.drop_key, a.drop_thr, a.drop_scale = drop
+    a.drop_key, a.drop_thr, a.drop_scale = drop if drop is not None else (0, 0, 0.0)
     if aux_ln is not None:
         _dev(*aux_ln)
         a.aux_mean, a.aux_rstd, a.aux_gamma, a.aux_beta = (t.data_ptr() for t in aux_ln)
-    _check(lib().unimm_gemm_nt(C.byref(a), _stream()), "unimm_gemm_nt")
+    else:
+        a.aux_mean = a.aux_rstd = a.aux_gamma = a.aux_beta = None
+    rc = fn(addr, _stream())
+    if rc != 0:
+        _check(rc, "unimm_gemm_nt")
     return out
 
 
@@ -166,17 +198,18 @@ def gemm_tn_grouped(problems, shared=None, ws=None):
         return
     arr = (GemmTnArgs * n)()
     for a, (dy, x, dw, M, N, K, dbias) in zip(arr, problems):
-        _dev(dy, x, dw, dbias)
+        if not dy.is_cuda:
+            _dev(dy, x, dw, dbias)
         a.dy, a.x, a.dw, a.dbias = dy.data_ptr(), x.data_ptr(), dw.data_ptr(), (dbias.data_ptr() if dbias is not None else None)
         a.M = dy.shape[0] if M is None else M
         a.N = dy.shape[1] if N is None else N
         a.K = x.shape[1] if K is None else K
         a.lddy, a.ldx, a.lddw = dy.stride(0), x.stride(0), dw.stride(0)
     if shared is None and ws is None:
-        _check(lib().unimm_gemm_tn_grouped(arr, C.c_int32(n), _stream()), "unimm_gemm_tn_grouped")
+        _check(lib().unimm_gemm_tn_grouped(C.addressof(arr), n, _stream()), "unimm_gemm_tn_grouped")
         return
-    _check(lib().unimm_gemm_tn_grouped_ws(arr, C.c_int32(n), C.c_int32(1 if shared else 0), _ptr(ws),
-                                          C.c_int64(ws.numel() if ws is not None else 0), _stream()), "unimm_gemm_tn_grouped_ws")
+    _check(lib().unimm_gemm_tn_grouped_ws(C.addressof(arr), n, 1 if shared else 0, _P(ws),
+                                          ws.numel() if ws is not None else 0, _stream()), "unimm_gemm_tn_grouped_ws")
 
 
 # ---------------------------------------------------------------------------------------------
@@ -211,36 +244,47 @@ def attn_fwd(q, k, v, out, lse, mask, B, H, Tq, Tk, D, scale, mask_q_stride, mas
              qvar=None, kvar=None):
     """q/k/v/out: 2-D bf16 views [rows, >=H*D] (row stride = stride(0)); mask: packed uint32 words.
     qvar / kvar: (offsets, lengths) int32 [B] tensors for the variable-length layout, or None."""
-    _dev(q, k, v, out, lse, mask)
-    a = AttnArgs()
-    a.q, a.k, a.v, a.out, a.lse, a.mask = _ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), _ptr(mask)
-    if qvar is not None:
-        a.q_off, a.q_len = _ptr(qvar[0]), _ptr(qvar[1])
-    if kvar is not None:
-        a.k_off, a.k_len = _ptr(kvar[0]), _ptr(kvar[1])
+    if not (q.is_cuda and k.is_cuda and out.is_cuda and mask.is_cuda):
+        _dev(q, k, v, out, lse, mask)
+    st = getattr(_tls, "af", None)
+    if st is None:
+        a = AttnArgs()
+        st = _tls.af = (a, C.addressof(a), lib().unimm_attn_fwd)
+    a, addr, fn = st
+    a.q, a.k, a.v, a.out, a.lse, a.mask = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _P(lse), mask.data_ptr()
+    a.q_off, a.q_len = (qvar[0].data_ptr(), qvar[1].data_ptr()) if qvar is not None else (None, None)
+    a.k_off, a.k_len = (kvar[0].data_ptr(), kvar[1].data_ptr()) if kvar is not None else (None, None)
     a.B, a.H, a.Tq, a.Tk, a.D = B, H, Tq, Tk, D
     a.ldq, a.ldk, a.ldv, a.ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
     a.mask_q_stride, a.mask_b_stride, a.scale = mask_q_stride, mask_b_stride, scale
     a.drop_key, a.drop_thr, a.drop_scale = drop
-    _check(lib().unimm_attn_fwd(C.byref(a), _stream()), "unimm_attn_fwd")
+    rc = fn(addr, _stream())
+    if rc != 0:
+        _check(rc, "unimm_attn_fwd")
 
 
 def attn_bwd(q, k, v, out, dout, lse, delta, dq, dk, dv, mask, B, H, Tq, Tk, D, scale, mask_q_stride,
              mask_b_stride, drop=NO_DROP, qvar=None, kvar=None):
-    _dev(q, k, v, out, dout, lse, delta, dq, dk, dv, mask)
-    a = AttnBwdArgs()
-    if qvar is not None:
-        a.q_off, a.q_len = _ptr(qvar[0]), _ptr(qvar[1])
-    if kvar is not None:
-        a.k_off, a.k_len = _ptr(kvar[0]), _ptr(kvar[1])
-    a.q, a.k, a.v, a.out, a.dout = _ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(dout)
-    a.lse, a.delta, a.dq, a.dk, a.dv, a.mask = _ptr(lse), _ptr(delta), _ptr(dq), _ptr(dk), _ptr(dv), _ptr(mask)
+    if not (q.is_cuda and k.is_cuda and dout.is_cuda and dq.is_cuda and dk.is_cuda and dv.is_cuda):
+        _dev(q, k, v, out, dout, lse, delta, dq, dk, dv, mask)
+    st = getattr(_tls, "ab", None)
+    if st is None:
+        a = AttnBwdArgs()
+        st = _tls.ab = (a, C.addressof(a), lib().unimm_attn_bwd)
+    a, addr, fn = st
+    a.q_off, a.q_len = (qvar[0].data_ptr(), qvar[1].data_ptr()) if qvar is not None else (None, None)
+    a.k_off, a.k_len = (kvar[0].data_ptr(), kvar[1].data_ptr()) if kvar is not None else (None, None)
+    a.q, a.k, a.v, a.out, a.dout = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr()
+    a.lse, a.delta, a.dq, a.dk, a.dv, a.mask = (lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
+                                                mask.data_ptr())
     a.B, a.H, a.Tq, a.Tk, a.D = B, H, Tq, Tk, D
     a.ldq, a.ldk, a.ldv, a.ldo, a.lddo = q.stride(0), k.stride(0), v.stride(0), out.stride(0), dout.stride(0)
     a.lddq, a.lddk, a.lddv = dq.stride(0), dk.stride(0), dv.stride(0)
     a.mask_q_stride, a.mask_b_stride, a.scale = mask_q_stride, mask_b_stride, scale
     a.drop_key, a.drop_thr, a.drop_scale = drop
-    _check(lib().unimm_attn_bwd(C.byref(a), _stream()), "unimm_attn_bwd")
+    rc = fn(addr, _stream())
+    if rc != 0:
+        _check(rc, "unimm_attn_bwd")
 
 
 # ---------------------------------------------------------------------------------------------
@@ -278,12 +322,14 @@ def layernorm_bwd_partials(dy, x, mean, rstd, gamma, dx, dx_drop, partials, M, H
     """LayerNorm backward row kernel only; returns the number of partial blocks (see unimm_layernorm_bwd_partials)."""
     drop = drop or NO_DROP
     out_drop = out_drop or NO_DROP
-    _dev(dy, x, mean, rstd, gamma, dx, dx_drop, partials)
+    if not (dy.is_cuda and x.is_cuda and dx.is_cuda):
+        _dev(dy, x, dx)
     blocks = C.c_int32(0)
-    _check(lib().unimm_layernorm_bwd_partials(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(dx), _ptr(dx_drop),
-                                              _ptr(partials), C.c_int32(M), C.c_int32(H), C.c_uint32(drop[0]), C.c_uint32(drop[1]),
-                                              C.c_float(drop[2]), C.c_uint32(out_drop[0]), C.c_uint32(out_drop[1]),
-                                              C.c_float(out_drop[2]), C.byref(blocks), _stream()), "unimm_layernorm_bwd_partials")
+    rc = lib().unimm_layernorm_bwd_partials(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                                            dx.data_ptr(), _P(dx_drop), partials.data_ptr(), M, H, drop[0], drop[1], drop[2],
+                                            out_drop[0], out_drop[1], out_drop[2], C.addressof(blocks), _stream())
+    if rc != 0:
+        _check(rc, "unimm_layernorm_bwd_partials")
     return blocks.value
 
 
@@ -297,24 +343,24 @@ def colpartials_finish_grouped(pending):
         d.partials, d.blocks, d.nq, d.H = part.data_ptr(), blocks, len(dsts), H
         for q, t in enumerate(dsts):
             d.dst[q] = t.data_ptr() if t is not None else None
-    _check(lib().unimm_colpartials_finish_grouped(arr, C.c_int32(n), _stream()), "unimm_colpartials_finish_grouped")
+    _check(lib().unimm_colpartials_finish_grouped(C.addressof(arr), n, _stream()), "unimm_colpartials_finish_grouped")
 
 
 def layernorm_fwd(x, gamma, beta, y32, y16, mean, rstd, M, H, eps=1e-12, drop=NO_DROP):
-    _dev(x, gamma, beta, y32, y16, mean, rstd)
-    _check(lib().unimm_layernorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y32), _ptr(y16), _ptr(mean), _ptr(rstd), C.c_int32(M),
-                                     C.c_int32(H), C.c_float(eps), C.c_uint32(drop[0]), C.c_uint32(drop[1]),
-                                     C.c_float(drop[2]), _stream()), "unimm_layernorm_fwd")
+    if not (x.is_cuda and y16.is_cuda):
+        _dev(x, y16)
+    rc = lib().unimm_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _P(y32), _P(y16), _P(mean), _P(rstd), M, H, eps,
+                                   drop[0], drop[1], drop[2], _stream())
+    if rc != 0:
+        _check(rc, "unimm_layernorm_fwd")
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dx_drop, dgamma, dbeta, dbias, partials, M, H, drop=NO_DROP,
                   out_drop=NO_DROP):
-    _dev(dy, x, mean, rstd, gamma, dx, dx_drop, dgamma, dbeta, dbias, partials)
-    _check(lib().unimm_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(dx), _ptr(dx_drop),
-                                     _ptr(dgamma), _ptr(dbeta), _ptr(dbias), _ptr(partials), C.c_int32(M), C.c_int32(H),
-                                     C.c_uint32(drop[0]), C.c_uint32(drop[1]), C.c_float(drop[2]),
-                                     C.c_uint32(out_drop[0]), C.c_uint32(out_drop[1]), C.c_float(out_drop[2]),
-                                     _stream()), "unimm_layernorm_bwd")
+    _dev(dy, x, dx)
+    _check(lib().unimm_layernorm_bwd(_P(dy), _P(x), _P(mean), _P(rstd), _P(gamma), _P(dx), _P(dx_drop),
+                                     _P(dgamma), _P(dbeta), _P(dbias), _P(partials), M, H, drop[0], drop[1], drop[2],
+                                     out_drop[0], out_drop[1], out_drop[2], _stream()), "unimm_layernorm_bwd")
 
 
 class EmbedArgs(C.Structure):
