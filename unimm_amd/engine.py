@@ -86,6 +86,8 @@ class Engine:
         # partial rounds; the same holds for the image half of a connection layer once the two co-attention
         # directions have exchanged their K/V.  Same kernels, same order within each stream.
         self.dual_stream = os.environ.get("UNIMM_DUAL_STREAM", "1") == "1"
+        self._text_stream = None      # the stream of the running engine entry (see _on_text_stream / _img)
+        self._text_scope = None       # ... and the raw-stream object lib.stream_scope installed for it
         self._vside = None
         self.text_priority = os.environ.get("UNIMM_TEXT_PRIORITY", "0") == "1"
         self._tstream = None
@@ -419,10 +421,22 @@ class Engine:
             return
         side = self._side_stream()
         was, self._on_side = self._on_side, True
+        main = self._text_stream
+        if was or main is None or L._SCOPED_STREAM is not self._text_scope:   # nested, outside an engine entry, or on a third stream
+            try:
+                with torch.cuda.stream(side), L.stream_scope(side):
+                    yield
+            finally:
+                self._on_side = was
+            return
+        # hot path (~110 blocks per step): torch.cuda.stream() costs ~15 us per entry (device-index lookups and a
+        # current_stream() query); the text stream of this engine entry is known, so switch and switch back directly
+        torch.cuda.set_stream(side)
         try:
-            with torch.cuda.stream(side), L.stream_scope(side):
+            with L.stream_scope(side):
                 yield
         finally:
+            torch.cuda.set_stream(main)
             self._on_side = was
 
     def _to_img(self, *reads):
@@ -631,16 +645,24 @@ class Engine:
             return fn(*args)
         caller = torch.cuda.current_stream()
         if not (self.text_priority and self._dual()):
-            with L.stream_scope(caller):
-                return fn(*args)
+            self._text_stream = caller
+            try:
+                with L.stream_scope(caller) as sc:
+                    self._text_scope = sc.ptr
+                    return fn(*args)
+            finally:
+                self._text_stream = self._text_scope = None
         if self._tstream is None:
             self._tstream = torch.cuda.Stream(device=self.arena.flat.device, priority=-1)
         hp = self._tstream
         hp.wait_stream(caller)
+        self._text_stream = hp
         try:
-            with torch.cuda.stream(hp), L.stream_scope(hp):
+            with torch.cuda.stream(hp), L.stream_scope(hp) as sc:
+                self._text_scope = sc.ptr
                 return fn(*args)
         finally:
+            self._text_stream = self._text_scope = None
             caller.wait_stream(hp)
 
     def forward(self, inp: dict, train: bool, save: bool, lm_rows: str, want_pred_v: bool):
