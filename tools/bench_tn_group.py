@@ -1,0 +1,31 @@
+"""Grouped weight-gradient launch of one text encoder block (QKV, out-proj, FFN-up, FFN-down) at M rows:
+python tools/bench_tn_group.py [M] [shared 0/1]   (UNIMM_TN_SKEW / UNIMM_TN_SPLITS are read once per process)"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from unimm_amd import lib
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 31162
+shared = bool(int(sys.argv[2])) if len(sys.argv) > 2 else False
+g = torch.Generator(device="cuda").manual_seed(0)
+probs = []
+fl = 0.0
+for (N, K) in [(2304, 768), (768, 768), (3072, 768), (768, 3072)]:
+    dy = torch.randn((M, N), generator=g, device="cuda").to(torch.bfloat16)
+    x = torch.randn((M, K), generator=g, device="cuda").to(torch.bfloat16)
+    dw = torch.zeros((N, K), device="cuda"); db = torch.zeros(N, device="cuda")
+    probs.append((dy, x, dw, None, None, None, db))
+    fl += 2.0 * M * N * K
+def run(): lib.gemm_tn_grouped(probs, shared=shared)
+for _ in range(5): run()
+torch.cuda.synchronize()
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+s.record()
+for _ in range(50): run()
+e.record(); torch.cuda.synchronize()
+t = s.elapsed_time(e) / 50 * 1e-3
+# correctness against an fp32 matmul of the first problem
+dy, x, dw, *_ = probs[1]
+dw.zero_(); lib.gemm_tn_grouped([probs[1]], shared=shared); torch.cuda.synchronize()
+ref = dy.float().t() @ x.float()
+err = ((dw - ref).abs().max() / ref.abs().max()).item()
+print(f"M={M} shared={int(shared)} skew={os.environ.get('UNIMM_TN_SKEW','0')} splits={os.environ.get('UNIMM_TN_SPLITS','auto')}: {t*1e6:7.1f} us  {fl/t/1e12:7.1f} TFLOP/s  err {err:.1e}")
