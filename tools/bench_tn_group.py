@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from unimm_amd import lib
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 31162
-shared = bool(int(sys.argv[2])) if len(sys.argv) > 2 else False
+shared = bool(int(sys.argv[2])) if len(sys.argv) > 2 else False     # a third argument "nobias": no bias gradients
 g = torch.Generator(device="cuda").manual_seed(0)
 probs = []
 fl = 0.0
@@ -13,7 +13,7 @@ for (N, K) in [(2304, 768), (768, 768), (3072, 768), (768, 3072)]:
     dy = torch.randn((M, N), generator=g, device="cuda").to(torch.bfloat16)
     x = torch.randn((M, K), generator=g, device="cuda").to(torch.bfloat16)
     dw = torch.zeros((N, K), device="cuda"); db = torch.zeros(N, device="cuda")
-    probs.append((dy, x, dw, None, None, None, db))
+    probs.append((dy, x, dw, None, None, None, None if "nobias" in sys.argv else db))
     fl += 2.0 * M * N * K
 def run(): lib.gemm_tn_grouped(probs, shared=shared)
 for _ in range(5): run()
@@ -28,4 +28,4 @@ dy, x, dw, *_ = probs[1]
 dw.zero_(); lib.gemm_tn_grouped([probs[1]], shared=shared); torch.cuda.synchronize()
 ref = dy.float().t() @ x.float()
 err = ((dw - ref).abs().max() / ref.abs().max()).item()
-print(f"M={M} shared={int(shared)} skew={os.environ.get('UNIMM_TN_SKEW','0')} splits={os.environ.get('UNIMM_TN_SPLITS','auto')}: {t*1e6:7.1f} us  {fl/t/1e12:7.1f} TFLOP/s  err {err:.1e}")
+print(f"{'nobias ' if 'nobias' in sys.argv else ''}M={M} shared={int(shared)} skew={os.environ.get('UNIMM_TN_SKEW','0')} splits={os.environ.get('UNIMM_TN_SPLITS','auto')}: {t*1e6:7.1f} us  {fl/t/1e12:7.1f} TFLOP/s  err {err:.1e}")
