@@ -1143,7 +1143,7 @@ __global__ __launch_bounds__(64 * WN * WK, (WN * WK * (NT == 4 ? 2 : 1) + 3) / 4
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
           acc[i_][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[(u) % 3], fb[ks_][j], acc[i_][j], 0, 0, 0); \
         if constexpr (UNIMM_EXP != 9 && (WITH_BIAS)) accb[i_] = dot_ones(fa[(u) % 3], accb[i_]);             \
-        if constexpr (SPREAD && (u) < PER_WAVE) {                                                            \
+        if constexpr (SPREAD && UNIMM_EXP != 10 && (u) < PER_WAVE) {                                         \
           if (t + 1 < nsteps)                                                                                \
             stage_one_tn<NW, NSUB_A, NSUB_B>(p, mt + TK, mend, n0, k0, smem + (cur ^ 1) * STAGE_BYTES, wave, lane, u); \
         }                                                                                                    \
