@@ -103,7 +103,7 @@ __device__ __forceinline__ void gelu_and_grad2(f32x2v x, f32x2v& y, f32x2v& dy) 
 }
 
 // Counter-based dropout.  Element (row, col) of a [rows, ncols] activation is kept iff the 16-bit field
-// (col & 1) of  mix32((row * ceil(ncols / 2) + (col >> 1)) ^ key)  is >= thr >> 16, key = per-(step, site)
+// (col & 1) of  drop_word(key, row * ceil(ncols / 2) + (col >> 1))  is >= thr >> 16, key = per-(step, site)
 // word built on the host (unimm_amd/dropout.py mirrors this bit for bit so the oracle can replay the
 // masks).  One hash serves two neighbouring columns: the two 32-bit multiplies of mix32 were 25 % of the
 // text-attention forward and a third of the dropout GEMM epilogue.  p is resolved to 2^-16.
@@ -118,7 +118,17 @@ struct DropoutArg {
   uint32_t thr;    // p * 2^32 (the kernels compare 16-bit fields against thr >> 16)
   float scale;     // 1 / (1 - p)
 };
-__device__ __forceinline__ uint32_t drop_word(const DropoutArg& d, uint32_t widx) { return mix32(widx ^ d.key); }
+// The key enters twice: XORed into the index and, multiplied by an odd constant (uniform: one scalar multiply per kernel),
+// added between the two multiplies.  With the XOR alone the mask of key k2 is the mask of key k1 read at index ^ k1 ^ k2:
+// every site and step would see an index permutation of ONE bit pattern.
+__device__ __forceinline__ uint32_t drop_word(const DropoutArg& d, uint32_t widx) {
+  uint32_t x = widx ^ d.key;
+  x ^= x >> 16; x *= 0x7feb352dU;
+  x += d.key * 0x9E3779B1u;
+  x ^= x >> 15; x *= 0x846ca68bU;
+  x ^= x >> 16;
+  return x;
+}
 __device__ __forceinline__ uint32_t drop_wbase(uint32_t row, uint32_t ncols, uint32_t col) { return row * ((ncols + 1u) >> 1) + (col >> 1); }
 __device__ __forceinline__ bool drop_keep(const DropoutArg& d, uint32_t w, uint32_t odd) {
   return (odd ? (w >> 16) : (w & 0xffffu)) >= (d.thr >> 16);
