@@ -68,39 +68,65 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // this wave's 16 LDS-DMA pieces of a K-step: per-lane byte offsets (constant over K) on scalar bases
+    uint32_t so[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int inst = r * 4 + wave;
+      const int rr = inst * 8 + (lane >> 3);
+      const int chunk = (lane & 7) ^ kswz(rr);
+      int g = rr < 256 ? n0 + rr : m0 + rr - 256;
+      const int lim = rr < 256 ? p.N : p.M;
+      g = g < lim ? g : lim - 1;
+      so[r] = (uint32_t)g * (uint32_t)(p.K * 2) + chunk * 16;
+    }
+    const uint32_t ldsw = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);
+#define DMA(r, kt)                                                                                                   \
+    {                                                                                                                \
+      const char* base_ = (const char*)(((r) * 4 + wave) * 8 < 256 ? p.w : p.x) + (size_t)(kt) * 128;                \
+      const uint32_t dst_ = ldsw + ((kt) & 1) * 65536 + (r) * 4096;                                                  \
+      uint32_t keep_;                                                                                                \
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0" \
+                   : "=&s"(keep_) : "v"(so[r]), "s"(dst_), "s"(base_) : "memory");                                   \
+    }
     __builtin_amdgcn_s_barrier();                    // the previous tile's fragment reads are over
-    stage(p, n0, m0, 0, smem, wave, lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) DMA(r, 0)
     for (int t = 0; t < nk; ++t) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      if (t + 1 < nk) stage(p, n0, m0, (t + 1) * 64, smem + ((t + 1) & 1) * 65536, wave, lane);
-      const uint32_t so = (uint32_t)((t & 1) * 65536);
+      const uint32_t so_l = (uint32_t)((t & 1) * 65536);
+      const bool more = t + 1 < nk;
       bf16x8 fw[2][8], fx[2][8];
-#define RD(buf, ks)                                                                                                  \
-      {                                                                                                              \
-        fw[buf][0] = lds_read_b128<0 * 2048>(aw0[ks] + so); fw[buf][1] = lds_read_b128<1 * 2048>(aw0[ks] + so);      \
-        fw[buf][2] = lds_read_b128<2 * 2048>(aw0[ks] + so); fw[buf][3] = lds_read_b128<3 * 2048>(aw0[ks] + so);      \
-        fw[buf][4] = lds_read_b128<4 * 2048>(aw0[ks] + so); fw[buf][5] = lds_read_b128<5 * 2048>(aw0[ks] + so);      \
-        fw[buf][6] = lds_read_b128<6 * 2048>(aw0[ks] + so); fw[buf][7] = lds_read_b128<7 * 2048>(aw0[ks] + so);      \
-        fx[buf][0] = lds_read_b128<0 * 2048>(ax0[ks] + so); fx[buf][1] = lds_read_b128<1 * 2048>(ax0[ks] + so);      \
-        fx[buf][2] = lds_read_b128<2 * 2048>(ax0[ks] + so); fx[buf][3] = lds_read_b128<3 * 2048>(ax0[ks] + so);      \
-        fx[buf][4] = lds_read_b128<4 * 2048>(ax0[ks] + so); fx[buf][5] = lds_read_b128<5 * 2048>(ax0[ks] + so);      \
-        fx[buf][6] = lds_read_b128<6 * 2048>(ax0[ks] + so); fx[buf][7] = lds_read_b128<7 * 2048>(ax0[ks] + so);      \
+#define RDW(buf, ks, i) fw[buf][i] = lds_read_b128<(i) * 2048>(aw0[ks] + so_l);
+#define RDX(buf, ks, j) fx[buf][j] = lds_read_b128<(j) * 2048>(ax0[ks] + so_l);
+      RDW(0, 0, 0) RDW(0, 0, 1) RDW(0, 0, 2) RDW(0, 0, 3) RDW(0, 0, 4) RDW(0, 0, 5) RDW(0, 0, 6) RDW(0, 0, 7)
+      RDX(0, 0, 0) RDX(0, 0, 1) RDX(0, 0, 2) RDX(0, 0, 3) RDX(0, 0, 4) RDX(0, 0, 5) RDX(0, 0, 6) RDX(0, 0, 7)
+      // sub-step 0: unit j = X fragment j against the eight W fragments; behind it two fragment reads of sub-step 1 and
+      // two LDS-DMA pieces of the next K-step
+#define UNIT0(j)                                                                                                     \
+      RDW(1, 1, j) RDX(1, 1, j)                                                                                      \
+      if (more) { DMA(2 * (j), t + 1) DMA(2 * (j) + 1, t + 1) }                                                      \
+      if ((j) == 0) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");                                               \
+      __builtin_amdgcn_s_setprio(1);                                                                                 \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                                  \
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fw[0][i]), "v"(fx[0][j]));    \
+      __builtin_amdgcn_s_setprio(0);                                                                                 \
+      __builtin_amdgcn_sched_barrier(0);
+      UNIT0(0) UNIT0(1) UNIT0(2) UNIT0(3) UNIT0(4) UNIT0(5) UNIT0(6) UNIT0(7)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fw[1][i]), "v"(fx[1][j]));
       }
-#define MM(buf)                                                                                                      \
-      _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                                  \
-        _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                                \
-          asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fw[buf][i]), "v"(fx[buf][j]));
-      RD(0, 0)
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      RD(1, 1)                                       // second 32-deep sub-step's fragments fly under the first one's 64 MFMAs
-      MM(0)
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      MM(1)
-#undef RD
-#undef MM
+#undef UNIT0
+#undef RDW
+#undef RDX
     }
+#undef DMA
     if (p.store) {                                   // accumulator layout: lane = row m, 4 consecutive n per register quad
 #pragma unroll
       for (int i = 0; i < 8; ++i)
