@@ -130,7 +130,7 @@ def test_gemm_tn(M, N, K):
     assert (db - ref_b).abs().max().item() <= 2e-3 * max(1.0, ref_b.abs().max().item())
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("cfg", [1, 3, 6, 7, 8])
 @pytest.mark.parametrize("M,N,K", [(300, 200, 64), (1000, 1000, 768), (515, 2304, 128), (4096, 768, 3072), (257, 257 * 3, 320)])
 def test_gemm_nt_every_tile_configuration(cfg, M, N, K):
     """All block-tile / ring configurations of unimm_gemm_nt give the same result (the automatic choice only
