@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const uint32_t ldsw = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);
 #define DMA(r, kt)                                                                                                   \
     {                                                                                                                \
-      const char* base_ = (const char*)(((r) * 4 + wave) * 8 < 256 ? p.w : p.x) + (size_t)(kt) * 128;                \
+      const char* base_ = (const char*)((r) < 8 ? p.w : p.x) + (size_t)(kt) * 128;   /* pieces 0-7 of a wave are W rows */                \
       const uint32_t dst_ = ldsw + ((kt) & 1) * 65536 + (r) * 4096;                                                  \
       uint32_t keep_;                                                                                                \
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0" \
@@ -146,10 +146,111 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 }
 
+// ---- the same wave tiling on a 4-slot ring of BK = 32 stages (32 KiB each): three stages in flight across the barrier
+__device__ __forceinline__ int kswz32(int row) { return (row >> 2) & 3; }
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void agpr_gemm_deep(P p, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nbn = (p.N + 255) / 256;
+  const int nk = p.K / 32;
+  const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)LDS_PTR(smem);
+  uint32_t aw0, ax0;
+  {
+    const int rw = wn * 128 + (lane & 15), rx = wm * 128 + (lane & 15), cq = lane >> 4;
+    aw0 = lds0 + rw * 64 + ((cq ^ kswz32(rw)) << 4);
+    ax0 = lds0 + (256 + rx) * 64 + ((cq ^ kswz32(rx)) << 4);
+  }
+  for (int lt = blockIdx.x; lt < ntiles; lt += gridDim.x) {
+    const int tm = lt / nbn, tn = lt - tm * nbn;
+    const int m0 = tm * 256, n0 = tn * 256;
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    uint32_t so[8];                                   // this wave's 8 LDS-DMA pieces of a stage (16 rows x 64 B each)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int inst = r * 4 + wave;
+      const int rr = inst * 16 + (lane >> 2);
+      const int chunk = (lane & 3) ^ kswz32(rr);
+      int g = rr < 256 ? n0 + rr : m0 + rr - 256;
+      const int lim = rr < 256 ? p.N : p.M;
+      g = g < lim ? g : lim - 1;
+      so[r] = (uint32_t)g * (uint32_t)(p.K * 2) + chunk * 16;
+    }
+    const uint32_t ldsw = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);
+#define DMA(r, kt)                                                                                                   \
+    {                                                                                                                \
+      const char* base_ = (const char*)((r) < 4 ? p.w : p.x) + (size_t)(kt) * 64;     /* pieces 0-3 of a wave are W rows */                \
+      const uint32_t dst_ = ldsw + ((kt) & 3) * 32768 + (r) * 4096;                                                  \
+      uint32_t keep_;                                                                                                \
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0" \
+                   : "=&s"(keep_) : "v"(so[r]), "s"(dst_), "s"(base_) : "memory");                                   \
+    }
+    __builtin_amdgcn_s_barrier();                    // the previous tile's fragment reads are over
+#pragma unroll
+    for (int st = 0; st < 3; ++st)
+      if (st < nk) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) DMA(r, st)
+      }
+    for (int t = 0; t < nk; ++t) {
+      // stage t has landed once at most the two younger stages (8 pieces each) are outstanding
+      const int rem = nk - 1 - t;
+      if (rem >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (rem == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      const uint32_t so_l = (uint32_t)((t & 3) * 32768);
+      const bool more = t + 3 < nk;
+      bf16x8 fw[8], fx[8];
+#define RDW(i) fw[i] = lds_read_b128<(i) * 1024>(aw0 + so_l);
+#define RDX(j) fx[j] = lds_read_b128<(j) * 1024>(ax0 + so_l);
+      RDW(0) RDW(1) RDW(2) RDW(3) RDW(4) RDW(5) RDW(6) RDW(7) RDX(0) RDX(1)
+      RDX(2) RDX(3) RDX(4) RDX(5) RDX(6) RDX(7)
+#define UNIT(j, PEND)                                                                                                \
+      if (more) DMA(j, t + 3)                                                                                        \
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(PEND) : "memory");                                                  \
+      __builtin_amdgcn_s_setprio(1);                                                                                 \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                                  \
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fw[i]), "v"(fx[j]));          \
+      __builtin_amdgcn_s_setprio(0);                                                                                 \
+      __builtin_amdgcn_sched_barrier(0);
+      UNIT(0, 7) UNIT(1, 6) UNIT(2, 5) UNIT(3, 4) UNIT(4, 3) UNIT(5, 2) UNIT(6, 1) UNIT(7, 0)
+#undef UNIT
+#undef RDW
+#undef RDX
+    }
+#undef DMA
+    if (p.store) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int m = m0 + wm * 128 + j * 16 + (lane & 15), n = n0 + wn * 128 + i * 16 + 4 * (lane >> 4);
+          if (m < p.M && n + 3 < p.N) *reinterpret_cast<f32x4*>(p.out + (size_t)m * p.N + n) = acc[i][j];
+        }
+    } else {
+      float sacc = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+      if (sacc == 12345.678f) p.out[0] = sacc;
+    }
+  }
+}
+
 static float bf2f(uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; }
 
 int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 31162, N = argc > 2 ? atoi(argv[2]) : 3072, K = argc > 3 ? atoi(argv[3]) : 768;
+  const bool deep = argc > 4 && atoi(argv[4]) == 1;          // 1: the 4-slot BK = 32 ring
+  auto kern = deep ? agpr_gemm_deep : agpr_gemm;
   void *x, *w, *out;
   hipMalloc(&x, (size_t)M * K * 2); hipMalloc(&w, (size_t)N * K * 2); hipMalloc(&out, (size_t)M * N * 4);
   std::vector<uint16_t> hx((size_t)M * K), hw((size_t)N * K);
@@ -157,11 +258,11 @@ int main(int argc, char** argv) {
   for (auto& v : hw) v = (uint16_t)(((rand() & 1) << 15) | ((0x7b + (rand() % 6)) << 7) | (rand() & 0x7f));
   hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice);
   hipMemcpy(w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
-  hipFuncSetAttribute((const void*)agpr_gemm, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
   P p{(const bf16_t*)x, (const bf16_t*)w, (float*)out, M, N, K, 1};
   const int ntiles = ((M + 255) / 256) * ((N + 255) / 256);
   hipMemset(out, 0, (size_t)M * N * 4);
-  hipLaunchKernelGGL(agpr_gemm, dim3(256), dim3(256), 131072, 0, p, ntiles);
+  hipLaunchKernelGGL(kern, dim3(256), dim3(256), 131072, 0, p, ntiles);
   if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed: %s\n", hipGetErrorString(hipGetLastError())); return 1; }
   std::vector<float> ho((size_t)M * N);
   hipMemcpy(ho.data(), out, ho.size() * 4, hipMemcpyDeviceToHost);
@@ -176,14 +277,15 @@ int main(int argc, char** argv) {
   printf("check: worst |err| / (1 + |ref|) on 2000 sampled elements = %.2e\n", worst);
   p.store = 0;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(agpr_gemm, dim3(256), dim3(256), 131072, 0, p, ntiles);
+  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kern, dim3(256), dim3(256), 131072, 0, p, ntiles);
   hipDeviceSynchronize();
   hipEventRecord(e0, 0);
   const int it = 100;
-  for (int i = 0; i < it; ++i) hipLaunchKernelGGL(agpr_gemm, dim3(256), dim3(256), 131072, 0, p, ntiles);
+  for (int i = 0; i < it; ++i) hipLaunchKernelGGL(kern, dim3(256), dim3(256), 131072, 0, p, ntiles);
   hipEventRecord(e1, 0); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   const double us = ms * 1e3 / it;
+  printf("%s", deep ? "[4-slot BK=32 ring] " : "[2-slot BK=64 ring] ");
   printf("agpr 4-wave 128x128 wave tiles, loop only: M=%d N=%d K=%d: %.1f us  %.1f TFLOP/s-equivalent (%d tiles, %.2f us per 256x256x64 step per workgroup)\n",
          M, N, K, us, 2.0 * M * N * K / us / 1e6, ntiles, us / ((ntiles + 255) / 256) / (K / 64));
   return 0;
