@@ -102,3 +102,22 @@ def test_weight_version_sees_writes_through_the_parameters(golden_dir):
     mid = eng.arena._probe[len(eng.arena._probe) // 2]         # first parameter of a bucket in the middle of the arena
     named[mid].data = named[mid].data.clone()                  # re-pointed (what a partial .to() / assign=True does)
     assert not eng.arena.is_current() and not eng.arena.is_current_full()
+
+
+def test_dropout_masks_of_two_keys_are_not_index_permutations_of_one_pattern():
+    """Host mirror of the device dropout word (unimm_amd/csrc/common.h: drop_word): keep rate 1 - p, and the mask of a
+    second key is NOT the first key's mask read at index ^ k1 ^ k2 (it was, when the key only entered by XOR)."""
+    from unimm_amd import dropout as DR
+    k1 = DR.make_key(1234, 7, 3)
+    k2 = k1 ^ 0x1234                                 # keys that differ in low bits only: the XOR distance stays inside the range
+    _, thr, _ = DR.drop_arg(0.1, k1)
+    n = 1 << 16
+    a = DR.keep_mask(k1, thr, 2 * n)[0::2]           # field 0 of word indices 0 .. n-1
+    b = DR.keep_mask(k2, thr, 2 * n)[0::2]
+    assert abs(a.mean() - 0.9) < 5e-3 and abs(b.mean() - 0.9) < 5e-3
+    d = (k1 ^ k2) & (n - 1)                          # low bits of the XOR distance: a permutation inside this index range
+    idx = np.arange(n) ^ d
+    agree = float((b == a[idx]).mean())
+    assert agree < 0.9, agree                        # independent masks agree on ~0.82 of the positions, a permutation on all
+    c = np.corrcoef(a.astype(np.float64), b.astype(np.float64))[0, 1]
+    assert abs(c) < 2e-2, c
