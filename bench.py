@@ -72,7 +72,7 @@ def parse():
                          "timestamp between back-to-back kernels) and 2 ms of 16 ms at 30 sequences per GPU (host launch rate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-tile", type=int, default=0, metavar="CODE",
-                    help="tuning: unimm_gemm_set_tile(CODE) before the run (1000 x tile columns per group + 100 x {1 persistent, "
+                    help="tuning: unimm_gemm_nt_args.tile = CODE for every launch of the run (1000 x tile columns per group + 100 x {1 persistent, "
                          "2 one workgroup per tile} + tile configuration; 0 = the library's defaults)")
     ap.add_argument("--host-profile", default=None, metavar="FILE",
                     help="after warm-up, cProfile 5 untimed steps of host-side enqueue work into FILE (text, by own time)")
@@ -353,8 +353,7 @@ def main():
         model.engine.arena.zero_grads()
         return fwd_bwd()
 
-    if args.gemm_tile:
-        lib.gemm_set_tile(args.gemm_tile)
+    model.engine.gemm_tile = args.gemm_tile      # per-call tuning code of every unimm_gemm_nt launch (0 = automatic)
     model.engine.ensure(dev)
     model.engine.arena.attach_grads()
     log(f"model + batch ready on {dev}: {per_gpu} sequences/GPU, {n_lm_rows} decoded MLM rows")

@@ -59,8 +59,10 @@ typedef struct {
   int32_t ldx, ldw, ldaux, ldo;
   int32_t epilogue;
   int32_t out_f32;
-  uint32_t drop_key; /* dropout (UNIMM_EPI_BIAS_DROP_RESID): keep iff mix32(idx ^ key) >= thr   */
-  uint32_t drop_thr; /* p * 2^32; 0 disables                                                    */
+  uint32_t drop_key; /* dropout (UNIMM_EPI_BIAS_DROP_RESID): element (m, n) is kept iff the 16-bit field (n & 1) of
+                      * drop_word(key, m * ceil(N / 2) + n / 2) is >= thr -- one counter-based hash per two neighbouring
+                      * columns (csrc/common.h: drop_word; unimm_amd/dropout.py is the bit-exact host mirror)  */
+  uint32_t drop_thr; /* p * 2^16; 0 disables                                                    */
   float drop_scale;  /* 1 / (1 - p)                                                             */
   /* UNIMM_EPI_BIAS_DROP_RESID only, all four or none: the residual operand is LayerNorm(aux) evaluated on
    * the fly, (aux[m,n] - aux_mean[m]) * aux_rstd[m] * aux_gamma[n] + aux_beta[n] -- the fp32 output of the
@@ -69,17 +71,17 @@ typedef struct {
   const float* aux_rstd;
   const float* aux_gamma;
   const float* aux_beta;
+  /* Per-call tuning (tests and A/B measurements; 0 = everything automatic): tile = gn * 1000 + p * 100 + cfg.
+   *   cfg: 0 automatic (a cost model over {256x256, 192x256, 128x128}; 64x128 for grids that do not fill the chip),
+   *        1 = 128x128 / 4 waves / 2-slot ring of BK 64 / 2 workgroups per CU,   3 = 256x256 / 8 waves / lock-step ring,
+   *        6 = 192x256 / 8 waves,   7 = 64x128 / 4 waves of 32x64 / 3 workgroups per CU,   8 = 256x256 / ping-pong loop;
+   *        anything else is rejected with UNIMM_E_ARG
+   *   p:   0 automatic, 1 persistent workgroups (one per CU slot walks several tiles), 2 one workgroup per tile
+   *   gn:  n-tiles per column group of the tile order (0 = default 4) */
+  int32_t tile;
 } unimm_gemm_nt_args;
 
 int unimm_gemm_nt(const unimm_gemm_nt_args* args, void* stream);
-/* Tuning knob (tests and A/B measurements): block tile of unimm_gemm_nt.  cfg = gn * 1000 + p * 100 + tile.
- *   tile: 0 automatic (default: 3 when >= 384 tiles of 256x256, 7 when < 256 tiles of 128x128, else 1),
- *         1 = 128x128 / 4 waves / 2-slot ring of BK 64 / 2 workgroups per CU,   2 = 256x256 / 8 waves / 4 x BK 32,
- *         3 = 256x256 / 8 waves / 2 x BK 64,   4, 5 = the 256x256 and 128x128 tiles behind a 5-slot ring of BK 32,
- *         6 = 256x128 / 8 waves,   7 = 64x128 / 4 waves of 32x64 / 3 workgroups per CU
- *   p:    0 automatic, 1 persistent workgroups (one per CU slot walks several tiles), 2 one workgroup per tile
- *   gn:   n-tiles per column group of the tile order (0 = default 6) */
-int unimm_gemm_set_tile(int32_t cfg);
 
 /* GEMM, "TN": DW[N,K] += DY[M,N]^T . X[M,K] (fp32 atomics; caller zeroes DW once per step) and,
  * when dbias != NULL, dbias[N] += column sums of DY (the bias gradient, one extra MFMA per tile).
@@ -97,11 +99,11 @@ typedef struct {
 int unimm_gemm_tn(const unimm_gemm_tn_args* args, void* stream);
 /* `count` independent TN problems (host array) in as few grids as possible: the weight gradients of one
  * encoder block (models/vilbert_dialog.py:386-388, 423-425, 453-454, 466-468 and twins) in one launch.
- * Same result as `count` calls of unimm_gemm_tn; the problems must not alias each other's dw / dbias
- * unless they are meant to accumulate (fp32 atomics make that safe). */
+ * Same result as `count` calls of unimm_gemm_tn; the problems may alias each other's dw / dbias when they are
+ * meant to accumulate (every path, with or without a workspace, ends in fp32 atomics). */
 int unimm_gemm_tn_grouped(const unimm_gemm_tn_args* args, int32_t count, void* stream);
-/* The same with (a) the "launches share the chip with another stream's kernels" hint of the split heuristic as a
- * per-call argument instead of the process-wide unimm_gemm_tn_set_shared, and (b) a caller-owned WORKSPACE: when the
+/* The same with (a) the "launches share the chip with another stream's kernels" hint of the split heuristic
+ * (shared_chip != 0: fewer, longer workgroups and fewer partial tiles), and (b) a caller-owned WORKSPACE: when the
  * reduction is split, every split stores its fp32 partial tile to a slab of the workspace (plain coalesced stores) and
  * the split that arrives last at the tile's counter sums the slabs and adds the tile into dw once, instead of every
  * split adding 256 KiB with memory-side atomics (8x the algorithmic write traffic, a ~43 us drain per launch).
@@ -162,9 +164,6 @@ typedef struct {
 } unimm_attn_bwd_args;
 
 int unimm_attn_bwd(const unimm_attn_bwd_args* args, void* stream);
-/* Tuning knob: workgroups per (sequence, head) item of the attention kernels: 0 = automatic, 1 = one
- * workgroup of up to 8 waves (= 1, the default), 2 = two 4-wave workgroups. */
-int unimm_attn_set_parts(int32_t parts);
 
 /* ---------------------------------------------------------------------------------------------
  * Row kernels (HBM-bound).
@@ -278,12 +277,31 @@ int unimm_transpose_cast_grouped(const unimm_transpose_desc* table, int32_t coun
  * the operand of the single image-embedding GEMM (models/vilbert_dialog.py:1488-1489). */
 int unimm_pack_image(const float* feat, const float* loc, void* out, int32_t rows, int32_t F, int32_t ld, void* stream);
 
-/* out = dropout(a * b) (pooled_t * pooled_v, models/vilbert_dialog.py:1065) and its backward, which also
- * folds in the pooler ReLU gradient (:951, :966): da = [a>0] drop(dout) b, db = [b>0] drop(dout) a. */
-int unimm_mul_dropout(const void* a, const void* b, void* out, int64_t n, uint32_t drop_key, uint32_t drop_thr,
+/* out = dropout(a * b) (pooled_t * pooled_v, models/vilbert_dialog.py:1065), fp32 flat [n], and its backward, which
+ * also folds in the pooler ReLU gradient (:951, :966): da = [a>0] drop(dout) b, db = [b>0] drop(dout) a. */
+int unimm_mul_dropout(const float* a, const float* b, float* out, int64_t n, uint32_t drop_key, uint32_t drop_thr,
                       float drop_scale, void* stream);
-int unimm_mul_dropout_bwd(const void* a, const void* b, const void* dout, void* da, void* db, int64_t n,
+int unimm_mul_dropout_bwd(const float* a, const float* b, const float* dout, float* da, float* db, int64_t n,
                           uint32_t drop_key, uint32_t drop_thr, float drop_scale, void* stream);
+
+/* fp32 linear algebra of the heads on top of the network (the two poolers :946-967, the NSP head :1070) and their
+ * backward, on the exact-fp32 matrix instruction v_mfma_f32_16x16x4_f32, straight from the fp32 master weights:
+ *   OUT[m, n] (+)= act( sum_k A(m, k) * B(k, n) + bias[n] ),  A(m, k) = a[m * sa_m + k * sa_k],  B(k, n) = b[k * sb_k + n * sb_n]
+ * (strides in elements), act = ReLU when relu != 0; accumulate != 0 adds into OUT with fp32 atomics (gradients
+ * accumulate); rowsum (or NULL): rowsum[m] += sum_k A(m, k), the bias gradient when A = dY^T.  One kernel gives
+ *   y = x W^T + b   (a = x: sa_m = ldx, sa_k = 1;  b = W [N, K]: sb_k = 1, sb_n = ldw),
+ *   dx = dy W        (a = dy: sa_m = lddy, sa_k = 1;  b = W: sb_k = ldw, sb_n = 1),
+ *   dW += dy^T x     (a = dy: sa_m = 1, sa_k = lddy;  b = x: sb_k = ldx, sb_n = 1;  M = out features, K = batch rows). */
+typedef struct {
+  const float* a; const float* b; const float* bias; float* out; float* rowsum;
+  int32_t M, N, K;
+  int64_t sa_m, sa_k, sb_k, sb_n, ldo;
+  int32_t relu, accumulate;
+} unimm_linear_f32_args;
+int unimm_linear_f32(const unimm_linear_f32_args* args, void* stream);
+/* dst[idx[r], :] += src[r, :]: bf16 rows of H elements, fp32 addend, idx unique (the pooler input gradient joins the
+ * gradient of the first-token rows, models/vilbert_dialog.py:949, :964). */
+int unimm_rows_add_f32(void* dst, const int32_t* idx, const float* src, int32_t n, int32_t H, void* stream);
 
 /* du = dt * GELU'(u), bf16 flat [n], n % 8 == 0 (prediction-head transforms, :983-985, :1002-1004) */
 int unimm_gelu_bwd(const void* dt, const void* u, void* du, int64_t n, void* stream);
@@ -316,8 +334,10 @@ int unimm_kl_loss_bwd(const float* pred, const float* target, const int32_t* lab
  * w0, w1 already divided by w0 (:1608). */
 int unimm_nsp_loss_fwd(const float* logits, const int32_t* labels, float w0, float w1, float* loss, int32_t B,
                        int32_t ld, void* stream);
-int unimm_nsp_loss_bwd(const float* logits, const int32_t* labels, float w0, float w1, const float* g,
-                       void* dlogits, int32_t B, int32_t ld, int32_t ldd, void* stream);
+/* dlogits: fp32 [B, ldd] (columns 2.. zeroed); extra (or NULL): fp32 [B, 2] added to it -- a gradient that arrives
+ * through the returned NSP scores (the ranking loss of dense_annotation_finetuning.py:263-293) */
+int unimm_nsp_loss_bwd(const float* logits, const int32_t* labels, float w0, float w1, const float* g, const float* extra,
+                       float* dlogits, int32_t B, int32_t ld, int32_t ldd, void* stream);
 /* dst[0] = scale * sum(src) (fixed order, deterministic); dst[seg[i]] += sign * src[i] */
 int unimm_reduce_sum(const float* src, int64_t n, float* dst, float scale, void* stream);
 int unimm_segment_sum(const float* src, const int32_t* seg, float* dst, int64_t n, float sign, void* stream);
@@ -378,11 +398,6 @@ typedef struct {
 } unimm_ndcg_args;
 
 int unimm_neural_ndcg(const unimm_ndcg_args* args, void* stream);
-
-/* Hint for the split heuristic of unimm_gemm_tn(_grouped): on = the launches share the chip with kernels of another
- * stream (the engine's two-stream schedule), so an under-filled last round is not idle time and fewer, longer
- * workgroups with fewer partial tiles to drain are preferred; off (default) = the launch has the chip to itself. */
-int unimm_gemm_tn_set_shared(int32_t on);
 
 /* Launch profiler for bench.py's `roofline` block: HIP events around every GEMM launch on its own
  * stream while enabled.  Variant index: 0..11 = unimm_gemm_nt (epilogue * 2 + out_f32), 12 = unimm_gemm_tn.

@@ -58,30 +58,29 @@ def full_b6_call(g):
 
 
 # Gates of the full-size backward (set from the measured worst cases printed below, plus margin).
-GRAD_NORM_GATE = 3e-2        # | ||g_hip|| - ||g_ref|| | / ||g_ref||, every tensor whose gradient is not numerically zero
-# The NSP head's bias gradient is two numbers, sum_b (p_b - y_b) over the 6 sequences: the terms cancel to 0.026 while each
-# carries the bf16 noise of a pooled logit (~1e-3), so the relative error of its norm moves with any change in rounding
-# order: 2.1e-2 with the round-1 attention kernels, 3.2e-2 with the log2-domain softmax (same inputs, both measured on
-# MI355X; the head's weight gradient, which does not cancel, is at 2.4e-2 on its sampled slice either way).
-GRAD_NORM_GATE_BY_NAME = {"cls.bi_seq_relationship.bias": 5e-2}
+GRAD_NORM_GATE = 2e-2        # | ||g_hip|| - ||g_ref|| | / ||g_ref||, every tensor whose gradient is not numerically zero
+#                              (round 3, poolers + NSP head in fp32: families 0.05-1.4 %; the 2-element NSP bias, which
+#                              needed its own 5 % gate while the head ran on bf16 operands, is at 0.15 %)
 GRAD_SLICE_L2_GATE = 1e-1    # ||g_hip - g_ref||_2 / ||g_ref||_2 on the sampled slices
 GRAD_SLICE_MAX_GATE = 1.5e-1  # max |g_hip - g_ref| / max |g_ref| on the sampled slices
-# The image side of the LAST connection block sits directly under the poolers (dense + ReLU on 6 rows, then the product of
-# the two pooled vectors): which of the 6 x 1024 units are active flips with the last bit of a forward value, and every
-# image-side gradient of this block moves with it.  Measured with tools/grad_noise.py on MI355X: two builds whose attention
-# kernels are equally close to the fp32 reference at kernel level (test_gpu_kernels prints 2.3e-3..5.1e-3 for out / dq /
-# dk / dv on all eight shapes for both) differ FROM EACH OTHER by 8 % in full-tensor L2 on every image-side tensor of
-# c_layer.5 (0.9 % on its text side, 2-5 % in c_layer.1), each being 4-8 % from the reference and up to 16 % on one
-# 16-row slice (v_intermediate.dense.weight); runs of one build are bit-identical.  So this block gets the poolers' gate.
+# The two poolers are ReLU(W h + b) on the first-token row of 6 sequences (models/vilbert_dialog.py:946-967): 6 x 1024
+# units.  Round 2 blamed bf16 pooler arithmetic for their 8-16 % slice errors; round 3 moved the poolers, the fused product
+# and the NSP head to exact fp32 (unimm_linear_f32, fp32 master weights, fp32 residual-stream input) forward and backward
+# -- the gradient NORMS of these tensors went from 1-3 % to 0.15-0.4 % -- but the sampled-slice error did not move
+# (10.7 % / 28.8 % before and after), because the switching units are decided by the pooler's INPUT: z = W h + b has
+# std ~0.55 rms(h) (W ~ N(0, 0.02), 768 inputs), the encoder output h carries the bf16 noise of 24 blocks (measured 0.5 %
+# of scale, test_gpu_model.py), so dz ~ 0.003 rms(h) and P(|z| < dz) ~ 0.4 % of the units = ~25 of 6,144 sit within the
+# noise of zero.  Each of those gains or loses its WHOLE gradient, so ~2.4 % of the elements of a pooler gradient are off
+# by O(1) of themselves: sqrt(0.024) = 15 % L2, worst element up to its full size.  That is a property of bf16 operands
+# anywhere below the poolers, not of the poolers; only an fp32 encoder removes it.  The image side of the LAST connection
+# block sits directly under the image pooler and inherits it (measured 11.8 % / 13 %; its text side 0.9 %).
 TOP_BLOCK = "bert.encoder.c_layer.5"
 POOLER_GATES = (2e-1, 3.5e-1)
-# Measured (the test prints the table): heads 0.6-2.4 %, encoder blocks 4-6.6 % L2 (worst element up to 12 % of the
-# tensor's largest on the image side, whose gradients average only 6 x 37 rows), embeddings 6.5 %, all with the tensor
-# NORMS within 2 % (most within 0.5 %): errors orthogonal to the signal, i.e. noise.  That is the bf16 floor of this depth:
+# Measured (the test prints the table): heads 0.6-1.5 %, encoder blocks 4-6.8 % L2 (worst element up to 9.5 % of the
+# tensor's largest on the image side, whose gradients average only 6 x 37 rows), embeddings 5.7 %, all with the tensor
+# NORMS within 1.4 % (most within 0.5 %): errors orthogonal to the signal, i.e. noise.  That is the bf16 floor of this depth:
 # every block perturbs the backward signal through its bf16 GEMM operands, bf16 attention probabilities and the bf16
-# gradient stream between blocks (2^-9 per rounding), ~0.5-1 % per block and uncorrelated, ~sqrt(24) x 1 %.  The two
-# pooler biases (ReLU(W h + b), models/vilbert_dialog.py:946-967) read 10.5 % L2 / 27 % worst element: pre-activations
-# within the forward's bf16 noise of zero switch their ReLU, and each switched unit gains or loses its whole gradient.
+# gradient stream between blocks (2^-9 per rounding), ~0.5-1 % per block and uncorrelated, ~sqrt(24) x 1 %.
 
 
 def test_full_config_b6_backward_matches_reference_golden(golden_dir):
@@ -116,7 +115,7 @@ def test_full_config_b6_backward_matches_reference_golden(golden_dir):
             continue
         rel = abs(got - want) / want
         worst[fam] = max(worst.get(fam, 0.0), rel)
-        assert rel <= GRAD_NORM_GATE_BY_NAME.get(n, GRAD_NORM_GATE), (n, got, want, rel)
+        assert rel <= GRAD_NORM_GATE, (n, got, want, rel)
         checked += 1
     assert checked > 450
     print("\nfull-config backward: worst relative error of a gradient norm, per tensor family")

@@ -143,12 +143,8 @@ def test_gemm_nt_every_tile_configuration(cfg, M, N, K):
     resid = torch.randn((M, ldo), generator=g, device="cuda")
     ref = x.float() @ w.float().t() + bias + resid[:, :N]
     out = torch.full((M, ldo), float("nan"), device="cuda")
-    lib.gemm_set_tile(cfg)
-    try:
-        lib.gemm_nt(x, w, out, bias=bias, epilogue=lib.EPI_BIAS_DROP_RESID, aux=resid, N=N)
-        torch.cuda.synchronize()
-    finally:
-        lib.gemm_set_tile(0)
+    lib.gemm_nt(x, w, out, bias=bias, epilogue=lib.EPI_BIAS_DROP_RESID, aux=resid, N=N, tile=cfg)
+    torch.cuda.synchronize()
     err = (out[:, :N] - ref).abs().max().item()
     assert err <= 2e-3 * max(1.0, ref.abs().max().item()), err
     if ldo > N:
@@ -167,13 +163,9 @@ def test_gemm_nt_persistent_workgroups(cfg):
     u = x.float() @ w.float().t() + bias
     out = torch.zeros((M, N), device="cuda", dtype=torch.bfloat16)
     out2 = torch.zeros_like(out)
-    lib.gemm_set_tile(cfg)
-    try:
-        for _ in range(2):                      # twice: a persistent workgroup must leave no state behind
-            lib.gemm_nt(x, w, out, bias=bias, epilogue=lib.EPI_BIAS_GELU_DG, out2=out2)
-        torch.cuda.synchronize()
-    finally:
-        lib.gemm_set_tile(0)
+    for _ in range(2):                      # twice: a persistent workgroup must leave no state behind
+        lib.gemm_nt(x, w, out, bias=bias, epilogue=lib.EPI_BIAS_GELU_DG, out2=out2, tile=cfg)
+    torch.cuda.synchronize()
     ref = _gelu(u)
     assert (out.float() - ref).abs().max().item() <= 2 ** -6 * max(1.0, ref.abs().max().item())
     cdf = 0.5 * (1 + torch.erf(u / math.sqrt(2.0)))
@@ -192,18 +184,13 @@ def test_gemm_nt_ping_pong_loop_is_race_free_and_bit_equal_to_the_ring_loop(K):
     x, w = _rand((M, K), g), _rand((N, K), g, 0.05)
     bias = torch.randn(N, generator=g, device="cuda")
     ref = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
-    lib.gemm_set_tile(3)
-    try:
-        lib.gemm_nt(x, w, ref, bias=bias, epilogue=lib.EPI_BIAS)
-        lib.gemm_set_tile(8)
-        for rep in range(8):
-            out = torch.zeros_like(ref)
-            lib.gemm_nt(x, w, out, bias=bias, epilogue=lib.EPI_BIAS)
-            torch.cuda.synchronize()
-            bad = (out.view(torch.int16) != ref.view(torch.int16)).sum().item()
-            assert bad == 0, (rep, bad)
-    finally:
-        lib.gemm_set_tile(0)
+    lib.gemm_nt(x, w, ref, bias=bias, epilogue=lib.EPI_BIAS, tile=3)
+    for rep in range(8):
+        out = torch.zeros_like(ref)
+        lib.gemm_nt(x, w, out, bias=bias, epilogue=lib.EPI_BIAS, tile=8)
+        torch.cuda.synchronize()
+        bad = (out.view(torch.int16) != ref.view(torch.int16)).sum().item()
+        assert bad == 0, (rep, bad)
 
 
 @pytest.mark.parametrize("M,N,K", [(515, 768, 128), (4096, 1024, 1024), (300, 200, 64)])
@@ -283,12 +270,13 @@ def test_gemm_rejects_bad_arguments():
         lib.gemm_nt(x.cpu(), w, out)
 
 
-@pytest.mark.parametrize("cfg", [1, 3, 7])
-@pytest.mark.parametrize("epi", ["add", "mul", "bias16", "resid_drop"])
+@pytest.mark.parametrize("cfg", [1, 3, 6, 7, 8])
+@pytest.mark.parametrize("epi", ["add", "mul", "bias16", "resid_drop", "resid_ln"])
 def test_gemm_nt_epilogue_layout_against_torch(cfg, epi):
-    """Every epilogue family on ragged M / N with strides that allow and forbid the 16-byte path (and the epilogue-operand
-    prefetch clamped at the edges), against torch on the same bf16 inputs; the dropout mask against the host mirror
-    of the counter-based generator."""
+    """Every epilogue family on every instantiated tile (the automatic rule picks 6 for N = 768 / 2304 and 8 for
+    N = 3072 on the hot path), ragged M / N with strides that allow and forbid the 16-byte path (and the
+    epilogue-operand prefetch clamped at the edges), against torch on the same bf16 inputs; the dropout mask against
+    the host mirror of the counter-based generator; "resid_ln" = the residual is a lazily evaluated LayerNorm."""
     from unimm_amd import lib
     from unimm_amd import dropout as DR
     g = torch.Generator(device="cuda").manual_seed(cfg * 10 + len(epi))
@@ -296,34 +284,47 @@ def test_gemm_nt_epilogue_layout_against_torch(cfg, epi):
         x, w = _rand((M, K), g), _rand((N, K), g, 0.05)
         base = x.float() @ w.float().t()
         bias = torch.randn(N, generator=g, device="cuda")
-        lib.gemm_set_tile(cfg)
-        try:
-            if epi in ("add", "mul"):
-                aux = torch.zeros((M, ldo), device="cuda", dtype=torch.bfloat16)
-                aux[:, :N] = _rand((M, N), g)
-                out = torch.full((M, ldo), 7.0, device="cuda", dtype=torch.bfloat16)
-                lib.gemm_nt(x, w, out, epilogue=lib.EPI_ADD if epi == "add" else lib.EPI_MUL, aux=aux, N=N)
-                ref = base + aux[:, :N].float() if epi == "add" else base * aux[:, :N].float()
-                tol = 2 ** -7
-            elif epi == "bias16":
-                out = torch.full((M, ldo), 7.0, device="cuda", dtype=torch.bfloat16)
-                lib.gemm_nt(x, w, out, bias=bias, N=N)
-                ref, tol = base + bias, 2 ** -7
-            else:
-                aux = torch.randn((M, ldo), generator=g, device="cuda")
-                out = torch.full((M, ldo), 7.0, device="cuda")
-                key = DR.make_key(3, 9, 77)
-                drop = DR.drop_arg(0.1, key)
-                lib.gemm_nt(x, w, out, bias=bias, epilogue=lib.EPI_BIAS_DROP_RESID, aux=aux, N=N, drop=drop)
-                keep = torch.from_numpy(DR.keep_mask2d(key, drop[1], M, N)).cuda()
-                ref, tol = (base + bias) * keep * drop[2] + aux[:, :N], 2e-3
-            torch.cuda.synchronize()
-        finally:
-            lib.gemm_set_tile(0)
+        if epi in ("add", "mul"):
+            aux = torch.zeros((M, ldo), device="cuda", dtype=torch.bfloat16)
+            aux[:, :N] = _rand((M, N), g)
+            out = torch.full((M, ldo), 7.0, device="cuda", dtype=torch.bfloat16)
+            lib.gemm_nt(x, w, out, epilogue=lib.EPI_ADD if epi == "add" else lib.EPI_MUL, aux=aux, N=N, tile=cfg)
+            ref = base + aux[:, :N].float() if epi == "add" else base * aux[:, :N].float()
+            tol = 2 ** -7
+        elif epi == "bias16":
+            out = torch.full((M, ldo), 7.0, device="cuda", dtype=torch.bfloat16)
+            lib.gemm_nt(x, w, out, bias=bias, N=N, tile=cfg)
+            ref, tol = base + bias, 2 ** -7
+        else:
+            aux = torch.randn((M, ldo), generator=g, device="cuda") * 2 + 0.5
+            out = torch.full((M, ldo), 7.0, device="cuda")
+            key = DR.make_key(3, 9, 77)
+            drop = DR.drop_arg(0.1, key)
+            resid, aux_ln = aux[:, :N], None
+            if epi == "resid_ln":
+                gamma, beta = torch.randn(N, generator=g, device="cuda"), torch.randn(N, generator=g, device="cuda")
+                mean = aux[:, :N].mean(1)
+                rstd = torch.rsqrt(aux[:, :N].var(1, unbiased=False) + 1e-12)
+                resid, aux_ln = (aux[:, :N] - mean[:, None]) * rstd[:, None] * gamma + beta, (mean, rstd, gamma, beta)
+            lib.gemm_nt(x, w, out, bias=bias, epilogue=lib.EPI_BIAS_DROP_RESID, aux=aux, N=N, drop=drop, aux_ln=aux_ln, tile=cfg)
+            keep = torch.from_numpy(DR.keep_mask2d(key, drop[1], M, N)).cuda()
+            ref, tol = (base + bias) * keep * drop[2] + resid, 2e-3
+        torch.cuda.synchronize()
         err = (out[:, :N].float() - ref).abs().max().item()
         assert err <= tol * max(1.0, ref.abs().max().item()), (M, N, K, ldo, err)
         if ldo > N:
             assert (out[:, N:].float() == 7.0).all()                 # pad columns untouched
+
+
+def test_gemm_nt_rejects_uninstantiated_tiles():
+    """Tile codes 2, 4, 5 (the BK = 32 rings that are no longer built) and anything above 8 fail at the call, not later."""
+    from unimm_amd import lib
+    x = torch.zeros((256, 64), device="cuda", dtype=torch.bfloat16)
+    w = torch.zeros((256, 64), device="cuda", dtype=torch.bfloat16)
+    out = torch.zeros((256, 256), device="cuda", dtype=torch.bfloat16)
+    for bad in (2, 4, 5, 9, 308, -1):
+        with pytest.raises(lib.UnimmHipError):
+            lib.gemm_nt(x, w, out, tile=bad)
 
 
 def test_gemm_tn_workspace_reducer_matches_atomic_path():

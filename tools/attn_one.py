@@ -46,11 +46,7 @@ def bench(name, H, D, Tq, Tk, q_rows, k_rows, mask, mq, mb, qvar, kvar):
     print(f"{name:6s} H={H} D={D} Tq={Tq} Tk={Tk}: fwd {res[0]:7.1f} us   bwd {res[1]:7.1f} us")
 
 
-which = [a for a in sys.argv[1:] if not a.startswith("parts=") and a != "nodrop"] or ["text", "img", "dir1", "dir2"]
-for a in sys.argv[1:]:
-    if a.startswith("parts="):
-        lib.attn_set_parts(int(a[6:]))
-        print("attn_set_parts", a[6:])
+which = [a for a in sys.argv[1:] if a != "nodrop"] or ["text", "img", "dir1", "dir2"]
 if "text" in which:
     m = torch.zeros((B, T, T), dtype=torch.bool, device="cuda")
     for b, l in enumerate(lens):

@@ -31,10 +31,8 @@ for (N, K, epi) in [(2304, 768, lib.EPI_BIAS), (768, 768, lib.EPI_BIAS_DROP_RESI
     o = torch.empty((M, N), device="cuda") if resid else out
     ax = torch.randn((M, N), device="cuda") if resid else aux
     for cfg in CFGS:
-        lib.gemm_set_tile(cfg)
-        t = timeit(lambda: lib.gemm_nt(x, w, o, bias=b, epilogue=epi, aux=ax, out2=out2 if epi == lib.EPI_BIAS_GELU_DG else None))
+        t = timeit(lambda: lib.gemm_nt(x, w, o, bias=b, epilogue=epi, aux=ax, out2=out2 if epi == lib.EPI_BIAS_GELU_DG else None, tile=cfg))
         print(f"NT  N={N:5d} K={K:5d} epi={epi} cfg={cfg}: {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TFLOP/s")
-    lib.gemm_set_tile(0)
 for (N, K) in [(2304, 768), (768, 768), (3072, 768), (768, 3072)]:
     dy = torch.randn((M, N), generator=g, device="cuda").to(torch.bfloat16)
     x = torch.randn((M, K), generator=g, device="cuda").to(torch.bfloat16)

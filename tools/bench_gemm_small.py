@@ -23,8 +23,6 @@ for M in ([int(a) for a in sys.argv[1].split(',')] if len(sys.argv) > 1 else (88
     out2 = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
     res = []
     for cfg in ([int(a) for a in sys.argv[2].split(',')] if len(sys.argv) > 2 else (0, 1, 3, 6, 7)):
-        lib.gemm_set_tile(cfg)
-        t = timeit(lambda: lib.gemm_nt(x, w, o, bias=b, epilogue=epi, aux=ax, out2=out2 if epi == lib.EPI_BIAS_GELU_DG else None))
+        t = timeit(lambda: lib.gemm_nt(x, w, o, bias=b, epilogue=epi, aux=ax, out2=out2 if epi == lib.EPI_BIAS_GELU_DG else None, tile=cfg))
         res.append(f"cfg{cfg} {t*1e6:6.1f}")
-    lib.gemm_set_tile(0)
     print(f"  N={N:5d} K={K:5d} epi={epi}: " + "  ".join(res))

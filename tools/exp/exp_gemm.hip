@@ -1,5 +1,8 @@
-// Bottleneck experiments for gemm_nt (not part of the product): built with -DUNIMM_EXP=k, times one shape.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DUNIMM_EXP=k tools/exp/exp_gemm.hip -o gpurun_out/exp_gemm_k
+// Stand-alone timing of one GEMM shape through the C ABI (not part of the product).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude tools/exp/exp_gemm.hip -o gpurun_out/exp_gemm
+// The ablation switches of rounds 1-2 (-DUNIMM_EXP=k: no staging, no epilogue, shared tiles, ... ; DESIGN.md 5 / 5b list
+// their results) lived inside csrc/gemm.hip up to commit 25f86ac and were removed from the product source in round 3.
+#define UNIMM_EXP 0
 #include "../../unimm_amd/csrc/gemm.hip"
 #include <cstdio>
 #include <cstdlib>
@@ -23,7 +26,7 @@ int main(int argc, char** argv) {
   a.x = x; a.w = w; a.bias = (const float*)bias; a.aux = aux; a.out = out; a.out2 = epi == UNIMM_EPI_BIAS_GELU_DG ? out2 : nullptr;
   a.M = M; a.N = N; a.K = K; a.ldx = K; a.ldw = K; a.ldaux = N; a.ldo = N; a.epilogue = epi; a.out_f32 = f32;
   a.drop_thr = 0; a.drop_scale = 1.f;
-  unimm_gemm_set_tile(cfg < 0 ? 0 : cfg);
+  a.tile = cfg < 0 ? 0 : cfg;
   if (cfg < 0) {   // TN: dw[N,K] += x1[M,N]^T x2[M,K]  (x reused as dy when N <= K, sizes are what matter)
     void *dy, *dw, *db;
     hipMalloc(&dy, (size_t)M * N * 2); hipMalloc(&dw, (size_t)N * K * 4); hipMalloc(&db, N * 4);

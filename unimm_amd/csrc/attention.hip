@@ -606,7 +606,7 @@ __global__ __launch_bounds__(MAXT, MAXT == 256 ? 1 : 2) void attn_bwd_dkv_kernel
 // Workgroups per (sequence, head).  Default: one workgroup (up to 8 waves) per item.  Two 4-wave
 // workgroups per item fit two to a CU and overlap each other's staging, but both stage the full K/V
 // (or Q/dO) images: measured 589 vs 545 us for the text fwd+bwd trio, so it stays a tuning knob.
-int g_attn_parts = 0;   // 0 = automatic (unimm_attn_set_parts)
+constexpr int g_attn_parts = 0;   // compile-time choice: 0 = one workgroup per item (2 = two 4-wave workgroups, 99 = no helper waves)
 // Threads per workgroup: one wave per 32-row tile that computes, but never fewer than the staging needs.
 // The co-attention direction with 37 region queries (or keys) has 2 compute waves and 2 x 64 KiB of text
 // K/V (or Q/dO) to stage; with 128 threads that is 32 dependent load->ds_write rounds per image.  Extra
@@ -735,10 +735,4 @@ extern "C" int unimm_attn_bwd(const unimm_attn_bwd_args* a, void* stream) {
   if (rc != UNIMM_OK) return rc;
   if (a->D == 64) return small_q ? launch_bwd_dkv<64, 2>(p, s) : launch_bwd_dkv<64, 8>(p, s);
   return small_q ? launch_bwd_dkv<128, 2>(p, s) : launch_bwd_dkv<128, 8>(p, s);
-}
-
-extern "C" int unimm_attn_set_parts(int32_t parts) {
-  if ((parts < 0 || parts > 2) && parts != 99) return UNIMM_E_ARG;
-  g_attn_parts = parts;
-  return UNIMM_OK;
 }

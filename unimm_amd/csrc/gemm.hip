@@ -49,7 +49,6 @@ __device__ __forceinline__ void tile_of(int lid, int nbm, int nbn, int gn, int& 
 // The ring is what hides HBM/L2 latency (~3-4k cycles under load): bytes staged per MFMA-cycle halve
 // with a 256x256 tile, so the same LDS covers twice the latency of the 128x128 tile.
 //   Cfg<2,2,4,64,2>: 128x128, 4 waves, 68 KiB LDS -> 2 workgroups per CU
-//   Cfg<2,4,8,32,4>: 256x256, 8 waves, BK=32, 4-slot ring (128 KiB): 3 K-steps in flight across barriers
 //   Cfg<2,4,8,64,2>: 256x256, 8 waves, BK=64, 2-slot ring (128 KiB)
 //   Cfg<2,4,6,64,2>: 192x256, 8 waves of 96x64, 2-slot ring (112 KiB): the tile for N = 768 at ~31k rows (489 tiles = 1.91
 //                     rounds of 256 CUs, where 256x256 gives 366 tiles = 1.43 rounds and 128x128 is staging-bound)
@@ -130,12 +129,9 @@ template <int N> __device__ __forceinline__ void lds_wait(bf16x8& a) { asm volat
 // [WPN W fragments of the next sub-step while j = v % MT is in [WP0, WP0 + 4/WPN)], all of which are
 // requested before the first X fragment of that sub-step.  pending(u) = reads requested after X(u)
 // by the time unit u waits for it.
-#ifndef UNIMM_READ_AFTER
-#define UNIMM_READ_AFTER 0     // 1: a unit requests its prefetches behind its MFMAs instead of in front of them
-#endif
 template <int MT, int KS> struct FragPipe {
   static constexpr int U = KS * MT;
-  static constexpr bool AFTER = UNIMM_READ_AFTER != 0;
+  static constexpr bool AFTER = false;   // true: a unit requests its prefetches behind its MFMAs instead of in front of them
   static constexpr int WP0 = MT >= 6 ? 2 : 0, WPN = MT >= 6 ? 1 : 2, WPU = 4 / WPN;   // first unit / frags per unit / units
   static constexpr int npref_w(int v) {
     return (v >= 0 && v / MT + 1 < KS && v % MT >= WP0 && v % MT < WP0 + WPU) ? WPN : 0;
@@ -170,15 +166,6 @@ template <int MT, int KS> struct FragPipe {
   static_assert(MT == 2 || MT == 4 || MT == 6 || MT == 8, "FragPipe: unit plans exist for 2, 4, 6 and 8 sub-tiles");
 };
 
-#ifndef UNIMM_TN_SPREAD
-#define UNIMM_TN_SPREAD 1
-#endif
-#ifndef UNIMM_NT_PERSIST_DEFAULT
-#define UNIMM_NT_PERSIST_DEFAULT 1
-#endif
-#ifndef UNIMM_EXP
-#define UNIMM_EXP 0   // bottleneck experiments of tools/exp_gemm.cpp; 0 in the product build
-#endif
 
 template <int BK> __device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int row, int chunk) {
   typedef __attribute__((address_space(3))) const bf16x8* lds_frag_ptr;
@@ -219,7 +206,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtParams& p, f32x4 (&acc)[
   constexpr bool AUX32 = EPI == UNIMM_EPI_BIAS_DROP_RESID;
   constexpr bool AUX16 = EPI == UNIMM_EPI_DGELU || EPI == UNIMM_EPI_ADD || EPI == UNIMM_EPI_MUL;
   constexpr int NIT = 2 * C::JP, NWALK = (MT / C::JP) * NIT;
-  constexpr int PF = (AUX32 || AUX16) ? (UNIMM_EXP == 21 ? 0 : (AUX32 && NIT % 2 == 0 ? NIT / 2 : NIT)) : 0;
+  constexpr int PF = (AUX32 || AUX16) ? (AUX32 && NIT % 2 == 0 ? NIT / 2 : NIT) : 0;
   constexpr int PFN = PF > 0 ? PF : 1;
   const bool pf_on = PF > 0 && p.aux != nullptr && ((p.ldaux * (AUX32 ? 4 : 2)) % 16 == 0);   // uniform
   const int pf_n = full_ ? n : 0;                     // lanes at the ragged N edge take the scalar path; their prefetch is ignored
@@ -284,7 +271,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtParams& p, f32x4 (&acc)[
   // lets the batched operand loads above work: with divergent load paths at every join the compiler's conservative
   // vmcnt(0)s also waited for the batch that had just been requested.
   const bool fastw = (n0 + wn * 64 + 64 <= p.N) && ((p.ldo * (OUT_F32 ? 4 : 2)) % 16 == 0) &&
-                     (!(AUX32 || AUX16) || (p.ldaux * (AUX32 ? 4 : 2)) % 16 == 0) && UNIMM_EXP != 22;
+                     (!(AUX32 || AUX16) || (p.ldaux * (AUX32 ? 4 : 2)) % 16 == 0);
   auto walk = [&](auto fast_tag) {
   constexpr bool FAST = decltype(fast_tag)::value;
   const bool ncols_ok = FAST ? true : ncols_ok_;
@@ -398,13 +385,9 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtParams& p, f32x4 (&acc)[
           for (int e = 0; e < 8; ++e) v[e] += a[e];
         } else {
           const bf16_t* ap = reinterpret_cast<const bf16_t*>(p.aux) + (size_t)m * p.ldaux + n;
-          if (UNIMM_EXP == 12 || UNIMM_EXP == 14) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) a[e] = 1.0f + (float)(lane & 1);
-          } else if (vec_aux) {
+          if (vec_aux) {
             const u32x4 raw = PF > 0 ? __builtin_bit_cast(u32x4, pfa0)
-                                     : (UNIMM_EXP == 18 ? *reinterpret_cast<const u32x4*>(ap)
-                                                        : __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ap)));
+                                     : __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ap));
 #pragma unroll
             for (int e = 0; e < 4; ++e) { a[2 * e] = __uint_as_float(raw[e] << 16); a[2 * e + 1] = __uint_as_float(raw[e] & 0xffff0000u); }
           } else {
@@ -454,12 +437,9 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtParams& p, f32x4 (&acc)[
         }
       } else {
         bf16_t* op = reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldo + n;
-        if (UNIMM_EXP == 13 || UNIMM_EXP == 14) {
-          if (v[0] + v[3] + v[5] == 12345.678f) op[0] = f2bf(v[1]);     // keeps the values live, never true
-        } else if (vec_out) {
+        if (vec_out) {
           const u32x4 pk = u32x4{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
-          if (UNIMM_EXP == 18) *reinterpret_cast<u32x4*>(op) = pk;
-          else __builtin_nontemporal_store(pk, reinterpret_cast<u32x4*>(op));
+          __builtin_nontemporal_store(pk, reinterpret_cast<u32x4*>(op));
         } else
           for (int e = 0; e < 8; ++e) if (n + e < p.N) op[e] = f2bf(v[e]);
       }
@@ -694,11 +674,7 @@ __device__ __forceinline__ void nt_tile(const GemmNtParams& p, char* smem, int l
   // prologue: fill S-1 ring slots
 #pragma unroll
   for (int s = 0; s < S - 1; ++s)
-#if UNIMM_EXP == 7                           // (experiment 7: every block stages the SAME tiles -> all L2 hits)
-    if (s < nk) stage_step<C>(p, 0, 0, s * BK, smem + s * C::STAGE_BYTES, wave, lane);
-#else
     if (s < nk) stage_step<C>(p, n0, m0, s * BK, smem + s * C::STAGE_BYTES, wave, lane);
-#endif
 
   for (int t = 0; t < nk; ++t) {
     // K-step t has landed once at most min(S-2, nk-1-t) younger steps are still in flight
@@ -708,34 +684,10 @@ __device__ __forceinline__ void nt_tile(const GemmNtParams& p, char* smem, int l
     else { if (rem >= 2) wait_vmcnt<2 * G>(); else if (rem == 1) wait_vmcnt<G>(); else wait_vmcnt<0>(); }
     __builtin_amdgcn_s_barrier();            // every wave's loads of step t landed; step t-1 fully read
     __builtin_amdgcn_sched_barrier(0);
-#if UNIMM_EXP != 3                           // (experiment 3: no global->LDS staging inside the loop)
     if (t + S - 1 < nk)                      // refill the slot step t-1 used
-#if UNIMM_EXP == 7
-      stage_step<C>(p, 0, 0, (t + S - 1) * BK, smem + ((t + S - 1) % S) * C::STAGE_BYTES, wave, lane);
-#elif UNIMM_EXP == 5
-      stage_step<C>(p, n0, m0, (t + S - 1) * BK, smem + ((t + S - 1) % S) * C::STAGE_BYTES, wave, lane);
-#else
       if constexpr (!SPREAD) stage_step<C>(p, n0, m0, (t + S - 1) * BK, smem + ((t + S - 1) % S) * C::STAGE_BYTES, wave, lane);
-#endif
-#endif
     const char* tw = smem + (t % S) * C::STAGE_BYTES;
     const char* tx = tw + BN * C::ROWB;
-#if UNIMM_EXP == 5                           // (experiment 5: the previous, compiler-scheduled fragment loop)
-#pragma unroll
-    for (int ks = 0; ks < BK / 32; ++ks) {
-      bf16x8 fw[4], fx[MT];
-      const int chunk = ks * 4 + (lane >> 4);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) fw[i] = read_frag<BK>(tw, wn * 64 + i * 16 + (lane & 15), chunk);
-#pragma unroll
-      for (int j = 0; j < MT; ++j) fx[j] = read_frag<BK>(tx, wm * 16 * MT + j * 16 + (lane & 15), chunk);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < MT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fx[j], acc[i][j], 0, 0, 0);
-    }
-#else
     // Software-pipelined fragment stream.  Left alone, the compiler reads all 12 fragments of a 32-deep
     // sub-step, waits lgkmcnt(0), and only then issues its 32 MFMAs; the 8 waves of the block run in
     // lock-step behind the barrier, so the matrix pipes idle while 96 KiB of fragments cross the LDS
@@ -778,7 +730,7 @@ __device__ __forceinline__ void nt_tile(const GemmNtParams& p, char* smem, int l
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                        \
           acc[i][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ks_ & 1][i], fx[(u) % 3], acc[i][j_], 0, 0, 0); \
         if constexpr (FragPipe<MT, KS>::AFTER) { UNIMM_PREFETCH(u) }                                         \
-        if constexpr (SPREAD && UNIMM_EXP != 7 && UNIMM_EXP != 3 && (u) < G) {   /* refill, one LDS-DMA per unit */ \
+        if constexpr (SPREAD && (u) < G) {                                         /* refill, one LDS-DMA per unit */ \
           if (t + 1 < nk) stage_one<C>(p, n0, m0, (t + 1) * BK, smem + ((t + 1) & 1) * C::STAGE_BYTES, wave, lane, u); \
         }                                                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
@@ -788,19 +740,7 @@ __device__ __forceinline__ void nt_tile(const GemmNtParams& p, char* smem, int l
 #undef UNIMM_UNIT
 #undef UNIMM_PREFETCH
     }
-#endif
   }
-#if UNIMM_EXP == 4                           // (experiment 4: no epilogue; one guarded store keeps acc live)
-  {
-    float sacc = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < MT; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-    if (sacc == 12345.678f) reinterpret_cast<float*>(p.out)[0] = sacc;
-    return;
-  }
-#endif
 
   nt_epilogue<C, EPI, OUT_F32>(p, acc, smem, m0, n0, wm, wn, wave, lane);
 }
@@ -822,122 +762,6 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES) void gemm_ntp_kernel(Gemm
     if (lt != (int)blockIdx.x) __builtin_amdgcn_s_barrier();   // every wave has left its epilogue slab (it aliases the ring)
     nt_tile<C, EPI, OUT_F32>(p, smem, xcd_remap(lt, ntiles));
   }
-}
-
-// ------------------------------------------------------------------------------------------------
-// gemm_nt2: the same tiles behind a deeper ring.  With a 2-slot ring one K-step (64 KiB per CU) is in
-// flight while the previous one is computed, and a load needs ~1.5 us under load against ~1.1 us of
-// MFMA per step: every step stalls (measured: the staging costs 40 us of a 167 us GEMM even when every
-// block reads the SAME tiles, i.e. with perfect L2 hits; without it the loop runs at 1.16 PFLOP/s).
-// Here the ring has S = 5 slots of BK = 32, the barrier at the top of step t certifies stage t+1 (not t),
-// and three stages (96 KiB per CU) stay in flight across it.  Because stage t+1 is already readable
-// during step t, the fragment pipeline never drains at a step boundary: the last two units of step t
-// request the first X fragments of step t+1 and units 0..3 its W fragments (second register buffer).
-// ------------------------------------------------------------------------------------------------
-template <int MT, bool LAST> struct FragPipe2 {
-  static constexpr int WPN = MT == 8 ? 1 : 2, WPU = 4 / WPN;          // W fragments per unit, units that fetch them
-  static constexpr int nwp(int u) { return (!LAST && ((u % MT + MT) % MT) < WPU) ? WPN : 0; }
-  // reads requested after X(u) by the time unit u waits for it
-  static constexpr int pending(int u) {
-    if (LAST) return (u + 1 < MT ? 1 : 0) + (u + 2 < MT ? 1 : 0);
-    return nwp(u - 2) + nwp(u - 1) + nwp(u) + 2;
-  }
-};
-
-template <int G, int S> __device__ __forceinline__ void wait_stages(int n) {
-  static_assert(S == 5, "wait_stages: written for a 5-slot ring");
-  if (n >= 2) wait_vmcnt<2 * G>(); else if (n == 1) wait_vmcnt<G>(); else wait_vmcnt<0>();
-}
-
-template <class C, int EPI, bool OUT_F32>
-__global__ __launch_bounds__(C::THREADS, C::MIN_WAVES) void gemm_nt2_kernel(GemmNtParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int BM = C::BM, BN = C::BN, BK = C::BK, S = C::STAGES, G = C::G, MT = C::MT, RB = C::ROWB;
-  static_assert(BK == 32, "gemm_nt2: one 32-deep sub-step per ring slot");
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
-  const int lid = xcd_remap(blockIdx.x, gridDim.x);
-  int tm, tn;
-  tile_of(lid, nbm, nbn, p.gn, tm, tn);
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int wm = wave / C::WN, wn = wave % C::WN;
-
-  f32x4 acc[4][MT];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  uint32_t aw0, ax0;   // this lane's fragment addresses in ring slot 0
-  {
-    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)LDS_PTR(smem);
-    const int rw = wn * 64 + (lane & 15), rx = wm * 16 * MT + (lane & 15), cq = lane >> 4;
-    aw0 = lds0 + rw * RB + ((cq ^ kswz<BK>(rw)) << 4);
-    ax0 = lds0 + (BN + rx) * RB + ((cq ^ kswz<BK>(rx)) << 4);
-  }
-  const int nk = p.K / BK;   // even (K % 64 == 0)
-#pragma unroll
-  for (int s = 0; s < S - 1; ++s)
-    if (s < nk) stage_step<C>(p, n0, m0, s * BK, smem + s * C::STAGE_BYTES, wave, lane);
-
-  // top of step t: stage t+1 has landed everywhere, step t-1 is fully read; refill the slot it used
-#define UNIMM_TOP(t_)                                                                                        \
-  {                                                                                                          \
-    const int issued_ = ((t_) + S - 2 < nk - 1) ? (t_) + S - 2 : nk - 1;                                     \
-    wait_stages<G, S>(issued_ - ((t_) + 1));                                                                 \
-    __builtin_amdgcn_s_barrier();                                                                            \
-    __builtin_amdgcn_sched_barrier(0);                                                                       \
-    if (UNIMM_EXP != 3 && (t_) + S - 1 < nk)                                                                 \
-      stage_step<C>(p, n0, m0, ((t_) + S - 1) * BK, smem + (((t_) + S - 1) % S) * C::STAGE_BYTES, wave, lane); \
-  }
-
-  bf16x8 fw[2][4], fx[4];
-#define UNIMM_UNIT2(P, LAST, u)                                                                              \
-  {                                                                                                          \
-    if constexpr ((u) + 2 < MT) fx[((u) + 2) % 4] = lds_read_b128<((u) + 2) * 16 * RB>(axc);                 \
-    else if constexpr (!(LAST)) fx[((u) + 2) % 4] = lds_read_b128<((u) + 2 - MT) * 16 * RB>(axn);            \
-    if constexpr (FragPipe2<MT, LAST>::nwp(u) > 0) {                                                         \
-      constexpr int w_ = (u) * FragPipe2<MT, LAST>::WPN;                                                     \
-      fw[(P) ^ 1][w_] = lds_read_b128<w_ * 16 * RB>(awn);                                                    \
-      if constexpr (FragPipe2<MT, LAST>::WPN == 2) fw[(P) ^ 1][w_ + 1] = lds_read_b128<(w_ + 1) * 16 * RB>(awn); \
-    }                                                                                                        \
-    lds_wait<FragPipe2<MT, LAST>::pending(u)>(fx[(u) % 4]);                                                  \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                            \
-      acc[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[P][i], fx[(u) % 4], acc[i][u], 0, 0, 0);        \
-    __builtin_amdgcn_sched_barrier(0);                                                                       \
-  }
-#define UNIMM_UNITS(P, LAST, t_)                                                                             \
-  {                                                                                                          \
-    const uint32_t axc = ax0 + (uint32_t)(((t_) % S) * C::STAGE_BYTES);                                      \
-    const uint32_t son_ = (uint32_t)((((t_) + 1) % S) * C::STAGE_BYTES);                                     \
-    const uint32_t axn = ax0 + son_, awn = aw0 + son_;                                                       \
-    (void)axn; (void)awn;                                                                                    \
-    UNIMM_UNIT2(P, LAST, 0) UNIMM_UNIT2(P, LAST, 1) UNIMM_UNIT2(P, LAST, 2) UNIMM_UNIT2(P, LAST, 3)          \
-    if constexpr (MT == 8) {                                                                                 \
-      UNIMM_UNIT2(P, LAST, 4) UNIMM_UNIT2(P, LAST, 5) UNIMM_UNIT2(P, LAST, 6) UNIMM_UNIT2(P, LAST, 7)        \
-    }                                                                                                        \
-  }
-
-  UNIMM_TOP(0)
-  fw[0][0] = lds_read_b128<0 * 16 * RB>(aw0);
-  fw[0][1] = lds_read_b128<1 * 16 * RB>(aw0);
-  fw[0][2] = lds_read_b128<2 * 16 * RB>(aw0);
-  fw[0][3] = lds_read_b128<3 * 16 * RB>(aw0);
-  fx[0] = lds_read_b128<0>(ax0);
-  fx[1] = lds_read_b128<16 * RB>(ax0);
-  int t = 0;
-  for (; t + 2 < nk; t += 2) {
-    UNIMM_UNITS(0, false, t)
-    UNIMM_TOP(t + 1)
-    UNIMM_UNITS(1, false, t + 1)
-    UNIMM_TOP(t + 2)
-  }
-  UNIMM_UNITS(0, false, t)
-  UNIMM_UNITS(1, true, t + 1)          // stage nk-1 was certified by the top of step nk-2
-#undef UNIMM_UNITS
-#undef UNIMM_UNIT2
-#undef UNIMM_TOP
-  nt_epilogue<C, EPI, OUT_F32>(p, acc, smem, m0, n0, wm, wn, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1096,9 +920,9 @@ __global__ __launch_bounds__(64 * WN * WK, (WN * WK * (NT == 4 ? 2 : 1) + 3) / 4
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();          // step t landed everywhere; step t-1 fully read
     __builtin_amdgcn_sched_barrier(0);
-    constexpr bool SPREAD = NW == 8 && UNIMM_TN_SPREAD;   // 8-wave tile: refill spread behind the units (as gemm_nt)
+    constexpr bool SPREAD = NW == 8;   // 8-wave tile: refill spread behind the units (as gemm_nt)
     constexpr int PER_WAVE = (NSUB_A + NSUB_B) * 16 / NW;
-    if (!SPREAD && UNIMM_EXP != 10 && t + 1 < nsteps)   // (experiment 10: no staging inside the loop)
+    if (!SPREAD && t + 1 < nsteps)
       stage_step_tn<NW, NSUB_A, NSUB_B>(p, mt + TK, mend, n0, k0, smem + (cur ^ 1) * STAGE_BYTES, wave, lane);
     const char* ta = smem + cur * STAGE_BYTES;
     const char* tb = ta + NSUB_A * TN_TILE_BYTES;
@@ -1142,8 +966,8 @@ __global__ __launch_bounds__(64 * WN * WK, (WN * WK * (NT == 4 ? 2 : 1) + 3) / 4
         lds_wait<2 * FragPipe<NT, 2>::pending(u)>(fa[(u) % 3]);                                              \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
           acc[i_][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[(u) % 3], fb[ks_][j], acc[i_][j], 0, 0, 0); \
-        if constexpr (UNIMM_EXP != 9 && (WITH_BIAS)) accb[i_] = dot_ones(fa[(u) % 3], accb[i_]);             \
-        if constexpr (SPREAD && UNIMM_EXP != 10 && (u) < PER_WAVE) {                                         \
+        if constexpr (WITH_BIAS)                  accb[i_] = dot_ones(fa[(u) % 3], accb[i_]);             \
+        if constexpr (SPREAD && (u) < PER_WAVE) {                                                             \
           if (t + 1 < nsteps)                                                                                \
             stage_one_tn<NW, NSUB_A, NSUB_B>(p, mt + TK, mend, n0, k0, smem + (cur ^ 1) * STAGE_BYTES, wave, lane, u); \
         }                                                                                                    \
@@ -1174,24 +998,13 @@ __global__ __launch_bounds__(64 * WN * WK, (WN * WK * (NT == 4 ? 2 : 1) + 3) / 4
     }
   }
 
-#if UNIMM_EXP == 6                           // (experiment 6: no atomic epilogue; one guarded store keeps acc live)
-  {
-    float sacc = 0.f;
-#pragma unroll
-    for (int i = 0; i < NT; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-    if (sacc == 12345.678f) p.dw[0] = sacc;
-    return;
-  }
-#endif
   // ---- partial tile -> gradient.  Without a workspace every split adds its fp32 partial with memory-side atomics:
   // one 256 KiB tile per resident workgroup at the END of every round, 67 MB at ~1.3 TB/s = ~43 us in which the chip
   // only drains (and 8x the algorithmic write traffic: 222 MB per text-block launch against 28 MB of gradients).
   // With a workspace the splits of a tile meet at a counter instead: each stores its partial to its own SLAB with plain,
   // fully coalesced 16-byte stores (register order: the reducer has the same layout), and whoever arrives LAST reads
   // the other slabs on top of the partial it still holds in registers and adds the sum into the gradient exactly once
-  // (plain read-modify-write: nobody else touches these elements in this launch).  Placement-independent hand-off (guide,
+  // (one fp32 atomic per element: a tied or concurrently accumulated dw stays safe).  Placement-independent hand-off (guide,
   // "in-launch split-K reduction"): slab stores -> every wave's vmcnt(0) -> workgroup barrier -> lane 0: agent-scope
   // release, vmcnt(0), relaxed agent-scope ticket; the last arriver: agent-scope acquire, vmcnt(0), barrier, plain loads.
   if (grp.slabs != nullptr && p.nsplit > 1) {
@@ -1238,7 +1051,7 @@ __global__ __launch_bounds__(64 * WN * WK, (WN * WK * (NT == 4 ? 2 : 1) + 3) / 4
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int k = k0 + wk * 64 + j * 16 + (lane & 15);
-          if (k < p.K) p.dw[(size_t)n * p.lddw + k] += acc[i][j][e];
+          if (k < p.K) atomicAdd(p.dw + (size_t)n * p.lddw + k, acc[i][j][e]);   // dw may alias another problem's / stream's
         }
       }
     }
@@ -1287,16 +1100,19 @@ inline ProfRec* prof_begin(int variant, double flops, hipStream_t s) {
 }
 inline void prof_end(ProfRec* r, hipStream_t s) { if (r) hipEventRecord(r->b, s); }
 
-bool g_tn_shared = false;   // unimm_gemm_tn_set_shared
-int g_nt_gn = 0;    // 0 = automatic
-int g_nt_cfg = 0;   // 0 = auto, 1 = 128x128 BK64 x2, 2 = 256x256 BK32 x4, 3 = 256x256 BK64 x2  (unimm_gemm_set_tile)
-
-template <class C, int EPI, bool F32> constexpr auto pick_nt_kernel() {
-  if constexpr (C::STAGES == 5) return &gemm_nt2_kernel<C, EPI, F32>;   // deep-ring kernel
-  else return &gemm_nt_kernel<C, EPI, F32>;
+// Per-call tuning of unimm_gemm_nt (unimm_gemm_nt_args.tile = gn * 1000 + p * 100 + cfg; 0 = everything automatic).
+struct NtTune { int cfg, persist, gn; };
+inline bool nt_tune_decode(int code, NtTune& t) {
+  if (code < 0 || code > 999 * 1000 + 999) return false;
+  const int pc = (code % 1000) / 100;
+  t.persist = pc == 0 ? -1 : (pc == 1 ? 1 : 0);           // x1xx persistent, x2xx one workgroup per tile, else automatic
+  t.cfg = code % 100;
+  t.gn = code / 1000;
+  return pc <= 2 && (t.cfg == 0 || t.cfg == 1 || t.cfg == 3 || t.cfg == 6 || t.cfg == 7 || t.cfg == 8);
 }
 
-int g_nt_persist = -1;   // -1 automatic, 0 one workgroup per tile, 1 persistent workgroups (unimm_gemm_set_tile)
+template <class C, int EPI, bool F32> constexpr auto pick_nt_kernel() { return &gemm_nt_kernel<C, EPI, F32>; }
+
 inline int cu_count() {
   static int n = 0;
   if (n == 0) {
@@ -1304,12 +1120,13 @@ inline int cu_count() {
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
     if (n <= 0) n = 256;
+    if (n < 8) n = 8;     // the slot arithmetic below works in multiples of the 8 XCDs
   }
   return n;
 }
 
 template <class C, int EPI>
-int launch_nt_cfg(const GemmNtParams& p, bool out_f32, hipStream_t s) {
+int launch_nt_cfg(const GemmNtParams& p, bool out_f32, int want_persist, hipStream_t s) {
   const int nwg = ((p.M + C::BM - 1) / C::BM) * ((p.N + C::BN - 1) / C::BN);
   auto k32 = pick_nt_kernel<C, EPI, true>();
   auto k16 = pick_nt_kernel<C, EPI, false>();
@@ -1323,9 +1140,9 @@ int launch_nt_cfg(const GemmNtParams& p, bool out_f32, hipStream_t s) {
     }
   }
   bool persist = false;
-  if constexpr (C::STAGES != 5) {
+  {
     const int slots = (cu_count() & ~7) * C::WG_PER_CU;
-    persist = (g_nt_persist < 0 ? UNIMM_NT_PERSIST_DEFAULT != 0 : g_nt_persist != 0) && nwg > slots && slots > 0;
+    persist = want_persist != 0 && nwg > slots && slots > 0;
     if (persist) {
       auto p32 = gemm_ntp_kernel<C, EPI, true>;
       auto p16 = gemm_ntp_kernel<C, EPI, false>;
@@ -1355,8 +1172,9 @@ int launch_nt_cfg(const GemmNtParams& p, bool out_f32, hipStream_t s) {
 }
 
 template <int EPI>
-int launch_nt(const GemmNtParams& p, bool out_f32, hipStream_t s) {
-  int cfg = g_nt_cfg;
+int launch_nt(const GemmNtParams& p, bool out_f32, const NtTune& tune, hipStream_t s) {
+  int cfg = tune.cfg;
+  const int wp = tune.persist;
   if (cfg == 0) {
     // Tile choice = the configuration with the smallest modelled time: rounds of `slots` workgroups, a round of a tile
     // with W workgroups per CU costs area x W / eff, the last (partial) round only the workgroups per CU it really
@@ -1367,15 +1185,12 @@ int launch_nt(const GemmNtParams& p, bool out_f32, hipStream_t s) {
     // give every CU 1.5 workgroups of 128x128 take the 64x128 tile (three workgroups per CU: per-GPU batches of 30).
     const int cus = cu_count() & ~7;
     const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-    if (UNIMM_EXP == 19) {                                  // (the round-1 rule, for A/B builds)
-      const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
-      cfg = (t256 >= 384) ? 3 : (t128 < 256 ? 7 : 1);
-    } else if (t128 < 384) {
+    if (t128 < 384) {
       cfg = 7;
     } else {
       struct Cand { int cfg, bm, bn, w; double eff; };
-      // 256x256 = the ping-pong loop (configuration 8; 3 = the lock-step ring, kept for A/B builds with UNIMM_EXP == 20)
-      const Cand cand[3] = {{UNIMM_EXP == 20 ? 3 : 8, 256, 256, 1, 1.0}, {6, 192, 256, 1, 0.95}, {1, 128, 128, 2, 0.85}};
+      // 256x256 = the ping-pong loop (configuration 8; 3 = the lock-step ring, reachable through unimm_gemm_set_tile for A/B runs)
+      const Cand cand[3] = {{8, 256, 256, 1, 1.0}, {6, 192, 256, 1, 0.95}, {1, 128, 128, 2, 0.85}};
       double best = 1e30;
       for (const Cand& c : cand) {
         const long tiles = (long)((p.M + c.bm - 1) / c.bm) * ((p.N + c.bn - 1) / c.bn);
@@ -1387,14 +1202,16 @@ int launch_nt(const GemmNtParams& p, bool out_f32, hipStream_t s) {
       }
     }
   }
-  if (cfg == 8) return launch_nt_cfg<Cfg<2, 4, 8, 64, 2, 1>, EPI>(p, out_f32, s);
-  // (configurations 2, 4, 5 - the BK = 32 rings of 4 and 5 slots, measured slower in round 1 - are no longer instantiated:
-  //  a third of this file's compile time; their loops stay in the source, DESIGN.md 5 has the numbers)
-  if (cfg == 2 || cfg == 4 || cfg == 5) return UNIMM_E_ARG;
-  if (cfg == 6) return launch_nt_cfg<Cfg<2, 4, 6, 64, 2>, EPI>(p, out_f32, s);
-  if (cfg == 7) return launch_nt_cfg<Cfg<2, 2, 2, 64, 2>, EPI>(p, out_f32, s);
-  if (cfg == 3) return launch_nt_cfg<Cfg<2, 4, 8, 64, 2>, EPI>(p, out_f32, s);
-  return launch_nt_cfg<Cfg<2, 2, 4, 64, 2>, EPI>(p, out_f32, s);
+  // The ping-pong loop addresses its LDS-DMA sources with a 32-bit byte offset per lane on the un-offset operand base
+  // (pp_stage_init): past 4 GiB of operand rows that offset would wrap, so such problems take the lock-step ring (size_t math).
+  if (cfg == 8 && ((size_t)p.M * (size_t)p.ldx * 2 >= ((size_t)1 << 32) || (size_t)p.N * (size_t)p.ldw * 2 >= ((size_t)1 << 32))) cfg = 3;
+  if (cfg == 8) return launch_nt_cfg<Cfg<2, 4, 8, 64, 2, 1>, EPI>(p, out_f32, wp, s);
+  // (configurations 2, 4, 5 - the BK = 32 rings of 4 and 5 slots, measured slower in round 1 - are not instantiated:
+  //  a third of this file's compile time; unimm_gemm_nt rejects them, DESIGN.md 5 has the numbers)
+  if (cfg == 6) return launch_nt_cfg<Cfg<2, 4, 6, 64, 2>, EPI>(p, out_f32, wp, s);
+  if (cfg == 7) return launch_nt_cfg<Cfg<2, 2, 2, 64, 2>, EPI>(p, out_f32, wp, s);
+  if (cfg == 3) return launch_nt_cfg<Cfg<2, 4, 8, 64, 2>, EPI>(p, out_f32, wp, s);
+  return launch_nt_cfg<Cfg<2, 2, 4, 64, 2>, EPI>(p, out_f32, wp, s);
 }
 
 }  // namespace
@@ -1417,30 +1234,22 @@ extern "C" int unimm_gemm_nt(const unimm_gemm_nt_args* a, void* stream) {
   const int n_ln = (a->aux_mean != nullptr) + (a->aux_rstd != nullptr) + (a->aux_gamma != nullptr) + (a->aux_beta != nullptr);
   if (n_ln != 0 && (n_ln != 4 || a->epilogue != UNIMM_EPI_BIAS_DROP_RESID)) return UNIMM_E_ARG;
   p.aux_mean = a->aux_mean; p.aux_rstd = a->aux_rstd; p.aux_gamma = a->aux_gamma; p.aux_beta = a->aux_beta;
-  p.gn = g_nt_gn > 0 ? g_nt_gn : 4;   // 4 tile columns per group: +1 % at 240 sequences, +5-8 % at 30 over 6 (A/B, two-stream schedule)
+  NtTune tune;
+  if (!nt_tune_decode(a->tile, tune)) return UNIMM_E_ARG;
+  p.gn = tune.gn > 0 ? tune.gn : 4;   // 4 tile columns per group: +1 % at 240 sequences, +5-8 % at 30 over 6 (A/B, two-stream schedule)
   hipStream_t s = (hipStream_t)stream;
   const bool f32 = a->out_f32 != 0;
   switch (a->epilogue) {
-    case UNIMM_EPI_BIAS: return launch_nt<UNIMM_EPI_BIAS>(p, f32, s);
-    case UNIMM_EPI_BIAS_GELU: return launch_nt<UNIMM_EPI_BIAS_GELU>(p, f32, s);
-    case UNIMM_EPI_BIAS_DROP_RESID: return launch_nt<UNIMM_EPI_BIAS_DROP_RESID>(p, f32, s);
-    case UNIMM_EPI_BIAS_RELU: return launch_nt<UNIMM_EPI_BIAS_RELU>(p, f32, s);
-    case UNIMM_EPI_DGELU: return launch_nt<UNIMM_EPI_DGELU>(p, f32, s);
-    case UNIMM_EPI_ADD: return launch_nt<UNIMM_EPI_ADD>(p, f32, s);
-    case UNIMM_EPI_MUL: return launch_nt<UNIMM_EPI_MUL>(p, f32, s);
-    case UNIMM_EPI_BIAS_GELU_DG: return launch_nt<UNIMM_EPI_BIAS_GELU_DG>(p, f32, s);
+    case UNIMM_EPI_BIAS: return launch_nt<UNIMM_EPI_BIAS>(p, f32, tune, s);
+    case UNIMM_EPI_BIAS_GELU: return launch_nt<UNIMM_EPI_BIAS_GELU>(p, f32, tune, s);
+    case UNIMM_EPI_BIAS_DROP_RESID: return launch_nt<UNIMM_EPI_BIAS_DROP_RESID>(p, f32, tune, s);
+    case UNIMM_EPI_BIAS_RELU: return launch_nt<UNIMM_EPI_BIAS_RELU>(p, f32, tune, s);
+    case UNIMM_EPI_DGELU: return launch_nt<UNIMM_EPI_DGELU>(p, f32, tune, s);
+    case UNIMM_EPI_ADD: return launch_nt<UNIMM_EPI_ADD>(p, f32, tune, s);
+    case UNIMM_EPI_MUL: return launch_nt<UNIMM_EPI_MUL>(p, f32, tune, s);
+    case UNIMM_EPI_BIAS_GELU_DG: return launch_nt<UNIMM_EPI_BIAS_GELU_DG>(p, f32, tune, s);
     default: return UNIMM_E_ARG;
   }
-}
-
-extern "C" int unimm_gemm_set_tile(int32_t cfg) {
-  if (cfg < 0 || cfg > 999 * 1000 + 999) return UNIMM_E_ARG;
-  g_nt_persist = (cfg % 1000) / 100 == 0 ? -1 : ((cfg % 1000) / 100 == 1 ? 1 : 0);   // x1xx persistent, x2xx not, else auto
-  cfg = cfg - ((cfg % 1000) / 100) * 100;
-  g_nt_cfg = cfg % 1000;          // tile configuration
-  g_nt_gn = cfg / 1000;           // tuning: n-tiles per column group (0 = default)
-  if (g_nt_cfg > 8) return UNIMM_E_ARG;
-  return UNIMM_OK;
 }
 
 namespace {
@@ -1483,7 +1292,7 @@ int launch_tn_group(const unimm_gemm_tn_args* const* a, int count, bool big, boo
   double best = 1e30;
   // cost of a split count: rounds x (steps of one workgroup + its fixed cost: pipeline fill and partial-tile
   // drain, ~8 steps' worth; 40 when the caller says the launch shares the chip with another stream's kernels
-  // (unimm_gemm_tn_set_shared): an under-filled round is then not idle time, so fewer, longer workgroups and fewer
+  // (the shared_chip argument of unimm_gemm_tn_grouped_ws): an under-filled round is then not idle time, so fewer, longer workgroups and fewer
   // partial tiles win: 51.5 -> 50.9 ms per step at 240 sequences, neutral at 30-120; alone on the chip it costs 10 %); the fixed term only matters for short reductions (per-GPU batches of 30-60
   // sequences under strong scaling), where three rounds of 17-step workgroups lose to one round of 61
   const double steps = (double)max_m / TK;
@@ -1562,17 +1371,12 @@ extern "C" int unimm_gemm_tn_grouped_ws(const unimm_gemm_tn_args* a, int32_t cou
 }
 
 extern "C" int unimm_gemm_tn_grouped(const unimm_gemm_tn_args* a, int32_t count, void* stream) {
-  return unimm_gemm_tn_grouped_ws(a, count, g_tn_shared ? 1 : 0, nullptr, 0, stream);
+  return unimm_gemm_tn_grouped_ws(a, count, 0, nullptr, 0, stream);
 }
 
 extern "C" int unimm_gemm_tn(const unimm_gemm_tn_args* a, void* stream) {
   if (a == nullptr) return UNIMM_E_ARG;
   return unimm_gemm_tn_grouped(a, 1, stream);
-}
-
-extern "C" int unimm_gemm_tn_set_shared(int32_t on) {
-  g_tn_shared = on != 0;
-  return UNIMM_OK;
 }
 
 extern "C" int unimm_prof_enable(int32_t on) {

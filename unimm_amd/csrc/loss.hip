@@ -193,7 +193,8 @@ __global__ __launch_bounds__(256) void nsp_loss_fwd_kernel(const float* __restri
 
 __global__ __launch_bounds__(256) void nsp_loss_bwd_kernel(const float* __restrict__ logits, const int32_t* __restrict__ labels,
                                                            float w0, float w1, const float* __restrict__ g,
-                                                           bf16_t* __restrict__ dlogits, int B, int ld, int ldd) {
+                                                           const float* __restrict__ extra, float* __restrict__ dlogits,
+                                                           int B, int ld, int ldd) {
   __shared__ float red[4];
   float den = 0.f;
   for (int i = threadIdx.x; i < B; i += 256) den += labels[i] == 0 ? w0 : w1;
@@ -206,10 +207,10 @@ __global__ __launch_bounds__(256) void nsp_loss_bwd_kernel(const float* __restri
     const float inv = 1.0f / (ea + eb);
     const int y = labels[i];
     const float w = (y == 0 ? w0 : w1) * gs;
-    bf16_t* d = dlogits + (size_t)i * ldd;
-    d[0] = f2bf(w * (ea * inv - (y == 0 ? 1.f : 0.f)));
-    d[1] = f2bf(w * (eb * inv - (y == 1 ? 1.f : 0.f)));
-    for (int c = 2; c < ldd; ++c) d[c] = 0;
+    float* d = dlogits + (size_t)i * ldd;
+    d[0] = w * (ea * inv - (y == 0 ? 1.f : 0.f)) + (extra != nullptr ? extra[2 * i] : 0.f);
+    d[1] = w * (eb * inv - (y == 1 ? 1.f : 0.f)) + (extra != nullptr ? extra[2 * i + 1] : 0.f);
+    for (int c = 2; c < ldd; ++c) d[c] = 0.f;
   }
 }
 
@@ -283,10 +284,10 @@ extern "C" int unimm_nsp_loss_fwd(const float* logits, const int32_t* labels, fl
 }
 
 extern "C" int unimm_nsp_loss_bwd(const float* logits, const int32_t* labels, float w0, float w1, const float* g,
-                                  void* dlogits, int32_t B, int32_t ld, int32_t ldd, void* stream) {
+                                  const float* extra, float* dlogits, int32_t B, int32_t ld, int32_t ldd, void* stream) {
   if (!logits || !labels || !g || !dlogits || B <= 0 || ld < 2 || ldd < 2) return UNIMM_E_ARG;
   hipLaunchKernelGGL(nsp_loss_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, labels, w0, w1, g,
-                     (bf16_t*)dlogits, B, ld, ldd);
+                     extra, dlogits, B, ld, ldd);
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;
 }

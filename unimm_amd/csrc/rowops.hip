@@ -790,28 +790,28 @@ __global__ void pack_image_kernel(const float* __restrict__ feat, const float* _
   }
 }
 
-// out = dropout(a * b)  bf16 [n]   (pooled_t * pooled_v, models/vilbert_dialog.py:1065)
-__global__ void mul_dropout_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, bf16_t* __restrict__ out,
+// out = dropout(a * b)  fp32 [n]   (pooled_t * pooled_v, models/vilbert_dialog.py:1065)
+__global__ void mul_dropout_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
                                    size_t n, DropoutArg drop) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  float v = bf2f(a[i]) * bf2f(b[i]);
+  float v = a[i] * b[i];
   if (drop.thr != 0u) v = drop_apply(drop, 0u, (uint32_t)n, (uint32_t)i, v);
-  out[i] = f2bf(v);
+  out[i] = v;
 }
 
 // backward of the above given dfused: da = drop(dfused) * b, db = drop(dfused) * a
-__global__ void mul_dropout_bwd_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
-                                       const bf16_t* __restrict__ dout, bf16_t* __restrict__ da, bf16_t* __restrict__ db,
+__global__ void mul_dropout_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                       const float* __restrict__ dout, float* __restrict__ da, float* __restrict__ db,
                                        size_t n, DropoutArg drop) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  float d = bf2f(dout[i]);
+  float d = dout[i];
   if (drop.thr != 0u) d = drop_apply(drop, 0u, (uint32_t)n, (uint32_t)i, d);
   // ReLU of the poolers (:951,:966) is folded in: a, b are post-ReLU, gradient is zero where they are
-  const float av = bf2f(a[i]), bv = bf2f(b[i]);
-  da[i] = f2bf(av > 0.f ? d * bv : 0.f);
-  db[i] = f2bf(bv > 0.f ? d * av : 0.f);
+  const float av = a[i], bv = b[i];
+  da[i] = av > 0.f ? d * bv : 0.f;
+  db[i] = bv > 0.f ? d * av : 0.f;
 }
 
 // du = dt * GELU'(u)  (backward of the erf-GELU that sits between a dense and a LayerNorm in the two
@@ -1057,20 +1057,20 @@ extern "C" int unimm_pack_image(const float* feat, const float* loc, void* out, 
   return UNIMM_OK;
 }
 
-extern "C" int unimm_mul_dropout(const void* a, const void* b, void* out, int64_t n, uint32_t drop_key, uint32_t drop_thr,
+extern "C" int unimm_mul_dropout(const float* a, const float* b, float* out, int64_t n, uint32_t drop_key, uint32_t drop_thr,
                                  float drop_scale, void* stream) {
   if (!a || !b || !out || n <= 0) return UNIMM_E_ARG;
   hipLaunchKernelGGL(mul_dropout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, (size_t)n, mk_drop(drop_key, drop_thr, drop_scale));
+                     a, b, out, (size_t)n, mk_drop(drop_key, drop_thr, drop_scale));
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;
 }
 
-extern "C" int unimm_mul_dropout_bwd(const void* a, const void* b, const void* dout, void* da, void* db, int64_t n,
+extern "C" int unimm_mul_dropout_bwd(const float* a, const float* b, const float* dout, float* da, float* db, int64_t n,
                                      uint32_t drop_key, uint32_t drop_thr, float drop_scale, void* stream) {
   if (!a || !b || !dout || !da || !db || n <= 0) return UNIMM_E_ARG;
   hipLaunchKernelGGL(mul_dropout_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)a, (const bf16_t*)b, (const bf16_t*)dout, (bf16_t*)da, (bf16_t*)db, (size_t)n,
+                     a, b, dout, da, db, (size_t)n,
                      mk_drop(drop_key, drop_thr, drop_scale));
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;

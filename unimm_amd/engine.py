@@ -104,6 +104,7 @@ class Engine:
         self.wgrad_ws_bytes = int(os.environ.get("UNIMM_WGRAD_WS_MB", "0")) << 20
         self._wgrad_ws = {}
         self._plist = []
+        self.gemm_tile = 0               # tuning code handed to every encoder GEMM (unimm_gemm_nt_args.tile; 0 = automatic)
 
     def register_arena_user(self, obj):
         import weakref
@@ -224,14 +225,15 @@ class Engine:
 
         ln("emb_t", "bert.embeddings.LayerNorm")
         ln("emb_v", "bert.v_embeddings.LayerNorm")
-        self._mk_lin("tpool", ["bert.t_pooler.dense.weight"], ["bert.t_pooler.dense.bias"], device)
-        self._mk_lin("vpool", ["bert.v_pooler.dense.weight"], ["bert.v_pooler.dense.bias"], device)
+        # poolers and the NSP head run in fp32 (unimm_linear_f32): fp32 master weight / bias and their gradient views
+        self.lin32 = {k: (A.view(n + ".weight"), A.view(n + ".bias"), A.grad(n + ".weight"), A.grad(n + ".bias"))
+                      for k, n in (("tpool", "bert.t_pooler.dense"), ("vpool", "bert.v_pooler.dense"),
+                                   ("nsp", "cls.bi_seq_relationship"))}
         self._mk_lin("lmtr", ["cls.predictions.transform.dense.weight"], ["cls.predictions.transform.dense.bias"], device)
         ln("lmtr", "cls.predictions.transform.LayerNorm")
         self._mk_lin("dec", [PM.WORD_EMB], None, device)
         d = self.lin["dec"]
         d.bias, d.gb = A.view("cls.predictions.bias"), A.grad("cls.predictions.bias")
-        self._mk_lin("nsp", ["cls.bi_seq_relationship.weight"], ["cls.bi_seq_relationship.bias"], device, kpad=64)
         self._mk_lin("imgtr", ["cls.imagePredictions.transform.dense.weight"],
                      ["cls.imagePredictions.transform.dense.bias"], device)
         ln("imgtr", "cls.imagePredictions.transform.LayerNorm")
@@ -297,8 +299,27 @@ class Engine:
         aux_ln = None
         if isinstance(aux, _LazyLN):
             aux, aux_ln = aux.x, (aux.mean, aux.rstd, aux.gamma, aux.beta)
-        L.gemm_nt(x, lin.w, out, bias=lin.bias, epilogue=epi, aux=aux, out2=u, drop=drop, M=M, N=lin.N, K=lin.K, aux_ln=aux_ln)
+        L.gemm_nt(x, lin.w, out, bias=lin.bias, epilogue=epi, aux=aux, out2=u, drop=drop, M=M, N=lin.N, K=lin.K, aux_ln=aux_ln,
+                  tile=self.gemm_tile)
         return (out, u) if want_u else out
+
+    def _linear32(self, x, key, relu=False, out=None):
+        """y = act(x W^T + b) in fp32 from the fp32 master weights (poolers, NSP head; models/vilbert_dialog.py:946-967, :1070)."""
+        w32, b32 = self.lin32[key][:2]
+        N, K = w32.shape
+        M = x.shape[0]
+        if out is None:
+            out = torch.empty((M, N), dtype=F32, device=x.device)
+        return L.linear_f32(x, w32, out, M, N, K, (x.stride(0), 1), (1, w32.stride(0)), bias=b32, relu=relu)
+
+    def _linear32_bwd(self, dy, x, key):
+        """dW += dy^T x, db += colsum(dy) (fp32 atomics into the gradient arena), returns dx = dy W; all fp32."""
+        w32, _, gw, gb = self.lin32[key]
+        N, K = w32.shape
+        M = dy.shape[0]
+        L.linear_f32(dy, x, gw, N, K, M, (1, dy.stride(0)), (x.stride(0), 1), accumulate=True, rowsum=gb)
+        dx = torch.empty((M, K), dtype=F32, device=dy.device)
+        return L.linear_f32(dy, w32, dx, M, K, N, (dy.stride(0), 1), (w32.stride(0), 1))
 
     def _wgrad(self, dy, x, gw, M, N, K, dbias=None):
         """dW += dy^T x (+ bias gradient).  Nothing downstream in the backward chain reads a weight gradient,
@@ -359,7 +380,7 @@ class Engine:
             return None
         dx = torch.empty((M, lin.K), dtype=BF16, device=dy.device)
         kdim = lin.wt.shape[1]
-        L.gemm_nt(dy, lin.wt, dx, bias=None, epilogue=epi, aux=aux, M=M, N=lin.K, K=kdim)
+        L.gemm_nt(dy, lin.wt, dx, bias=None, epilogue=epi, aux=aux, M=M, N=lin.K, K=kdim, tile=self.gemm_tile)
         return dx
 
     def _layernorm(self, x, key, save, drop=L.NO_DROP, want32=True, lazy=False):
@@ -422,7 +443,7 @@ class Engine:
         side = self._side_stream()
         was, self._on_side = self._on_side, True
         main = self._text_stream
-        if was or main is None or L._SCOPED_STREAM is not self._text_scope:   # nested, outside an engine entry, or on a third stream
+        if was or main is None or L.scoped_stream() is not self._text_scope:   # nested, outside an engine entry, or on a third stream
             try:
                 with torch.cuda.stream(side), L.stream_scope(side):
                     yield
@@ -860,19 +881,22 @@ class Engine:
         out = dict(seq_out_t=seq_t, seq_out_v=seq_v, seq32_t=xt32, seq32_v=xv32, B=B, T=T, R=R, plan=plan, Mt=Mt,
                    nsp_weight_host=st_nspw, n_img=n_img, img_label32=il32)
         # ---- poolers + NSP (models/vilbert_dialog.py:946-967, 1064-1070) -------------------------
-        tp, vp, nspl = self.lin["tpool"], self.lin["vpool"], self.lin["nsp"]
         cls_idx_t = var[0] if var is not None else torch.arange(0, B * T, T, dtype=torch.int32, device=dev)
         cls_idx_v = torch.arange(0, B * R, R, dtype=torch.int32, device=dev)
-        cls_t = torch.empty((B, H), dtype=BF16, device=dev)        # first-token rows (:949, :964)
-        cls_v = torch.empty((B, Hv), dtype=BF16, device=dev)
-        L.gather_rows(seq_t, cls_idx_t, cls_t, B, H)
-        L.gather_rows(seq_v, cls_idx_v, cls_v, B, Hv)
-        pooled_t = self._linear(cls_t, tp, L.EPI_BIAS_RELU, M=B)
-        pooled_v = self._linear(cls_v, vp, L.EPI_BIAS_RELU, M=B)
+        # Everything above the encoder's last LayerNorm runs in fp32 from the fp32 residual stream and the fp32 master
+        # weights (unimm_linear_f32): 0.4 GFLOP, but with bf16 operands ReLU units of the B pooled rows switched with the
+        # last bit of the forward and the pooler gradients were 8-16 % off the reference's (round 2).
+        cls_t = torch.empty((B, H), dtype=F32, device=dev)         # first-token rows (:949, :964)
+        cls_v = torch.empty((B, Hv), dtype=F32, device=dev)
+        L.gather_rows(xt32.view(BF16), cls_idx_t, cls_t.view(BF16), B, 2 * H)      # fp32 rows moved as 2 H 16-bit elements
+        L.gather_rows(xv32.view(BF16), cls_idx_v, cls_v.view(BF16), B, 2 * Hv)
+        pooled_t = self._linear32(cls_t, "tpool", relu=True)
+        pooled_v = self._linear32(cls_v, "vpool", relu=True)
         d_fuse = self._drop("fuse", 0.1, train)
         fused = torch.empty_like(pooled_t)
         L.mul_dropout(pooled_t, pooled_v, fused, fused.numel(), d_fuse)
-        nsp = self._linear(fused, nspl, out_f32=True, ldo=4)
+        nsp = torch.zeros((B, 4), dtype=F32, device=dev)
+        self._linear32(fused, "nsp", out=nsp)
         out["nsp"] = nsp[:, :2]
 
         # ---- MLM head: transform + tied decoder on the selected rows (:982-986, :1023-1026) -------
@@ -1034,20 +1058,19 @@ class Engine:
         dseq_v = self._linear_bwd(duv, seq_v, itr)
         # ---- NSP + poolers ------------------------------------------------------------------------
         nlab, w0, w1 = out["nsp_state"]
-        nspl, tp, vp = self.lin["nsp"], self.lin["tpool"], self.lin["vpool"]
-        dnsp = torch.empty((B, 64), dtype=BF16, device=dev)
-        L.nsp_loss_bwd(bw["nsp_pad"], nlab, w0, w1, gvec(g_nsp), dnsp, B)
-        if g_nsp_scores is not None:      # gradient arriving through the returned NSP scores (dense fine-tune ranking loss)
-            dnsp[:, :2] += g_nsp_scores.to(BF16)
-        dfused = self._linear_bwd(dnsp, bw["fused"], nspl, M=B, N=2)
+        dnsp = torch.empty((B, 2), dtype=F32, device=dev)
+        extra = None                      # gradient arriving through the returned NSP scores (dense fine-tune ranking loss)
+        if g_nsp_scores is not None:
+            extra = g_nsp_scores.detach().to(device=dev, dtype=F32).reshape(B, 2).contiguous()
+        L.nsp_loss_bwd(bw["nsp_pad"], nlab, w0, w1, gvec(g_nsp), dnsp, B, extra=extra)
+        dfused = self._linear32_bwd(dnsp, bw["fused"], "nsp")
         dpt, dpv = torch.empty_like(dfused), torch.empty_like(dfused)
         L.mul_dropout_bwd(bw["pooled_t"], bw["pooled_v"], dfused, dpt, dpv, dfused.numel(), bw["d_fuse"])
         # pooler input gradients land on the first-token rows
-        for dp, lin, cls, dseq, cidx in ((dpt, tp, bw["cls_t"], dseq_t, bw["cls_idx_t"]), (dpv, vp, bw["cls_v"], dseq_v, bw["cls_idx_v"])):
-            self._wgrad(dp, cls, lin.gw, B, lin.N, lin.K, dbias=lin.gb)
-            dcls = torch.empty((B, lin.K), dtype=BF16, device=dev)
-            L.gemm_nt(dp, lin.wt, dcls, M=B, N=lin.K, K=lin.wt.shape[1])
-            dseq.index_add_(0, cidx.long(), dcls)
+        for dp, key, cls, dseq, cidx in ((dpt, "tpool", bw["cls_t"], dseq_t, bw["cls_idx_t"]),
+                                         (dpv, "vpool", bw["cls_v"], dseq_v, bw["cls_idx_v"])):
+            dcls = self._linear32_bwd(dp, cls, key)
+            L.rows_add_f32(dseq, cidx, dcls, B, dcls.shape[1])
         self._bucket_done("heads")
         # ---- encoder blocks in reverse -------------------------------------------------------------
         gt, gv = dseq_t, dseq_v

@@ -13,7 +13,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libunimm_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROP_RESID, EPI_BIAS_RELU, EPI_DGELU, EPI_ADD, EPI_MUL, EPI_BIAS_GELU_DG = range(8)
 
@@ -31,7 +31,8 @@ class GemmNtArgs(C.Structure):
                 ("ldx", C.c_int32), ("ldw", C.c_int32), ("ldaux", C.c_int32), ("ldo", C.c_int32),
                 ("epilogue", C.c_int32), ("out_f32", C.c_int32),
                 ("drop_key", C.c_uint32), ("drop_thr", C.c_uint32), ("drop_scale", C.c_float),
-                ("aux_mean", C.c_void_p), ("aux_rstd", C.c_void_p), ("aux_gamma", C.c_void_p), ("aux_beta", C.c_void_p)]
+                ("aux_mean", C.c_void_p), ("aux_rstd", C.c_void_p), ("aux_gamma", C.c_void_p), ("aux_beta", C.c_void_p),
+                ("tile", C.c_int32)]
 
 
 class GemmTnArgs(C.Structure):
@@ -84,8 +85,8 @@ SYMBOLS = ["unimm_version", "unimm_arch", "unimm_gemm_nt", "unimm_gemm_tn", "uni
            "unimm_embed_fwd", "unimm_embed_bwd", "unimm_colsum", "unimm_cast_f32_bf16", "unimm_transpose_cast",
            "unimm_pack_image", "unimm_mul_dropout", "unimm_mul_dropout_bwd", "unimm_lm_loss_fwd",
            "unimm_lm_loss_bwd", "unimm_kl_loss_fwd", "unimm_kl_loss_bwd", "unimm_nsp_loss_fwd",
-           "unimm_nsp_loss_bwd", "unimm_reduce_sum", "unimm_segment_sum", "unimm_gelu_bwd", "unimm_gather_rows", "unimm_prof_enable", "unimm_prof_collect", "unimm_gemm_set_tile", "unimm_attn_set_parts", "unimm_adamw_step", "unimm_transpose_cast_grouped", "unimm_mask_synth", "unimm_neural_ndcg", "unimm_plan_lengths", "unimm_plan_build", "unimm_layernorm_bwd_partials",
-           "unimm_colpartials_finish_grouped", "unimm_gemm_tn_set_shared", "unimm_gemm_tn_grouped_ws"]
+           "unimm_nsp_loss_bwd", "unimm_reduce_sum", "unimm_segment_sum", "unimm_gelu_bwd", "unimm_gather_rows", "unimm_prof_enable", "unimm_prof_collect", "unimm_adamw_step", "unimm_transpose_cast_grouped", "unimm_mask_synth", "unimm_neural_ndcg", "unimm_plan_lengths", "unimm_plan_build", "unimm_layernorm_bwd_partials",
+           "unimm_colpartials_finish_grouped", "unimm_gemm_tn_grouped_ws", "unimm_linear_f32", "unimm_rows_add_f32"]
 
 
 def _check(rc, what):
@@ -93,12 +94,19 @@ def _check(rc, what):
         raise UnimmHipError(f"{what} failed: {_ERR.get(rc, rc)}")
 
 
-_SCOPED_STREAM = None     # raw stream of the innermost stream_scope(); None = ask torch on every call
+_tls = threading.local()      # per thread: argument structs of the hot wrappers (the C side reads them before it returns)
+                              # and the raw stream of the innermost stream_scope() (None = ask torch on every call)
+
+
+def scoped_stream():
+    """The raw stream object the calling thread's innermost `stream_scope` installed, or None."""
+    return getattr(_tls, "stream", None)
 
 
 def _stream():
-    if _SCOPED_STREAM is not None:
-        return _SCOPED_STREAM
+    s = getattr(_tls, "stream", None)
+    if s is not None:
+        return s
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -111,13 +119,11 @@ class stream_scope:
         self.ptr = C.c_void_p(stream.cuda_stream)
 
     def __enter__(self):
-        global _SCOPED_STREAM
-        self.old, _SCOPED_STREAM = _SCOPED_STREAM, self.ptr
+        self.old, _tls.stream = getattr(_tls, "stream", None), self.ptr
         return self
 
     def __exit__(self, *exc):
-        global _SCOPED_STREAM
-        _SCOPED_STREAM = self.old
+        _tls.stream = self.old
         return False
 
 
@@ -130,20 +136,17 @@ def _P(t):
     return t.data_ptr() if t is not None else None
 
 
-_tls = threading.local()      # per-thread argument structs of the hot wrappers (the C side reads them before it returns)
-
-
 def _dev(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
             raise UnimmHipError("unimm_amd kernels need device tensors (got a CPU tensor)")
 
 
-def gemm_nt(x, w, out, bias=None, epilogue=EPI_BIAS, aux=None, out2=None, drop=None, M=None, N=None, K=None, aux_ln=None):
+def gemm_nt(x, w, out, bias=None, epilogue=EPI_BIAS, aux=None, out2=None, drop=None, M=None, N=None, K=None, aux_ln=None, tile=0):
     """out[M,N] = epi(x[M,K] @ w[N,K]^T).  x/w bf16 2-D (row stride = stride(0)); out bf16 or fp32.
-    aux_ln = (mean[M], rstd[M], gamma[N], beta[N]): the DROP_RESID residual is LayerNorm(aux) computed on the fly."""
-    if not (x.is_cuda and w.is_cuda and out.is_cuda):
-        _dev(x, w, out)
+    aux_ln = (mean[M], rstd[M], gamma[N], beta[N]): the DROP_RESID residual is LayerNorm(aux) computed on the fly.
+    tile: per-call tuning code (include/unimm_hip.h: unimm_gemm_nt_args.tile); 0 = automatic."""
+    _dev(x, w, out, bias, aux, out2)
     st = getattr(_tls, "nt", None)
     if st is None:
         a = GemmNtArgs()
@@ -161,6 +164,7 @@ def gemm_nt(x, w, out, bias=None, epilogue=EPI_BIAS, aux=None, out2=None, drop=N
     a.K = x.shape[1] if K is None else K
     a.ldx, a.ldw, a.ldo = x.stride(0), w.stride(0), out.stride(0)
     a.epilogue = epilogue
+    a.tile = tile
     a.out_f32 = 1 if out.dtype == torch.float32 else 0
     a.drop_key, a.drop_thr, a.drop_scale = drop if drop is not None else (0, 0, 0.0)
     if aux_ln is not None:
@@ -198,8 +202,7 @@ def gemm_tn_grouped(problems, shared=None, ws=None):
         return
     arr = (GemmTnArgs * n)()
     for a, (dy, x, dw, M, N, K, dbias) in zip(arr, problems):
-        if not dy.is_cuda:
-            _dev(dy, x, dw, dbias)
+        _dev(dy, x, dw, dbias)
         a.dy, a.x, a.dw, a.dbias = dy.data_ptr(), x.data_ptr(), dw.data_ptr(), (dbias.data_ptr() if dbias is not None else None)
         a.M = dy.shape[0] if M is None else M
         a.N = dy.shape[1] if N is None else N
@@ -244,8 +247,7 @@ def attn_fwd(q, k, v, out, lse, mask, B, H, Tq, Tk, D, scale, mask_q_stride, mas
              qvar=None, kvar=None):
     """q/k/v/out: 2-D bf16 views [rows, >=H*D] (row stride = stride(0)); mask: packed uint32 words.
     qvar / kvar: (offsets, lengths) int32 [B] tensors for the variable-length layout, or None."""
-    if not (q.is_cuda and k.is_cuda and out.is_cuda and mask.is_cuda):
-        _dev(q, k, v, out, lse, mask)
+    _dev(q, k, v, out, lse, mask)
     st = getattr(_tls, "af", None)
     if st is None:
         a = AttnArgs()
@@ -265,8 +267,7 @@ def attn_fwd(q, k, v, out, lse, mask, B, H, Tq, Tk, D, scale, mask_q_stride, mas
 
 def attn_bwd(q, k, v, out, dout, lse, delta, dq, dk, dv, mask, B, H, Tq, Tk, D, scale, mask_q_stride,
              mask_b_stride, drop=NO_DROP, qvar=None, kvar=None):
-    if not (q.is_cuda and k.is_cuda and dout.is_cuda and dq.is_cuda and dk.is_cuda and dv.is_cuda):
-        _dev(q, k, v, out, dout, lse, delta, dq, dk, dv, mask)
+    _dev(q, k, v, out, dout, lse, delta, dq, dk, dv, mask)
     st = getattr(_tls, "ab", None)
     if st is None:
         a = AttnBwdArgs()
@@ -322,8 +323,7 @@ def layernorm_bwd_partials(dy, x, mean, rstd, gamma, dx, dx_drop, partials, M, H
     """LayerNorm backward row kernel only; returns the number of partial blocks (see unimm_layernorm_bwd_partials)."""
     drop = drop or NO_DROP
     out_drop = out_drop or NO_DROP
-    if not (dy.is_cuda and x.is_cuda and dx.is_cuda):
-        _dev(dy, x, dx)
+    _dev(dy, x, mean, rstd, gamma, dx, dx_drop, partials)
     blocks = C.c_int32(0)
     rc = lib().unimm_layernorm_bwd_partials(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
                                             dx.data_ptr(), _P(dx_drop), partials.data_ptr(), M, H, drop[0], drop[1], drop[2],
@@ -347,8 +347,7 @@ def colpartials_finish_grouped(pending):
 
 
 def layernorm_fwd(x, gamma, beta, y32, y16, mean, rstd, M, H, eps=1e-12, drop=NO_DROP):
-    if not (x.is_cuda and y16.is_cuda):
-        _dev(x, y16)
+    _dev(x, gamma, beta, y32, y16, mean, rstd)
     rc = lib().unimm_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _P(y32), _P(y16), _P(mean), _P(rstd), M, H, eps,
                                    drop[0], drop[1], drop[2], _stream())
     if rc != 0:
@@ -357,7 +356,7 @@ def layernorm_fwd(x, gamma, beta, y32, y16, mean, rstd, M, H, eps=1e-12, drop=NO
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dx_drop, dgamma, dbeta, dbias, partials, M, H, drop=NO_DROP,
                   out_drop=NO_DROP):
-    _dev(dy, x, dx)
+    _dev(dy, x, mean, rstd, gamma, dx, dx_drop, dgamma, dbeta, dbias, partials)
     _check(lib().unimm_layernorm_bwd(_P(dy), _P(x), _P(mean), _P(rstd), _P(gamma), _P(dx), _P(dx_drop),
                                      _P(dgamma), _P(dbeta), _P(dbias), _P(partials), M, H, drop[0], drop[1], drop[2],
                                      out_drop[0], out_drop[1], out_drop[2], _stream()), "unimm_layernorm_bwd")
@@ -531,11 +530,43 @@ def nsp_loss_fwd(logits, labels, w0, w1, loss, B):
                                     C.c_int32(logits.stride(0)), _stream()), "unimm_nsp_loss_fwd")
 
 
-def nsp_loss_bwd(logits, labels, w0, w1, g, dlogits, B):
-    _dev(logits, labels, g, dlogits)
-    _check(lib().unimm_nsp_loss_bwd(_ptr(logits), _ptr(labels), C.c_float(w0), C.c_float(w1), _ptr(g), _ptr(dlogits),
+def nsp_loss_bwd(logits, labels, w0, w1, g, dlogits, B, extra=None):
+    """dlogits: fp32 [B, >= 2]; extra: fp32 [B, 2] contiguous gradient added in (or None)."""
+    _dev(logits, labels, g, dlogits, extra)
+    if dlogits.dtype != torch.float32 or (extra is not None and (extra.dtype != torch.float32 or not extra.is_contiguous())):
+        raise UnimmHipError("nsp_loss_bwd: dlogits / extra must be fp32 (extra contiguous [B, 2])")
+    _check(lib().unimm_nsp_loss_bwd(_ptr(logits), _ptr(labels), C.c_float(w0), C.c_float(w1), _ptr(g), _ptr(extra), _ptr(dlogits),
                                     C.c_int32(B), C.c_int32(logits.stride(0)), C.c_int32(dlogits.stride(0)), _stream()),
            "unimm_nsp_loss_bwd")
+
+
+class LinearF32Args(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p), ("rowsum", C.c_void_p),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("sa_m", C.c_int64), ("sa_k", C.c_int64), ("sb_k", C.c_int64), ("sb_n", C.c_int64), ("ldo", C.c_int64),
+                ("relu", C.c_int32), ("accumulate", C.c_int32)]
+
+
+def linear_f32(a, b, out, M, N, K, sa, sb, bias=None, relu=False, accumulate=False, rowsum=None):
+    """out[M, N] (+)= act(A . B + bias), all fp32; sa = (stride of A over m, over k), sb = (stride of B over k, over n),
+    in elements (include/unimm_hip.h: unimm_linear_f32)."""
+    _dev(a, b, out, bias, rowsum)
+    for t in (a, b, out, bias, rowsum):
+        if t is not None and t.dtype != torch.float32:
+            raise UnimmHipError("linear_f32: every operand is fp32")
+    g = LinearF32Args()
+    g.a, g.b, g.bias, g.out, g.rowsum = a.data_ptr(), b.data_ptr(), _P(bias), out.data_ptr(), _P(rowsum)
+    g.M, g.N, g.K = M, N, K
+    g.sa_m, g.sa_k, g.sb_k, g.sb_n, g.ldo = sa[0], sa[1], sb[0], sb[1], out.stride(0)
+    g.relu, g.accumulate = int(bool(relu)), int(bool(accumulate))
+    _check(lib().unimm_linear_f32(C.byref(g), _stream()), "unimm_linear_f32")
+    return out
+
+
+def rows_add_f32(dst, idx, src, n, H):
+    """dst (bf16 [*, H] contiguous rows)[idx[r], :] += src (fp32 [n, H] contiguous)[r, :]"""
+    _dev(dst, idx, src)
+    _check(lib().unimm_rows_add_f32(_ptr(dst), _ptr(idx), _ptr(src), C.c_int32(n), C.c_int32(H), _stream()), "unimm_rows_add_f32")
 
 
 def reduce_sum(src, n, dst, scale=1.0):
@@ -637,15 +668,3 @@ def prof_collect():
     ms, fl, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_int32 * n)()
     _check(lib().unimm_prof_collect(ms, fl, cnt, C.c_int32(n)), "unimm_prof_collect")
     return {GEMM_VARIANTS.get(i, f"variant{i}"): (ms[i], fl[i], cnt[i]) for i in range(n) if cnt[i] > 0}
-
-
-def gemm_tn_set_shared(on: bool):
-    _check(lib().unimm_gemm_tn_set_shared(C.c_int32(1 if on else 0)), "unimm_gemm_tn_set_shared")
-
-
-def gemm_set_tile(cfg: int):
-    _check(lib().unimm_gemm_set_tile(C.c_int32(cfg)), "unimm_gemm_set_tile")
-
-
-def attn_set_parts(parts: int):
-    _check(lib().unimm_attn_set_parts(C.c_int32(parts)), "unimm_attn_set_parts")
