@@ -382,6 +382,8 @@ def main():
         torch.cuda.synchronize()
 
     fence()
+    if world > 1:
+        net.comm_stats(reset=True)
     prof_all = args.gemm_profile == "all"
     lib.prof_enable(1 if prof_all else 2)
     t0 = time.perf_counter()
@@ -389,6 +391,9 @@ def main():
         loss = step()
     fence()
     dt = time.perf_counter() - t0
+    if world > 1:          # every gradient bucket was exchanged exactly once per timed step
+        st_timed = net.comm_stats()
+        assert st_timed["buckets"] == st_timed["n_buckets_expected"] * args.steps, st_timed
     prof = lib.prof_collect()
     lib.prof_enable(False)
     loss_val = float(loss.detach())
@@ -448,7 +453,7 @@ def main():
         fence()
         tc = time.perf_counter()
         for _ in range(3):
-            net._exchange(flat)
+            net._exchange(0, flat.numel())
         fence()
         t_ar = (time.perf_counter() - tc) / 3
         fence()
@@ -462,6 +467,7 @@ def main():
         busbw = wire * 2 * (world - 1) / world / t_ar / 1e9
         comm = {"wire_dtype": net.wire_dtype, "algorithm": net.algorithm, "bytes_per_step": wire,
                 "bucket_bytes": st["bucket_bytes"], "buckets_per_step": len(st["bucket_bytes"]),
+                "collectives_per_step": st["calls"] // max(1, args.steps),
                 "exchange_alone_ms": round(t_ar * 1e3, 3), "busbw_GBps": round(busbw, 1),
                 "xgmi_budget_GBps": 7 * 153, "busbw_frac_of_xgmi": round(busbw / (7 * 153), 3),
                 "step_ms_without_exchange": round(t_nosync * 1e3, 3),

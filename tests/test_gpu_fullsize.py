@@ -238,7 +238,7 @@ def test_full_size_text_and_image_layer_fwd_bwd(golden_dir, full3):
         dy *= valid[:, :, None]
         dy_t = T_(dy)
         dx = st["tape"][-1][1](dy_t.reshape(B * n, Hd).to(dev).to(torch.bfloat16))
-        eng._flush_wgrad()
+        eng._flush_wgrad(force=True)
         torch.cuda.synchronize()
         leaves = _leaves(sd, pfx)
         xr = T_(x_np).clone().requires_grad_(True)
@@ -287,7 +287,7 @@ def test_full_size_connection_layer_fwd_bwd(golden_dir, full3):
     gt = dt_t.reshape(B * T, H).to(dev).to(torch.bfloat16)
     eng._to_img(gv)
     dxv, dxt = st["tape"][-1][1](gv, gt)
-    eng._flush_wgrad()
+    eng._flush_wgrad(force=True)
     eng._to_txt(dxv)
     torch.cuda.synchronize()
     leaves = _leaves(sd, pfx)

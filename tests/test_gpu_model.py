@@ -260,13 +260,19 @@ def test_data_parallel_wrapper_over_rccl_single_rank(golden_dir):
         dp = DataParallelRCCL(model, reduce_when_single=True)
         seen = []
         orig = dp._reduce_slice
-        dp._reduce_slice = lambda lo, hi: (seen.append((lo, hi)), orig(lo, hi))[1]
+        dp._reduce_slice = lambda lo, hi, n=1: (seen.append((lo, hi, n)), orig(lo, hi, n))[1]
         model.engine.arena.zero_grads()
         lm, img, nsp_l, _, _, _ = dp(*args, **kw, _want_lm_scores=False)
         (lm + img + nsp_l).sum().backward()
         torch.cuda.synchronize()
-        assert len(seen) == len(model.engine.arena.buckets)          # every bucket reduced exactly once, in backward
-        assert sorted(seen) == sorted((lo, hi) for _, lo, hi in model.engine.arena.buckets)
+        # every bucket reduced exactly once, in backward; buckets whose weight gradients were launched together travel
+        # as one collective over their adjacent slices: the exchanged ranges tile the gradient arena without overlap
+        assert sum(n for _, _, n in seen) == len(model.engine.arena.buckets)
+        assert dp.comm_stats()["buckets"] == len(model.engine.arena.buckets)
+        cover = sorted((lo, hi) for lo, hi, _ in seen)
+        assert cover[0][0] == min(lo for _, lo, _ in model.engine.arena.buckets)
+        assert all(a[1] == b[0] for a, b in zip(cover, cover[1:])), cover
+        assert cover[-1][1] == max(hi for _, _, hi in model.engine.arena.buckets)
         got = model.engine.arena.grad_flat
         assert (got - want).abs().max() <= 1e-2 * want.abs().max()   # fp32 atomics order differs run to run
         with dp.no_sync():

@@ -786,7 +786,7 @@ struct GemmTnParams {
 // drain of one fp32 partial tile per resident workgroup (256 x 256 KiB = 67 MB of memory-side atomics,
 // ~43 us, whatever the shape), so a block's 4-10 weight gradients pay that tail once instead of once each,
 // and the bigger tile pool lets the split count land on a whole number of rounds.
-constexpr int TN_MAXG = 12;
+constexpr int TN_MAXG = 48;   // 48 descriptors of 72 bytes + header = 3.5 KiB of kernel arguments (limit 4 KiB)
 struct GemmTnGroup {
   int count, total_tiles;
   int splits;            // reduction ranges per tile
@@ -855,6 +855,97 @@ __device__ __forceinline__ bf16x8 read_frag_tr(const char* lds_tile, int c16, in
   return __builtin_bit_cast(bf16x8, v);
 }
 
+// Partial tile -> gradient (shared by both weight-gradient kernels).  acc[i][j]: n-subtile i, k-subtile j of the wave's
+// (16 NT) x 64 piece of the tile at (n0, k0); D[n][k]: lane holds k = .. + (lane & 15) (column), n = .. + 4 (lane >> 4) + e.
+template <int NW, int NT>
+__device__ __forceinline__ void tn_store_partial(const GemmTnGroup& grp, const GemmTnParams& p, f32x4 (&acc)[NT][4], char* smem,
+                                                 int gtile, int split, int n0, int k0, int wn, int wk, int wave, int lane, int tid) {
+  // ---- partial tile -> gradient.  Without a workspace every split adds its fp32 partial with memory-side atomics:
+  // one 256 KiB tile per resident workgroup at the END of every round, 67 MB at ~1.3 TB/s = ~43 us in which the chip
+  // only drains (and 8x the algorithmic write traffic: 222 MB per text-block launch against 28 MB of gradients).
+  // With a workspace the splits of a tile meet at a counter instead: each stores its partial to its own SLAB with plain,
+  // fully coalesced 16-byte stores (register order: the reducer has the same layout), and whoever arrives LAST reads
+  // the other slabs on top of the partial it still holds in registers and adds the sum into the gradient exactly once
+  // (one fp32 atomic per element: a tied or concurrently accumulated dw stays safe).  Placement-independent hand-off (guide,
+  // "in-launch split-K reduction"): slab stores -> every wave's vmcnt(0) -> workgroup barrier -> lane 0: agent-scope
+  // release, vmcnt(0), relaxed agent-scope ticket; the last arriver: agent-scope acquire, vmcnt(0), barrier, plain loads.
+  if (grp.slabs != nullptr && p.nsplit > 1) {
+    constexpr int TILE_F4 = NW * NT * 4 * 64;                      // f32x4 per partial tile
+    f32x4* mine = reinterpret_cast<f32x4*>(grp.slabs) + ((size_t)gtile * grp.splits + split) * TILE_F4;
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mine[((wave * NT + i) * 4 + j) * 64 + lane] = acc[i][j];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                               // (the ring is dead: smem[0..3] carries the ticket)
+    int* flag = reinterpret_cast<int*>(smem);
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int ticket = __hip_atomic_fetch_add(grp.counters + gtile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (ticket == p.nsplit - 1) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(grp.counters + gtile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+      }
+      *flag = ticket;
+    }
+    __syncthreads();
+    if (*flag != p.nsplit - 1) return;                             // block-uniform
+    const f32x4* base = reinterpret_cast<const f32x4*>(grp.slabs) + (size_t)gtile * grp.splits * TILE_F4;
+    for (int sp = 0; sp < p.nsplit; ++sp) {
+      if (sp == split) continue;
+      const f32x4* other = base + (size_t)sp * TILE_F4;
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 o = other[((wave * NT + i) * 4 + j) * 64 + lane];
+          acc[i][j][0] += o[0]; acc[i][j][1] += o[1]; acc[i][j][2] += o[2]; acc[i][j][3] += o[3];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = n0 + wn * 16 * NT + i * 16 + 4 * (lane >> 4) + e;
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = k0 + wk * 64 + j * 16 + (lane & 15);
+          if (k < p.K) atomicAdd(p.dw + (size_t)n * p.lddw + k, acc[i][j][e]);   // dw may alias another problem's / stream's
+        }
+      }
+    }
+    return;
+  }
+  // D[n][k]: lane holds k = .. + (lane&15) (column), n = .. + 4*(lane>>4) + e (rows)
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int n = n0 + wn * 16 * NT + i * 16 + 4 * (lane >> 4) + e;
+      if (n >= p.N) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = k0 + wk * 64 + j * 16 + (lane & 15);
+        if (k < p.K) atomicAdd(p.dw + (size_t)n * p.lddw + k, acc[i][j][e]);
+      }
+    }
+  }
+}
+
+// Problem that owns grouped tile index `tile`: the last descriptor with tile0 <= tile (binary search: <= 6 dependent
+// scalar loads from the kernel-argument segment instead of `count` of them).
+__device__ __forceinline__ int tn_find_problem(const GemmTnGroup& grp, int tile) {
+  int lo = 0, hi = grp.count - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (grp.pr[mid].tile0 <= tile) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
 // WN x WK waves; a wave owns (16*NT)(n) x 64(k) of the [TNB x TKB] output tile.
 //   <2,2,4>: 128x128 tile, 4 waves, 64 KiB LDS (2 workgroups per CU)      -- small problems
 //   <2,4,8>: 256x256 tile, 8 waves, 128 KiB LDS: half the staged bytes per MFMA, so one m-step of
@@ -870,8 +961,7 @@ __global__ __launch_bounds__(64 * WN * WK, (WN * WK * (NT == 4 ? 2 : 1) + 3) / 4
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
   const int split = lid / grp.total_tiles;
   int tile = lid - split * grp.total_tiles;
-  int gi = 0;
-  for (int i = 1; i < grp.count; ++i) gi = (tile >= grp.pr[i].tile0) ? i : gi;
+  int gi = tn_find_problem(grp, tile);
   gi = __builtin_amdgcn_readfirstlane(gi);   // wave-uniform: the descriptor is fetched once, into SGPRs
   const GemmTnParams p = grp.pr[gi];
   const int gtile = tile;                    // tile index inside the grouped launch (slab / counter index)
@@ -998,79 +1088,229 @@ __global__ __launch_bounds__(64 * WN * WK, (WN * WK * (NT == 4 ? 2 : 1) + 3) / 4
     }
   }
 
-  // ---- partial tile -> gradient.  Without a workspace every split adds its fp32 partial with memory-side atomics:
-  // one 256 KiB tile per resident workgroup at the END of every round, 67 MB at ~1.3 TB/s = ~43 us in which the chip
-  // only drains (and 8x the algorithmic write traffic: 222 MB per text-block launch against 28 MB of gradients).
-  // With a workspace the splits of a tile meet at a counter instead: each stores its partial to its own SLAB with plain,
-  // fully coalesced 16-byte stores (register order: the reducer has the same layout), and whoever arrives LAST reads
-  // the other slabs on top of the partial it still holds in registers and adds the sum into the gradient exactly once
-  // (one fp32 atomic per element: a tied or concurrently accumulated dw stays safe).  Placement-independent hand-off (guide,
-  // "in-launch split-K reduction"): slab stores -> every wave's vmcnt(0) -> workgroup barrier -> lane 0: agent-scope
-  // release, vmcnt(0), relaxed agent-scope ticket; the last arriver: agent-scope acquire, vmcnt(0), barrier, plain loads.
-  if (grp.slabs != nullptr && p.nsplit > 1) {
-    constexpr int TILE_F4 = NW * NT * 4 * 64;                      // f32x4 per partial tile
-    f32x4* mine = reinterpret_cast<f32x4*>(grp.slabs) + ((size_t)gtile * grp.splits + split) * TILE_F4;
+  tn_store_partial<NW, NT>(grp, p, acc, smem, gtile, split, n0, k0, wn, wk, wave, lane, tid);
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm_tn_pp: the 256x256 weight-gradient tile behind the ping-pong main loop of gemm_nt (nt_mainloop_pp above, same
+// phases, same barrier / vmcnt proof with W <-> X columns "B", X <-> DY columns "A").
+//
+// Round-2 counters of the lock-step loop (profiles/r3_pmc_gemm_tn.txt): waves parked at s_waitcnt / s_barrier 38 % of
+// their life, MFMA pipe busy 40 %, LDS array busy 15 %, 77 VALU + 44 SALU instructions per wave and 64-row step next to
+// its 64 MFMAs -- two waves per SIMD then want ~2,000 issue cycles in a 2,048-cycle step: the loop was issue-bound and
+// drained (vmcnt(0) + barrier + 12 dependent transposed reads) at the top of every step.  Here
+//   * the two half-workgroups (n-halves of the tile) run one barrier apart: one issues nothing but its 16 MFMAs per
+//     interval while the other requests fragments and issues its two LDS-DMA instructions;
+//   * staging is buffer_load_dwordx4 ... lds through one buffer descriptor per operand whose num_records ends at the
+//     split's last reduction row: the per-lane offset (row * ld + swizzled chunk) is constant over the steps, the step
+//     advance is the scalar offset, and rows past the end come back as ZEROS from the range check (measured:
+//     tools/exp/oob_lds_dma.hip) -- no address arithmetic, no row clamps and no ragged-tail code in the loop;
+//   * one counted vmcnt per step certifies the next step's 64 KiB.
+// LDS: two buffers of four 16 KiB half-tiles [X cols 0-127 | X cols 128-255 | DY cols 0-127 | DY cols 128-255] x 64 rows.
+// ------------------------------------------------------------------------------------------------
+struct TnPpStage {
+  uint32_t so[4][2];   // per-lane source byte offsets inside the split's row range (row * ld + swizzled chunk)
+  uint32_t lds;        // LDS byte address of this wave's first instruction slot in half-tile 0 of buffer 0 (uniform)
+};
+
+__device__ __forceinline__ void tn_pp_stage_init(TnPpStage& st, const GemmTnParams& p, int n0, int k0, uint32_t lds0, int wave, int lane) {
+  const int inst0 = (wave >> 2) * 8 + (wave & 3) * 2;          // two of a half-tile's 16 wave-instructions (4 rows x 256 B each)
+  st.lds = __builtin_amdgcn_readfirstlane(lds0 + inst0 * 1024);
 #pragma unroll
-    for (int i = 0; i < NT; ++i)
+  for (int ht = 0; ht < 4; ++ht)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) mine[((wave * NT + i) * 4 + j) * 64 + lane] = acc[i][j];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                               // (the ring is dead: smem[0..3] carries the ticket)
-    int* flag = reinterpret_cast<int*>(smem);
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const int ticket = __hip_atomic_fetch_add(grp.counters + gtile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (ticket == p.nsplit - 1) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(grp.counters + gtile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-      }
-      *flag = ticket;
+    for (int r = 0; r < 2; ++r) {
+      const int row = (inst0 + r) * 4 + (lane >> 4);           // reduction row inside the 64-row step
+      const int chunk = (lane & 15) ^ tn_swz(row);
+      const bool is_b = ht < 2;
+      const int ncols = is_b ? p.K : p.N, ld = is_b ? p.ldx : p.lddy;
+      int gc = (is_b ? k0 : n0) + (ht & 1) * 128 + chunk * 8;
+      const int cmax = ((ncols + 7) & ~7) - 8;                  // columns past round_up(ncols, 8) re-read the last readable chunk
+      gc = gc <= cmax ? gc : cmax;                              // (they only feed outputs that are never stored)
+      st.so[ht][r] = (uint32_t)row * (uint32_t)(ld * 2) + (uint32_t)gc * 2u;
     }
-    __syncthreads();
-    if (*flag != p.nsplit - 1) return;                             // block-uniform
-    const f32x4* base = reinterpret_cast<const f32x4*>(grp.slabs) + (size_t)gtile * grp.splits * TILE_F4;
-    for (int sp = 0; sp < p.nsplit; ++sp) {
-      if (sp == split) continue;
-      const f32x4* other = base + (size_t)sp * TILE_F4;
+}
+
+// Issued through inline asm (see pp_stage): the compiler must not see LDS-DMA in flight.  soff = step * 64 rows in bytes.
+__device__ __forceinline__ void tn_pp_stage(const TnPpStage& st, const u32x4& srd, uint32_t soff, int buf, int ht) {
 #pragma unroll
-      for (int i = 0; i < NT; ++i)
+  for (int r = 0; r < 2; ++r) {
+    const uint32_t dst = st.lds + buf * 65536 + ht * 16384 + r * 1024;
+    uint32_t keep;                                             // m0 is the compiler's: hand it back as found
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(st.so[ht][r]), "s"(dst), "s"(srd), "s"(soff) : "memory");
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmTnGroup grp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NW = 8, NT = 8, TNB = 256, TKB = 256;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);            // split-major order, as gemm_tn_kernel
+  const int split = lid / grp.total_tiles;
+  int tile = lid - split * grp.total_tiles;
+  int gi = tn_find_problem(grp, tile);
+  gi = __builtin_amdgcn_readfirstlane(gi);
+  const GemmTnParams p = grp.pr[gi];
+  const int gtile = tile;
+  tile -= p.tile0;
+  const int nbk = (p.K + TKB - 1) / TKB;
+  const int tn = tile / nbk, tk = tile - tn * nbk;
+  const int n0 = tn * TNB, k0 = tk * TKB;
+  const int mbeg = split * p.rows_per_split;
+  int mend = mbeg + p.rows_per_split;
+  mend = mend < p.M ? mend : p.M;
+  if (mbeg >= mend) return;
+  const int wn = wave >> 2, wk = wave & 3;                      // G0 = waves 0-3 (n-half 0), G1 = waves 4-7 (n-half 1)
+  const int nk = (mend - mbeg + TK - 1) / TK;
+
+  f32x4 acc[NT][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const f32x4 o = other[((wave * NT + i) * 4 + j) * 64 + lane];
-          acc[i][j][0] += o[0]; acc[i][j][1] += o[1]; acc[i][j][2] += o[2]; acc[i][j][3] += o[3];
-        }
-    }
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool do_bias = p.dbias != nullptr && tk == 0 && wk == 0;   // wave-uniform (wave comes from readfirstlane)
+  float accb[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) accb[i] = 0.f;
+
+  // buffer descriptors: base = first reduction row of this split, num_records = the split's bytes (range check = zero fill)
+  u32x4 srd_a, srd_b;
+  uint32_t step_a, step_b;
+  {
+    const uint64_t ba = (uint64_t)(uintptr_t)(p.dy + (size_t)mbeg * p.lddy), bb = (uint64_t)(uintptr_t)(p.x + (size_t)mbeg * p.ldx);
+    const uint32_t rows = (uint32_t)(mend - mbeg);
+    srd_a = u32x4{(uint32_t)ba, (uint32_t)(ba >> 32) & 0xffffu, rows * (uint32_t)p.lddy * 2u, 0x00020000u};
+    srd_b = u32x4{(uint32_t)bb, (uint32_t)(bb >> 32) & 0xffffu, rows * (uint32_t)p.ldx * 2u, 0x00020000u};
+    step_a = (uint32_t)(TK * p.lddy * 2);
+    step_b = (uint32_t)(TK * p.ldx * 2);
+  }
+  TnPpStage st;
+  uint32_t aa0[8], ab0[4];                                      // transposed-read addresses of the wave's fragments, buffer 0
+  {
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)LDS_PTR(smem);
+    tn_pp_stage_init(st, p, n0, k0, lds0, wave, lane);
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int row = 8 * g + q;
+    const uint32_t lc = lds0 + row * 256 + ((tn_swz(row) | (pp >> 1)) << 4) + (pp & 1) * 8;
+    const uint32_t la = lc + (2 + wn) * 16384;                  // DY half-tile of this wave's n-half
+    const uint32_t lb = (lc ^ (uint32_t)((wk & 1) * 128)) + (wk >> 1) * 16384;
+#pragma unroll
+    for (int x = 0; x < 8; ++x) aa0[x] = la ^ (uint32_t)(x * 32);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) ab0[x] = lb ^ (uint32_t)(x * 32);
+  }
+#define UNIMM_TN_STAGE(KT, HT)                                                                                  \
+  {                                                                                                             \
+    if ((HT) < 2) tn_pp_stage(st, srd_b, (uint32_t)(KT) * step_b, (KT) & 1, (HT));                              \
+    else tn_pp_stage(st, srd_a, (uint32_t)(KT) * step_a, (KT) & 1, (HT));                                       \
+  }
+  // prologue: step 0 (4 half-tiles) and half-tile 0 of step 1
+  UNIMM_TN_STAGE(0, 0) UNIMM_TN_STAGE(0, 1) UNIMM_TN_STAGE(0, 2) UNIMM_TN_STAGE(0, 3)
+  if (nk > 1) UNIMM_TN_STAGE(1, 0)
+  __builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0), visible to the compiler (see nt_mainloop_pp)
+  __builtin_amdgcn_s_barrier();                                 // step 0 has landed for every wave
+  if (wn == 1) __builtin_amdgcn_s_barrier();                    // G1 runs one barrier behind G0
+  __builtin_amdgcn_sched_barrier(0);
+
+  bf16x8 fa[2][4], fb[2][4];
+#define UNIMM_TN_RD(addr, ks) __builtin_bit_cast(bf16x8, __builtin_shufflevector(                               \
+      lds_read_tr<(ks) * 8192>(addr), lds_read_tr<(ks) * 8192 + 1024>(addr), 0, 1, 2, 3, 4, 5, 6, 7))
+#define UNIMM_TN_READ_A(JH)                                                                                     \
+  {                                                                                                             \
+    fa[0][0] = UNIMM_TN_RD(aa[4 * (JH) + 0], 0); fa[0][1] = UNIMM_TN_RD(aa[4 * (JH) + 1], 0);                   \
+    fa[0][2] = UNIMM_TN_RD(aa[4 * (JH) + 2], 0); fa[0][3] = UNIMM_TN_RD(aa[4 * (JH) + 3], 0);                   \
+    fa[1][0] = UNIMM_TN_RD(aa[4 * (JH) + 0], 1); fa[1][1] = UNIMM_TN_RD(aa[4 * (JH) + 1], 1);                   \
+    fa[1][2] = UNIMM_TN_RD(aa[4 * (JH) + 2], 1); fa[1][3] = UNIMM_TN_RD(aa[4 * (JH) + 3], 1);                   \
+  }
+#define UNIMM_TN_READ_B(IH)                                                                                     \
+  {                                                                                                             \
+    fb[0][2 * (IH)] = UNIMM_TN_RD(ab[2 * (IH)], 0); fb[0][2 * (IH) + 1] = UNIMM_TN_RD(ab[2 * (IH) + 1], 0);     \
+    fb[1][2 * (IH)] = UNIMM_TN_RD(ab[2 * (IH)], 1); fb[1][2 * (IH) + 1] = UNIMM_TN_RD(ab[2 * (IH) + 1], 1);     \
+  }
+#define UNIMM_TN_SYNC_READS()                                                                                   \
+  __builtin_amdgcn_s_barrier();                                                                                 \
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(fa[1][0]), \
+               "+v"(fa[1][1]), "+v"(fa[1][2]), "+v"(fa[1][3]), "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2]), "+v"(fb[0][3]), \
+               "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[1][2]), "+v"(fb[1][3]));                                 \
+  __builtin_amdgcn_sched_barrier(0);
+#define UNIMM_TN_MFMA(JH, IH)                                                                                   \
+  {                                                                                                             \
+    __builtin_amdgcn_s_setprio(1);                                                                              \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                            \
+      _Pragma("unroll") for (int jj = 0; jj < 4; ++jj)                                                          \
+        _Pragma("unroll") for (int ii = 0; ii < 2; ++ii)                                                        \
+          acc[4 * (JH) + jj][2 * (IH) + ii] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                          \
+              fa[ks][jj], fb[ks][2 * (IH) + ii], acc[4 * (JH) + jj][2 * (IH) + ii], 0, 0, 0);                   \
+    __builtin_amdgcn_s_setprio(0);                                                                              \
+  }
+  // bias gradient = column sums of DY: on the fragments of ONE wave in four of one tile column, behind its MFMAs
+#define UNIMM_TN_BIAS(JH)                                                                                       \
+  if (do_bias) {                                                                                                \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                            \
+      _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) accb[4 * (JH) + jj] = dot_ones(fa[ks][jj], accb[4 * (JH) + jj]); \
+  }
+
+  for (int t = 0; t < nk; ++t) {
+    const uint32_t off = (uint32_t)((t & 1) * 65536);
+    uint32_t aa[8], ab[4];
+#pragma unroll
+    for (int x = 0; x < 8; ++x) aa[x] = aa0[x] + off;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) ab[x] = ab0[x] + off;
+    // ---- phase 0 (stages half-tile 1 of step t+1)
+    UNIMM_TN_READ_B(0)
+    UNIMM_TN_READ_A(0)
+    if (t + 1 < nk) UNIMM_TN_STAGE(t + 1, 1)
+    UNIMM_TN_SYNC_READS()
+    UNIMM_TN_MFMA(0, 0)
+    UNIMM_TN_BIAS(0)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase 1
+    UNIMM_TN_READ_B(1)
+    if (t + 1 < nk) UNIMM_TN_STAGE(t + 1, 2)
+    UNIMM_TN_SYNC_READS()
+    UNIMM_TN_MFMA(0, 1)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase 2
+    UNIMM_TN_READ_A(1)
+    if (t + 1 < nk) UNIMM_TN_STAGE(t + 1, 3)
+    UNIMM_TN_SYNC_READS()
+    UNIMM_TN_MFMA(1, 1)
+    UNIMM_TN_BIAS(1)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase 3: no fragment reads; certify step t+1 (every DMA older than this phase's two has landed)
+    if (t + 2 < nk) { UNIMM_TN_STAGE(t + 2, 0) wait_vmcnt<2>(); } else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    UNIMM_TN_MFMA(1, 0)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (wn == 0) __builtin_amdgcn_s_barrier();                    // G0 waits for G1's last phase (barrier counts match again)
+#undef UNIMM_TN_STAGE
+#undef UNIMM_TN_RD
+#undef UNIMM_TN_READ_A
+#undef UNIMM_TN_READ_B
+#undef UNIMM_TN_SYNC_READS
+#undef UNIMM_TN_MFMA
+#undef UNIMM_TN_BIAS
+
+  if (do_bias) {
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int n = n0 + wn * 16 * NT + i * 16 + 4 * (lane >> 4) + e;
-        if (n >= p.N) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int k = k0 + wk * 64 + j * 16 + (lane & 15);
-          if (k < p.K) atomicAdd(p.dw + (size_t)n * p.lddw + k, acc[i][j][e]);   // dw may alias another problem's / stream's
-        }
-      }
-    }
-    return;
-  }
-  // D[n][k]: lane holds k = .. + (lane&15) (column), n = .. + 4*(lane>>4) + e (rows)
-#pragma unroll
-  for (int i = 0; i < NT; ++i) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int n = n0 + wn * 16 * NT + i * 16 + 4 * (lane >> 4) + e;
-      if (n >= p.N) continue;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int k = k0 + wk * 64 + j * 16 + (lane & 15);
-        if (k < p.K) atomicAdd(p.dw + (size_t)n * p.lddw + k, acc[i][j][e]);
-      }
+      float v = accb[i];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      const int n = n0 + wn * 16 * NT + i * 16 + (lane & 15);
+      if (lane < 16 && n < p.N) atomicAdd(p.dbias + n, v);
     }
   }
+  tn_store_partial<NW, NT>(grp, p, acc, smem, gtile, split, n0, k0, wn, wk, wave, lane, tid);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1265,8 +1505,8 @@ int check_tn(const unimm_gemm_tn_args* a) {
 inline bool tn_is_big(const unimm_gemm_tn_args* a) { return a->N >= 256 && a->K >= 256 && a->M >= 4096; }
 
 // One launch of `count` (<= TN_MAXG) problems that all use the same tile size.
-int launch_tn_group(const unimm_gemm_tn_args* const* a, int count, bool big, bool shared, void* ws, int64_t ws_bytes,
-                    hipStream_t s) {
+int launch_tn_group(const unimm_gemm_tn_args* const* a, int count, bool big, bool shared, bool legacy_loop, void* ws,
+                    int64_t ws_bytes, hipStream_t s) {
   GemmTnGroup g;
   const int tb = big ? 256 : 128;
   int tiles = 0, max_m = 0;
@@ -1322,12 +1562,12 @@ int launch_tn_group(const unimm_gemm_tn_args* const* a, int count, bool big, boo
   }
   ProfRec* pr = prof_begin(16, flops, s);
   if (big) {
-    auto kern = gemm_tn_kernel<2, 4, 8>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    auto kern = legacy_loop ? gemm_tn_kernel<2, 4, 8> : gemm_tn_pp_kernel;
+    static bool attr_done[2] = {false, false};
+    if (!attr_done[legacy_loop]) {
       if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * TN_TILE_BYTES) != hipSuccess)
         return UNIMM_E_HIP;
-      attr_done = true;
+      attr_done[legacy_loop] = true;
     }
     hipLaunchKernelGGL(kern, dim3(tiles * splits), dim3(512), 8 * TN_TILE_BYTES, s, g);
   } else {
@@ -1343,7 +1583,8 @@ int launch_tn_group(const unimm_gemm_tn_args* const* a, int count, bool big, boo
 extern "C" int unimm_gemm_tn_grouped_ws(const unimm_gemm_tn_args* a, int32_t count, int32_t shared_chip, void* ws,
                                         int64_t ws_bytes, void* stream) {
   if (a == nullptr || count <= 0 || (ws != nullptr && (ws_bytes < 0 || ((uintptr_t)ws & 255)))) return UNIMM_E_ARG;
-  const bool shared = shared_chip != 0;
+  const bool shared = (shared_chip & 1) != 0;
+  const bool legacy_loop = (shared_chip & 2) != 0;   // A/B only: the lock-step loop of rounds 1-2 for the 256x256 tile
   for (int i = 0; i < count; ++i) {
     const int rc = check_tn(a + i);
     if (rc != UNIMM_OK) return rc;
@@ -1357,13 +1598,13 @@ extern "C" int unimm_gemm_tn_grouped_ws(const unimm_gemm_tn_args* a, int32_t cou
       if (tn_is_big(a + i) != big) continue;
       sel[n++] = a + i;
       if (n == TN_MAXG) {
-        const int rc = launch_tn_group(sel, n, big, shared, ws, ws_bytes, s);
+        const int rc = launch_tn_group(sel, n, big, shared, legacy_loop, ws, ws_bytes, s);
         if (rc != UNIMM_OK) return rc;
         n = 0;
       }
     }
     if (n > 0) {
-      const int rc = launch_tn_group(sel, n, big, shared, ws, ws_bytes, s);
+      const int rc = launch_tn_group(sel, n, big, shared, legacy_loop, ws, ws_bytes, s);
       if (rc != UNIMM_OK) return rc;
     }
   }

@@ -68,11 +68,11 @@ class Engine:
         self._w_version = None
         self.lin: Dict[str, _Lin] = {}
         self.ln: Dict[str, tuple] = {}
-        self.grad_bucket_hook = None     # set by the data-parallel wrapper: f(group_name, lo, hi)
+        self.grad_bucket_hook = None     # set by the data-parallel wrapper: f(group_name, more_follow_at_once)
         self._anchor = None
         self.last_seq_t = None
         self.unpad = True                # run the text stream on valid rows only (see the plan step of _forward)
-        self._wq = []                    # queued weight-gradient problems of the block being back-propagated
+        self._wq = []                    # queued weight-gradient problems (text side) waiting for their grouped launch
         self.lazy_ln = os.environ.get("UNIMM_LAZY_LN", "1") == "1"   # residual epilogues evaluate the previous LayerNorm
         # Option: grouped weight-gradient launches on a side stream (UNIMM_WGRAD_STREAM=1): +1.8 % throughput in
         # interleaved runs (61.2 -> 60.1 ms) because the next block's GEMMs fill the partial last round and the
@@ -105,6 +105,12 @@ class Engine:
         self._wgrad_ws = {}
         self._plist = []
         self.gemm_tile = 0               # tuning code handed to every encoder GEMM (unimm_gemm_nt_args.tile; 0 = automatic)
+        # Weight-gradient launches cover SEVERAL encoder blocks (see `_flush_due`): a launch is due once its 256x256 tiles
+        # fill about `wgrad_group_rounds` rounds of the chip; a data-parallel wrapper may lower it (smaller, earlier buckets).
+        self.wgrad_group_rounds = 4
+        self._pending = []               # gradient buckets whose weight gradients are still queued: (group, #text, #image queued)
+        self._nq = [0, 0]                # weight-gradient problems ever queued (text side, image side) ...
+        self._nf = [0, 0]                # ... and launched
 
     def register_arena_user(self, obj):
         import weakref
@@ -323,9 +329,40 @@ class Engine:
 
     def _wgrad(self, dy, x, gw, M, N, K, dbias=None):
         """dW += dy^T x (+ bias gradient).  Nothing downstream in the backward chain reads a weight gradient,
-        so the call is only queued; `_flush_wgrad` (end of each encoder block = one gradient bucket) hands
-        the block's whole list to one grouped launch.  dy / x stay referenced by the queue until then."""
+        so the call is only queued; `_flush_wgrad` hands the list of SEVERAL encoder blocks to one grouped launch
+        (`_flush_due` says when).  dy / x stay referenced by the queue until then."""
         (self._wq_img if self._on_side else self._wq).append((dy, x, gw, M, N, K, dbias))
+        self._nq[1 if self._on_side else 0] += 1
+
+    @staticmethod
+    def _big_tiles(queue):
+        """256x256 output tiles of the queue's problems that take the big tile (csrc/gemm.hip: tn_is_big)."""
+        t = 0
+        for dy, x, gw, M, N, K, _ in queue:
+            M = dy.shape[0] if M is None else M
+            N = dy.shape[1] if N is None else N
+            K = x.shape[1] if K is None else K
+            if N >= 256 and K >= 256 and M >= 4096:
+                t += ((N + 255) // 256) * ((K + 255) // 256)
+        return t
+
+    def _flush_due(self, queue):
+        """Weight-gradient launches are grouped over blocks.  One block's 4-5 gradients are ~110 tiles: less than half a
+        round of the 256 CUs, so the launcher had to split the reduction 7 ways and every one of the 756 workgroups ended
+        by adding its 256 KiB partial tile with fp32 atomics (51 us per workgroup at the per-CU atomic rate against
+        118 us of main loop; 8x the algorithmic write traffic).  Nothing waits for a weight gradient, so the queue
+        simply keeps growing until its tiles fill whole rounds WITHOUT a split: each tile is then reduced by one
+        workgroup over all rows and written once (round 3: 484 -> 394 us per text block at 7 blocks per launch).
+        Due = the tile count sits just below a multiple of 256 (<= 12.5 % of the last round idle) and covers at least half
+        of `wgrad_group_rounds`, or exceeds it, or the launch's descriptor table (48 problems) is nearly full."""
+        if len(queue) >= 40:
+            return True
+        t = self._big_tiles(queue)
+        slots = 256
+        if t >= self.wgrad_group_rounds * slots:
+            return True
+        waste = (-t) % slots
+        return t >= max(2, self.wgrad_group_rounds // 2) * slots - 32 and waste <= slots // 8
 
     def _ws(self, which):
         """Zero-initialised workspace of the weight-gradient launches of one stream (0 bytes = fp32-atomic path)."""
@@ -336,17 +373,22 @@ class Engine:
             t = self._wgrad_ws[which] = torch.zeros(self.wgrad_ws_bytes, dtype=torch.uint8, device=self.arena.flat.device)
         return t
 
-    def _flush_wgrad(self):
+    def _flush_wgrad(self, force=False):
+        """Launch the queues that are due (all of them with force=True)."""
         shared = self._dual()                     # the launches of this backward share the chip with the other stream's
-        if self._wq_img or self._fq_img:          # image-side problems: operands were produced on that stream
-            with self._img():
+        if (self._wq_img or self._fq_img) and (force or self._flush_due(self._wq_img)):
+            with self._img():                     # image-side problems: operands were produced on that stream
                 L.gemm_tn_grouped(self._wq_img, shared=shared, ws=self._ws("img"))
                 L.colpartials_finish_grouped(self._fq_img)
             self._wq_img, self._fq_img = [], []
+            self._nf[1] = self._nq[1]
         if self._on_side:
             return                                # the text side's queues are flushed from the text side
+        if not (force or self._flush_due(self._wq)):
+            return
         L.colpartials_finish_grouped(self._fq)
         self._fq = []
+        self._nf[0] = self._nq[0]
         if not self._wq:
             return
         if not self.wgrad_stream:
@@ -1104,11 +1146,28 @@ class Engine:
         self._bucket_done("text_embeddings")
 
     def _bucket_done(self, group):
-        self._flush_wgrad()                       # the bucket's queued weight gradients
+        """A block's backward is enqueued.  Its weight gradients may stay queued for a later grouped launch (`_flush_due`);
+        the data-parallel hook of a bucket fires once the launches that cover it are enqueued, in bucket order."""
+        last = group == "text_embeddings"
+        force = last or group == "heads"          # the decoder's gradient has its own row count: a launch of its own
         if self.grad_bucket_hook is not None:
-            self._join_wgrad()                    # the exchange reads them
-            if not self._on_side:
-                self._to_txt()                    # ... including the ones the image side produced for this bucket
-            self.grad_bucket_hook(group)
-        elif group == "text_embeddings":          # last bucket: everything joined before the caller continues
+            self._pending.append((group, self._nq[0], self._nq[1]))
+        self._flush_wgrad(force=force)
+        if self.grad_bucket_hook is not None:
+            fired = False
+            while self._pending and not self._on_side:
+                g, nt, ni = self._pending[0]
+                if self._nf[0] < nt or self._nf[1] < ni:
+                    break
+                if not fired:
+                    self._join_wgrad()            # the exchange reads them
+                    self._to_txt()                # ... including the ones the image side produced for these buckets
+                    fired = True
+                self._pending.pop(0)
+                nxt = self._pending[0] if self._pending else None
+                more = nxt is not None and self._nf[0] >= nxt[1] and self._nf[1] >= nxt[2]
+                self.grad_bucket_hook(g, more)    # more: the next bucket follows at once (adjacent slices can travel together)
+            assert not (last and self._pending), self._pending
+        elif last:                                # last bucket: everything joined before the caller continues
             self._join_wgrad()
+            self._to_txt()                        # ... including the image side's last grouped launch

@@ -211,7 +211,7 @@ def gemm_tn_grouped(problems, shared=None, ws=None):
     if shared is None and ws is None:
         _check(lib().unimm_gemm_tn_grouped(C.addressof(arr), n, _stream()), "unimm_gemm_tn_grouped")
         return
-    _check(lib().unimm_gemm_tn_grouped_ws(C.addressof(arr), n, 1 if shared else 0, _P(ws),
+    _check(lib().unimm_gemm_tn_grouped_ws(C.addressof(arr), n, int(shared or 0), _P(ws),
                                           ws.numel() if ws is not None else 0, _stream()), "unimm_gemm_tn_grouped_ws")
 
 

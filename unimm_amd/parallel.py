@@ -44,6 +44,9 @@ class DataParallelRCCL(nn.Module):
         self._pending = []
         self._comm_stream = None
         self._done = set()
+        self._run = None                 # open run of adjacent buckets: [lo, hi, count]
+        self._wire16 = None              # persistent exchange buffers (see _exchange_buffers)
+        self._shard = None
         eng = self._engine()
         if eng is not None:
             if device is None:
@@ -79,6 +82,7 @@ class DataParallelRCCL(nn.Module):
 
     def forward(self, *inputs, **kwargs):
         self._done.clear()
+        self._run = None
         return self.module(*inputs, **kwargs)
 
     # -- gradient exchange ---------------------------------------------------------------------
@@ -91,15 +95,36 @@ class DataParallelRCCL(nn.Module):
         finally:
             self._sync = old
 
-    def _exchange(self, t):
-        """Average `t` (a contiguous fp32 slice of the gradient arena) over the ranks, in place."""
-        inv = 1.0 / self.world
-        wire = t
+    def _exchange_buffers(self, lo, hi):
+        """Persistent exchange buffers (allocated once, on first use): a bf16 mirror of the gradient arena for the bf16
+        wire (a bucket travels as the same [lo, hi) slice of it) and one reduce-scatter shard sized for the largest
+        exchange.  A step allocates nothing."""
+        wire = None
         if self.wire_dtype == "bf16":
-            wire = (t * inv).to(torch.bfloat16)          # pre-divided: the bf16 sum stays in range
+            if self._wire16 is None:
+                self._wire16 = torch.empty(self.arena.grad_flat.numel(), dtype=torch.bfloat16, device=self.arena.grad_flat.device)
+            wire = self._wire16[lo:hi]
+        shard = None
+        if self.algorithm == "rs_ag" and self.world > 1 and (hi - lo) % self.world == 0:
+            need = (hi - lo) // self.world
+            dt = torch.bfloat16 if self.wire_dtype == "bf16" else torch.float32
+            if self._shard is None or self._shard.numel() < need:
+                self._shard = torch.empty(max(need, self.arena.grad_flat.numel() // self.world + 64), dtype=dt,
+                                          device=self.arena.grad_flat.device)
+            shard = self._shard[:need]
+        return wire, shard
+
+    def _exchange(self, lo, hi):
+        """Average grad_flat[lo:hi] (a contiguous fp32 slice of the gradient arena) over the ranks, in place."""
+        t = self.arena.grad_flat[lo:hi]
+        inv = 1.0 / self.world
+        wire, shard = self._exchange_buffers(lo, hi)
+        if wire is None:
+            wire = t
+        else:
+            torch.mul(t, inv, out=wire)                  # pre-divided: the bf16 sum stays in range
         n = wire.numel()
-        if self.algorithm == "rs_ag" and self.world > 1 and n % self.world == 0:
-            shard = torch.empty(n // self.world, dtype=wire.dtype, device=wire.device)
+        if shard is not None:
             dist.reduce_scatter_tensor(shard, wire, op=dist.ReduceOp.SUM, group=self.group)
             dist.all_gather_into_tensor(wire, shard, group=self.group)
         else:
@@ -111,15 +136,14 @@ class DataParallelRCCL(nn.Module):
         self._stats["bytes_wire"] += n * wire.element_size()
         self._stats["calls"] += 1
 
-    def _reduce_slice(self, lo, hi):
-        t = self.arena.grad_flat[lo:hi]
+    def _reduce_slice(self, lo, hi, n_buckets=1):
         if self._comm_stream is not None:
             self._comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._comm_stream):
-                self._exchange(t)
+                self._exchange(lo, hi)
         else:
-            self._exchange(t)
-        self._stats["buckets"] += 1
+            self._exchange(lo, hi)
+        self._stats["buckets"] += n_buckets
 
     def comm_stats(self, reset=False):
         """Buckets exchanged, bytes put on the wire per rank (payload, before the algorithm's factor), collective calls."""
@@ -129,15 +153,29 @@ class DataParallelRCCL(nn.Module):
             self._stats = dict(buckets=0, bytes_wire=0, calls=0)
         return out
 
-    def _on_bucket(self, group):
-        """Called by the engine when backward has finished every gradient of one arena group."""
+    def _on_bucket(self, group, more=False):
+        """Called by the engine when every gradient of one arena group is final (its kernels are enqueued).  The engine
+        launches the weight gradients of several blocks together, so buckets arrive in runs (`more` = the next one
+        follows at once): adjacent slices of a run travel as ONE collective."""
         if not self._sync or (self.world == 1 and not self._single_ok):
             return
+        if group in self._done:
+            raise RuntimeError(f"gradient bucket {group!r} was handed over twice in one step")
         lo, hi = self._ranges[group]
-        self._reduce_slice(lo, hi)
         self._done.add(group)
-        if len(self._done) == len(self._ranges) and self._comm_stream is not None:
-            torch.cuda.current_stream().wait_stream(self._comm_stream)   # optimizer sees reduced grads
+        if self._run and (self._run[0] == hi or self._run[1] == lo):          # extends the open run
+            self._run = [min(lo, self._run[0]), max(hi, self._run[1]), self._run[2] + 1]
+        else:
+            if self._run:
+                self._reduce_slice(*self._run)
+            self._run = [lo, hi, 1]
+        if not more:
+            self._reduce_slice(*self._run)
+            self._run = None
+        if len(self._done) == len(self._ranges):
+            assert self._run is None
+            if self._comm_stream is not None:
+                torch.cuda.current_stream().wait_stream(self._comm_stream)   # optimizer sees reduced grads
 
     def sync_gradients(self):
         """Explicit reduction of whatever has not been reduced yet (generic modules without the engine
