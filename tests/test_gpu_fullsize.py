@@ -416,3 +416,136 @@ def test_bs240_full_config_properties(golden_dir):
             assert e <= 1e-2 * (1 + abs(float(want[name]))), (c, name, e)
         e = float((got[5].cpu() - want["nsp"]).abs().max())
         assert e <= 1e-2 * (1 + float(want["nsp"].abs().max())), (c, "nsp", e)
+
+
+# ------------------------------------------------------------------------------------------------------
+# BASELINE configs[3] and [4] at the full config: the two workloads that were bench-only until round 3
+# ------------------------------------------------------------------------------------------------------
+def _call_kwargs(b, sl=slice(None), dev=None, labels=True):
+    mv = (lambda t: t[sl].to(dev)) if dev else (lambda t: t[sl])
+    kw = dict(token_type_ids=mv(b["token_type_ids"]), position_ids=mv(b["token_position_ids"]), attention_mask=mv(b["attention_mask"]),
+              co_attention_mask=mv(b["co_attention_mask"]), image_attention_mask=mv(b["image_attention_mask"]))
+    if labels:
+        kw.update(masked_lm_labels=mv(b["masked_lm_labels"]), image_label=mv(b["image_label"]), image_target=mv(b["image_target"]),
+                  next_sentence_label=mv(b["next_sentence_label"]),
+                  nsp_weight=b["nsp_weight"].to(dev) if dev else b["nsp_weight"], lm_weight=mv(b["lm_weight"]))
+    return (mv(b["input_ids"]), mv(b["image_feat"]), mv(b["image_loc"])), kw
+
+
+def test_dense_finetune_b100_full_config_properties():
+    """BASELINE configs[3] (dense_annotation_finetuning.py:253-296): one micro-step of 100 discriminative sequences,
+    2 per image, objective = NeuralNDCG^T over the 100 options + LM loss + 0 x NSP, full config, dropout off:
+    finite; unpadded == padded; two streams == one; the ranking term equals the PyTorch (CPU-formulation) path of
+    unimm_amd.ranking on the same scores; losses and NSP logits of two 6-row chunks == the CPU oracle."""
+    from oracle import vilbert_ref as R
+    from unimm_amd import ranking, synth
+    model, ocfg, sd = build_full(seed=5)
+    eng = model.engine
+    n = 100
+    b = synth.make_batch(n_seq=n, T=256, R=37, cfg=model.config, seed=4321, sequences_per_image=2, device="cuda", modes=["dis"] * n)
+    g = torch.Generator().manual_seed(77)
+    relevance = torch.tensor([0, 0, 0, 0, 0.2, 0.4, 0.6, 1.0])[torch.randint(0, 8, (1, n), generator=g)].cuda()
+
+    def run(unpad, dual):
+        eng.unpad, eng.dual_stream = unpad, dual
+        model.zero_grad(set_to_none=True)
+        args, kw = _call_kwargs(b)
+        lm, img, nsp_l, _, _, nsp = model(*args, **kw, _want_lm_scores=False)
+        loss, parts = ranking.dense_finetune_loss(nsp, b["next_sentence_label"], relevance, lm, 0.0, num_options=n)
+        loss.backward()
+        torch.cuda.synchronize()
+        return (torch.stack([loss.detach().reshape(()), lm.detach().reshape(()), parts["target"].detach().reshape(())]).clone(),
+                nsp.detach().clone(), eng.arena.grad_flat.clone())
+
+    was = (eng.unpad, eng.dual_stream)
+    try:
+        base = run(True, True)
+        padded = run(False, True)
+        single = run(True, False)
+    finally:
+        eng.unpad, eng.dual_stream = was
+    assert torch.isfinite(base[0]).all() and torch.isfinite(base[2]).all()
+    print(f"\ndense b=100 (loss, lm, NeuralNDCG^T term): {[round(float(x), 4) for x in base[0]]}")
+    d_loss = float((base[0] - padded[0]).abs().max())
+    d_nsp = float((base[1] - padded[1]).abs().max())
+    d_grad = float((base[2] - padded[2]).abs().max() / padded[2].abs().max())
+    print(f"  unpadded vs padded: losses {d_loss:.2e}, nsp {d_nsp:.2e}, gradients {d_grad:.2e} of max|g|")
+    assert d_loss <= 2e-3 and d_nsp <= 2e-3 and d_grad <= 1e-2
+    assert torch.equal(base[0], single[0]) and torch.equal(base[1], single[1])
+    d2 = float((base[2] - single[2]).abs().max() / single[2].abs().max())
+    print(f"  two streams vs one: losses bit-identical, gradients {d2:.2e} of max|g| (atomics order)")
+    assert d2 <= 1e-4
+    # the fused NeuralNDCG^T kernel against the PyTorch formulation (the one tests/test_ranking_cpu.py pins to the
+    # reference's utils/rank_loss.py) on this step's scores, evaluated on the CPU
+    p_answer = torch.softmax(base[1].float().view(1, n, 2), dim=-1)[:, :, 0].cpu()
+    want = ranking.neuralNDCG_transposed_torch(p_answer, relevance.float().cpu())
+    e = abs(float(base[0][2]) - float(want))
+    print(f"  NeuralNDCG^T: kernel {float(base[0][2]):.6f} torch/CPU {float(want):.6f}")
+    assert e <= 1e-4 * max(1.0, abs(float(want))), e
+    for c in (0, 11):
+        sl = slice(6 * c, 6 * c + 6)
+        args, kw = _call_kwargs(b, sl)
+        with torch.no_grad():
+            got = model(*args, **kw, _want_lm_scores=False)
+            cargs, ckw = _call_kwargs(b, sl, dev="cpu")
+            want = R.forward(dict(sd), ocfg, *cargs, **ckw)
+        for name, gi in (("lm_loss", 0), ("img_loss", 1), ("nsp_loss", 2)):
+            e = abs(float(got[gi]) - float(want[name]))
+            print(f"  chunk {c}: {name} hip {float(got[gi]):.4f} oracle {float(want[name]):.4f}")
+            assert e <= 1e-2 * (1 + abs(float(want[name]))), (c, name, e)
+        e = float((got[5].cpu() - want["nsp"]).abs().max())
+        assert e <= 1e-2 * (1 + float(want["nsp"].abs().max())), (c, "nsp", e)
+
+
+def test_generative_scoring_chunk250_full_config_properties():
+    """BASELINE configs[4] (val_lm.py:121-149): one chunk of 250 generative candidate sequences, full config: the
+    sequence log-likelihoods (decoded on the labelled rows only) are finite, the unpadded schedule == the padded one,
+    12 sampled sequences == the oracle's dense-logits cross entropy summed per sequence, and the ranks the scores
+    induce agree with the oracle's wherever the oracle's margin between two candidates exceeds the tolerance."""
+    from oracle import vilbert_ref as R
+    from unimm_amd import synth
+    from unimm_amd.harness import scores_to_ranks
+    model, ocfg, sd = build_full(seed=5)
+    eng = model.engine
+    n = 250
+    b = synth.make_batch(n_seq=n, T=256, R=37, cfg=model.config, seed=999, sequences_per_image=250, device="cuda",
+                         modes=["gen"] * n, mask_prob=0.0)
+    args, kw = _call_kwargs(b, labels=False)
+    res = {}
+    was = eng.unpad
+    try:
+        for unpad in (True, False):
+            eng.unpad = unpad
+            scores, _ = model.sequence_log_likelihood(*args, b["masked_lm_labels"], **kw)
+            torch.cuda.synchronize()
+            res[unpad] = scores.clone()
+    finally:
+        eng.unpad = was
+    got = res[True]
+    assert torch.isfinite(got).all() and (got < 0).all()
+    d = float((res[True] - res[False]).abs().max())
+    print(f"\nscoring chunk of 250: log-likelihoods {float(got.min()):.2f} .. {float(got.max()):.2f}; unpadded vs padded {d:.2e}")
+    assert d <= 2e-3 * float(got.abs().max())
+    pick = list(range(0, n, 21))[:12]
+    want = []
+    for i in pick:                                   # the oracle, one sequence at a time (dense logits: [1, 256, 30522])
+        cargs, ckw = _call_kwargs(b, slice(i, i + 1), dev="cpu", labels=False)
+        with torch.no_grad():
+            o = R.forward(dict(sd), ocfg, *cargs, **ckw)
+            lab = b["masked_lm_labels"][i:i + 1].cpu()
+            nll = torch.nn.functional.cross_entropy(o["pred_t"].view(-1, o["pred_t"].shape[-1]), lab.view(-1), ignore_index=-1,
+                                                    reduction="none").view(1, -1)
+        want.append(float(-nll.sum()))
+    want = torch.tensor(want)
+    sel = got[pick].cpu()
+    tol = 1e-2 * float(want.abs().max())
+    print(f"  12 sequences vs oracle: max |err| {float((sel - want).abs().max()):.3e} (values {float(want.min()):.2f} .. {float(want.max()):.2f}, gate {tol:.3e})")
+    assert float((sel - want).abs().max()) <= tol
+    # ranks among the 12 sampled candidates: every pair the oracle separates by more than 2 x tol keeps its order
+    r_got = scores_to_ranks(sel.view(1, 1, -1)).view(-1)
+    r_want = scores_to_ranks(want.view(1, 1, -1)).view(-1)
+    for a_ in range(12):
+        for c_ in range(12):
+            if want[a_] - want[c_] > 2 * tol:
+                assert r_got[a_] < r_got[c_], (a_, c_, float(want[a_]), float(want[c_]), float(sel[a_]), float(sel[c_]))
+    assert sorted(r_got.tolist()) == list(range(1, 13)) and sorted(r_want.tolist()) == list(range(1, 13))

@@ -23,13 +23,18 @@ struct LinF32 {
   int relu, accumulate;
 };
 
-// One wave per 16x16 output tile, four tiles per workgroup.  v_mfma_f32_16x16x4_f32: lane l supplies A[i = l & 15][k = l >> 4]
-// and B[k = l >> 4][j = l & 15]; D[row = 4 (l >> 4) + r][col = l & 15] in register r.  Bit for bit a k-ordered fmaf chain.
+// One workgroup per 16x16 output tile; its four waves split the reduction (K) four ways and meet in LDS.  With one wave
+// per tile and one dependent load -> MFMA chain of K / 16 steps, the 9 launches of a step were pure latency (48 us each for
+// 0.4 GFLOP in all: 960-3,072 waves on 1,024 SIMDs, nothing to hide a load behind); a quarter of the chain per wave and four
+// chunks of loads in flight per wave bring them to a few microseconds.
+// v_mfma_f32_16x16x4_f32: lane l supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; D[row = 4 (l >> 4) + r]
+// [col = l & 15] in register r.  Bit for bit a k-ordered fmaf chain per wave; the four partial sums are added in wave order.
 __global__ __launch_bounds__(256) void linear_f32_kernel(LinF32 p) {
-  const int lane = threadIdx.x & 63;
-  const int tiles_n = (p.N + 15) >> 4, tiles_m = (p.M + 15) >> 4;
-  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (tile >= tiles_m * tiles_n) return;                       // wave-uniform
+  __shared__ float red[3][64][4];
+  __shared__ float reds[3][16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tiles_n = (p.N + 15) >> 4;
+  const int tile = blockIdx.x;
   const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
   const int i = lane & 15, q = lane >> 4;
   const int am = tm * 16 + i, bn = tn * 16 + i;
@@ -38,11 +43,33 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(LinF32 p) {
   const float* bp = p.b + (long)(b_ok ? bn : 0) * p.sb_n;
   v4f acc = {0.f, 0.f, 0.f, 0.f};
   float asum = 0.f;                                           // sum over k of this lane's A elements (row sums of A)
+  // this wave's share of the reduction: whole 16-deep chunks
+  const int chunks = (p.K + 15) >> 4, per = (chunks + 3) >> 2;
+  const int kbeg = wave * per * 16;
+  int kend = kbeg + per * 16;
+  kend = kend < p.K ? kend : p.K;
   if (p.sa_k == 1 && p.sb_k == 1 && (p.K & 15) == 0 && ((p.sa_m | p.sb_n) & 3) == 0 &&
       ((((uintptr_t)p.a) | ((uintptr_t)p.b)) & 15) == 0) {
     // both operands reduction-contiguous: 16-byte loads; MFMA e of a 16-deep chunk sums k = k0 + 4 q' + e over q' = 0..3
     // (the same k permutation on both operands, so every product of the chunk is taken exactly once)
-    for (int k0 = 0; k0 < p.K; k0 += 16) {
+    int k0 = kbeg;
+    for (; k0 + 64 <= kend; k0 += 64) {                       // four chunks of loads in flight
+      v4f av[4], bv[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        av[c] = *reinterpret_cast<const v4f*>(ap + k0 + 16 * c + 4 * q);
+        bv[c] = *reinterpret_cast<const v4f*>(bp + k0 + 16 * c + 4 * q);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (!a_ok) av[c] = v4f{0.f, 0.f, 0.f, 0.f};
+        if (!b_ok) bv[c] = v4f{0.f, 0.f, 0.f, 0.f};
+        asum += (av[c][0] + av[c][1]) + (av[c][2] + av[c][3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][e], bv[c][e], acc, 0, 0, 0);
+      }
+    }
+    for (; k0 < kend; k0 += 16) {
       v4f av = *reinterpret_cast<const v4f*>(ap + k0 + 4 * q);
       v4f bv = *reinterpret_cast<const v4f*>(bp + k0 + 4 * q);
       if (!a_ok) av = v4f{0.f, 0.f, 0.f, 0.f};
@@ -52,21 +79,37 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(LinF32 p) {
       for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[e], acc, 0, 0, 0);
     }
   } else {
-#pragma unroll 4
-    for (int k0 = 0; k0 < p.K; k0 += 4) {
-      const int k = k0 + q;
-      const bool k_ok = k < p.K;
-      const float av = (a_ok && k_ok) ? ap[(long)k * p.sa_k] : 0.f;
-      const float bv = (b_ok && k_ok) ? bp[(long)k * p.sb_k] : 0.f;
-      asum += av;
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {                // eight loads per operand in flight
+      float av[8], bv[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int k = k0 + 4 * c + q;
+        const bool k_ok = k < kend;
+        av[c] = (a_ok && k_ok) ? ap[(long)k * p.sa_k] : 0.f;
+        bv[c] = (b_ok && k_ok) ? bp[(long)k * p.sb_k] : 0.f;
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        asum += av[c];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c], bv[c], acc, 0, 0, 0);
+      }
     }
   }
-  if (p.rowsum != nullptr && tn == 0) {                       // rowsum[m] += sum_k A[m, k]: the bias gradient of the dW form
-    asum += __shfl_xor(asum, 16, 64);
-    asum += __shfl_xor(asum, 32, 64);
-    if (q == 0 && a_ok) atomicAdd(p.rowsum + am, asum);
+  asum += __shfl_xor(asum, 16, 64);
+  asum += __shfl_xor(asum, 32, 64);
+  if (wave > 0) {
+    *reinterpret_cast<v4f*>(&red[wave - 1][lane][0]) = acc;
+    if (lane < 16) reds[wave - 1][lane] = asum;
   }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int w = 0; w < 3; ++w) {
+    const v4f o = *reinterpret_cast<const v4f*>(&red[w][lane][0]);
+    acc += o;
+    if (lane < 16) asum += reds[w][lane];
+  }
+  if (p.rowsum != nullptr && tn == 0 && q == 0 && a_ok) atomicAdd(p.rowsum + am, asum);   // rowsum[m] += sum_k A[m, k]
   const int n = tn * 16 + i;
   if (n >= p.N) return;
   const float bias = p.bias != nullptr ? p.bias[n] : 0.f;
@@ -103,7 +146,7 @@ extern "C" int unimm_linear_f32(const unimm_linear_f32_args* a, void* stream) {
   p.sa_m = a->sa_m; p.sa_k = a->sa_k; p.sb_k = a->sb_k; p.sb_n = a->sb_n; p.ldo = a->ldo;
   p.relu = a->relu; p.accumulate = a->accumulate;
   const long tiles = (long)((p.M + 15) / 16) * ((p.N + 15) / 16);
-  hipLaunchKernelGGL(linear_f32_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(linear_f32_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, p);
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;
 }
