@@ -94,6 +94,8 @@ typedef struct {
   float* dbias;   /* [N] fp32 or NULL */
   int32_t M, N, K;
   int32_t lddy, ldx, lddw;
+  const int32_t* m_dev; /* or NULL: device word holding the number of reduction rows actually present; M is then the
+                         * CAPACITY the launch is sized for (replayed launch sequences: see unimm_plan_build) */
 } unimm_gemm_tn_args;
 
 int unimm_gemm_tn(const unimm_gemm_tn_args* args, void* stream);
@@ -198,9 +200,18 @@ int unimm_plan_lengths(const uint32_t* text_words, int32_t t_q_stride, int32_t t
                        int32_t c_q_stride, int32_t c_b_stride, int32_t R, const int32_t* labels, const int32_t* weights,
                        const float* nsp_weight, const int32_t* image_label, int32_t B, int32_t T, int32_t* header,
                        void* stream);
+/* Replayed launch sequences (unimm_amd/graphs.py: the step as two hipGraphs): kernel ARGUMENTS are frozen at capture, so a
+ * launch is sized for a CAPACITY (the step's row counts rounded up to a bucket) and every kernel whose result would change
+ * with the surplus rows reads the REAL count from device memory (the `*_dev` arguments below and in the structs above;
+ * NULL = the argument is exact).  unimm_plan_build writes those words: dims_i = {valid text rows, decoded rows, regions in
+ * the masked-region loss}, dims_f = {1 / decoded rows, 1 / regions (inf when none, as the reference's division)}; it also
+ * fills rows[real .. rows_cap) and the lm_* lists [real .. lm_cap) with safe values (index 0, label -1, weight 0) so that
+ * row-independent kernels (GEMM, LayerNorm forward, gathers) may run over the whole capacity.  dims_i / dims_f both or
+ * neither; capacities 0 = lists are exact. */
 int unimm_plan_build(const int32_t* header, const int32_t* labels, const int32_t* weights, int32_t B, int32_t T,
                      int32_t* off, int32_t* lens, int64_t* rows, int64_t* inv, int32_t* lm_pos, int32_t* lm_idx,
-                     int32_t* lm_label, int32_t* lm_weight, void* stream);
+                     int32_t* lm_label, int32_t* lm_weight, int32_t rows_cap, int32_t lm_cap, int32_t* dims_i, float* dims_f,
+                     void* stream);
 
 /* y = LayerNorm(x) (eps inside sqrt, torch.nn.LayerNorm; models/vilbert_dialog.py:279) with optional
  * dropout on y.  The residual stream is fp32 (as under the reference's autocast, where layer_norm and
@@ -229,7 +240,7 @@ int unimm_layernorm_bwd(const void* dy, const float* x, const float* mean, const
 int unimm_layernorm_bwd_partials(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                                  void* dx, void* dx_drop, float* partials, int32_t M, int32_t H, uint32_t drop_key,
                                  uint32_t drop_thr, float drop_scale, uint32_t odrop_key, uint32_t odrop_thr,
-                                 float odrop_scale, int32_t* blocks_out, void* stream);
+                                 float odrop_scale, int32_t* blocks_out, const int32_t* m_dev, void* stream);
 #define UNIMM_FINISH_MAX 8
 typedef struct {
   const float* partials;
@@ -248,6 +259,8 @@ typedef struct {
   int32_t M, H, type_vocab;
   float eps;
   uint32_t drop_key, drop_thr; float drop_scale;
+  const int32_t* m_dev; /* or NULL: device word with the rows actually present (M = capacity) */
+  const int64_t* rows;  /* or NULL: row r takes ids / pos / typ at index rows[r] (the unpadded schedule's row map) */
 } unimm_embed_args;
 
 int unimm_embed_fwd(const unimm_embed_args* args, float* y32, void* y16, void* stream);
@@ -308,7 +321,8 @@ int unimm_gelu_bwd(const void* dt, const void* u, void* du, int64_t n, void* str
 /* scatter == 0: dst[i,:] = src[idx[i],:]; scatter != 0: dst[idx[i],:] = src[i,:]  (bf16 rows of H, idx unique).
  * Selects the labelled token rows the decoder runs on (the reference decodes all 256 rows and then
  * boolean-gathers, models/vilbert_dialog.py:1583-1584). */
-int unimm_gather_rows(const void* src, const int32_t* idx, void* dst, int32_t n, int32_t H, int32_t scatter, void* stream);
+int unimm_gather_rows(const void* src, const int32_t* idx, void* dst, int32_t n, int32_t H, int32_t scatter,
+                      const int32_t* n_dev, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Losses.  Row kernels (one workgroup per row) keep logits, log-sum-exp and 1-p in fp32.
@@ -319,17 +333,18 @@ int unimm_gather_rows(const void* src, const int32_t* idx, void* dst, int32_t n,
  * rowloss is the un-normalised contribution, rownll = -log p_y (generative scoring, val_lm.py:131-136),
  * lse the row's log-sum-exp.  The :1600-1604 CrossEntropy fallback is this with w = [y != -1]. */
 int unimm_lm_loss_fwd(const float* logits, const int32_t* labels, const int32_t* weights, float* rowloss,
-                      float* rownll, float* lse, int32_t n, int32_t V, int32_t ld, void* stream);
-/* dlogits (bf16 [n, ldd], columns >= V zero-filled) = g * inv_denom * d(rowloss)/d(logits) */
+                      float* rownll, float* lse, int32_t n, int32_t V, int32_t ld, const int32_t* n_dev, void* stream);
+/* dlogits (bf16 [n, ldd], columns >= V zero-filled) = g * inv_denom * d(rowloss)/d(logits); inv_dev (or NULL): the
+ * denominator's reciprocal as a device word instead of the host float */
 int unimm_lm_loss_bwd(const float* logits, const int32_t* labels, const int32_t* weights, const float* lse,
                       const float* g, float inv_denom, void* dlogits, int32_t n, int32_t V, int32_t ld,
-                      int32_t ldd, void* stream);
+                      int32_t ldd, const int32_t* n_dev, const float* inv_dev, void* stream);
 /* Masked-region KL (models/vilbert_dialog.py:1569-1574): rowloss = [label==1] * sum_j t_j (log t_j - logp_j) */
 int unimm_kl_loss_fwd(const float* pred, const float* target, const int32_t* label, float* rowloss, float* lse,
                       int32_t rows, int32_t C, int32_t ld, void* stream);
 int unimm_kl_loss_bwd(const float* pred, const float* target, const int32_t* label, const float* lse,
                       const float* g, float inv_denom, void* dpred, int32_t rows, int32_t C, int32_t ld,
-                      int32_t ldd, void* stream);
+                      int32_t ldd, const float* inv_dev, void* stream);
 /* Weighted 2-way cross-entropy, reduction 'mean' = sum w_y l / sum w_y (models/vilbert_dialog.py:1617-1621);
  * w0, w1 already divided by w0 (:1608). */
 int unimm_nsp_loss_fwd(const float* logits, const int32_t* labels, float w0, float w1, float* loss, int32_t B,
@@ -339,7 +354,8 @@ int unimm_nsp_loss_fwd(const float* logits, const int32_t* labels, float w0, flo
 int unimm_nsp_loss_bwd(const float* logits, const int32_t* labels, float w0, float w1, const float* g, const float* extra,
                        float* dlogits, int32_t B, int32_t ld, int32_t ldd, void* stream);
 /* dst[0] = scale * sum(src) (fixed order, deterministic); dst[seg[i]] += sign * src[i] */
-int unimm_reduce_sum(const float* src, int64_t n, float* dst, float scale, void* stream);
+int unimm_reduce_sum(const float* src, int64_t n, float* dst, float scale, const int32_t* n_dev, const float* scale_dev,
+                     void* stream);
 int unimm_segment_sum(const float* src, const int32_t* seg, float* dst, int64_t n, float sign, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

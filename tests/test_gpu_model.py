@@ -214,6 +214,52 @@ def test_full_config_b6_matches_reference_golden(golden_dir):
     assert torch.equal(scores_to_ranks(scores.view(1, 1, -1)).cpu(), R.scores_to_ranks(T_(want_ll).view(1, 1, -1)))
 
 
+def test_row_capacities_with_device_side_counts_equal_exact_sizes(golden_dir, small):
+    """The graph executor sizes every launch for a CAPACITY (valid rows / decoded rows rounded up to a bucket) and the
+    kernels read the real counts from device memory (unimm_plan_build -> Engine._dims).  Run eagerly with buckets
+    of 64 rows / 16 decoded rows, the step must equal the exact-size step: the surplus rows hold garbage (here: NaN-filled
+    allocations) and must never reach a loss, a column sum or a weight gradient."""
+    model, _, _ = small
+    model.eval()
+    eng = model.engine
+    g = np.load(os.path.join(golden_dir, "small_mixed.npz"))
+    args, kw = kwargs_from(g)
+    res = {}
+    was = (eng.row_bucket, eng.lm_bucket)
+    real_empty = torch.empty
+
+    def nan_empty(*a, **k):                      # surplus rows of every activation start as NaN / garbage
+        t = real_empty(*a, **k)
+        if t.is_floating_point():
+            t.fill_(float("nan"))
+        elif t.dtype in (torch.int32, torch.int64):
+            t.fill_(2 ** 30)
+        return t
+
+    try:
+        for buckets in ((1, 1), (64, 16)):
+            eng.row_bucket, eng.lm_bucket = buckets
+            model.zero_grad(set_to_none=True)
+            torch.empty = nan_empty
+            try:
+                lm, img, nsp_l, _, _, nsp = model(*args, **kw, _want_lm_scores=False)
+                (lm + img + nsp_l).sum().backward()
+            finally:
+                torch.empty = real_empty
+            torch.cuda.synchronize()
+            if buckets != (1, 1):
+                assert eng.last_plan is not None and eng.last_plan["Mv"] % 64 == 0
+            grads = torch.cat([p.grad.flatten() for p in model.parameters() if p.grad is not None]).clone()
+            res[buckets] = (torch.stack([lm, img, nsp_l]).flatten().detach().clone(), nsp.detach().clone(), grads)
+    finally:
+        eng.row_bucket, eng.lm_bucket = was
+    a, b = res[(1, 1)], res[(64, 16)]
+    assert torch.isfinite(b[0]).all() and torch.isfinite(b[2]).all()
+    assert (a[0] - b[0]).abs().max() <= 1e-6 and (a[1] - b[1]).abs().max() <= 1e-6
+    d = (a[2] - b[2]).abs().max() / a[2].abs().max()
+    assert d <= 1e-5, d                          # fp32 summation order of the weight gradients (split count follows the capacity)
+
+
 def test_unpadded_run_equals_padded_run(golden_dir, small):
     """The variable-length (valid rows only) schedule and the padded one give the same losses, scores and
     gradients: padding rows are inert (SURVEY.md 7 'hard parts': they never reach a loss or a valid row)."""

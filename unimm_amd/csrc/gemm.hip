@@ -778,6 +778,7 @@ constexpr int TN_TILE_BYTES = TK * 128 * 2;  // 16 KiB
 
 struct GemmTnParams {
   const bf16_t* dy; const bf16_t* x; float* dw; float* dbias;
+  const int32_t* m_dev;   // or NULL: reduction rows actually present (M is then a capacity)
   int M, N, K, lddy, ldx, lddw, rows_per_split;
   int tile0;   // first tile index of this problem inside a grouped launch
   int nsplit;  // splits of this problem that own rows (the others leave at once and never arrive at the tile's counter)
@@ -786,7 +787,7 @@ struct GemmTnParams {
 // drain of one fp32 partial tile per resident workgroup (256 x 256 KiB = 67 MB of memory-side atomics,
 // ~43 us, whatever the shape), so a block's 4-10 weight gradients pay that tail once instead of once each,
 // and the bigger tile pool lets the split count land on a whole number of rounds.
-constexpr int TN_MAXG = 48;   // 48 descriptors of 72 bytes + header = 3.5 KiB of kernel arguments (limit 4 KiB)
+constexpr int TN_MAXG = 48;   // 48 descriptors of 80 bytes + header = 3.8 KiB of kernel arguments (limit 4 KiB)
 struct GemmTnGroup {
   int count, total_tiles;
   int splits;            // reduction ranges per tile
@@ -971,7 +972,8 @@ __global__ __launch_bounds__(64 * WN * WK, (WN * WK * (NT == 4 ? 2 : 1) + 3) / 4
   const int n0 = tn * TNB, k0 = tk * TKB;
   const int mbeg = split * p.rows_per_split;
   int mend = mbeg + p.rows_per_split;
-  mend = mend < p.M ? mend : p.M;
+  const int mtot = p.m_dev != nullptr ? min(p.M, p.m_dev[0]) : p.M;
+  mend = mend < mtot ? mend : mtot;
   if (mbeg >= mend) return;
   const int wn = wave / WK, wk = wave % WK;
 
@@ -1160,7 +1162,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmTnGroup grp) {
   const int n0 = tn * TNB, k0 = tk * TKB;
   const int mbeg = split * p.rows_per_split;
   int mend = mbeg + p.rows_per_split;
-  mend = mend < p.M ? mend : p.M;
+  const int mtot = p.m_dev != nullptr ? min(p.M, p.m_dev[0]) : p.M;
+  mend = mend < mtot ? mend : mtot;
   if (mbeg >= mend) return;
   const int wn = wave >> 2, wk = wave & 3;                      // G0 = waves 0-3 (n-half 0), G1 = waves 4-7 (n-half 1)
   const int nk = (mend - mbeg + TK - 1) / TK;
@@ -1514,6 +1517,7 @@ int launch_tn_group(const unimm_gemm_tn_args* const* a, int count, bool big, boo
   for (int i = 0; i < count; ++i) {
     GemmTnParams& p = g.pr[i];
     p.dy = (const bf16_t*)a[i]->dy; p.x = (const bf16_t*)a[i]->x; p.dw = a[i]->dw; p.dbias = a[i]->dbias;
+    p.m_dev = a[i]->m_dev;
     p.M = a[i]->M; p.N = a[i]->N; p.K = a[i]->K; p.lddy = a[i]->lddy; p.ldx = a[i]->ldx; p.lddw = a[i]->lddw;
     p.tile0 = tiles;
     tiles += ((p.N + tb - 1) / tb) * ((p.K + tb - 1) / tb);
@@ -1552,7 +1556,9 @@ int launch_tn_group(const unimm_gemm_tn_args* const* a, int count, bool big, boo
   g.splits = splits;
   g.slabs = nullptr;
   g.counters = nullptr;
-  if (ws != nullptr && splits > 1) {
+  bool dyn_rows = false;                       // a device-side row count may leave splits without rows: they would never
+  for (int i = 0; i < count; ++i) dyn_rows = dyn_rows || g.pr[i].m_dev != nullptr;   // reach the tile's arrival counter
+  if (ws != nullptr && splits > 1 && !dyn_rows) {
     const int64_t cbytes = 16384;
     const int64_t need = cbytes + (int64_t)tiles * splits * tb * tb * 4;
     if (need <= ws_bytes && tiles <= 4096) {

@@ -65,9 +65,10 @@ __device__ __forceinline__ float row_lse(const float* __restrict__ z, int V, boo
 __global__ __launch_bounds__(256) void lm_loss_fwd_kernel(const float* __restrict__ logits, const int32_t* __restrict__ labels,
                                                           const int32_t* __restrict__ weights, float* __restrict__ rowloss,
                                                           float* __restrict__ rownll, float* __restrict__ lse_o, int V,
-                                                          int ld, float clamp_min) {
+                                                          int ld, float clamp_min, const int32_t* __restrict__ n_dev) {
   __shared__ float red[4];
   const int row = blockIdx.x;
+  if (n_dev != nullptr && row >= n_dev[0]) return;      // rows of the launch's capacity beyond the step's real count
   const float* z = logits + (size_t)row * ld;
   const float lse = row_lse(z, V, (ld & 3) == 0, red);
   if (threadIdx.x == 0) {
@@ -89,8 +90,11 @@ __global__ __launch_bounds__(256) void lm_loss_bwd_kernel(const float* __restric
                                                           const int32_t* __restrict__ weights, const float* __restrict__ lse_i,
                                                           const float* __restrict__ g, float inv_denom,
                                                           bf16_t* __restrict__ dlogits, int V, int ld, int ldd,
-                                                          float clamp_min) {
+                                                          float clamp_min, const int32_t* __restrict__ n_dev,
+                                                          const float* __restrict__ inv_dev) {
   const int row = blockIdx.x;
+  if (n_dev != nullptr && row >= n_dev[0]) return;
+  if (inv_dev != nullptr) inv_denom = inv_dev[0];
   const float* z = logits + (size_t)row * ld;
   bf16_t* dz = dlogits + (size_t)row * ldd;
   const int y = labels[row], w = weights[row];
@@ -152,9 +156,11 @@ __global__ __launch_bounds__(256) void kl_loss_fwd_kernel(const float* __restric
 __global__ __launch_bounds__(256) void kl_loss_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ target,
                                                           const int32_t* __restrict__ label, const float* __restrict__ lse_i,
                                                           const float* __restrict__ g, float inv_denom,
-                                                          bf16_t* __restrict__ dpred, int C, int ld, int ldd) {
+                                                          bf16_t* __restrict__ dpred, int C, int ld, int ldd,
+                                                          const float* __restrict__ inv_dev) {
   __shared__ float red[4];
   const int row = blockIdx.x;
+  if (inv_dev != nullptr) inv_denom = inv_dev[0];
   const float* z = pred + (size_t)row * ld;
   const float* t = target + (size_t)row * C;
   bf16_t* dz = dpred + (size_t)row * ldd;
@@ -216,8 +222,11 @@ __global__ __launch_bounds__(256) void nsp_loss_bwd_kernel(const float* __restri
 
 // dst[0] = scale * sum(src[0..n))  -- single workgroup, fixed order (deterministic)
 __global__ __launch_bounds__(256) void reduce_sum_kernel(const float* __restrict__ src, int64_t n, float* __restrict__ dst,
-                                                         float scale) {
+                                                         float scale, const int32_t* __restrict__ n_dev,
+                                                         const float* __restrict__ scale_dev) {
   __shared__ float red[4];
+  if (n_dev != nullptr) n = n_dev[0] < n ? n_dev[0] : n;
+  if (scale_dev != nullptr) scale = scale_dev[0];
   float s = 0.f;
   for (int64_t i = threadIdx.x; i < n; i += 256) s += src[i];
   s = block_sum(s, red);
@@ -234,22 +243,22 @@ __global__ void segment_sum_kernel(const float* __restrict__ src, const int32_t*
 }  // namespace
 
 extern "C" int unimm_lm_loss_fwd(const float* logits, const int32_t* labels, const int32_t* weights, float* rowloss,
-                                 float* rownll, float* lse, int32_t n, int32_t V, int32_t ld, void* stream) {
+                                 float* rownll, float* lse, int32_t n, int32_t V, int32_t ld, const int32_t* n_dev, void* stream) {
   if (!logits || !labels || !weights || !rowloss || !rownll || !lse) return UNIMM_E_ARG;
   if (n <= 0 || V <= 0 || ld < V) return UNIMM_E_SHAPE;
   hipLaunchKernelGGL(lm_loss_fwd_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, logits, labels, weights, rowloss,
-                     rownll, lse, V, ld, 1e-6f);
+                     rownll, lse, V, ld, 1e-6f, n_dev);
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;
 }
 
 extern "C" int unimm_lm_loss_bwd(const float* logits, const int32_t* labels, const int32_t* weights, const float* lse,
                                  const float* g, float inv_denom, void* dlogits, int32_t n, int32_t V, int32_t ld,
-                                 int32_t ldd, void* stream) {
+                                 int32_t ldd, const int32_t* n_dev, const float* inv_dev, void* stream) {
   if (!logits || !labels || !weights || !lse || !g || !dlogits) return UNIMM_E_ARG;
   if (n <= 0 || V <= 0 || ld < V || ldd < V || (ldd % 8)) return UNIMM_E_SHAPE;
   hipLaunchKernelGGL(lm_loss_bwd_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, logits, labels, weights, lse, g,
-                     inv_denom, (bf16_t*)dlogits, V, ld, ldd, 1e-6f);
+                     inv_denom, (bf16_t*)dlogits, V, ld, ldd, 1e-6f, n_dev, inv_dev);
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;
 }
@@ -266,11 +275,11 @@ extern "C" int unimm_kl_loss_fwd(const float* pred, const float* target, const i
 
 extern "C" int unimm_kl_loss_bwd(const float* pred, const float* target, const int32_t* label, const float* lse,
                                  const float* g, float inv_denom, void* dpred, int32_t rows, int32_t C, int32_t ld,
-                                 int32_t ldd, void* stream) {
+                                 int32_t ldd, const float* inv_dev, void* stream) {
   if (!pred || !target || !label || !lse || !g || !dpred) return UNIMM_E_ARG;
   if (rows <= 0 || C <= 0 || ld < C || ldd < C) return UNIMM_E_SHAPE;
   hipLaunchKernelGGL(kl_loss_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, pred, target, label, lse, g,
-                     inv_denom, (bf16_t*)dpred, C, ld, ldd);
+                     inv_denom, (bf16_t*)dpred, C, ld, ldd, inv_dev);
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;
 }
@@ -292,9 +301,10 @@ extern "C" int unimm_nsp_loss_bwd(const float* logits, const int32_t* labels, fl
   return UNIMM_OK;
 }
 
-extern "C" int unimm_reduce_sum(const float* src, int64_t n, float* dst, float scale, void* stream) {
+extern "C" int unimm_reduce_sum(const float* src, int64_t n, float* dst, float scale, const int32_t* n_dev,
+                                const float* scale_dev, void* stream) {
   if (!src || !dst || n <= 0) return UNIMM_E_ARG;
-  hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, src, n, dst, scale);
+  hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, src, n, dst, scale, n_dev, scale_dev);
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;
 }

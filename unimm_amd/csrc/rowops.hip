@@ -182,9 +182,34 @@ __global__ __launch_bounds__(256) void plan_build_kernel(const int32_t* __restri
                                                          int32_t* __restrict__ off, int32_t* __restrict__ lens,
                                                          int64_t* __restrict__ rows, int64_t* __restrict__ inv,
                                                          int32_t* __restrict__ lm_pos, int32_t* __restrict__ lm_idx,
-                                                         int32_t* __restrict__ lm_lab, int32_t* __restrict__ lm_w) {
+                                                         int32_t* __restrict__ lm_lab, int32_t* __restrict__ lm_w,
+                                                         int rows_cap, int lm_cap, int32_t* __restrict__ dims_i,
+                                                         float* __restrict__ dims_f) {
   __shared__ int s_off, s_lmoff, wave_cnt[4];
   const int b = blockIdx.x, t = threadIdx.x;
+  if (b == (int)gridDim.x - 1) {
+    // The extra workgroup: totals of the step into device memory (kernels of a replayed launch sequence read their row
+    // counts and loss denominators from here, their launch arguments only hold CAPACITIES), and safe values in the unused
+    // tail of every index list so that row-independent kernels may run over the whole capacity.
+    __shared__ int tot[3][4];
+    int a = 0, c = 0, g = 0;
+    for (int i = t; i < B; i += 256) { a += header[i]; c += header[B + i]; g += header[2 * B + 2 + i]; }
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); g += __shfl_xor(g, o, 64); }
+    if ((t & 63) == 0) { tot[0][t >> 6] = a; tot[1][t >> 6] = c; tot[2][t >> 6] = g; }
+    __syncthreads();
+    const int mv = tot[0][0] + tot[0][1] + tot[0][2] + tot[0][3];
+    const int nlm = tot[1][0] + tot[1][1] + tot[1][2] + tot[1][3];
+    const int nimg = tot[2][0] + tot[2][1] + tot[2][2] + tot[2][3];
+    if (t == 0 && dims_i != nullptr) {
+      dims_i[0] = mv; dims_i[1] = lm_pos != nullptr ? nlm : 0; dims_i[2] = nimg;
+      dims_f[0] = 1.0f / (float)max(nlm, 1);
+      dims_f[1] = nimg > 0 ? 1.0f / (float)nimg : __builtin_inff();      // the reference divides by max(n, 0) (:1574)
+    }
+    if (rows != nullptr) for (int i = mv + t; i < rows_cap; i += 256) rows[i] = 0;
+    if (lm_pos != nullptr)
+      for (int i = nlm + t; i < lm_cap; i += 256) { lm_pos[i] = 0; lm_idx[i] = 0; lm_lab[i] = -1; lm_w[i] = 0; }
+    return;
+  }
   // exclusive prefix sums over the sequences before this one (B is a few hundred: one strided pass)
   int a = 0, c = 0;
   for (int i = t; i < b; i += 256) { a += header[i]; c += header[B + i]; }
@@ -353,8 +378,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
                                                             const float* __restrict__ rstd_i,
                                                             const float* __restrict__ gamma, bf16_t* __restrict__ dx,
                                                             bf16_t* __restrict__ dx_drop, float* __restrict__ partials,
-                                                            int M, int H, DropoutArg drop, DropoutArg out_drop) {
+                                                            int M, int H, DropoutArg drop, DropoutArg out_drop,
+                                                            const int32_t* __restrict__ m_dev) {
   __shared__ float red[4 * 1024];  // [wave][col], reused for each of the three quantities
+  if (m_dev != nullptr) M = min(M, m_dev[0]);     // M is a capacity: rows past the real count never enter the column sums
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wave = blockIdx.x * 4 + wv;
   const int nwaves = gridDim.x * 4;
@@ -543,10 +570,13 @@ struct EmbArgs {
   int M, H, type_vocab;
   float eps;
   DropoutArg drop;
+  const int32_t* m_dev;    // or NULL: rows actually present (the launch's M is then a capacity)
+  const int64_t* rows;     // or NULL: packed row -> index into ids / pos / typ (the unpadded schedule's row map)
 };
 
 __device__ __forceinline__ void emb_gather(const EmbArgs& a, int row, int lane, Row8& x, int& id, int& pid, int& tt) {
-  id = a.ids[row]; pid = a.pos[row]; tt = a.typ[row];
+  const size_t src = a.rows != nullptr ? (size_t)a.rows[row] : (size_t)row;
+  id = a.ids[src]; pid = a.pos[src]; tt = a.typ[src];
   Row8 t1, t2;
   load_vec_f32(a.word + (size_t)id * a.H, a.H, lane, x);
   load_vec_f32(a.post + (size_t)pid * a.H, a.H, lane, t1);
@@ -565,7 +595,8 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(EmbArgs a, float* __rest
   Row8 g, b;
   load_vec_f32(a.gamma, a.H, lane, g);
   load_vec_f32(a.beta, a.H, lane, b);
-  for (int row = wave; row < a.M; row += nwaves) {
+  const int M = a.m_dev != nullptr ? min(a.M, a.m_dev[0]) : a.M;
+  for (int row = wave; row < M; row += nwaves) {
     Row8 x;
     int id, pid, tt;
     emb_gather(a, row, lane, x, id, pid, tt);
@@ -601,7 +632,8 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbArgs a, const bf16_t*
 #pragma unroll
     for (int j = 0; j < 8; ++j) { dg.v[i][j] = 0.f; db.v[i][j] = 0.f; dt0.v[i][j] = 0.f; dt1.v[i][j] = 0.f; }
   const float invH = 1.0f / (float)a.H;
-  for (int row = wave; row < a.M; row += nwaves) {
+  const int M = a.m_dev != nullptr ? min(a.M, a.m_dev[0]) : a.M;
+  for (int row = wave; row < M; row += nwaves) {
     Row8 x, dyv;
     int id, pid, tt;
     emb_gather(a, row, lane, x, id, pid, tt);
@@ -836,7 +868,8 @@ __global__ void gelu_bwd_kernel(const bf16_t* __restrict__ dt, const bf16_t* __r
 
 // dst[i, :] = src[idx[i], :]  /  dst[idx[i], :] = src[i, :]   (bf16 rows of H elements, H % 8 == 0)
 __global__ void gather_rows_kernel(const bf16_t* __restrict__ src, const int32_t* __restrict__ idx, bf16_t* __restrict__ dst,
-                                   int n, int H, int scatter) {
+                                   int n, int H, int scatter, const int32_t* __restrict__ n_dev) {
+  if (n_dev != nullptr) n = min(n, n_dev[0]);
   const int cpr = H / 8;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)n * cpr;
@@ -891,7 +924,7 @@ extern "C" int unimm_layernorm_bwd(const void* dy, const float* x, const float* 
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, s, (const bf16_t*)dy, x, mean, rstd,
                      gamma, (bf16_t*)dx, (bf16_t*)dx_drop, partials, M, H, mk_drop(drop_key, drop_thr, drop_scale),
-                     mk_drop(odrop_key, odrop_thr, odrop_scale));
+                     mk_drop(odrop_key, odrop_thr, odrop_scale), (const int32_t*)nullptr);
   UNIMM_CHECK_LAUNCH();
   hipLaunchKernelGGL(colpartials_finish_kernel, dim3((H + 63) / 64, 3), dim3(1024), 0, s, partials, blocks, 3, H, dgamma,
                      dbeta, dbias, (float*)nullptr);
@@ -902,14 +935,15 @@ extern "C" int unimm_layernorm_bwd(const void* dy, const float* x, const float* 
 extern "C" int unimm_layernorm_bwd_partials(const void* dy, const float* x, const float* mean, const float* rstd,
                                             const float* gamma, void* dx, void* dx_drop, float* partials, int32_t M, int32_t H,
                                             uint32_t drop_key, uint32_t drop_thr, float drop_scale, uint32_t odrop_key,
-                                            uint32_t odrop_thr, float odrop_scale, int32_t* blocks_out, void* stream) {
+                                            uint32_t odrop_thr, float odrop_scale, int32_t* blocks_out, const int32_t* m_dev,
+                                            void* stream) {
   if (!dy || !x || !mean || !rstd || !gamma || !dx || !partials || !blocks_out) return UNIMM_E_ARG;
   if (M <= 0 || H <= 0 || H > MAXC * 512 || (H % 8)) return UNIMM_E_SHAPE;
   int blocks = (M + 3) / 4;
   blocks = blocks > RED_BLOCKS ? RED_BLOCKS : blocks;
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, x, mean, rstd,
                      gamma, (bf16_t*)dx, (bf16_t*)dx_drop, partials, M, H, mk_drop(drop_key, drop_thr, drop_scale),
-                     mk_drop(odrop_key, odrop_thr, odrop_scale));
+                     mk_drop(odrop_key, odrop_thr, odrop_scale), m_dev);
   UNIMM_CHECK_LAUNCH();
   *blocks_out = blocks;
   return UNIMM_OK;
@@ -945,6 +979,7 @@ extern "C" int unimm_embed_fwd(const unimm_embed_args* a, float* y32, void* y, v
   e.ext = a->ext; e.gamma = a->gamma; e.beta = a->beta;
   e.M = a->M; e.H = a->H; e.type_vocab = a->type_vocab; e.eps = a->eps;
   e.drop = mk_drop(a->drop_key, a->drop_thr, a->drop_scale);
+  e.m_dev = a->m_dev; e.rows = a->rows;
   int blocks = (a->M + 3) / 4;
   blocks = blocks > 2048 ? 2048 : blocks;
   hipLaunchKernelGGL(embed_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, e, y32, (bf16_t*)y);
@@ -962,6 +997,7 @@ extern "C" int unimm_embed_bwd(const unimm_embed_args* a, const void* dy, float*
   e.ext = a->ext; e.gamma = a->gamma; e.beta = a->beta;
   e.M = a->M; e.H = a->H; e.type_vocab = a->type_vocab; e.eps = a->eps;
   e.drop = mk_drop(a->drop_key, a->drop_thr, a->drop_scale);
+  e.m_dev = a->m_dev; e.rows = a->rows;
   int blocks = (a->M + 3) / 4;
   blocks = blocks > RED_BLOCKS ? RED_BLOCKS : blocks;
   hipStream_t s = (hipStream_t)stream;
@@ -987,12 +1023,14 @@ extern "C" int unimm_plan_lengths(const uint32_t* text_words, int32_t t_q_stride
 
 extern "C" int unimm_plan_build(const int32_t* header, const int32_t* labels, const int32_t* weights, int32_t B, int32_t T,
                                 int32_t* off, int32_t* lens, int64_t* rows, int64_t* inv, int32_t* lm_pos, int32_t* lm_idx,
-                                int32_t* lm_label, int32_t* lm_weight, void* stream) {
+                                int32_t* lm_label, int32_t* lm_weight, int32_t rows_cap, int32_t lm_cap, int32_t* dims_i,
+                                float* dims_f, void* stream) {
+  if ((dims_i == nullptr) != (dims_f == nullptr)) return UNIMM_E_ARG;
   if (header == nullptr || off == nullptr || lens == nullptr) return UNIMM_E_ARG;
   if (lm_pos != nullptr && (lm_idx == nullptr || lm_label == nullptr || lm_weight == nullptr || labels == nullptr)) return UNIMM_E_ARG;
   if (B <= 0 || T <= 0 || T > 256) return UNIMM_E_SHAPE;
-  hipLaunchKernelGGL(plan_build_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, header, labels, weights, B, T, off, lens, rows,
-                     inv, lm_pos, lm_idx, lm_label, lm_weight);
+  hipLaunchKernelGGL(plan_build_kernel, dim3(B + 1), dim3(256), 0, (hipStream_t)stream, header, labels, weights, B, T, off, lens,
+                     rows, inv, lm_pos, lm_idx, lm_label, lm_weight, rows_cap, lm_cap, dims_i, dims_f);
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;
 }
@@ -1087,12 +1125,12 @@ extern "C" int unimm_gelu_bwd(const void* dt, const void* u, void* du, int64_t n
 }
 
 extern "C" int unimm_gather_rows(const void* src, const int32_t* idx, void* dst, int32_t n, int32_t H, int32_t scatter,
-                                 void* stream) {
+                                 const int32_t* n_dev, void* stream) {
   if (!src || !idx || !dst || n <= 0 || H <= 0 || (H % 8)) return UNIMM_E_ARG;
   size_t blocks = ((size_t)n * (H / 8) + 255) / 256;
   blocks = blocks > 8192 ? 8192 : blocks;
   hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, idx,
-                     (bf16_t*)dst, n, H, scatter);
+                     (bf16_t*)dst, n, H, scatter, n_dev);
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;
 }

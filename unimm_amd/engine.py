@@ -108,6 +108,12 @@ class Engine:
         # Weight-gradient launches cover SEVERAL encoder blocks (see `_flush_due`): a launch is due once its 256x256 tiles
         # fill about `wgrad_group_rounds` rounds of the chip; a data-parallel wrapper may lower it (smaller, earlier buckets).
         self.wgrad_group_rounds = 4
+        # Row-count capacities.  Launch arguments hold CAPACITIES (the step's valid text rows / decoded rows rounded up to
+        # these buckets); kernels whose result depends on the surplus rows read the real counts from `_dims` (written on
+        # the device by unimm_plan_build).  1 = exact sizes (default); the graph executor (unimm_amd/graphs.py) raises them
+        # so that steps with nearby row counts replay one captured launch sequence.
+        self.row_bucket, self.lm_bucket = 1, 1
+        self._dims = None                # (int32 [8], fp32 [8]) device words: {valid rows, decoded rows, regions}, {1/decoded, 1/regions}
         self._pending = []               # gradient buckets whose weight gradients are still queued: (group, #text, #image queued)
         self._nq = [0, 0]                # weight-gradient problems ever queued (text side, image side) ...
         self._nf = [0, 0]                # ... and launched
@@ -327,18 +333,18 @@ class Engine:
         dx = torch.empty((M, K), dtype=F32, device=dy.device)
         return L.linear_f32(dy, w32, dx, M, K, N, (dy.stride(0), 1), (w32.stride(0), 1))
 
-    def _wgrad(self, dy, x, gw, M, N, K, dbias=None):
+    def _wgrad(self, dy, x, gw, M, N, K, dbias=None, m_dev=None):
         """dW += dy^T x (+ bias gradient).  Nothing downstream in the backward chain reads a weight gradient,
         so the call is only queued; `_flush_wgrad` hands the list of SEVERAL encoder blocks to one grouped launch
         (`_flush_due` says when).  dy / x stay referenced by the queue until then."""
-        (self._wq_img if self._on_side else self._wq).append((dy, x, gw, M, N, K, dbias))
+        (self._wq_img if self._on_side else self._wq).append((dy, x, gw, M, N, K, dbias, m_dev))
         self._nq[1 if self._on_side else 0] += 1
 
     @staticmethod
     def _big_tiles(queue):
         """256x256 output tiles of the queue's problems that take the big tile (csrc/gemm.hip: tn_is_big)."""
         t = 0
-        for dy, x, gw, M, N, K, _ in queue:
+        for dy, x, gw, M, N, K, *_ in queue:
             M = dy.shape[0] if M is None else M
             N = dy.shape[1] if N is None else N
             K = x.shape[1] if K is None else K
@@ -412,12 +418,13 @@ class Engine:
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
 
-    def _linear_bwd(self, dy, x, lin, epi=L.EPI_BIAS, aux=None, need_dx=True, bias_grad=True, M=None, N=None, xk=None):
-        """dW += dy^T x ; db += colsum(dy) ; returns dx = epi(dy @ W)."""
+    def _linear_bwd(self, dy, x, lin, epi=L.EPI_BIAS, aux=None, need_dx=True, bias_grad=True, M=None, N=None, xk=None, m_dev=None):
+        """dW += dy^T x ; db += colsum(dy) ; returns dx = epi(dy @ W).  m_dev: device word with the real row count when
+        dy / x hold a capacity of rows (the surplus rows must not enter the reduction over rows)."""
         M = dy.shape[0] if M is None else M
         N = lin.N if N is None else N
         self._wgrad(dy, x, lin.gw, M, N, lin.K if xk is None else xk,
-                    dbias=lin.gb if (bias_grad and lin.gb is not None) else None)
+                    dbias=lin.gb if (bias_grad and lin.gb is not None) else None, m_dev=m_dev)
         if not need_dx:
             return None
         dx = torch.empty((M, lin.K), dtype=BF16, device=dy.device)
@@ -525,7 +532,7 @@ class Engine:
         for t in reads:
             self._touch(t, main)
 
-    def _layernorm_bwd(self, dy, x, mean, rstd, key, dbias=None, drop=L.NO_DROP, out_drop=L.NO_DROP, defer=True):
+    def _layernorm_bwd(self, dy, x, mean, rstd, key, dbias=None, drop=L.NO_DROP, out_drop=L.NO_DROP, defer=True, m_dev=None):
         """Row kernel now; the column sums (dgamma, dbeta, dbias) of all the calls of a block are reduced by one grouped
         launch at the end of the block (`_flush_wgrad`), where nothing waits for them.  defer=False: reduce right away."""
         gmm, _, gg, gb = self.ln[key]
@@ -537,7 +544,7 @@ class Engine:
             L.layernorm_bwd(dy, x, mean, rstd, gmm, dx, dxd, gg, gb, dbias, scratch, M, H, drop=drop, out_drop=out_drop)
             return dx, (dxd if dxd is not None else dx)
         part = torch.empty(self.part[H].numel(), dtype=F32, device=x.device)      # private until the grouped reduction
-        blocks = L.layernorm_bwd_partials(dy, x, mean, rstd, gmm, dx, dxd, part, M, H, drop=drop, out_drop=out_drop)
+        blocks = L.layernorm_bwd_partials(dy, x, mean, rstd, gmm, dx, dxd, part, M, H, drop=drop, out_drop=out_drop, m_dev=m_dev)
         (self._fq_img if self._on_side else self._fq).append((part, blocks, H, [gg, gb, dbias]))
         return dx, (dxd if dxd is not None else dx)
 
@@ -571,19 +578,20 @@ class Engine:
         d_out = self._drop(pname + "out", p_hid, train)
         pre2 = self._linear(h, ff2, L.EPI_BIAS_DROP_RESID, aux=x1_32, drop=d_out, out_f32=True)
         x2_32, x2, m2, r2 = self._layernorm(pre2, key + ".ln2", save, lazy=True)
+        md = var[2] if var is not None else None      # device word: valid rows, when the row dimension is a capacity
         if save:
             def bwd(dx2):
-                dpre2, dpre2d = self._layernorm_bwd(dx2, pre2, m2, r2, key + ".ln2", dbias=ff2.gb, drop=d_out)
-                du = self._linear_bwd(dpre2d, h, ff2, L.EPI_MUL, aux=u, bias_grad=False)
-                dx1 = self._linear_bwd(du, x1, ff1, L.EPI_ADD, aux=dpre2)
-                dpre1, dpre1d = self._layernorm_bwd(dx1, pre1, m1, r1, key + ".ln1", dbias=so.gb, drop=d_so)
-                dctx = self._linear_bwd(dpre1d, ctx, so, bias_grad=False)
+                dpre2, dpre2d = self._layernorm_bwd(dx2, pre2, m2, r2, key + ".ln2", dbias=ff2.gb, drop=d_out, m_dev=md)
+                du = self._linear_bwd(dpre2d, h, ff2, L.EPI_MUL, aux=u, bias_grad=False, m_dev=md)
+                dx1 = self._linear_bwd(du, x1, ff1, L.EPI_ADD, aux=dpre2, m_dev=md)
+                dpre1, dpre1d = self._layernorm_bwd(dx1, pre1, m1, r1, key + ".ln1", dbias=so.gb, drop=d_so, m_dev=md)
+                dctx = self._linear_bwd(dpre1d, ctx, so, bias_grad=False, m_dev=md)
                 dqkv = torch.empty_like(qkv)
                 delta = torch.empty_like(lse)
                 words, mq, mb = mask
                 L.attn_bwd(q, k, v, ctx, dctx, lse, delta, dqkv[:, :Hd], dqkv[:, Hd:2 * Hd], dqkv[:, 2 * Hd:], words,
                            B, heads, T, T, D, 1.0 / math.sqrt(D), mq, mb, d_attn, qvar=var, kvar=var)
-                return self._linear_bwd(dqkv, x, qkv_l, L.EPI_ADD, aux=dpre1)
+                return self._linear_bwd(dqkv, x, qkv_l, L.EPI_ADD, aux=dpre1, m_dev=md)
             tape.append((key, bwd))
         return x2_32, x2
 
@@ -631,6 +639,7 @@ class Engine:
             ht, ut = self._linear(at, tff1, L.EPI_BIAS_GELU), None
         pret2 = self._linear(ht, tff2, L.EPI_BIAS_DROP_RESID, aux=at32, drop=dto, out_f32=True)
         ot32, ot, mt2, rt2 = self._layernorm(pret2, key + ".lnt", save, lazy=True)
+        md = var[2] if var is not None else None      # device word: valid text rows (capacity-sized text tensors)
         if save:
             def bwd(dov, dot):
                 sc = 1.0 / math.sqrt(D)
@@ -651,11 +660,11 @@ class Engine:
                     w, mq, mb = comask
                     L.attn_bwd(q1, k2, v2, ctx_v, dctx_v, lse_v, delta_v, dqkv1[:, :Hb], dqkv2[:, Hb:2 * Hb], dqkv2[:, 2 * Hb:],
                                w, B, nh, R, T, D, sc, mq, mb, da2, kvar=var)
-                dp, dpd = self._layernorm_bwd(dot, pret2, mt2, rt2, key + ".lnt", dbias=tff2.gb, drop=dto)   # text half
-                dut = self._linear_bwd(dpd, ht, tff2, L.EPI_MUL, aux=ut, bias_grad=False)
-                dat = self._linear_bwd(dut, at, tff1, L.EPI_ADD, aux=dp)
-                dpret, dpretd = self._layernorm_bwd(dat, pret, mt1, rt1, key + ".lnb2", dbias=d2.gb, drop=db2)
-                dctx_t = self._linear_bwd(dpretd, ctx_t, d2, bias_grad=False)
+                dp, dpd = self._layernorm_bwd(dot, pret2, mt2, rt2, key + ".lnt", dbias=tff2.gb, drop=dto, m_dev=md)   # text half
+                dut = self._linear_bwd(dpd, ht, tff2, L.EPI_MUL, aux=ut, bias_grad=False, m_dev=md)
+                dat = self._linear_bwd(dut, at, tff1, L.EPI_ADD, aux=dp, m_dev=md)
+                dpret, dpretd = self._layernorm_bwd(dat, pret, mt1, rt1, key + ".lnb2", dbias=d2.gb, drop=db2, m_dev=md)
+                dctx_t = self._linear_bwd(dpretd, ctx_t, d2, bias_grad=False, m_dev=md)
                 delta_t = torch.empty_like(lse_t)
                 w, mq, mb = vmask
                 L.attn_bwd(q2, k1, v1, ctx_t, dctx_t, lse_t, delta_t, dqkv2[:, :Hb], dqkv1[:, Hb:2 * Hb], dqkv1[:, 2 * Hb:],
@@ -664,7 +673,7 @@ class Engine:
                 self._to_txt()                                      # dK2/dV2 written by the image side
                 with self._img():
                     dxv = self._linear_bwd(dqkv1, xv, lq1, L.EPI_ADD, aux=dprev)
-                dxt = self._linear_bwd(dqkv2, xt, lq2, L.EPI_ADD, aux=dpret)
+                dxt = self._linear_bwd(dqkv2, xt, lq2, L.EPI_ADD, aux=dpret, m_dev=md)
                 return dxv, dxt
             tape.append((key, bwd))
         return ov32, ov, ot32, ot
@@ -842,18 +851,28 @@ class Engine:
         il = inp.get("image_label")
         il32 = self._i32(il.reshape(B, R), dev) if (il is not None and inp.get("image_target") is not None) else None
         plan, sel, n_img = None, None, None
+        dyn = None
         if self.unpad or want_sel or nw_dev is not None or il32 is not None:
             header = L.plan_lengths(tmask, comask, R, lab32, w32, nw_dev, B, T, image_label=il32)
             hh = header.tolist()                                          # the step's one host sync
             n_img = sum(hh[2 * B + 2:3 * B + 2]) if il32 is not None else None
             lens_h, n_lm = hh[:B], (sum(hh[B:2 * B]) if want_sel else 0)
             Mv = sum(lens_h)
-            unpadded = self.unpad and Mv < B * T
-            built = L.plan_build(header, lab32 if want_sel else None, w32 if want_sel else None, B, T, Mv, n_lm, want_rows=unpadded)
+            # capacities: what the launches are sized for (= the real counts unless the graph executor set buckets)
+            Mcap = min(_rup(Mv, self.row_bucket), B * T)
+            ncap = _rup(n_lm, self.lm_bucket) if n_lm > 0 else 0
+            unpadded = self.unpad and Mcap < B * T
+            if self._dims is None:
+                self._dims = (torch.zeros(8, dtype=torch.int32, device=dev), torch.zeros(8, dtype=F32, device=dev))
+            di, df = self._dims
+            built = L.plan_build(header, lab32 if want_sel else None, w32 if want_sel else None, B, T, Mcap if unpadded else Mv,
+                                 ncap, want_rows=unpadded, dims=self._dims)
+            dyn = dict(m=di[0:1], n_lm=di[1:2], n_img=di[2:3], inv_lm=df[0:1], inv_img=df[1:2])
             if unpadded:
-                plan = dict(Mv=Mv, lens_h=lens_h, rows=built["rows"], inv=built["inv"], var=(built["off"], built["lens"]))
+                plan = dict(Mv=Mcap, lens_h=lens_h, rows=built["rows"], inv=built["inv"],
+                            var=(built["off"], built["lens"], dyn["m"]))
             if want_sel:
-                sel = dict(n=n_lm, pos=built["lm_pos"], idx=built["lm_idx"] if unpadded else built["lm_pos"],
+                sel = dict(n=ncap, pos=built["lm_pos"], idx=built["lm_idx"] if unpadded else built["lm_pos"],
                            label=built["lm_label"], weight=built["lm_weight"])
             if nw_dev is not None:
                 import struct
@@ -867,14 +886,14 @@ class Engine:
         Mt = plan["Mv"] if plan is not None else B * T      # text rows actually computed
 
         # ---- embeddings --------------------------------------------------------------------------
-        if plan is not None:
-            ids32, typ32, pos32 = (t.index_select(0, plan["rows"]) for t in (ids32, typ32, pos32))
+        erows = plan["rows"] if plan is not None else None      # packed row -> padded row (the kernels gather through it)
+        emd = plan["var"][2] if plan is not None else None
         gmm, bta, ggm, gbt = self.ln["emb_t"]
         d_embt = self._drop("emb_t", cfg.hidden_dropout_prob, train)
         xt = torch.empty((Mt, H), dtype=BF16, device=dev)
         xt32 = torch.empty((Mt, H), dtype=F32, device=dev)
         tabs = (self.tab["word"], self.tab["pos"], self.tab["type"], self.tab["ext"])
-        L.embed_fwd(ids32, pos32, typ32, *tabs, gmm, bta, xt32, xt, Mt, H, cfg.type_vocab_size, drop=d_embt)
+        L.embed_fwd(ids32, pos32, typ32, *tabs, gmm, bta, xt32, xt, Mt, H, cfg.type_vocab_size, drop=d_embt, m_dev=emd, rows=erows)
         A = self.arena
         e = "bert.embeddings."
         if save:
@@ -882,7 +901,7 @@ class Engine:
                 L.embed_bwd(ids32, pos32, typ32, *tabs, gmm, bta, dxt, A.grad(e + "word_embeddings.weight"),
                             A.grad(e + "position_embeddings.weight"), A.grad(e + "token_type_embeddings.weight"),
                             A.grad(e + "token_type_embeddings_extension.weight"), ggm, gbt, self.part[H], Mt, H,
-                            cfg.type_vocab_size, drop=d_embt)
+                            cfg.type_vocab_size, drop=d_embt, m_dev=emd, rows=erows)
 
         # ---- encoder (schedule of models/vilbert_dialog.py:842-929) ------------------------------
         # Two streams: the image stream (embedding, image layers, the image half of every connection layer) and the
@@ -921,7 +940,7 @@ class Engine:
 
         xt32, xv32 = self._dense32(xt32), self._dense32(xv32)      # the final residual stream is an output
         out = dict(seq_out_t=seq_t, seq_out_v=seq_v, seq32_t=xt32, seq32_v=xv32, B=B, T=T, R=R, plan=plan, Mt=Mt,
-                   nsp_weight_host=st_nspw, n_img=n_img, img_label32=il32)
+                   nsp_weight_host=st_nspw, n_img=n_img, img_label32=il32, dyn=dyn)
         # ---- poolers + NSP (models/vilbert_dialog.py:946-967, 1064-1070) -------------------------
         cls_idx_t = var[0] if var is not None else torch.arange(0, B * T, T, dtype=torch.int32, device=dev)
         cls_idx_v = torch.arange(0, B * R, R, dtype=torch.int32, device=dev)
@@ -947,12 +966,12 @@ class Engine:
         lmtr, dec = self.lin["lmtr"], self.lin["dec"]
         lm = None
         if lm_rows == "labelled" and labels is not None:
-            n = sel["n"]                                          # rows chosen by the plan kernels at the start of forward
+            n = sel["n"]                                          # rows chosen by the plan kernels at the start of forward (a capacity)
             if n > 0:
                 xs = torch.empty((n, H), dtype=BF16, device=dev)
-                L.gather_rows(seq_t, sel["idx"], xs, n, H)
-                lm = self._lm_head(xs, n, sel["label"], sel["weight"], save)
-                lm.update(idx=sel["idx"], pos_idx=sel["pos"], n=n)
+                L.gather_rows(seq_t, sel["idx"], xs, n, H, n_dev=dyn["n_lm"])
+                lm = self._lm_head(xs, n, sel["label"], sel["weight"], save, n_dev=dyn["n_lm"])
+                lm.update(idx=sel["idx"], pos_idx=sel["pos"], n=n, n_dev=dyn["n_lm"], inv_dev=dyn["inv_lm"])
             out["lm"] = lm
         elif lm_rows == "all":
             out["pred_t"] = self.decode_rows(self.padded(out, seq_t), B * T).view(B, T, Vp)[:, :, :V]
@@ -985,10 +1004,15 @@ class Engine:
         if plan is None:
             return x
         full = torch.zeros((out["B"] * out["T"], x.shape[1]), dtype=x.dtype, device=x.device)
-        full.index_copy_(0, plan["rows"], x)
+        if "rows32" not in plan:
+            plan["rows32"] = plan["rows"].to(torch.int32)
+        w = 2 if x.dtype == F32 else 1                  # fp32 rows move as 2 H 16-bit elements
+        # the row dimension of x is a capacity: only the step's real rows are scattered (device-side count)
+        L.gather_rows(x.view(BF16) if w == 2 else x, plan["rows32"], full.view(BF16) if w == 2 else full, x.shape[0],
+                      w * x.shape[1], scatter=True, n_dev=plan["var"][2])
         return full
 
-    def _lm_head(self, xs, n, lab_sel, w_sel, save):
+    def _lm_head(self, xs, n, lab_sel, w_sel, save, n_dev=None):
         cfg = self.cfg
         V = cfg.vocab_size
         Vp = _rup(V, 64)
@@ -1000,7 +1024,7 @@ class Engine:
         _, hn, mean, rstd = self._layernorm(t1, "lmtr", save, want32=False)
         logits = self._linear(hn, dec, out_f32=True, ldo=Vp)
         rowloss, rownll, lse = (torch.empty(n, dtype=F32, device=xs.device) for _ in range(3))
-        L.lm_loss_fwd(logits, lab_sel, w_sel, rowloss, rownll, lse, n, V)
+        L.lm_loss_fwd(logits, lab_sel, w_sel, rowloss, rownll, lse, n, V, n_dev=n_dev)
         return dict(xs=xs, t1=t1, u=u, hn=hn, mean=mean, rstd=rstd, logits=logits, rowloss=rowloss, rownll=rownll,
                     lse=lse, labels=lab_sel, weights=w_sel)
 
@@ -1024,7 +1048,7 @@ class Engine:
         if lm is None:
             lm_loss.fill_(float("nan"))        # 0 / 0 in the reference when nothing is labelled
         else:
-            L.reduce_sum(lm["rowloss"], lm["n"], lm_loss, 1.0 / lm["n"])
+            L.reduce_sum(lm["rowloss"], lm["n"], lm_loss, 1.0 / lm["n"], n_dev=lm.get("n_dev"), scale_dev=lm.get("inv_dev"))
         res["lm_loss"] = lm_loss
         # image KL
         img = out["img"]
@@ -1040,8 +1064,10 @@ class Engine:
         L.kl_loss_fwd(img["pred"], tgt, lab32, rl, lse, B * R, C)
         img_loss = torch.empty(1, dtype=F32, device=dev)
         inv_img = 1.0 / n_img if n_img > 0 else float("inf")
-        L.reduce_sum(rl, B * R, img_loss, inv_img)
-        img.update(target=tgt, label=lab32, lse=lse, inv=inv_img)
+        # (the plan kernels counted the regions: the divisor is then read from the device word, not from a launch argument)
+        inv_img_dev = out["dyn"]["inv_img"] if (out.get("dyn") is not None and out.get("n_img") is not None) else None
+        L.reduce_sum(rl, B * R, img_loss, inv_img, scale_dev=inv_img_dev)
+        img.update(target=tgt, label=lab32, lse=lse, inv=inv_img, inv_dev=inv_img_dev)
         res["img_loss"] = img_loss
         # NSP
         nw = inp.get("nsp_weight")
@@ -1079,20 +1105,23 @@ class Engine:
             Vp = _rup(V, 64)
             lmtr, dec = self.lin["lmtr"], self.lin["dec"]
             dlog = torch.empty((n, Vp), dtype=BF16, device=dev)
-            L.lm_loss_bwd(lm["logits"], lm["labels"], lm["weights"], lm["lse"], gvec(g_lm), 1.0 / n, dlog, n, V)
-            dhn = self._linear_bwd(dlog, lm["hn"], dec, M=n, N=V)             # dE += dlog^T hn ; dbias ; dhn = dlog @ E
-            dt1, _ = self._layernorm_bwd(dhn, lm["t1"], lm["mean"], lm["rstd"], "lmtr")
+            nd = lm.get("n_dev")                                              # n is a capacity: the real count lives on the device
+            L.lm_loss_bwd(lm["logits"], lm["labels"], lm["weights"], lm["lse"], gvec(g_lm), 1.0 / n, dlog, n, V, n_dev=nd,
+                          inv_dev=lm.get("inv_dev"))
+            dhn = self._linear_bwd(dlog, lm["hn"], dec, M=n, N=V, m_dev=nd)   # dE += dlog^T hn ; dbias ; dhn = dlog @ E
+            dt1, _ = self._layernorm_bwd(dhn, lm["t1"], lm["mean"], lm["rstd"], "lmtr", m_dev=nd)
             du = torch.empty_like(dt1)
             L.gelu_bwd(dt1, lm["u"], du, du.numel())
-            dxs = self._linear_bwd(du, lm["xs"], lmtr)
-            L.gather_rows(dxs, lm["idx"], dseq_t, n, H, scatter=True)
+            dxs = self._linear_bwd(du, lm["xs"], lmtr, m_dev=nd)
+            L.gather_rows(dxs, lm["idx"], dseq_t, n, H, scatter=True, n_dev=nd)
         # ---- image head --------------------------------------------------------------------------
         img = out["img"]
         C = cfg.v_target_size
         itr, idec = self.lin["imgtr"], self.lin["imgdec"]
         Cp = idec.wt.shape[1]
         dpred = torch.empty((B * R, Cp), dtype=BF16, device=dev)
-        L.kl_loss_bwd(img["pred"], img["target"], img["label"], img["lse"], gvec(g_img), img["inv"], dpred, B * R, C)
+        L.kl_loss_bwd(img["pred"], img["target"], img["label"], img["lse"], gvec(g_img), img["inv"], dpred, B * R, C,
+                      inv_dev=img.get("inv_dev"))
         dhn = self._linear_bwd(dpred, img["hn"], idec, M=B * R, N=C)
         dtv, _ = self._layernorm_bwd(dhn, img["tv"], img["mean"], img["rstd"], "imgtr")
         duv = torch.empty_like(dtv)

@@ -13,7 +13,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libunimm_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROP_RESID, EPI_BIAS_RELU, EPI_DGELU, EPI_ADD, EPI_MUL, EPI_BIAS_GELU_DG = range(8)
 
@@ -38,7 +38,7 @@ class GemmNtArgs(C.Structure):
 class GemmTnArgs(C.Structure):
     _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("dbias", C.c_void_p),
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
-                ("lddy", C.c_int32), ("ldx", C.c_int32), ("lddw", C.c_int32)]
+                ("lddy", C.c_int32), ("ldx", C.c_int32), ("lddw", C.c_int32), ("m_dev", C.c_void_p)]
 
 
 _lib = None
@@ -73,7 +73,7 @@ def lib():
     L.unimm_gemm_tn_grouped_ws.argtypes = [VP, I32, I32, VP, I64, VP]
     L.unimm_colpartials_finish_grouped.argtypes = [VP, I32, VP]
     L.unimm_layernorm_fwd.argtypes = [VP] * 7 + [I32, I32, F32, U32, U32, F32, VP]
-    L.unimm_layernorm_bwd_partials.argtypes = [VP] * 8 + [I32, I32, U32, U32, F32, U32, U32, F32, VP, VP]
+    L.unimm_layernorm_bwd_partials.argtypes = [VP] * 8 + [I32, I32, U32, U32, F32, U32, U32, F32, VP, VP, VP]
     L.unimm_layernorm_bwd.argtypes = [VP] * 11 + [I32, I32, U32, U32, F32, U32, U32, F32, VP]
     _lib = L
     return L
@@ -178,11 +178,13 @@ def gemm_nt(x, w, out, bias=None, epilogue=EPI_BIAS, aux=None, out2=None, drop=N
     return out
 
 
-def gemm_tn(dy, x, dw, M=None, N=None, K=None, dbias=None):
-    """dw[N,K] += dy[M,N]^T @ x[M,K] (fp32 atomics); dbias[N] += colsum(dy) when given."""
-    _dev(dy, x, dw, dbias)
+def gemm_tn(dy, x, dw, M=None, N=None, K=None, dbias=None, m_dev=None):
+    """dw[N,K] += dy[M,N]^T @ x[M,K] (fp32 atomics); dbias[N] += colsum(dy) when given.
+    m_dev: int32 device word with the rows actually present (M is then a capacity)."""
+    _dev(dy, x, dw, dbias, m_dev)
     a = GemmTnArgs()
     a.dy, a.x, a.dw, a.dbias = _ptr(dy), _ptr(x), _ptr(dw), _ptr(dbias)
+    a.m_dev = _P(m_dev)
     a.M = dy.shape[0] if M is None else M
     a.N = dy.shape[1] if N is None else N
     a.K = x.shape[1] if K is None else K
@@ -192,7 +194,7 @@ def gemm_tn(dy, x, dw, M=None, N=None, K=None, dbias=None):
 
 
 def gemm_tn_grouped(problems, shared=None, ws=None):
-    """problems: list of (dy, x, dw, M, N, K, dbias) -- every dw[N,K] += dy[:M,:N]^T @ x[:M,:K] in as few
+    """problems: list of (dy, x, dw, M, N, K, dbias[, m_dev]) -- every dw[N,K] += dy[:M,:N]^T @ x[:M,:K] in as few
     launches as possible (one per <= 12 problems of the same tile class).
     shared: the launches run beside another stream's kernels (split heuristic hint; None = the process-wide default).
     ws: zero-initialised uint8 device tensor private to the launch stream (partial-tile slabs + arrival counters);
@@ -201,9 +203,10 @@ def gemm_tn_grouped(problems, shared=None, ws=None):
     if n == 0:
         return
     arr = (GemmTnArgs * n)()
-    for a, (dy, x, dw, M, N, K, dbias) in zip(arr, problems):
+    for a, (dy, x, dw, M, N, K, dbias, *rest) in zip(arr, problems):
         _dev(dy, x, dw, dbias)
         a.dy, a.x, a.dw, a.dbias = dy.data_ptr(), x.data_ptr(), dw.data_ptr(), (dbias.data_ptr() if dbias is not None else None)
+        a.m_dev = rest[0].data_ptr() if rest and rest[0] is not None else None
         a.M = dy.shape[0] if M is None else M
         a.N = dy.shape[1] if N is None else N
         a.K = x.shape[1] if K is None else K
@@ -319,7 +322,7 @@ class FinishDesc(C.Structure):
                 ("pad_", C.c_int32)]
 
 
-def layernorm_bwd_partials(dy, x, mean, rstd, gamma, dx, dx_drop, partials, M, H, drop=None, out_drop=None):
+def layernorm_bwd_partials(dy, x, mean, rstd, gamma, dx, dx_drop, partials, M, H, drop=None, out_drop=None, m_dev=None):
     """LayerNorm backward row kernel only; returns the number of partial blocks (see unimm_layernorm_bwd_partials)."""
     drop = drop or NO_DROP
     out_drop = out_drop or NO_DROP
@@ -327,7 +330,7 @@ def layernorm_bwd_partials(dy, x, mean, rstd, gamma, dx, dx_drop, partials, M, H
     blocks = C.c_int32(0)
     rc = lib().unimm_layernorm_bwd_partials(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
                                             dx.data_ptr(), _P(dx_drop), partials.data_ptr(), M, H, drop[0], drop[1], drop[2],
-                                            out_drop[0], out_drop[1], out_drop[2], C.addressof(blocks), _stream())
+                                            out_drop[0], out_drop[1], out_drop[2], C.addressof(blocks), _P(m_dev), _stream())
     if rc != 0:
         _check(rc, "unimm_layernorm_bwd_partials")
     return blocks.value
@@ -367,29 +370,33 @@ class EmbedArgs(C.Structure):
                 ("word", C.c_void_p), ("post", C.c_void_p), ("type", C.c_void_p), ("ext", C.c_void_p),
                 ("gamma", C.c_void_p), ("beta", C.c_void_p),
                 ("M", C.c_int32), ("H", C.c_int32), ("type_vocab", C.c_int32), ("eps", C.c_float),
-                ("drop_key", C.c_uint32), ("drop_thr", C.c_uint32), ("drop_scale", C.c_float)]
+                ("drop_key", C.c_uint32), ("drop_thr", C.c_uint32), ("drop_scale", C.c_float),
+                ("m_dev", C.c_void_p), ("rows", C.c_void_p)]
 
 
-def _embed_args(ids, pos, typ, word, post, type_, ext, gamma, beta, M, H, type_vocab, eps, drop):
-    _dev(ids, pos, typ, word, post, type_, ext, gamma, beta)
+def _embed_args(ids, pos, typ, word, post, type_, ext, gamma, beta, M, H, type_vocab, eps, drop, m_dev=None, rows=None):
+    _dev(ids, pos, typ, word, post, type_, ext, gamma, beta, m_dev, rows)
     a = EmbedArgs()
     a.ids, a.pos, a.typ = _ptr(ids), _ptr(pos), _ptr(typ)
     a.word, a.post, a.type, a.ext = _ptr(word), _ptr(post), _ptr(type_), _ptr(ext)
     a.gamma, a.beta = _ptr(gamma), _ptr(beta)
     a.M, a.H, a.type_vocab, a.eps = M, H, type_vocab, eps
     a.drop_key, a.drop_thr, a.drop_scale = drop
+    a.m_dev, a.rows = _P(m_dev), _P(rows)
     return a
 
 
-def embed_fwd(ids, pos, typ, word, post, type_, ext, gamma, beta, y32, y16, M, H, type_vocab=2, eps=1e-12, drop=NO_DROP):
-    a = _embed_args(ids, pos, typ, word, post, type_, ext, gamma, beta, M, H, type_vocab, eps, drop)
+def embed_fwd(ids, pos, typ, word, post, type_, ext, gamma, beta, y32, y16, M, H, type_vocab=2, eps=1e-12, drop=NO_DROP,
+              m_dev=None, rows=None):
+    """rows (int64 [M]): row r embeds ids / pos / typ at index rows[r]; m_dev: int32 device word, rows actually present."""
+    a = _embed_args(ids, pos, typ, word, post, type_, ext, gamma, beta, M, H, type_vocab, eps, drop, m_dev, rows)
     _dev(y32, y16)
     _check(lib().unimm_embed_fwd(C.byref(a), _ptr(y32), _ptr(y16), _stream()), "unimm_embed_fwd")
 
 
 def embed_bwd(ids, pos, typ, word, post, type_, ext, gamma, beta, dy, dword, dpos, dtype, dext, dgamma, dbeta,
-              partials, M, H, type_vocab=2, eps=1e-12, drop=NO_DROP):
-    a = _embed_args(ids, pos, typ, word, post, type_, ext, gamma, beta, M, H, type_vocab, eps, drop)
+              partials, M, H, type_vocab=2, eps=1e-12, drop=NO_DROP, m_dev=None, rows=None):
+    a = _embed_args(ids, pos, typ, word, post, type_, ext, gamma, beta, M, H, type_vocab, eps, drop, m_dev, rows)
     _dev(dy, dword, dpos, dtype, dext, dgamma, dbeta, partials)
     _check(lib().unimm_embed_bwd(C.byref(a), _ptr(dy), _ptr(dword), _ptr(dpos), _ptr(dtype), _ptr(dext), _ptr(dgamma),
                                  _ptr(dbeta), _ptr(partials), _stream()), "unimm_embed_bwd")
@@ -433,16 +440,21 @@ def plan_lengths(text_mask, co_mask, R, labels, weights, nsp_weight, B, T, image
     return header
 
 
-def plan_build(header, labels, weights, B, T, Mv, n_lm, want_rows=True):
-    """-> dict(off, lens, rows, inv, lm_pos, lm_idx, lm_label, lm_weight) built on the device from the header."""
+def plan_build(header, labels, weights, B, T, Mv, n_lm, want_rows=True, dims=None):
+    """-> dict(off, lens, rows, inv, lm_pos, lm_idx, lm_label, lm_weight) built on the device from the header.
+    Mv / n_lm are CAPACITIES (>= the header's totals): the lists' unused tails get safe values.  dims = (int32 [>=3],
+    fp32 [>=2]) device tensors that receive the step's real counts and loss denominators (unimm_hip.h)."""
     dev = header.device
     i32 = lambda n: torch.empty(max(n, 1), dtype=torch.int32, device=dev)
     off, lens = i32(B), i32(B)
     rows = torch.empty(Mv, dtype=torch.int64, device=dev) if want_rows else None
     inv = torch.empty(B * T, dtype=torch.int64, device=dev) if want_rows else None
     lm = [i32(n_lm) for _ in range(4)] if (n_lm > 0 and labels is not None) else [None] * 4
+    di, df = dims if dims is not None else (None, None)
+    _dev(di, df)
     _check(lib().unimm_plan_build(_ptr(header), _ptr(labels), _ptr(weights), C.c_int32(B), C.c_int32(T), _ptr(off), _ptr(lens),
-                                  _ptr(rows), _ptr(inv), *[_ptr(t) for t in lm], _stream()), "unimm_plan_build")
+                                  _ptr(rows), _ptr(inv), *[_ptr(t) for t in lm], C.c_int32(Mv if want_rows else 0),
+                                  C.c_int32(n_lm if lm[0] is not None else 0), _ptr(di), _ptr(df), _stream()), "unimm_plan_build")
     return dict(off=off, lens=lens, rows=rows, inv=inv, lm_pos=lm[0], lm_idx=lm[1], lm_label=lm[2], lm_weight=lm[3])
 
 
@@ -497,18 +509,18 @@ def mul_dropout_bwd(a, b, dout, da, db, n, drop=NO_DROP):
 # ---------------------------------------------------------------------------------------------
 # losses
 # ---------------------------------------------------------------------------------------------
-def lm_loss_fwd(logits, labels, weights, rowloss, rownll, lse, n, V):
-    _dev(logits, labels, weights, rowloss, rownll, lse)
+def lm_loss_fwd(logits, labels, weights, rowloss, rownll, lse, n, V, n_dev=None):
+    _dev(logits, labels, weights, rowloss, rownll, lse, n_dev)
     _check(lib().unimm_lm_loss_fwd(_ptr(logits), _ptr(labels), _ptr(weights), _ptr(rowloss), _ptr(rownll), _ptr(lse),
-                                   C.c_int32(n), C.c_int32(V), C.c_int32(logits.stride(0)), _stream()),
+                                   C.c_int32(n), C.c_int32(V), C.c_int32(logits.stride(0)), _ptr(n_dev), _stream()),
            "unimm_lm_loss_fwd")
 
 
-def lm_loss_bwd(logits, labels, weights, lse, g, inv_denom, dlogits, n, V):
-    _dev(logits, labels, weights, lse, g, dlogits)
+def lm_loss_bwd(logits, labels, weights, lse, g, inv_denom, dlogits, n, V, n_dev=None, inv_dev=None):
+    _dev(logits, labels, weights, lse, g, dlogits, n_dev, inv_dev)
     _check(lib().unimm_lm_loss_bwd(_ptr(logits), _ptr(labels), _ptr(weights), _ptr(lse), _ptr(g), C.c_float(inv_denom),
                                    _ptr(dlogits), C.c_int32(n), C.c_int32(V), C.c_int32(logits.stride(0)),
-                                   C.c_int32(dlogits.stride(0)), _stream()), "unimm_lm_loss_bwd")
+                                   C.c_int32(dlogits.stride(0)), _ptr(n_dev), _ptr(inv_dev), _stream()), "unimm_lm_loss_bwd")
 
 
 def kl_loss_fwd(pred, target, label, rowloss, lse, rows, Cn):
@@ -517,11 +529,11 @@ def kl_loss_fwd(pred, target, label, rowloss, lse, rows, Cn):
                                    C.c_int32(Cn), C.c_int32(pred.stride(0)), _stream()), "unimm_kl_loss_fwd")
 
 
-def kl_loss_bwd(pred, target, label, lse, g, inv_denom, dpred, rows, Cn):
-    _dev(pred, target, label, lse, g, dpred)
+def kl_loss_bwd(pred, target, label, lse, g, inv_denom, dpred, rows, Cn, inv_dev=None):
+    _dev(pred, target, label, lse, g, dpred, inv_dev)
     _check(lib().unimm_kl_loss_bwd(_ptr(pred), _ptr(target), _ptr(label), _ptr(lse), _ptr(g), C.c_float(inv_denom),
                                    _ptr(dpred), C.c_int32(rows), C.c_int32(Cn), C.c_int32(pred.stride(0)),
-                                   C.c_int32(dpred.stride(0)), _stream()), "unimm_kl_loss_bwd")
+                                   C.c_int32(dpred.stride(0)), _ptr(inv_dev), _stream()), "unimm_kl_loss_bwd")
 
 
 def nsp_loss_fwd(logits, labels, w0, w1, loss, B):
@@ -569,9 +581,10 @@ def rows_add_f32(dst, idx, src, n, H):
     _check(lib().unimm_rows_add_f32(_ptr(dst), _ptr(idx), _ptr(src), C.c_int32(n), C.c_int32(H), _stream()), "unimm_rows_add_f32")
 
 
-def reduce_sum(src, n, dst, scale=1.0):
-    _dev(src, dst)
-    _check(lib().unimm_reduce_sum(_ptr(src), C.c_int64(n), _ptr(dst), C.c_float(scale), _stream()), "unimm_reduce_sum")
+def reduce_sum(src, n, dst, scale=1.0, n_dev=None, scale_dev=None):
+    _dev(src, dst, n_dev, scale_dev)
+    _check(lib().unimm_reduce_sum(_ptr(src), C.c_int64(n), _ptr(dst), C.c_float(scale), _ptr(n_dev), _ptr(scale_dev), _stream()),
+           "unimm_reduce_sum")
 
 
 def segment_sum(src, seg, dst, n, sign=1.0):
@@ -585,10 +598,10 @@ def gelu_bwd(dt, u, du, n):
     _check(lib().unimm_gelu_bwd(_ptr(dt), _ptr(u), _ptr(du), C.c_int64(n), _stream()), "unimm_gelu_bwd")
 
 
-def gather_rows(src, idx, dst, n, H, scatter=False):
-    _dev(src, idx, dst)
+def gather_rows(src, idx, dst, n, H, scatter=False, n_dev=None):
+    _dev(src, idx, dst, n_dev)
     _check(lib().unimm_gather_rows(_ptr(src), _ptr(idx), _ptr(dst), C.c_int32(n), C.c_int32(H),
-                                   C.c_int32(1 if scatter else 0), _stream()), "unimm_gather_rows")
+                                   C.c_int32(1 if scatter else 0), _ptr(n_dev), _stream()), "unimm_gather_rows")
 
 
 GEMM_VARIANTS = {0: "gemm_nt<BIAS,bf16>", 1: "gemm_nt<BIAS,f32>", 2: "gemm_nt<BIAS_GELU,bf16>", 3: "gemm_nt<BIAS_GELU,f32>",
