@@ -70,6 +70,10 @@ def parse():
                          "what the roofline block needs; all = every GEMM launch (adds the all_gemm_* fields).  Two event records "
                          "around each of ~340 GEMM launches are not free: measured 1.3 ms of a 56 ms step at bs=240 (drain + "
                          "timestamp between back-to-back kernels) and 2 ms of 16 ms at 30 sequences per GPU (host launch rate)")
+    ap.add_argument("--graphs", action="store_true",
+                    help="run the step as replayed hipGraphs (unimm_amd/graphs.py: two graph launches per step instead of ~650 "
+                         "host calls; N = 1 only). The timed region then has no per-launch events: the roofline block comes from "
+                         "the eager steps after it.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-tile", type=int, default=0, metavar="CODE",
                     help="tuning: unimm_gemm_nt_args.tile = CODE for every launch of the run (1000 x tile columns per group + 100 x {1 persistent, "
@@ -381,11 +385,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    use_graphs = args.graphs and world == 1 and args.workload == "train"
+    if use_graphs:
+        model.engine.enable_graphs(True)
+        for _ in range(3):                      # eager once more, capture, first replay
+            step()
     fence()
     if world > 1:
         net.comm_stats(reset=True)
     prof_all = args.gemm_profile == "all"
-    lib.prof_enable(1 if prof_all else 2)
+    if not use_graphs:
+        lib.prof_enable(1 if prof_all else 2)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -394,6 +404,12 @@ def main():
     if world > 1:          # every gradient bucket was exchanged exactly once per timed step
         st_timed = net.comm_stats()
         assert st_timed["buckets"] == st_timed["n_buckets_expected"] * args.steps, st_timed
+    graph_stats = dict(model.engine.graphs.stats) if use_graphs else None
+    if use_graphs:                             # the per-kernel figures below come from eager steps
+        model.engine.enable_graphs(False)
+        lib.prof_enable(2)
+        step(); step()
+        torch.cuda.synchronize()
     prof = lib.prof_collect()
     lib.prof_enable(False)
     loss_val = float(loss.detach())
@@ -529,6 +545,7 @@ def main():
             "config": {"workload": wl,
                        "global_batch": global_batch, "per_gpu_batch": per_gpu, "seq_len": 256, "regions": 37,
                        "parallelism": f"dp{world}", "lm_rows_decoded_per_seq": round(n_lm_rows / per_gpu, 2),
+                       "executor": ("hipGraph replay (unimm_amd/graphs.py): " + json.dumps(graph_stats)) if graph_stats else "eager launches",
                        "valid_token_rows": valid_rows, "token_rows_padded": per_gpu * 256,
                        "gflop_per_seq_fwd_padded_equivalent": round(f_fwd, 3),
                        "gemm_gflop_per_seq_executed_fwd_bwd": round(exec_gf_seq, 3),

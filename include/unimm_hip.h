@@ -79,6 +79,11 @@ typedef struct {
    *   p:   0 automatic, 1 persistent workgroups (one per CU slot walks several tiles), 2 one workgroup per tile
    *   gn:  n-tiles per column group of the tile order (0 = default 4) */
   int32_t tile;
+  /* or NULL: a device word XORed into drop_key at kernel entry.  The argument then carries the per-(seed, site) part of the
+   * key and memory the per-step part, so that a captured / replayed launch (unimm_amd/graphs.py) draws a fresh mask every
+   * step; unimm_amd/dropout.py: make_key(seed, step, site) = site_key(seed, site) ^ step_salt(seed, step).  Every entry
+   * point that takes a dropout triple takes such a word. */
+  const uint32_t* drop_salt;
 } unimm_gemm_nt_args;
 
 int unimm_gemm_nt(const unimm_gemm_nt_args* args, void* stream);
@@ -143,7 +148,8 @@ typedef struct {
   int32_t ldq, ldk, ldv, ldo;
   int32_t mask_q_stride, mask_b_stride; /* in 32-bit words */
   float scale;
-  uint32_t drop_key, drop_thr; float drop_scale; /* element index = ((b*H+h)*Tq+q)*Tk+k */
+  uint32_t drop_key, drop_thr; float drop_scale;
+  const uint32_t* drop_salt; /* or NULL (see unimm_gemm_nt_args.drop_salt) */ /* element index = ((b*H+h)*Tq+q)*Tk+k */
 } unimm_attn_args;
 
 int unimm_attn_fwd(const unimm_attn_args* args, void* stream);
@@ -163,6 +169,7 @@ typedef struct {
   int32_t mask_q_stride, mask_b_stride;
   float scale;
   uint32_t drop_key, drop_thr; float drop_scale;
+  const uint32_t* drop_salt;
 } unimm_attn_bwd_args;
 
 int unimm_attn_bwd(const unimm_attn_bwd_args* args, void* stream);
@@ -219,7 +226,7 @@ int unimm_plan_build(const int32_t* header, const int32_t* labels, const int32_t
  * operand) are written; mean/rstd fp32 [M] saved for backward (may be NULL). */
 int unimm_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y32, void* y16, float* mean,
                         float* rstd, int32_t M, int32_t H, float eps, uint32_t drop_key, uint32_t drop_thr,
-                        float drop_scale, void* stream);
+                        float drop_scale, const uint32_t* drop_salt, void* stream);
 
 /* bytes of the `partials` scratch the two backward row kernels need for hidden size H */
 int64_t unimm_colpartials_bytes(int32_t H);
@@ -231,7 +238,7 @@ int64_t unimm_colpartials_bytes(int32_t H);
 int unimm_layernorm_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                         void* dx, void* dx_drop, float* dgamma, float* dbeta, float* dbias, float* partials,
                         int32_t M, int32_t H, uint32_t drop_key, uint32_t drop_thr, float drop_scale,
-                        uint32_t odrop_key, uint32_t odrop_thr, float odrop_scale, void* stream);
+                        uint32_t odrop_key, uint32_t odrop_thr, float odrop_scale, const uint32_t* drop_salt, void* stream);
 /* The same row kernel without the reduction of its column partials: `partials` (unimm_colpartials_bytes(H), private to
  * this call until it is reduced) holds [blocks][3][H] = per-block sums for dgamma, dbeta, dbias; *blocks_out (host)
  * receives the block count.  unimm_colpartials_finish_grouped then adds the column sums of up to many pending calls
@@ -240,7 +247,8 @@ int unimm_layernorm_bwd(const void* dy, const float* x, const float* mean, const
 int unimm_layernorm_bwd_partials(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                                  void* dx, void* dx_drop, float* partials, int32_t M, int32_t H, uint32_t drop_key,
                                  uint32_t drop_thr, float drop_scale, uint32_t odrop_key, uint32_t odrop_thr,
-                                 float odrop_scale, int32_t* blocks_out, const int32_t* m_dev, void* stream);
+                                 float odrop_scale, int32_t* blocks_out, const int32_t* m_dev, const uint32_t* drop_salt,
+                                 void* stream);
 #define UNIMM_FINISH_MAX 8
 typedef struct {
   const float* partials;
@@ -261,6 +269,7 @@ typedef struct {
   uint32_t drop_key, drop_thr; float drop_scale;
   const int32_t* m_dev; /* or NULL: device word with the rows actually present (M = capacity) */
   const int64_t* rows;  /* or NULL: row r takes ids / pos / typ at index rows[r] (the unpadded schedule's row map) */
+  const uint32_t* drop_salt; /* or NULL (see unimm_gemm_nt_args.drop_salt) */
 } unimm_embed_args;
 
 int unimm_embed_fwd(const unimm_embed_args* args, float* y32, void* y16, void* stream);
@@ -293,9 +302,9 @@ int unimm_pack_image(const float* feat, const float* loc, void* out, int32_t row
 /* out = dropout(a * b) (pooled_t * pooled_v, models/vilbert_dialog.py:1065), fp32 flat [n], and its backward, which
  * also folds in the pooler ReLU gradient (:951, :966): da = [a>0] drop(dout) b, db = [b>0] drop(dout) a. */
 int unimm_mul_dropout(const float* a, const float* b, float* out, int64_t n, uint32_t drop_key, uint32_t drop_thr,
-                      float drop_scale, void* stream);
+                      float drop_scale, const uint32_t* drop_salt, void* stream);
 int unimm_mul_dropout_bwd(const float* a, const float* b, const float* dout, float* da, float* db, int64_t n,
-                          uint32_t drop_key, uint32_t drop_thr, float drop_scale, void* stream);
+                          uint32_t drop_key, uint32_t drop_thr, float drop_scale, const uint32_t* drop_salt, void* stream);
 
 /* fp32 linear algebra of the heads on top of the network (the two poolers :946-967, the NSP head :1070) and their
  * backward, on the exact-fp32 matrix instruction v_mfma_f32_16x16x4_f32, straight from the fp32 master weights:

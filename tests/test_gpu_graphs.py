@@ -1,0 +1,73 @@
+"""The step executor (unimm_amd/graphs.py): the training step replayed as two hipGraphs per row-count bucket must equal
+the eager step -- same losses, same NSP logits, same gradients -- over a sequence of different batches, with dropout on
+(the per-step salt is read from device memory) and with valid-row / decoded-row counts that move inside and across
+buckets (the real counts are read from device memory; launches are sized for the bucket)."""
+import copy
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(golden_dir):
+    from oracle import vilbert_ref as R
+    from unimm_amd import BertConfig, BertForMultiModalPreTraining
+    cfgd = json.load(open(os.path.join(golden_dir, "small_config.json")))
+    model = BertForMultiModalPreTraining(BertConfig.from_dict(cfgd))
+    model.load_state_dict(R.init_state_dict(R.make_config(cfgd), seed=11), strict=True)
+    return model.cuda()
+
+
+def _step(model, b):
+    model.engine.arena.zero_grads() if model.engine.arena is not None else None
+    lm, img, nsp_l, _, _, nsp = model(
+        b["input_ids"], b["image_feat"], b["image_loc"], token_type_ids=b["token_type_ids"], position_ids=b["token_position_ids"],
+        attention_mask=b["attention_mask"], image_attention_mask=b["image_attention_mask"], co_attention_mask=b["co_attention_mask"],
+        masked_lm_labels=b["masked_lm_labels"], image_label=b["image_label"], image_target=b["image_target"],
+        next_sentence_label=b["next_sentence_label"], nsp_weight=b["nsp_weight"], lm_weight=b["lm_weight"], _want_lm_scores=False)
+    (lm + 0.5 * img + 2.0 * nsp_l).sum().backward()
+    torch.cuda.synchronize()
+    return (torch.stack([lm, img, nsp_l]).flatten().detach().clone(), nsp.detach().clone(), model.engine.arena.grad_flat.clone())
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_graph_replay_equals_eager_steps(golden_dir, train):
+    from unimm_amd import synth
+    ref, gm = _build(golden_dir), _build(golden_dir)
+    for m in (ref, gm):
+        m.train(train)
+        m.set_dropout_seed(321)
+    cfg = ref.config
+    seeds = [5, 5, 6, 5, 7, 6, 8, 5]                       # repeated batches (replays) and new ones (other row counts)
+    batches = {s: synth.make_batch(n_seq=12, T=64, R=37, cfg=cfg, seed=s, device="cuda") for s in set(seeds)}
+    # eager first (both models see the same step counter)
+    want = [_step(ref, batches[s]) for s in seeds]
+    g = gm.engine
+    g.ensure(torch.device("cuda", 0))
+    graphs = g.enable_graphs(row_bucket=64, lm_bucket=16, capture_after=1, max_entries=8)
+    got = [_step(gm, batches[s]) for s in seeds]
+    st = graphs.stats
+    print(f"\\ngraph executor: {st}")
+    assert st["replays"] >= 3 and st["captures"] >= 2
+    for i, (w, h) in enumerate(zip(want, got)):
+        assert torch.isfinite(h[0]).all() and torch.isfinite(h[2]).all(), i
+        assert (w[0] - h[0]).abs().max() <= 2e-6 * max(1.0, float(w[0].abs().max())), (i, w[0], h[0])
+        assert (w[1] - h[1]).abs().max() <= 2e-6, i
+        d = float((w[2] - h[2]).abs().max() / w[2].abs().max())
+        assert d <= 2e-5, (i, d)                          # fp32 summation order of the weight gradients
+
+
+def test_graph_executor_falls_back_when_not_eligible(golden_dir):
+    """Host inputs, dense LM scores and the data-parallel hook keep the eager path (and still work)."""
+    from unimm_amd import synth
+    m = _build(golden_dir)
+    m.train(False)
+    m.engine.ensure(torch.device("cuda", 0))
+    graphs = m.engine.enable_graphs(capture_after=0)
+    b = synth.make_batch(n_seq=6, T=64, R=37, cfg=m.config, seed=3, device="cpu")
+    _step(m, b)
+    assert graphs.stats["replays"] == 0 and graphs.stats["captures"] == 0

@@ -110,6 +110,7 @@ __device__ __forceinline__ int key_of_reg(int reg, int h) { return (reg & 3) + 8
 // ------------------------------------------------------------------------------------------------
 template <int D, int NKT>
 __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnParams p) {
+  drop_resolve(p.drop);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KPAD = NKT * 32;
   char* kimg = smem;
@@ -298,6 +299,7 @@ struct AttnBwdParams {
 
 template <int D, int NKT>
 __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
+  drop_resolve(p.drop);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KPAD = NKT * 32;
   char* kimg = smem;
@@ -441,6 +443,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
 // SIMD, so the D = 128 instance gets 512 registers and stops spilling (148 bytes of scratch at 256)
 template <int D, int NQT, int MAXT = 512>
 __global__ __launch_bounds__(MAXT, MAXT == 256 ? 1 : 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
+  drop_resolve(p.drop);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int QPAD = NQT * 32;
   char* qimg = smem;
@@ -697,7 +700,7 @@ extern "C" int unimm_attn_fwd(const unimm_attn_args* a, void* stream) {
   p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo;
   p.mask_q_stride = a->mask_q_stride; p.mask_b_stride = a->mask_b_stride;
   p.scale = a->scale;
-  p.drop.key = a->drop_key; p.drop.thr = a->drop_thr; p.drop.scale = a->drop_scale;
+  p.drop.key = a->drop_key; p.drop.thr = a->drop_thr; p.drop.scale = a->drop_scale; p.drop.salt = a->drop_salt;
   hipStream_t s = (hipStream_t)stream;
   const bool small_k = a->Tk <= 64;
   if (a->D == 64) return small_k ? launch_fwd<64, 2>(p, s) : launch_fwd<64, 8>(p, s);
@@ -726,7 +729,7 @@ extern "C" int unimm_attn_bwd(const unimm_attn_bwd_args* a, void* stream) {
   p.lddq = a->lddq; p.lddk = a->lddk; p.lddv = a->lddv;
   p.mask_q_stride = a->mask_q_stride; p.mask_b_stride = a->mask_b_stride;
   p.scale = a->scale;
-  p.drop.key = a->drop_key; p.drop.thr = a->drop_thr; p.drop.scale = a->drop_scale;
+  p.drop.key = a->drop_key; p.drop.thr = a->drop_thr; p.drop.scale = a->drop_scale; p.drop.salt = a->drop_salt;
   hipStream_t s = (hipStream_t)stream;
   const bool small_k = a->Tk <= 64, small_q = a->Tq <= 64;
   int rc;

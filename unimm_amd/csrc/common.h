@@ -117,7 +117,13 @@ struct DropoutArg {
   uint32_t key;    // 0 with thr == 0 => disabled
   uint32_t thr;    // p * 2^32 (the kernels compare 16-bit fields against thr >> 16)
   float scale;     // 1 / (1 - p)
+  const uint32_t* salt;   // or NULL: device word XORed into the key at kernel entry.  Replayed launch sequences freeze their
+                          // arguments, so the per-(seed, site) key is the argument and the per-step part lives in memory.
 };
+// effective key of this launch (call once at kernel entry, on the kernel's own copy of its parameters)
+__device__ __forceinline__ void drop_resolve(DropoutArg& d) {
+  if (d.salt != nullptr) { d.key ^= d.salt[0]; d.salt = nullptr; }
+}
 // The key enters twice: XORed into the index and, multiplied by an odd constant (uniform: one scalar multiply per kernel),
 // added between the two multiplies.  With the XOR alone the mask of key k2 is the mask of key k1 read at index ^ k1 ^ k2:
 // every site and step would see an index permutation of ONE bit pattern.

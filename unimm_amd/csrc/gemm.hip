@@ -748,6 +748,7 @@ __device__ __forceinline__ void nt_tile(const GemmNtParams& p, char* smem, int l
 template <class C, int EPI, bool OUT_F32>
 __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES) void gemm_nt_kernel(GemmNtParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if constexpr (EPI == UNIMM_EPI_BIAS_DROP_RESID) drop_resolve(p.drop);
   nt_tile<C, EPI, OUT_F32>(p, smem, xcd_remap(blockIdx.x, gridDim.x));
 }
 
@@ -758,6 +759,7 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES) void gemm_nt_kernel(GemmN
 template <class C, int EPI, bool OUT_F32>
 __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES) void gemm_ntp_kernel(GemmNtParams p, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if constexpr (EPI == UNIMM_EPI_BIAS_DROP_RESID) drop_resolve(p.drop);
   for (int lt = blockIdx.x; lt < ntiles; lt += gridDim.x) {
     if (lt != (int)blockIdx.x) __builtin_amdgcn_s_barrier();   // every wave has left its epilogue slab (it aliases the ring)
     nt_tile<C, EPI, OUT_F32>(p, smem, xcd_remap(lt, ntiles));
@@ -1473,7 +1475,7 @@ extern "C" int unimm_gemm_nt(const unimm_gemm_nt_args* a, void* stream) {
   p.x = (const bf16_t*)a->x; p.w = (const bf16_t*)a->w; p.bias = a->bias; p.aux = a->aux;
   p.out = a->out; p.out2 = (bf16_t*)a->out2;
   p.M = a->M; p.N = a->N; p.K = a->K; p.ldx = a->ldx; p.ldw = a->ldw; p.ldaux = a->ldaux; p.ldo = a->ldo;
-  p.drop.key = a->drop_key; p.drop.thr = a->drop_thr; p.drop.scale = a->drop_scale;
+  p.drop.key = a->drop_key; p.drop.thr = a->drop_thr; p.drop.scale = a->drop_scale; p.drop.salt = a->drop_salt;
   const int n_ln = (a->aux_mean != nullptr) + (a->aux_rstd != nullptr) + (a->aux_gamma != nullptr) + (a->aux_beta != nullptr);
   if (n_ln != 0 && (n_ln != 4 || a->epilogue != UNIMM_EPI_BIAS_DROP_RESID)) return UNIMM_E_ARG;
   p.aux_mean = a->aux_mean; p.aux_rstd = a->aux_rstd; p.aux_gamma = a->aux_gamma; p.aux_beta = a->aux_beta;

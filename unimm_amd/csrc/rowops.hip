@@ -333,6 +333,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                                                             bf16_t* __restrict__ y,
                                                             float* __restrict__ mean_o, float* __restrict__ rstd_o, int M,
                                                             int H, float eps, DropoutArg drop) {
+  drop_resolve(drop);
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * (blockDim.x >> 6);
@@ -381,6 +382,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
                                                             int M, int H, DropoutArg drop, DropoutArg out_drop,
                                                             const int32_t* __restrict__ m_dev) {
   __shared__ float red[4 * 1024];  // [wave][col], reused for each of the three quantities
+  drop_resolve(drop);
+  drop_resolve(out_drop);
   if (m_dev != nullptr) M = min(M, m_dev[0]);     // M is a capacity: rows past the real count never enter the column sums
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wave = blockIdx.x * 4 + wv;
@@ -589,6 +592,7 @@ __device__ __forceinline__ void emb_gather(const EmbArgs& a, int row, int lane, 
 }
 
 __global__ __launch_bounds__(256) void embed_fwd_kernel(EmbArgs a, float* __restrict__ y32, bf16_t* __restrict__ y) {
+  drop_resolve(a.drop);
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * 4;
@@ -621,6 +625,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbArgs a, const bf16_t*
                                                         float* __restrict__ dpos, float* __restrict__ dext,
                                                         float* __restrict__ partials) {
   __shared__ float red[4 * 1024];
+  drop_resolve(a.drop);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wave = blockIdx.x * 4 + wv;
   const int nwaves = gridDim.x * 4;
@@ -825,6 +830,7 @@ __global__ void pack_image_kernel(const float* __restrict__ feat, const float* _
 // out = dropout(a * b)  fp32 [n]   (pooled_t * pooled_v, models/vilbert_dialog.py:1065)
 __global__ void mul_dropout_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
                                    size_t n, DropoutArg drop) {
+  drop_resolve(drop);
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float v = a[i] * b[i];
@@ -836,6 +842,7 @@ __global__ void mul_dropout_kernel(const float* __restrict__ a, const float* __r
 __global__ void mul_dropout_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                        const float* __restrict__ dout, float* __restrict__ da, float* __restrict__ db,
                                        size_t n, DropoutArg drop) {
+  drop_resolve(drop);
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float d = dout[i];
@@ -882,7 +889,9 @@ __global__ void gather_rows_kernel(const bf16_t* __restrict__ src, const int32_t
   }
 }
 
-inline DropoutArg mk_drop(uint32_t key, uint32_t thr, float scale) { DropoutArg d; d.key = key; d.thr = thr; d.scale = scale; return d; }
+inline DropoutArg mk_drop(uint32_t key, uint32_t thr, float scale, const uint32_t* salt = nullptr) {
+  DropoutArg d; d.key = key; d.thr = thr; d.scale = scale; d.salt = salt; return d;
+}
 
 }  // namespace
 
@@ -900,13 +909,13 @@ extern "C" int unimm_mask_pack(const void* mask, int dtype, uint32_t* out, int64
 
 extern "C" int unimm_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y32, void* y16, float* mean,
                                    float* rstd, int32_t M, int32_t H, float eps, uint32_t drop_key, uint32_t drop_thr,
-                                   float drop_scale, void* stream) {
+                                   float drop_scale, const uint32_t* drop_salt, void* stream) {
   if (!x || !gamma || !beta || (!y32 && !y16)) return UNIMM_E_ARG;
   if (M <= 0 || H <= 0 || H > MAXC * 512 || (H % 8)) return UNIMM_E_SHAPE;
   int blocks = (M + 3) / 4;
   blocks = blocks > 2048 ? 2048 : blocks;
   hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y32,
-                     (bf16_t*)y16, mean, rstd, M, H, eps, mk_drop(drop_key, drop_thr, drop_scale));
+                     (bf16_t*)y16, mean, rstd, M, H, eps, mk_drop(drop_key, drop_thr, drop_scale, drop_salt));
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;
 }
@@ -916,15 +925,16 @@ extern "C" int64_t unimm_colpartials_bytes(int32_t H) { return (int64_t)RED_BLOC
 extern "C" int unimm_layernorm_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                                    void* dx, void* dx_drop, float* dgamma, float* dbeta, float* dbias, float* partials,
                                    int32_t M, int32_t H, uint32_t drop_key, uint32_t drop_thr, float drop_scale,
-                                   uint32_t odrop_key, uint32_t odrop_thr, float odrop_scale, void* stream) {
+                                   uint32_t odrop_key, uint32_t odrop_thr, float odrop_scale, const uint32_t* drop_salt,
+                                   void* stream) {
   if (!dy || !x || !mean || !rstd || !gamma || !dx || !partials) return UNIMM_E_ARG;
   if (M <= 0 || H <= 0 || H > MAXC * 512 || (H % 8)) return UNIMM_E_SHAPE;
   int blocks = (M + 3) / 4;
   blocks = blocks > RED_BLOCKS ? RED_BLOCKS : blocks;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, s, (const bf16_t*)dy, x, mean, rstd,
-                     gamma, (bf16_t*)dx, (bf16_t*)dx_drop, partials, M, H, mk_drop(drop_key, drop_thr, drop_scale),
-                     mk_drop(odrop_key, odrop_thr, odrop_scale), (const int32_t*)nullptr);
+                     gamma, (bf16_t*)dx, (bf16_t*)dx_drop, partials, M, H, mk_drop(drop_key, drop_thr, drop_scale, drop_salt),
+                     mk_drop(odrop_key, odrop_thr, odrop_scale, drop_salt), (const int32_t*)nullptr);
   UNIMM_CHECK_LAUNCH();
   hipLaunchKernelGGL(colpartials_finish_kernel, dim3((H + 63) / 64, 3), dim3(1024), 0, s, partials, blocks, 3, H, dgamma,
                      dbeta, dbias, (float*)nullptr);
@@ -936,14 +946,14 @@ extern "C" int unimm_layernorm_bwd_partials(const void* dy, const float* x, cons
                                             const float* gamma, void* dx, void* dx_drop, float* partials, int32_t M, int32_t H,
                                             uint32_t drop_key, uint32_t drop_thr, float drop_scale, uint32_t odrop_key,
                                             uint32_t odrop_thr, float odrop_scale, int32_t* blocks_out, const int32_t* m_dev,
-                                            void* stream) {
+                                            const uint32_t* drop_salt, void* stream) {
   if (!dy || !x || !mean || !rstd || !gamma || !dx || !partials || !blocks_out) return UNIMM_E_ARG;
   if (M <= 0 || H <= 0 || H > MAXC * 512 || (H % 8)) return UNIMM_E_SHAPE;
   int blocks = (M + 3) / 4;
   blocks = blocks > RED_BLOCKS ? RED_BLOCKS : blocks;
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, x, mean, rstd,
-                     gamma, (bf16_t*)dx, (bf16_t*)dx_drop, partials, M, H, mk_drop(drop_key, drop_thr, drop_scale),
-                     mk_drop(odrop_key, odrop_thr, odrop_scale), m_dev);
+                     gamma, (bf16_t*)dx, (bf16_t*)dx_drop, partials, M, H, mk_drop(drop_key, drop_thr, drop_scale, drop_salt),
+                     mk_drop(odrop_key, odrop_thr, odrop_scale, drop_salt), m_dev);
   UNIMM_CHECK_LAUNCH();
   *blocks_out = blocks;
   return UNIMM_OK;
@@ -978,7 +988,7 @@ extern "C" int unimm_embed_fwd(const unimm_embed_args* a, float* y32, void* y, v
   e.word = a->word; e.post = a->post; e.type = a->type;
   e.ext = a->ext; e.gamma = a->gamma; e.beta = a->beta;
   e.M = a->M; e.H = a->H; e.type_vocab = a->type_vocab; e.eps = a->eps;
-  e.drop = mk_drop(a->drop_key, a->drop_thr, a->drop_scale);
+  e.drop = mk_drop(a->drop_key, a->drop_thr, a->drop_scale, a->drop_salt);
   e.m_dev = a->m_dev; e.rows = a->rows;
   int blocks = (a->M + 3) / 4;
   blocks = blocks > 2048 ? 2048 : blocks;
@@ -996,7 +1006,7 @@ extern "C" int unimm_embed_bwd(const unimm_embed_args* a, const void* dy, float*
   e.word = a->word; e.post = a->post; e.type = a->type;
   e.ext = a->ext; e.gamma = a->gamma; e.beta = a->beta;
   e.M = a->M; e.H = a->H; e.type_vocab = a->type_vocab; e.eps = a->eps;
-  e.drop = mk_drop(a->drop_key, a->drop_thr, a->drop_scale);
+  e.drop = mk_drop(a->drop_key, a->drop_thr, a->drop_scale, a->drop_salt);
   e.m_dev = a->m_dev; e.rows = a->rows;
   int blocks = (a->M + 3) / 4;
   blocks = blocks > RED_BLOCKS ? RED_BLOCKS : blocks;
@@ -1096,20 +1106,21 @@ extern "C" int unimm_pack_image(const float* feat, const float* loc, void* out, 
 }
 
 extern "C" int unimm_mul_dropout(const float* a, const float* b, float* out, int64_t n, uint32_t drop_key, uint32_t drop_thr,
-                                 float drop_scale, void* stream) {
+                                 float drop_scale, const uint32_t* drop_salt, void* stream) {
   if (!a || !b || !out || n <= 0) return UNIMM_E_ARG;
   hipLaunchKernelGGL(mul_dropout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     a, b, out, (size_t)n, mk_drop(drop_key, drop_thr, drop_scale));
+                     a, b, out, (size_t)n, mk_drop(drop_key, drop_thr, drop_scale, drop_salt));
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;
 }
 
 extern "C" int unimm_mul_dropout_bwd(const float* a, const float* b, const float* dout, float* da, float* db, int64_t n,
-                                     uint32_t drop_key, uint32_t drop_thr, float drop_scale, void* stream) {
+                                     uint32_t drop_key, uint32_t drop_thr, float drop_scale, const uint32_t* drop_salt,
+                                     void* stream) {
   if (!a || !b || !dout || !da || !db || n <= 0) return UNIMM_E_ARG;
   hipLaunchKernelGGL(mul_dropout_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      a, b, dout, da, db, (size_t)n,
-                     mk_drop(drop_key, drop_thr, drop_scale));
+                     mk_drop(drop_key, drop_thr, drop_scale, drop_salt));
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;
 }

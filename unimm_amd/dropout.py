@@ -20,9 +20,20 @@ def mix32_int(x: int) -> int:
     return x
 
 
+def site_key(seed: int, site: int) -> int:
+    """The per-(seed, site) part of a dropout key: what a launch carries as its argument."""
+    return mix32_int(mix32_int(seed * 0x9E3779B1 + 0x51ED270B) ^ (site * 0x85EBCA77 + 0x165667B1))
+
+
+def step_salt(seed: int, step: int) -> int:
+    """The per-step part: one word for the whole step, XORed into every site's key.  A replayed launch sequence reads it
+    from device memory (its arguments are frozen at capture); an eager launch gets the combined key as its argument."""
+    return mix32_int(mix32_int(seed * 0xC2B2AE3D + 0x27D4EB2F) + step * 0x9E3779B1)
+
+
 def make_key(seed: int, step: int, site: int) -> int:
     """One word per dropout site and step (site ids are assigned by the engine)."""
-    return mix32_int(mix32_int(seed * 0x9E3779B1 + step) ^ (site * 0x85EBCA77 + 0x165667B1))
+    return site_key(seed, site) ^ step_salt(seed, step)
 
 
 def drop_arg(p: float, key: int):

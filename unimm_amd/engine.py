@@ -113,6 +113,9 @@ class Engine:
         # the device by unimm_plan_build).  1 = exact sizes (default); the graph executor (unimm_amd/graphs.py) raises them
         # so that steps with nearby row counts replay one captured launch sequence.
         self.row_bucket, self.lm_bucket = 1, 1
+        self.salt_word = None            # int32 [1] device tensor holding dropout.step_salt(seed, step), or None (see _drop)
+        self._inject_header = None       # header values of the step, read ahead of a graph capture (see _forward, graphs.py)
+        self.graphs = None               # unimm_amd.graphs.StepGraphs once enable_graphs() was called
         self._dims = None                # (int32 [8], fp32 [8]) device words: {valid rows, decoded rows, regions}, {1/decoded, 1/regions}
         self._pending = []               # gradient buckets whose weight gradients are still queued: (group, #text, #image queued)
         self._nq = [0, 0]                # weight-gradient problems ever queued (text side, image side) ...
@@ -299,8 +302,13 @@ class Engine:
     # small op helpers (each returns its output and pushes its backward onto the tape)
     # ------------------------------------------------------------------------------------------
     def _drop(self, name, p, train):
+        """Dropout triple of one site.  Eagerly the key carries seed, step and site; with `salt_word` set (the graph
+        executor) the argument is the per-site key and the per-step salt is read from that device word at kernel entry:
+        the same masks either way (dropout.make_key = site_key ^ step_salt)."""
         if not train or p <= 0.0:
             return L.NO_DROP
+        if self.salt_word is not None:
+            return DR.drop_arg(p, DR.site_key(self.seed, _site(name))) + (self.salt_word,)
         return DR.drop_arg(p, DR.make_key(self.seed, self.step, _site(name)))
 
     def _linear(self, x, lin, epi=L.EPI_BIAS, aux=None, want_u=False, drop=None, out_f32=False, ldo=None, M=None):
@@ -737,6 +745,37 @@ class Engine:
             self._text_stream = self._text_scope = None
             caller.wait_stream(hp)
 
+    def enable_graphs(self, on=True, **kw):
+        """Run the training step as two replayed hipGraphs per row-count bucket (unimm_amd/graphs.py) instead of ~650
+        Python -> C launches: what the small per-GPU batches of the 8-GPU split need (host-bound otherwise)."""
+        from .graphs import StepGraphs
+        self.graphs = StepGraphs(self, **kw) if on else None
+        return self.graphs
+
+    def count_rows(self, inp: dict, lm_rows="labelled"):
+        """The header of the step plan as host values, computed ahead of the step: what `_forward` reads at its one host
+        sync.  Same kernels on the same inputs (masks bit-packed, unimm_plan_lengths)."""
+        dev = self.arena.device
+        ids, feat = inp["input_ids"], inp["image_feat"]
+        B, T = ids.shape
+        R = feat.shape[1]
+        am, im, cm = inp.get("attention_mask"), inp.get("image_attention_mask"), inp.get("co_attention_mask")
+        if am is None or isinstance(am, DialogMaskSpec) or cm is None:
+            raise ValueError("count_rows needs dense attention_mask / co_attention_mask tensors")
+        self._dev_masks = []
+        tmask = self._pack_mask(am, dev, T)
+        comask = self._pack_mask(cm, dev, R)
+        self._dev_masks = []
+        labels, weights = inp.get("masked_lm_labels"), inp.get("lm_weight")
+        lab32 = self._i32(labels.reshape(B, T), dev) if labels is not None else None
+        w32 = self._i32(weights.reshape(B, T), dev) if (weights is not None and labels is not None) else None
+        il = inp.get("image_label")
+        il32 = self._i32(il.reshape(B, R), dev) if (il is not None and inp.get("image_target") is not None) else None
+        nw_in = inp.get("nsp_weight")
+        nw_dev = nw_in.reshape(-1)[:2].to(F32).contiguous() if (torch.is_tensor(nw_in) and nw_in.is_cuda) else None
+        header = L.plan_lengths(tmask, comask, R, lab32, w32, nw_dev, B, T, image_label=il32)
+        return header.tolist()
+
     def forward(self, inp: dict, train: bool, save: bool, lm_rows: str, want_pred_v: bool):
         return self._on_text_stream(self._forward, inp, train, save, lm_rows, want_pred_v)
 
@@ -854,7 +893,9 @@ class Engine:
         dyn = None
         if self.unpad or want_sel or nw_dev is not None or il32 is not None:
             header = L.plan_lengths(tmask, comask, R, lab32, w32, nw_dev, B, T, image_label=il32)
-            hh = header.tolist()                                          # the step's one host sync
+            # the step's one host sync (the graph executor has read the same header in its pre-pass and injects the values:
+            # a captured launch sequence cannot synchronise)
+            hh = self._inject_header if self._inject_header is not None else header.tolist()
             n_img = sum(hh[2 * B + 2:3 * B + 2]) if il32 is not None else None
             lens_h, n_lm = hh[:B], (sum(hh[B:2 * B]) if want_sel else 0)
             Mv = sum(lens_h)

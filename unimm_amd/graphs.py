@@ -1,0 +1,180 @@
+"""The training step as replayed hipGraphs (the executor of the small-batch regime).
+
+Eagerly a step is ~650 Python -> ctypes -> hipLaunchKernelGGL calls plus ~750 tensor allocations: ~10 ms of host work, as
+much as the GPU needs for the 30 sequences a GPU holds when 240 are split over 8 (the strong-scaling
+ceiling).  Here the launch sequence of `Engine._forward` + `_losses` and of `Engine._backward` is captured ONCE per
+signature (`torch.cuda.graph`: our C-ABI launches go to torch's capturing stream, the image side forks and joins through
+events, every `torch.empty` of the step comes from the graph's private pool = a static activation arena) and replayed with
+two `hipGraphLaunch` calls per step.  What a replay cannot take from frozen launch arguments lives in device memory:
+
+  * row counts: launches are sized for CAPACITIES (valid text rows / decoded rows rounded up to `row_bucket` /
+    `lm_bucket`), kernels that reduce over rows read the real counts written by unimm_plan_build (Engine._dims);
+  * loss denominators (1 / decoded rows, 1 / masked regions): the same words;
+  * dropout: the launch argument is the per-(seed, site) key, the per-step salt is one device word (Engine.salt_word);
+  * inputs: copied into static buffers before the replay; gradients of the three losses likewise.
+
+The host still reads ONE header per step (valid lengths, decoded rows: `Engine.count_rows`) to pick the bucket; a
+signature is captured the second time it is seen (the first time runs eagerly) and at most `max_entries` signatures are
+kept (each owns its activations: ~0.19 GB per sequence at the full config).
+
+Not covered (falls back to the eager path): inputs on the host, mask descriptors (`DialogMaskSpec`), dense LM scores
+(`output_lm_scores=True`), the data-parallel wrapper's per-bucket hooks (collectives between the launches of backward)."""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import torch
+
+from . import dropout as DR
+from . import lib as L
+
+_TENSOR_KEYS = ("input_ids", "image_feat", "image_loc", "token_type_ids", "position_ids", "attention_mask",
+                "image_attention_mask", "co_attention_mask", "masked_lm_labels", "image_label", "image_target",
+                "next_sentence_label", "lm_weight", "image_index")
+
+
+def _rup(x, m):
+    return (x + m - 1) // m * m
+
+
+class _Entry:
+    __slots__ = ("pool", "sin", "gF", "out", "losses", "nsp", "gB", "gin", "gkey", "stream")
+
+
+class StepGraphs:
+    def __init__(self, engine, row_bucket=128, lm_bucket=64, max_entries=4, capture_after=1):
+        self.eng = engine
+        self.row_bucket, self.lm_bucket = row_bucket, lm_bucket
+        self.max_entries, self.capture_after = max_entries, capture_after
+        self.entries = OrderedDict()
+        self.seen = {}
+        self.salt = None
+        self.stats = dict(replays=0, captures=0, eager=0)
+
+    # ------------------------------------------------------------------------------------------
+    def eligible(self, inp, opts):
+        eng = self.eng
+        if opts.get("want_seq") or eng.grad_bucket_hook is not None or eng.wgrad_stream or eng.text_priority:
+            return False
+        for k in _TENSOR_KEYS:
+            v = inp.get(k)
+            if v is None:
+                continue
+            if not torch.is_tensor(v) or not v.is_cuda:
+                return False
+        for k in ("attention_mask", "co_attention_mask", "masked_lm_labels", "image_target", "next_sentence_label"):
+            if inp.get(k) is None:
+                return False
+        nw = inp.get("nsp_weight")
+        return nw is None or (torch.is_tensor(nw) and not nw.is_cuda)
+
+    @staticmethod
+    def _key0(inp, opts):
+        parts = [bool(opts["train"])]
+        for k in _TENSOR_KEYS:
+            v = inp.get(k)
+            parts.append(None if v is None else (tuple(v.shape), v.dtype))
+        nw = inp.get("nsp_weight")
+        parts.append(None if nw is None else tuple(float(x) for x in nw.reshape(-1).tolist()))
+        return tuple(parts)
+
+    def _set_salt(self):
+        eng = self.eng
+        if self.salt is None:
+            self.salt = torch.zeros(1, dtype=torch.int32, device=eng.arena.device)
+        v = DR.step_salt(eng.seed, eng.step)
+        self.salt.fill_(v - (1 << 32) if v >= (1 << 31) else v)
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, inp, opts):
+        """-> (lm_loss, img_loss, nsp_loss, nsp, entry) from a replay, or None (the caller runs the eager path)."""
+        eng = self.eng
+        eng.refresh_weights()
+        hh = eng.count_rows(inp)                               # the step's one host sync
+        B, T = inp["input_ids"].shape
+        Mv, n_lm = sum(hh[:B]), sum(hh[B:2 * B])
+        Mcap = min(_rup(Mv, self.row_bucket), B * T)
+        ncap = _rup(n_lm, self.lm_bucket) if n_lm > 0 else 0
+        sig = self._key0(inp, opts) + (Mcap, ncap, eng.dual_stream, eng.unpad, eng.lazy_ln, eng.gemm_tile, eng.wgrad_group_rounds)
+        ent = self.entries.get(sig)
+        if ent is None:
+            n = self.seen.get(sig, 0)
+            self.seen[sig] = n + 1
+            if n < self.capture_after:
+                self.stats["eager"] += 1
+                return None
+            ent = self._capture_forward(sig, inp, opts, hh)
+        else:
+            self.entries.move_to_end(sig)
+            for k, t in ent.sin.items():
+                if torch.is_tensor(t):
+                    t.copy_(inp[k], non_blocking=True)
+        self._set_salt()
+        ent.gF.replay()
+        self.stats["replays"] += 1
+        ls = ent.losses
+        return ls["lm_loss"].clone(), ls["img_loss"].clone(), ls["nsp_loss"].clone(), ent.nsp.clone(), ent
+
+    def _capture_forward(self, sig, inp, opts, hh):
+        eng = self.eng
+        dev = eng.arena.device
+        while len(self.entries) >= self.max_entries:           # each signature owns its activations
+            self.entries.popitem(last=False)
+        ent = _Entry()
+        ent.pool = torch.cuda.graph_pool_handle()
+        ent.sin = {k: (v.clone() if torch.is_tensor(v) and v.is_cuda else v) for k, v in inp.items()}
+        ent.gB, ent.gin, ent.gkey = None, None, None
+        ent.stream = torch.cuda.Stream(device=dev)
+        was = (eng.row_bucket, eng.lm_bucket, eng.salt_word, eng._inject_header)
+        if self.salt is None:
+            self._set_salt()
+        eng.row_bucket, eng.lm_bucket, eng.salt_word, eng._inject_header = self.row_bucket, self.lm_bucket, self.salt, hh
+        try:
+            # warm-up on the capture stream with the capture's own sizes (first-use initialisation of kernels / tiles)
+            ent.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(ent.stream):
+                with torch.no_grad():
+                    out = eng.forward(ent.sin, train=opts["train"], save=False, lm_rows="labelled", want_pred_v=True)
+                    eng.losses(out, ent.sin)
+                del out
+            torch.cuda.current_stream().wait_stream(ent.stream)
+            torch.cuda.synchronize()
+            ent.gF = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ent.gF, pool=ent.pool, stream=ent.stream):
+                ent.out = eng.forward(ent.sin, train=opts["train"], save=True, lm_rows="labelled", want_pred_v=True)
+                ent.losses = eng.losses(ent.out, ent.sin)
+                ent.nsp = ent.out["nsp"]
+        finally:
+            eng.row_bucket, eng.lm_bucket, eng.salt_word, eng._inject_header = was
+        self.entries[sig] = ent
+        self.stats["captures"] += 1
+        return ent
+
+    # ------------------------------------------------------------------------------------------
+    def backward(self, ent, g_lm, g_img, g_nsp, g_scores):
+        eng = self.eng
+        dev = eng.arena.device
+        grads = (g_lm, g_img, g_nsp, g_scores)
+        gkey = tuple(None if g is None else tuple(g.shape) for g in grads)
+        if ent.gB is None or ent.gkey != gkey:
+            ent.gkey = gkey
+            ent.gin = [None if g is None else torch.zeros(g.shape, dtype=torch.float32, device=dev) for g in grads]
+            for s, g in zip(ent.gin, grads):
+                if s is not None:
+                    s.copy_(g.detach().to(torch.float32))
+            was = (eng.row_bucket, eng.lm_bucket, eng.salt_word)
+            eng.row_bucket, eng.lm_bucket, eng.salt_word = self.row_bucket, self.lm_bucket, self.salt
+            try:
+                torch.cuda.synchronize()
+                ent.gB = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ent.gB, pool=ent.pool, stream=ent.stream):
+                    eng.backward(ent.out, *ent.gin)
+            finally:
+                eng.row_bucket, eng.lm_bucket, eng.salt_word = was
+            self.stats["captures"] += 1
+        else:
+            for s, g in zip(ent.gin, grads):
+                if s is not None:
+                    s.copy_(g.detach(), non_blocking=True)
+        eng.arena.attach_grads()
+        ent.gB.replay()

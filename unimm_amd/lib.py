@@ -13,7 +13,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libunimm_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROP_RESID, EPI_BIAS_RELU, EPI_DGELU, EPI_ADD, EPI_MUL, EPI_BIAS_GELU_DG = range(8)
 
@@ -32,7 +32,7 @@ class GemmNtArgs(C.Structure):
                 ("epilogue", C.c_int32), ("out_f32", C.c_int32),
                 ("drop_key", C.c_uint32), ("drop_thr", C.c_uint32), ("drop_scale", C.c_float),
                 ("aux_mean", C.c_void_p), ("aux_rstd", C.c_void_p), ("aux_gamma", C.c_void_p), ("aux_beta", C.c_void_p),
-                ("tile", C.c_int32)]
+                ("tile", C.c_int32), ("drop_salt", C.c_void_p)]
 
 
 class GemmTnArgs(C.Structure):
@@ -72,9 +72,9 @@ def lib():
     L.unimm_gemm_tn_grouped.argtypes = [VP, I32, VP]
     L.unimm_gemm_tn_grouped_ws.argtypes = [VP, I32, I32, VP, I64, VP]
     L.unimm_colpartials_finish_grouped.argtypes = [VP, I32, VP]
-    L.unimm_layernorm_fwd.argtypes = [VP] * 7 + [I32, I32, F32, U32, U32, F32, VP]
-    L.unimm_layernorm_bwd_partials.argtypes = [VP] * 8 + [I32, I32, U32, U32, F32, U32, U32, F32, VP, VP, VP]
-    L.unimm_layernorm_bwd.argtypes = [VP] * 11 + [I32, I32, U32, U32, F32, U32, U32, F32, VP]
+    L.unimm_layernorm_fwd.argtypes = [VP] * 7 + [I32, I32, F32, U32, U32, F32, VP, VP]
+    L.unimm_layernorm_bwd_partials.argtypes = [VP] * 8 + [I32, I32, U32, U32, F32, U32, U32, F32, VP, VP, VP, VP]
+    L.unimm_layernorm_bwd.argtypes = [VP] * 11 + [I32, I32, U32, U32, F32, U32, U32, F32, VP, VP]
     _lib = L
     return L
 
@@ -136,6 +136,14 @@ def _P(t):
     return t.data_ptr() if t is not None else None
 
 
+def _salt(*drops):
+    """Device address of the salt word a dropout triple may carry as a 4th element: (key, thr, scale[, salt tensor])."""
+    for d in drops:
+        if d is not None and len(d) > 3 and d[3] is not None:
+            return d[3].data_ptr()
+    return None
+
+
 def _dev(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -166,7 +174,8 @@ def gemm_nt(x, w, out, bias=None, epilogue=EPI_BIAS, aux=None, out2=None, drop=N
     a.epilogue = epilogue
     a.tile = tile
     a.out_f32 = 1 if out.dtype == torch.float32 else 0
-    a.drop_key, a.drop_thr, a.drop_scale = drop if drop is not None else (0, 0, 0.0)
+    a.drop_key, a.drop_thr, a.drop_scale = drop[:3] if drop is not None else (0, 0, 0.0)
+    a.drop_salt = _salt(drop)
     if aux_ln is not None:
         _dev(*aux_ln)
         a.aux_mean, a.aux_rstd, a.aux_gamma, a.aux_beta = (t.data_ptr() for t in aux_ln)
@@ -228,7 +237,7 @@ class AttnArgs(C.Structure):
                 ("B", C.c_int32), ("H", C.c_int32), ("Tq", C.c_int32), ("Tk", C.c_int32), ("D", C.c_int32),
                 ("ldq", C.c_int32), ("ldk", C.c_int32), ("ldv", C.c_int32), ("ldo", C.c_int32),
                 ("mask_q_stride", C.c_int32), ("mask_b_stride", C.c_int32), ("scale", C.c_float),
-                ("drop_key", C.c_uint32), ("drop_thr", C.c_uint32), ("drop_scale", C.c_float)]
+                ("drop_key", C.c_uint32), ("drop_thr", C.c_uint32), ("drop_scale", C.c_float), ("drop_salt", C.c_void_p)]
 
 
 class AttnBwdArgs(C.Structure):
@@ -240,7 +249,7 @@ class AttnBwdArgs(C.Structure):
                 ("ldq", C.c_int32), ("ldk", C.c_int32), ("ldv", C.c_int32), ("ldo", C.c_int32), ("lddo", C.c_int32),
                 ("lddq", C.c_int32), ("lddk", C.c_int32), ("lddv", C.c_int32),
                 ("mask_q_stride", C.c_int32), ("mask_b_stride", C.c_int32), ("scale", C.c_float),
-                ("drop_key", C.c_uint32), ("drop_thr", C.c_uint32), ("drop_scale", C.c_float)]
+                ("drop_key", C.c_uint32), ("drop_thr", C.c_uint32), ("drop_scale", C.c_float), ("drop_salt", C.c_void_p)]
 
 
 NO_DROP = (0, 0, 1.0)
@@ -262,7 +271,8 @@ def attn_fwd(q, k, v, out, lse, mask, B, H, Tq, Tk, D, scale, mask_q_stride, mas
     a.B, a.H, a.Tq, a.Tk, a.D = B, H, Tq, Tk, D
     a.ldq, a.ldk, a.ldv, a.ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
     a.mask_q_stride, a.mask_b_stride, a.scale = mask_q_stride, mask_b_stride, scale
-    a.drop_key, a.drop_thr, a.drop_scale = drop
+    a.drop_key, a.drop_thr, a.drop_scale = drop[:3]
+    a.drop_salt = _salt(drop)
     rc = fn(addr, _stream())
     if rc != 0:
         _check(rc, "unimm_attn_fwd")
@@ -285,7 +295,8 @@ def attn_bwd(q, k, v, out, dout, lse, delta, dq, dk, dv, mask, B, H, Tq, Tk, D, 
     a.ldq, a.ldk, a.ldv, a.ldo, a.lddo = q.stride(0), k.stride(0), v.stride(0), out.stride(0), dout.stride(0)
     a.lddq, a.lddk, a.lddv = dq.stride(0), dk.stride(0), dv.stride(0)
     a.mask_q_stride, a.mask_b_stride, a.scale = mask_q_stride, mask_b_stride, scale
-    a.drop_key, a.drop_thr, a.drop_scale = drop
+    a.drop_key, a.drop_thr, a.drop_scale = drop[:3]
+    a.drop_salt = _salt(drop)
     rc = fn(addr, _stream())
     if rc != 0:
         _check(rc, "unimm_attn_bwd")
@@ -330,7 +341,8 @@ def layernorm_bwd_partials(dy, x, mean, rstd, gamma, dx, dx_drop, partials, M, H
     blocks = C.c_int32(0)
     rc = lib().unimm_layernorm_bwd_partials(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
                                             dx.data_ptr(), _P(dx_drop), partials.data_ptr(), M, H, drop[0], drop[1], drop[2],
-                                            out_drop[0], out_drop[1], out_drop[2], C.addressof(blocks), _P(m_dev), _stream())
+                                            out_drop[0], out_drop[1], out_drop[2], C.addressof(blocks), _P(m_dev),
+                                            _salt(drop, out_drop), _stream())
     if rc != 0:
         _check(rc, "unimm_layernorm_bwd_partials")
     return blocks.value
@@ -352,7 +364,7 @@ def colpartials_finish_grouped(pending):
 def layernorm_fwd(x, gamma, beta, y32, y16, mean, rstd, M, H, eps=1e-12, drop=NO_DROP):
     _dev(x, gamma, beta, y32, y16, mean, rstd)
     rc = lib().unimm_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _P(y32), _P(y16), _P(mean), _P(rstd), M, H, eps,
-                                   drop[0], drop[1], drop[2], _stream())
+                                   drop[0], drop[1], drop[2], _salt(drop), _stream())
     if rc != 0:
         _check(rc, "unimm_layernorm_fwd")
 
@@ -362,7 +374,7 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dx_drop, dgamma, dbeta, dbias, p
     _dev(dy, x, mean, rstd, gamma, dx, dx_drop, dgamma, dbeta, dbias, partials)
     _check(lib().unimm_layernorm_bwd(_P(dy), _P(x), _P(mean), _P(rstd), _P(gamma), _P(dx), _P(dx_drop),
                                      _P(dgamma), _P(dbeta), _P(dbias), _P(partials), M, H, drop[0], drop[1], drop[2],
-                                     out_drop[0], out_drop[1], out_drop[2], _stream()), "unimm_layernorm_bwd")
+                                     out_drop[0], out_drop[1], out_drop[2], _salt(drop, out_drop), _stream()), "unimm_layernorm_bwd")
 
 
 class EmbedArgs(C.Structure):
@@ -371,7 +383,7 @@ class EmbedArgs(C.Structure):
                 ("gamma", C.c_void_p), ("beta", C.c_void_p),
                 ("M", C.c_int32), ("H", C.c_int32), ("type_vocab", C.c_int32), ("eps", C.c_float),
                 ("drop_key", C.c_uint32), ("drop_thr", C.c_uint32), ("drop_scale", C.c_float),
-                ("m_dev", C.c_void_p), ("rows", C.c_void_p)]
+                ("m_dev", C.c_void_p), ("rows", C.c_void_p), ("drop_salt", C.c_void_p)]
 
 
 def _embed_args(ids, pos, typ, word, post, type_, ext, gamma, beta, M, H, type_vocab, eps, drop, m_dev=None, rows=None):
@@ -381,7 +393,8 @@ def _embed_args(ids, pos, typ, word, post, type_, ext, gamma, beta, M, H, type_v
     a.word, a.post, a.type, a.ext = _ptr(word), _ptr(post), _ptr(type_), _ptr(ext)
     a.gamma, a.beta = _ptr(gamma), _ptr(beta)
     a.M, a.H, a.type_vocab, a.eps = M, H, type_vocab, eps
-    a.drop_key, a.drop_thr, a.drop_scale = drop
+    a.drop_key, a.drop_thr, a.drop_scale = drop[:3]
+    a.drop_salt = _salt(drop)
     a.m_dev, a.rows = _P(m_dev), _P(rows)
     return a
 
@@ -496,14 +509,14 @@ def pack_image(feat, loc, out, rows, F, ld):
 def mul_dropout(a, b, out, n, drop=NO_DROP):
     _dev(a, b, out)
     _check(lib().unimm_mul_dropout(_ptr(a), _ptr(b), _ptr(out), C.c_int64(n), C.c_uint32(drop[0]), C.c_uint32(drop[1]),
-                                   C.c_float(drop[2]), _stream()), "unimm_mul_dropout")
+                                   C.c_float(drop[2]), C.c_void_p(_salt(drop)), _stream()), "unimm_mul_dropout")
 
 
 def mul_dropout_bwd(a, b, dout, da, db, n, drop=NO_DROP):
     _dev(a, b, dout, da, db)
     _check(lib().unimm_mul_dropout_bwd(_ptr(a), _ptr(b), _ptr(dout), _ptr(da), _ptr(db), C.c_int64(n),
-                                       C.c_uint32(drop[0]), C.c_uint32(drop[1]), C.c_float(drop[2]), _stream()),
-           "unimm_mul_dropout_bwd")
+                                       C.c_uint32(drop[0]), C.c_uint32(drop[1]), C.c_float(drop[2]), C.c_void_p(_salt(drop)),
+                                       _stream()), "unimm_mul_dropout_bwd")
 
 
 # ---------------------------------------------------------------------------------------------

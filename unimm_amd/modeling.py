@@ -91,6 +91,13 @@ class _HotPath(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, engine, inp, opts):
         ctx.set_materialize_grads(False)
+        ctx.graph_entry = None
+        if engine.graphs is not None and engine.graphs.eligible(inp, opts):     # the step as two replayed hipGraphs
+            res = engine.graphs.forward(inp, opts)
+            if res is not None:
+                ctx.engine, ctx.out, ctx.graph_entry = engine, None, res[4]
+                engine.last_seq_t = (None, None)
+                return res[0], res[1], res[2], res[3]
         out = engine.forward(inp, train=opts["train"], save=True, lm_rows="labelled", want_pred_v=True)
         losses = engine.losses(out, inp)
         ctx.engine, ctx.out = engine, out
@@ -103,6 +110,9 @@ class _HotPath(torch.autograd.Function):
     def backward(ctx, g_lm, g_img, g_nsp, g_scores):
         engine, out = ctx.engine, ctx.out
         ctx.out = None
+        if ctx.graph_entry is not None:
+            engine.graphs.backward(ctx.graph_entry, g_lm, g_img, g_nsp, g_scores)
+            return None, None, None, None
         engine.backward(out, g_lm, g_img, g_nsp, g_scores)
         return None, None, None, None
 
