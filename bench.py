@@ -70,10 +70,13 @@ def parse():
                          "what the roofline block needs; all = every GEMM launch (adds the all_gemm_* fields).  Two event records "
                          "around each of ~340 GEMM launches are not free: measured 1.3 ms of a 56 ms step at bs=240 (drain + "
                          "timestamp between back-to-back kernels) and 2 ms of 16 ms at 30 sequences per GPU (host launch rate)")
-    ap.add_argument("--graphs", action="store_true",
+    ap.add_argument("--single-stream", action="store_true",
+                    help="everything on one HIP stream (engine.dual_stream = False): exclusive kernel durations for rocprofv3 "
+                         "breakdowns; the production schedule runs the image side on a second stream")
+    ap.add_argument("--graphs", choices=["auto", "on", "off"], default="auto",
                     help="run the step as replayed hipGraphs (unimm_amd/graphs.py: two graph launches per step instead of ~650 "
-                         "host calls; N = 1 only). The timed region then has no per-launch events: the roofline block comes from "
-                         "the eager steps after it.")
+                         "host calls; N = 1 only; auto = on for <= 120 sequences per GPU, where the host would otherwise bound the "
+                         "step). The timed region then has no per-launch events: the roofline block comes from eager steps after it.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-tile", type=int, default=0, metavar="CODE",
                     help="tuning: unimm_gemm_nt_args.tile = CODE for every launch of the run (1000 x tile columns per group + 100 x {1 persistent, "
@@ -358,6 +361,8 @@ def main():
         return fwd_bwd()
 
     model.engine.gemm_tile = args.gemm_tile      # per-call tuning code of every unimm_gemm_nt launch (0 = automatic)
+    if args.single_stream:
+        model.engine.dual_stream = False
     model.engine.ensure(dev)
     model.engine.arena.attach_grads()
     log(f"model + batch ready on {dev}: {per_gpu} sequences/GPU, {n_lm_rows} decoded MLM rows")
@@ -385,7 +390,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    use_graphs = args.graphs and world == 1 and args.workload == "train"
+    use_graphs = (args.graphs == "on" or (args.graphs == "auto" and per_gpu <= 120)) and world == 1 and args.workload == "train" \
+        and not args.compact_inputs and not args.host_profile
     if use_graphs:
         model.engine.enable_graphs(True)
         for _ in range(3):                      # eager once more, capture, first replay

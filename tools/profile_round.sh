@@ -6,7 +6,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 python bench.py > $out/bench_b240.json 2> $out/bench_b240.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o run -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-padded > $out/bench_b240_under_rocprof.json 2> $out/stats.err
-UNIMM_DUAL_STREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats1 -o run -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-padded > $out/bench_b240_single_stream_under_rocprof.json 2> $out/stats1.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats1 -o run -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-padded --single-stream > $out/bench_b240_single_stream_under_rocprof.json 2> $out/stats1.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o run -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-padded > /dev/null 2> $out/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_write -o run -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-padded > /dev/null 2> $out/pmc_write.err
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $out/pmc_sq -o run -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-padded > /dev/null 2> $out/pmc_sq.err

@@ -1211,9 +1211,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmTnGroup grp) {
     if ((HT) < 2) tn_pp_stage(st, srd_b, (uint32_t)(KT) * step_b, (KT) & 1, (HT));                              \
     else tn_pp_stage(st, srd_a, (uint32_t)(KT) * step_a, (KT) & 1, (HT));                                       \
   }
-  // prologue: step 0 (4 half-tiles) and half-tile 0 of step 1
+  // prologue: step 0 (4 half-tiles) and the two X half-tiles of step 1
   UNIMM_TN_STAGE(0, 0) UNIMM_TN_STAGE(0, 1) UNIMM_TN_STAGE(0, 2) UNIMM_TN_STAGE(0, 3)
-  if (nk > 1) UNIMM_TN_STAGE(1, 0)
+  if (nk > 1) { UNIMM_TN_STAGE(1, 0) UNIMM_TN_STAGE(1, 1) }
   __builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0), visible to the compiler (see nt_mainloop_pp)
   __builtin_amdgcn_s_barrier();                                 // step 0 has landed for every wave
   if (wn == 1) __builtin_amdgcn_s_barrier();                    // G1 runs one barrier behind G0
@@ -1264,10 +1264,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmTnGroup grp) {
     for (int x = 0; x < 8; ++x) aa[x] = aa0[x] + off;
 #pragma unroll
     for (int x = 0; x < 4; ++x) ab[x] = ab0[x] + off;
-    // ---- phase 0 (stages half-tile 1 of step t+1)
+    // Staging runs as far ahead as the two buffers allow: the X half-tiles of step t+2 go out in phase 3 of step t (their
+    // buffer's X fragments were last read in phase 1), the DY half-tiles of step t+1 in phases 0 and 1 (last read in
+    // phase 2 of step t-1); a half-tile has 0.5-1.25 steps to land (0.25-1.0 with one half-tile per phase).
+    // ---- phase 0 (stages DY half-tile 0 of step t+1)
     UNIMM_TN_READ_B(0)
     UNIMM_TN_READ_A(0)
-    if (t + 1 < nk) UNIMM_TN_STAGE(t + 1, 1)
+    if (t + 1 < nk) UNIMM_TN_STAGE(t + 1, 2)
     UNIMM_TN_SYNC_READS()
     UNIMM_TN_MFMA(0, 0)
     UNIMM_TN_BIAS(0)
@@ -1275,21 +1278,20 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmTnGroup grp) {
     __builtin_amdgcn_sched_barrier(0);
     // ---- phase 1
     UNIMM_TN_READ_B(1)
-    if (t + 1 < nk) UNIMM_TN_STAGE(t + 1, 2)
+    if (t + 1 < nk) UNIMM_TN_STAGE(t + 1, 3)
     UNIMM_TN_SYNC_READS()
     UNIMM_TN_MFMA(0, 1)
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     // ---- phase 2
     UNIMM_TN_READ_A(1)
-    if (t + 1 < nk) UNIMM_TN_STAGE(t + 1, 3)
     UNIMM_TN_SYNC_READS()
     UNIMM_TN_MFMA(1, 1)
     UNIMM_TN_BIAS(1)
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    // ---- phase 3: no fragment reads; certify step t+1 (every DMA older than this phase's two has landed)
-    if (t + 2 < nk) { UNIMM_TN_STAGE(t + 2, 0) wait_vmcnt<2>(); } else wait_vmcnt<0>();
+    // ---- phase 3: no fragment reads; certify step t+1 (every DMA older than this phase's four has landed)
+    if (t + 2 < nk) { UNIMM_TN_STAGE(t + 2, 0) UNIMM_TN_STAGE(t + 2, 1) wait_vmcnt<4>(); } else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     UNIMM_TN_MFMA(1, 0)

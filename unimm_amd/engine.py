@@ -15,7 +15,6 @@ compute step is a C-ABI call and raises if the library is missing."""
 from __future__ import annotations
 
 import math
-import os
 import zlib
 from contextlib import contextmanager
 from typing import Dict, List, Optional
@@ -73,23 +72,25 @@ class Engine:
         self.last_seq_t = None
         self.unpad = True                # run the text stream on valid rows only (see the plan step of _forward)
         self._wq = []                    # queued weight-gradient problems (text side) waiting for their grouped launch
-        self.lazy_ln = os.environ.get("UNIMM_LAZY_LN", "1") == "1"   # residual epilogues evaluate the previous LayerNorm
-        # Option: grouped weight-gradient launches on a side stream (UNIMM_WGRAD_STREAM=1): +1.8 % throughput in
+        # Schedule options are plain attributes (set them on `model.engine` before the first step; bench.py has flags for
+        # the ones that are measured: --single-stream).  No environment switches.
+        self.lazy_ln = True              # residual epilogues evaluate the previous LayerNorm instead of reading its fp32 output
+        # Option: grouped weight-gradient launches on a side stream (`wgrad_stream = True`): +1.8 % throughput in
         # interleaved runs (61.2 -> 60.1 ms) because the next block's GEMMs fill the partial last round and the
         # atomic drain.  Off by default: overlapped kernels stretch each other's durations, so per-kernel event /
         # rocprof timings (bench.py's roofline block) would no longer be exclusive.
-        self.wgrad_stream = os.environ.get("UNIMM_WGRAD_STREAM", "0") == "1"
+        self.wgrad_stream = False
         self._side = None
-        # Image-stream blocks on their own HIP stream (UNIMM_DUAL_STREAM): between two connection layers the
+        # Image-stream blocks on their own HIP stream (`dual_stream`, default on): between two connection layers the
         # image layer and the text layer are independent (models/vilbert_dialog.py:842-929), and the image side's
         # kernels are too small to fill 256 CUs (M = B*37 rows), so they run beside the text layer's and fill its
         # partial rounds; the same holds for the image half of a connection layer once the two co-attention
         # directions have exchanged their K/V.  Same kernels, same order within each stream.
-        self.dual_stream = os.environ.get("UNIMM_DUAL_STREAM", "1") == "1"
+        self.dual_stream = True
         self._text_stream = None      # the stream of the running engine entry (see _on_text_stream / _img)
         self._text_scope = None       # ... and the raw-stream object lib.stream_scope installed for it
         self._vside = None
-        self.text_priority = os.environ.get("UNIMM_TEXT_PRIORITY", "0") == "1"
+        self.text_priority = False       # text side on an internal high-priority stream (measured -0.6 %: off)
         self._tstream = None
         self._on_side = False            # inside `_img()`: launches (and queued weight gradients) belong to the image side
         self._wq_img = []
@@ -100,8 +101,8 @@ class Engine:
         # OFF by default (0 MB = every split adds its partial tile with fp32 atomics): the slab + last-arriver reducer
         # of unimm_gemm_tn_grouped_ws measured SLOWER at 240 sequences (4,797 against 4,949 sequences/s, interleaved
         # runs on one box; single problems 220 against 128 us): the last round's ~108 reducers each read 1.5 MB of
-        # slabs serially and every split's agent-scope release writes back its XCD's L2.  UNIMM_WGRAD_WS_MB=512 enables it.
-        self.wgrad_ws_bytes = int(os.environ.get("UNIMM_WGRAD_WS_MB", "0")) << 20
+        # slabs serially and every split's agent-scope release writes back its XCD's L2.  `wgrad_ws_bytes = 512 << 20` enables it.
+        self.wgrad_ws_bytes = 0
         self._wgrad_ws = {}
         self._plist = []
         self.gemm_tile = 0               # tuning code handed to every encoder GEMM (unimm_gemm_nt_args.tile; 0 = automatic)
@@ -719,7 +720,7 @@ class Engine:
     # ------------------------------------------------------------------------------------------
     def _on_text_stream(self, fn, *args):
         """Run one engine entry on the text stream.  Normally that is the caller's current stream.  With
-        UNIMM_TEXT_PRIORITY=1 (and two streams) it is an internal HIGH-priority stream bracketed by waits in both
+        `text_priority` (and two streams) it is an internal HIGH-priority stream bracketed by waits in both
         directions, so that the text kernels - the critical path - are placed before the image side's."""
         if not self.arena.flat.is_cuda:
             return fn(*args)
