@@ -76,29 +76,54 @@ struct Cfg {
 // 128-B rows (BK=64): chunk ^= (row>>1)&7 ; 64-B rows (BK=32): chunk ^= (row>>2)&3
 template <int BK> __device__ __forceinline__ int kswz(int row) { return BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
 
-// Stage one K-step of the block's [W tile (BN rows) | X tile (BM rows)] x BK bf16 into LDS by LDS-DMA:
-// 1 KiB per wave-instruction, lane-linear image, swizzle applied on the source side.
+// Stage one K-step of the block's [W tile (BN rows) | X tile (BM rows)] x BK bf16 into LDS by LDS-DMA: 1 KiB per
+// wave-instruction, lane-linear image, swizzle applied on the source side -- with no address arithmetic in the K loop:
+// one buffer descriptor per operand with its base at the tile's first row, per-lane byte offsets (row * ld + swizzled
+// chunk, constant over K) computed once per tile, the K advance as the instruction's scalar offset.  (Rounds 1-2 formed a
+// 64-bit address per LDS-DMA instruction and K step: ~6 VALU + a multiply-add each, on the issue port two waves per SIMD
+// share with the MFMAs; the descriptor form is 1-3 % faster on every ring-loop shape, 2-5 % on the 64x128 tile of the
+// small per-GPU batches: interleaved A/B of the two builds, round 3.)
+template <class C> struct RingStage {
+  uint32_t so[C::G];     // per-lane source byte offsets of this wave's G LDS-DMA instructions of a K step
+  u32x4 srd_w, srd_x;    // buffer descriptors: W rows from n0, X rows from m0
+  uint32_t lds;          // LDS byte address of ring slot 0 (uniform)
+};
 template <class C>
-__device__ __forceinline__ void stage_one(const GemmNtParams& p, int n0, int m0, int k0, char* stage, int wave, int lane, int r) {
-  constexpr int CPR = C::ROWB / 16;   // chunks per row
-  const int rr = (r * C::NW + wave) * C::RPI + lane / CPR;   // row in the concatenated tile
-  const int chunk = (lane % CPR) ^ kswz<C::BK>(rr);
-  const bf16_t* src;
-  if (rr < C::BN) {
-    int g = n0 + rr;
-    g = g < p.N ? g : p.N - 1;     // edge rows re-read a valid row; their outputs are never stored
-    src = p.w + (size_t)g * p.ldw + k0 + chunk * 8;
-  } else {
-    int g = m0 + rr - C::BN;
-    g = g < p.M ? g : p.M - 1;
-    src = p.x + (size_t)g * p.ldx + k0 + chunk * 8;
+__device__ __forceinline__ void ring_stage_init(RingStage<C>& st, const GemmNtParams& p, int n0, int m0, uint32_t lds0, int wave, int lane) {
+  constexpr int CPR = C::ROWB / 16;
+  static_assert(C::BN % (C::RPI * C::NW) == 0, "an LDS-DMA instruction round must not straddle the W / X boundary");
+  const uint64_t bw = (uint64_t)(uintptr_t)(p.w + (size_t)n0 * p.ldw), bx = (uint64_t)(uintptr_t)(p.x + (size_t)m0 * p.ldx);
+  st.srd_w = u32x4{(uint32_t)bw, (uint32_t)(bw >> 32) & 0xffffu, 0xffffffffu, 0x00020000u};
+  st.srd_x = u32x4{(uint32_t)bx, (uint32_t)(bx >> 32) & 0xffffu, 0xffffffffu, 0x00020000u};
+  st.lds = __builtin_amdgcn_readfirstlane(lds0);
+#pragma unroll
+  for (int r = 0; r < C::G; ++r) {
+    const int rr = (r * C::NW + wave) * C::RPI + lane / CPR;   // row in the concatenated [W | X] tile
+    const int chunk = (lane % CPR) ^ kswz<C::BK>(rr);
+    const bool is_w = r < C::BN / (C::RPI * C::NW);            // compile-time per r
+    int g = is_w ? rr : rr - C::BN;                            // row inside the operand's tile
+    const int lim = is_w ? p.N - n0 : p.M - m0;
+    g = g < lim ? g : lim - 1;                                 // edge rows re-read a valid row; their outputs are never stored
+    st.so[r] = (uint32_t)g * (uint32_t)((is_w ? p.ldw : p.ldx) * 2) + (uint32_t)chunk * 16u;
   }
-  __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(stage + (r * C::NW + wave) * 1024), 16, 0, 0);
 }
 template <class C>
-__device__ __forceinline__ void stage_step(const GemmNtParams& p, int n0, int m0, int k0, char* stage, int wave, int lane) {
+__device__ __forceinline__ void ring_stage_one(const RingStage<C>& st, int k0, int slot, int wave, int r) {
+  const bool is_w = r < C::BN / (C::RPI * C::NW);
+  const uint32_t dst = st.lds + (uint32_t)(slot * C::STAGE_BYTES + (r * C::NW + wave) * 1024);
+  const uint32_t soff = (uint32_t)k0 * 2u;
+  uint32_t keep;
+  if (is_w)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(st.so[r]), "s"(dst), "s"(st.srd_w), "s"(soff) : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(st.so[r]), "s"(dst), "s"(st.srd_x), "s"(soff) : "memory");
+}
+template <class C>
+__device__ __forceinline__ void ring_stage_step(const RingStage<C>& st, int k0, int slot, int wave) {
 #pragma unroll
-  for (int r = 0; r < C::G; ++r) stage_one<C>(p, n0, m0, k0, stage, wave, lane, r);
+  for (int r = 0; r < C::G; ++r) ring_stage_one<C>(st, k0, slot, wave, r);
 }
 
 // ---- hand-counted LDS fragment reads (see the main loop of gemm_nt_kernel) -------------------------
@@ -666,6 +691,9 @@ __device__ __forceinline__ void nt_tile(const GemmNtParams& p, char* smem, int l
     return;
   }
   const int nk = p.K / BK;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  RingStage<C> rst;
+  ring_stage_init<C>(rst, p, n0, m0, (uint32_t)(size_t)(__attribute__((address_space(3))) char*)LDS_PTR(smem), wave, lane);
   // One 8-wave workgroup per CU: spread the ring refill over the MFMA units (see the main loop).  With two
   // 4-wave workgroups per CU the other workgroup's MFMAs already cover the issue phase and the later
   // issue only shortens the time the loads have to land (measured 15-20 % slower), so those refill at
@@ -674,7 +702,7 @@ __device__ __forceinline__ void nt_tile(const GemmNtParams& p, char* smem, int l
   // prologue: fill S-1 ring slots
 #pragma unroll
   for (int s = 0; s < S - 1; ++s)
-    if (s < nk) stage_step<C>(p, n0, m0, s * BK, smem + s * C::STAGE_BYTES, wave, lane);
+    if (s < nk) ring_stage_step<C>(rst, s * BK, s, wave_u);
 
   for (int t = 0; t < nk; ++t) {
     // K-step t has landed once at most min(S-2, nk-1-t) younger steps are still in flight
@@ -685,7 +713,7 @@ __device__ __forceinline__ void nt_tile(const GemmNtParams& p, char* smem, int l
     __builtin_amdgcn_s_barrier();            // every wave's loads of step t landed; step t-1 fully read
     __builtin_amdgcn_sched_barrier(0);
     if (t + S - 1 < nk)                      // refill the slot step t-1 used
-      if constexpr (!SPREAD) stage_step<C>(p, n0, m0, (t + S - 1) * BK, smem + ((t + S - 1) % S) * C::STAGE_BYTES, wave, lane);
+      if constexpr (!SPREAD) ring_stage_step<C>(rst, (t + S - 1) * BK, (t + S - 1) % S, wave_u);
     const char* tw = smem + (t % S) * C::STAGE_BYTES;
     const char* tx = tw + BN * C::ROWB;
     // Software-pipelined fragment stream.  Left alone, the compiler reads all 12 fragments of a 32-deep
@@ -731,7 +759,7 @@ __device__ __forceinline__ void nt_tile(const GemmNtParams& p, char* smem, int l
           acc[i][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ks_ & 1][i], fx[(u) % 3], acc[i][j_], 0, 0, 0); \
         if constexpr (FragPipe<MT, KS>::AFTER) { UNIMM_PREFETCH(u) }                                         \
         if constexpr (SPREAD && (u) < G) {                                         /* refill, one LDS-DMA per unit */ \
-          if (t + 1 < nk) stage_one<C>(p, n0, m0, (t + 1) * BK, smem + ((t + 1) & 1) * C::STAGE_BYTES, wave, lane, u); \
+          if (t + 1 < nk) ring_stage_one<C>(rst, (t + 1) * BK, (t + 1) & 1, wave_u, u);                    \
         }                                                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
       }
@@ -1509,7 +1537,9 @@ int check_tn(const unimm_gemm_tn_args* a) {
   return UNIMM_OK;
 }
 
-inline bool tn_is_big(const unimm_gemm_tn_args* a) { return a->N >= 256 && a->K >= 256 && a->M >= 4096; }
+// (M >= 1024: with launches grouped over several blocks the 256x256 ping-pong tile also wins at the ~4k rows of a 30-sequence
+// batch -- the 128x128 class it used to take there was chosen when one block's ~110 tiles had to fill the chip)
+inline bool tn_is_big(const unimm_gemm_tn_args* a) { return a->N >= 256 && a->K >= 256 && a->M >= 1024; }
 
 // One launch of `count` (<= TN_MAXG) problems that all use the same tile size.
 int launch_tn_group(const unimm_gemm_tn_args* const* a, int count, bool big, bool shared, bool legacy_loop, void* ws,

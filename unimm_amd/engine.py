@@ -357,7 +357,7 @@ class Engine:
             M = dy.shape[0] if M is None else M
             N = dy.shape[1] if N is None else N
             K = x.shape[1] if K is None else K
-            if N >= 256 and K >= 256 and M >= 4096:
+            if N >= 256 and K >= 256 and M >= 1024:
                 t += ((N + 255) // 256) * ((K + 255) // 256)
         return t
 
