@@ -70,6 +70,10 @@ def parse():
                          "what the roofline block needs; all = every GEMM launch (adds the all_gemm_* fields).  Two event records "
                          "around each of ~340 GEMM launches are not free: measured 1.3 ms of a 56 ms step at bs=240 (drain + "
                          "timestamp between back-to-back kernels) and 2 ms of 16 ms at 30 sequences per GPU (host launch rate)")
+    ap.add_argument("--wgrad-rounds", type=int, default=0, metavar="R",
+                    help="tuning: engine.wgrad_group_rounds (rounds of 256 tiles a grouped weight-gradient launch aims at; 0 = default)")
+    ap.add_argument("--wgrad-stream", action="store_true",
+                    help="A/B: the text side's grouped weight-gradient launches on a third stream (engine.wgrad_stream = True)")
     ap.add_argument("--single-stream", action="store_true",
                     help="everything on one HIP stream (engine.dual_stream = False): exclusive kernel durations for rocprofv3 "
                          "breakdowns; the production schedule runs the image side on a second stream")
@@ -363,6 +367,10 @@ def main():
     model.engine.gemm_tile = args.gemm_tile      # per-call tuning code of every unimm_gemm_nt launch (0 = automatic)
     if args.single_stream:
         model.engine.dual_stream = False
+    if args.wgrad_stream:
+        model.engine.wgrad_stream = True
+    if args.wgrad_rounds > 0:
+        model.engine.wgrad_group_rounds = args.wgrad_rounds
     model.engine.ensure(dev)
     model.engine.arena.attach_grads()
     log(f"model + batch ready on {dev}: {per_gpu} sequences/GPU, {n_lm_rows} decoded MLM rows")

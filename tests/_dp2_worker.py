@@ -3,7 +3,8 @@
 `DataParallelRCCL` -> `Engine.grad_bucket_hook` -> per-bucket all-reduce issued from inside backward, on the comm
 stream, with the dual-stream joins of `Engine._bucket_done`.
 
-    python tests/_dp2_worker.py <rank> <world> <port> <out.pt> [bf16|fp32] [allreduce|rs_ag]"""
+    python tests/_dp2_worker.py <rank> <world> <port> <out.pt> [bf16|fp32] [allreduce|rs_ag] [gloo|nccl]
+(nccl = RCCL, rank r on device r: the path bench.py --gpus N takes; needs as many GPUs as ranks)"""
 import json
 import os
 import sys
@@ -20,9 +21,14 @@ def main():
     rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
     wire = sys.argv[5] if len(sys.argv) > 5 else "fp32"
     algo = sys.argv[6] if len(sys.argv) > 6 else "allreduce"
+    backend = sys.argv[7] if len(sys.argv) > 7 else "gloo"
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":                                 # real RCCL: one device per rank (needs >= `world` GPUs)
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import vilbert_ref as R
     from unimm_amd import BertConfig, BertForMultiModalPreTraining
     from unimm_amd.parallel import DataParallelRCCL, shard_range

@@ -87,3 +87,19 @@ def test_two_engine_ranks_equal_single_rank_mean_of_means(tmp_path, single_rank,
         assert acc_err <= 2e-5 * scale, (r, acc_err)
         assert out["stats"]["buckets"] == out["stats"]["n_buckets_expected"]
     assert res[0]["seed"] != res[1]["seed"]              # every replica draws its own dropout masks
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one device per rank: this box has a single GPU")
+@pytest.mark.parametrize("wire,algo,tol", [("fp32", "allreduce", 2e-5), ("bf16", "rs_ag", 6e-3)])
+def test_two_engine_ranks_over_rccl(tmp_path, single_rank, wire, algo, tol):
+    """The same two ranks with the exchange on RCCL over xGMI (backend "nccl", rank r on device r) -- what
+    `bench.py --gpus N` runs.  Skipped on one-GPU boxes; there the gloo variant above covers the engine-side logic."""
+    res = _run_ranks(tmp_path, f"rccl_{wire}_{algo}", [wire, algo, "nccl"])
+    want = 0.5 * (single_rank["grads"][0] + single_rank["grads"][1])
+    scale = float(want.abs().max())
+    for r, out in enumerate(res):
+        assert torch.equal(out["flat"], single_rank["flat"])
+        assert np.allclose(out["losses"], single_rank["losses"][r], rtol=0, atol=2e-5)
+        err = float((out["grad"] - want).abs().max())
+        assert err <= tol * scale, (r, err, scale)
+        assert out["stats"]["buckets"] == out["stats"]["n_buckets_expected"]
