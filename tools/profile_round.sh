@@ -12,6 +12,14 @@ rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_write
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $out/pmc_sq -o run -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-padded > /dev/null 2> $out/pmc_sq.err
 python tools/pmc_report.py $out/pmc_fetch $out/pmc_write $out/pmc_sq $out/traffic_dominant_kernel.json "profiles/${tag}_pmc_bench.txt (rocprofv3 --pmc, separate passes: FETCH_SIZE | WRITE_SIZE GRBM_GUI_ACTIVE | SQ_VALU_MFMA_BUSY_CYCLES; python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-padded)" > $out/pmc_bench.txt 2> $out/pmc_report.err
 python bench.py --batch 30 --steps 30 --no-cpu-baseline --no-padded > $out/bench_b30.json 2> $out/bench_b30.err
+python bench.py --batch 30 --steps 30 --no-cpu-baseline --no-padded --graphs off > $out/bench_b30_eager.json 2> $out/bench_b30_eager.err
+python bench.py --batch 60 --steps 20 --no-cpu-baseline --no-padded > $out/bench_b60.json 2> $out/bench_b60.err
+TN_BLOCKS=7 python tools/bench_tn_group.py > $out/tn_group7.log 2>&1
+TN_BLOCKS=1 python tools/bench_tn_group.py > $out/tn_group1.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $out/pmc_tn7 -o run -- python tools/bench_tn_group.py > /dev/null 2> $out/pmc_tn7.err
+python tools/queue_gaps.py $out/stats/run_kernel_trace.csv 3 > $out/queue_gaps.txt 2>&1
+python tools/queue_breakdown.py $out/stats/run_kernel_trace.csv 3 > $out/two_stream_step_breakdown.txt 2>&1
+python tools/queue_breakdown.py $out/stats1/run_kernel_trace.csv 3 > $out/single_stream_step_breakdown.txt 2>&1
 python bench.py --workload dense --steps 16 --warmup 16 --no-cpu-baseline > $out/bench_dense_b100.json 2> $out/bench_dense.err
 python bench.py --workload scoring --no-cpu-baseline > $out/bench_scoring.json 2> $out/bench_scoring.err
 rm -rf $out/pmc_fetch $out/pmc_write $out/pmc_sq
