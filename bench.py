@@ -77,6 +77,9 @@ def parse():
     ap.add_argument("--single-stream", action="store_true",
                     help="everything on one HIP stream (engine.dual_stream = False): exclusive kernel durations for rocprofv3 "
                          "breakdowns; the production schedule runs the image side on a second stream")
+    ap.add_argument("--decoder-dx-rows", type=int, default=-1,
+                    help="A/B: decoded-row count up to which the decoder's input gradient runs as a split reduction over the "
+                         "vocabulary (Engine._decoder_dx); 0 = always the NT GEMM; -1 = the engine's default")
     ap.add_argument("--graphs", choices=["auto", "on", "off"], default="auto",
                     help="run the step as replayed hipGraphs (unimm_amd/graphs.py: two graph launches per step instead of ~650 "
                          "host calls; N = 1 only; auto = on for <= 120 sequences per GPU, where the host would otherwise bound the "
@@ -371,6 +374,8 @@ def main():
         model.engine.wgrad_stream = True
     if args.wgrad_rounds > 0:
         model.engine.wgrad_group_rounds = args.wgrad_rounds
+    if args.decoder_dx_rows >= 0:
+        model.engine.skinny_dx_rows = args.decoder_dx_rows
     model.engine.ensure(dev)
     model.engine.arena.attach_grads()
     log(f"model + batch ready on {dev}: {per_gpu} sequences/GPU, {n_lm_rows} decoded MLM rows")
@@ -398,12 +403,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    use_graphs = (args.graphs == "on" or (args.graphs == "auto" and per_gpu <= 120)) and world == 1 and args.workload == "train" \
+    use_graphs = (args.graphs == "on" or (args.graphs == "auto" and per_gpu <= 120)) and args.workload == "train" \
         and not args.compact_inputs and not args.host_profile
+    gx = None
     if use_graphs:
-        model.engine.enable_graphs(True)
-        for _ in range(3):                      # eager once more, capture, first replay
-            step()
+        gx = model.engine.enable_graphs(True)
+        try:
+            for _ in range(3):                  # eager once more, capture, first replay
+                step()
+            torch.cuda.synchronize()
+        except Exception as e:                  # never lose a run to the executor: the eager path computes the same step
+            log(f"graph executor unavailable ({type(e).__name__}: {e}); continuing with eager launches")
+            model.engine.enable_graphs(False)
+            use_graphs, gx = False, None
+            model.engine.arena.zero_grads()
+    if world > 1:                               # every rank runs the same executor (their collectives pair up either way)
+        flag = torch.tensor([1 if use_graphs else 0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if use_graphs and int(flag) == 0:
+            model.engine.enable_graphs(False)
+            use_graphs, gx = False, None
     fence()
     if world > 1:
         net.comm_stats(reset=True)
@@ -420,7 +439,7 @@ def main():
         assert st_timed["buckets"] == st_timed["n_buckets_expected"] * args.steps, st_timed
     graph_stats = dict(model.engine.graphs.stats) if use_graphs else None
     if use_graphs:                             # the per-kernel figures below come from eager steps
-        model.engine.enable_graphs(False)
+        model.engine.graphs = None
         lib.prof_enable(2)
         step(); step()
         torch.cuda.synchronize()
@@ -486,6 +505,9 @@ def main():
             net._exchange(0, flat.numel())
         fence()
         t_ar = (time.perf_counter() - tc) / 3
+        model.engine.graphs = gx                # the executor of the timed region (None = eager launches)
+        with net.no_sync():
+            step_fb()
         fence()
         tc = time.perf_counter()
         with net.no_sync():
@@ -493,11 +515,12 @@ def main():
                 step_fb()
         fence()
         t_nosync = (time.perf_counter() - tc) / 2
+        model.engine.graphs = None
         wire = flat.numel() * (2 if net.wire_dtype == "bf16" else 4)
         busbw = wire * 2 * (world - 1) / world / t_ar / 1e9
         comm = {"wire_dtype": net.wire_dtype, "algorithm": net.algorithm, "bytes_per_step": wire,
                 "bucket_bytes": st["bucket_bytes"], "buckets_per_step": len(st["bucket_bytes"]),
-                "collectives_per_step": st["calls"] // max(1, args.steps),
+                "collectives_per_step": st_timed["calls"] // max(1, args.steps),
                 "exchange_alone_ms": round(t_ar * 1e3, 3), "busbw_GBps": round(busbw, 1),
                 "xgmi_budget_GBps": 7 * 153, "busbw_frac_of_xgmi": round(busbw / (7 * 153), 3),
                 "step_ms_without_exchange": round(t_nosync * 1e3, 3),

@@ -285,6 +285,11 @@ int unimm_colsum(const void* dy, float* db, int32_t M, int32_t N, int32_t ld, vo
  * R..ldd-1 zero-filled) for the transposed copies the input-gradient GEMMs read. */
 int unimm_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
 int unimm_transpose_cast(const float* src, void* dst, int32_t R, int32_t C, int32_t ldd, void* stream);
+/* bf16 -> bf16 transpose: dst[c][r] = src[r][c]; src [R, C] row stride lds, dst [C, ldd] with columns R..ldd-1
+ * zero-filled; lds, ldd multiples of 8, both pointers 16-byte aligned.  Puts the decoder-logit gradient of
+ * models/vilbert_dialog.py:1023-1026 reduction-major so that its input gradient (a few hundred rows x 768 over the
+ * 30,522-long vocabulary axis) can run as a split reduction on unimm_gemm_tn_grouped. */
+int unimm_transpose_bf16(const void* src, void* dst, int32_t R, int32_t C, int32_t lds, int32_t ldd, void* stream);
 /* The same for `count` matrices in one launch.  `table` is a DEVICE array; entry i owns blocks
  * [tile0_i, tile0_{i+1}) with ceil(C/32) * ceil(ldd/32) blocks each (tile0 ascending, tile0_0 = 0);
  * total_tiles = their sum.  Used after the optimizer step to rebuild every transposed weight copy. */

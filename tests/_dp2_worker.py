@@ -3,8 +3,9 @@
 `DataParallelRCCL` -> `Engine.grad_bucket_hook` -> per-bucket all-reduce issued from inside backward, on the comm
 stream, with the dual-stream joins of `Engine._bucket_done`.
 
-    python tests/_dp2_worker.py <rank> <world> <port> <out.pt> [bf16|fp32] [allreduce|rs_ag] [gloo|nccl]
-(nccl = RCCL, rank r on device r: the path bench.py --gpus N takes; needs as many GPUs as ranks)"""
+    python tests/_dp2_worker.py <rank> <world> <port> <out.pt> [bf16|fp32] [allreduce|rs_ag] [gloo|nccl] [eager|graphs]
+(nccl = RCCL, rank r on device r: the path bench.py --gpus N takes; needs as many GPUs as ranks.
+ graphs = the step executor of unimm_amd/graphs.py: the backward replayed as a chain of graphs cut at the bucket hand-overs)"""
 import json
 import os
 import sys
@@ -22,6 +23,7 @@ def main():
     wire = sys.argv[5] if len(sys.argv) > 5 else "fp32"
     algo = sys.argv[6] if len(sys.argv) > 6 else "allreduce"
     backend = sys.argv[7] if len(sys.argv) > 7 else "gloo"
+    graphs = len(sys.argv) > 8 and sys.argv[8] == "graphs"
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     if backend == "nccl":                                 # real RCCL: one device per rank (needs >= `world` GPUs)
         torch.cuda.set_device(rank)
@@ -44,6 +46,8 @@ def main():
     n = batch["input_ids"].shape[0]
     lo, hi = shard_range(n, rank, world)
     sh = {k: (v if k == "nsp_weight" else v[lo:hi]) for k, v in batch.items()}
+    if graphs:                                            # the executor takes device-resident inputs
+        sh = {k: (v if k == "nsp_weight" else v.cuda()) for k, v in sh.items()}
     args = (sh["input_ids"], sh["image_feat"], sh["image_loc"])
     kw = dict(token_type_ids=sh["token_type_ids"], position_ids=sh["position_ids"], attention_mask=sh["attention_mask"],
               image_attention_mask=sh["image_attention_mask"], co_attention_mask=sh["co_attention_mask"],
@@ -54,6 +58,7 @@ def main():
         model(*args, **kw)
     dp = DataParallelRCCL(model, wire_dtype=wire, algorithm=algo)
     seed_after = model.engine.seed
+    gx = model.engine.enable_graphs(capture_after=0, row_bucket=64, lm_bucket=16) if graphs else None
     model.zero_grad(set_to_none=True)
     lm, img, nsp_l, _, _, _ = dp(*args, **kw)
     (lm + img + nsp_l).sum().backward()
@@ -64,8 +69,18 @@ def main():
         (lm2 + img2 + nsp2).sum().backward()
     torch.cuda.synchronize()
     acc = model.engine.arena.grad_flat.clone()
+    gstats = None
+    if graphs:                                           # a third step: replayed forward + chain, exchange on again
+        model.engine.arena.zero_grads()
+        dp.comm_stats(reset=True)
+        lm3, img3, nsp3, _, _, _ = dp(*args, **kw)
+        (lm3 + img3 + nsp3).sum().backward()
+        torch.cuda.synchronize()
+        g3 = model.engine.arena.grad_flat.clone()
+        gstats = dict(gx.stats, segments=[sum(1 for i in e.gB if not isinstance(i, tuple)) for e in gx.entries.values()],
+                      replay_err=float((g3 - g1).abs().max()), replay_loss=[float(lm3), float(img3), float(nsp3)])
     torch.save(dict(grad=g1.cpu(), acc=acc.cpu(), losses=[float(lm), float(img), float(nsp_l)], shard=(lo, hi),
-                    flat=model.engine.arena.flat.detach().cpu(), seed=seed_after, stats=dp.comm_stats()), out)
+                    flat=model.engine.arena.flat.detach().cpu(), seed=seed_after, stats=dp.comm_stats(), graphs=gstats), out)
     dist.barrier()
     dist.destroy_process_group()
 

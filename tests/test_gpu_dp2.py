@@ -89,6 +89,28 @@ def test_two_engine_ranks_equal_single_rank_mean_of_means(tmp_path, single_rank,
     assert res[0]["seed"] != res[1]["seed"]              # every replica draws its own dropout masks
 
 
+def test_two_engine_ranks_with_graph_executor(tmp_path, single_rank):
+    """Data parallelism + the step executor: backward is replayed as a chain of graphs cut where gradient buckets are
+    handed over to the exchange; gradients equal the eager 2-rank semantics (mean of the ranks' means), no_sync accumulates
+    the local gradient, a further replay reproduces the first step."""
+    res = _run_ranks(tmp_path, "graphs", ["fp32", "allreduce", "gloo", "graphs"])
+    want = 0.5 * (single_rank["grads"][0] + single_rank["grads"][1])
+    scale = float(want.abs().max())
+    for r, out in enumerate(res):
+        gs = out["graphs"]
+        print(f"rank {r}: {gs}; comm {out['stats']}")
+        assert gs["replays"] == 3 and gs["eager"] == 0 and gs["captures"] == 2, gs
+        assert gs["segments"] and gs["segments"][0] >= 2, gs         # really a chain, not one graph
+        assert np.allclose(out["losses"], single_rank["losses"][r], rtol=0, atol=2e-5)
+        assert np.allclose(gs["replay_loss"], single_rank["losses"][r], rtol=0, atol=2e-5)
+        err = float((out["grad"] - want).abs().max())
+        assert err <= 2e-5 * scale, (r, err, scale)
+        acc_err = float((out["acc"] - (out["grad"] + single_rank["grads"][r])).abs().max())
+        assert acc_err <= 2e-5 * scale, (r, acc_err)
+        assert gs["replay_err"] <= 2e-5 * scale, gs
+        assert out["stats"]["buckets"] == out["stats"]["n_buckets_expected"]      # third step: every bucket exactly once
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one device per rank: this box has a single GPU")
 @pytest.mark.parametrize("wire,algo,tol", [("fp32", "allreduce", 2e-5), ("bf16", "rs_ag", 6e-3)])
 def test_two_engine_ranks_over_rccl(tmp_path, single_rank, wire, algo, tol):

@@ -62,7 +62,7 @@ def test_graph_replay_equals_eager_steps(golden_dir, train):
 
 
 def test_graph_executor_falls_back_when_not_eligible(golden_dir):
-    """Host inputs, dense LM scores and the data-parallel hook keep the eager path (and still work)."""
+    """Host inputs (and dense LM scores) keep the eager path (and still work)."""
     from unimm_amd import synth
     m = _build(golden_dir)
     m.train(False)

@@ -511,3 +511,17 @@ def test_plan_kernels_match_the_dense_formulation():
     assert sum(header.tolist()[B:2 * B]) == 0
     b2 = L.plan_build(header, None, None, B, T, sum(header.tolist()[:B]), 0)
     assert b2["lm_pos"] is None and b2["rows"].numel() == sum(header.tolist()[:B])
+
+
+@pytest.mark.parametrize("R,C,lds", [(37, 1000, 1008), (627, 30522, 30528), (64, 64, 64), (1, 9, 16)])
+def test_transpose_bf16_exact(R, C, lds):
+    """unimm_transpose_bf16: dst[c, r] = src[r, c] bit for bit, surplus destination columns zero, source padding ignored."""
+    from unimm_amd import lib as L
+    g = torch.Generator(device="cuda").manual_seed(R * 131 + C)
+    src = torch.randn((R, lds), generator=g, device="cuda").to(torch.bfloat16)
+    ldd = (R + 63) // 64 * 64
+    dst = torch.full((C, ldd), 7.0, dtype=torch.bfloat16, device="cuda")
+    L.transpose_bf16(src[:, :C], dst, R, C)
+    torch.cuda.synchronize()
+    assert torch.equal(dst[:, :R], src[:, :C].t())
+    assert (dst[:, R:] == 0).all()

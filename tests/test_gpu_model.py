@@ -260,6 +260,34 @@ def test_row_capacities_with_device_side_counts_equal_exact_sizes(golden_dir, sm
     assert d <= 1e-5, d                          # fp32 summation order of the weight gradients (split count follows the capacity)
 
 
+def test_decoder_input_gradient_as_split_reduction_equals_nt_gemm(golden_dir, small):
+    """For few decoded rows the decoder's input gradient (dlog @ E, a 30,522-long reduction for a few hundred rows) runs on
+    the weight-gradient kernel as a split reduction over the vocabulary (Engine._decoder_dx); it must equal the NT GEMM it
+    replaces up to the bf16 rounding of the result (fp32 sums in another order)."""
+    model, _, _ = small
+    model.eval()
+    eng = model.engine
+    g = np.load(os.path.join(golden_dir, "small_mixed.npz"))
+    args, kw = kwargs_from(g)
+    res = {}
+    was = eng.skinny_dx_rows
+    try:
+        for rows in (0, 3072):
+            eng.skinny_dx_rows = rows
+            model.zero_grad(set_to_none=True)
+            lm, img, nsp_l, _, _, _ = model(*args, **kw, _want_lm_scores=False)
+            (lm + img + nsp_l).sum().backward()
+            torch.cuda.synchronize()
+            res[rows] = eng.arena.grad_flat.clone()
+    finally:
+        eng.skinny_dx_rows = was
+    a, b = res[0], res[3072]
+    assert torch.isfinite(b).all()
+    d = float((a - b).abs().max() / a.abs().max())
+    print(f"\nsplit-reduction decoder dX vs NT GEMM: max |dg| / max |g| = {d:.2e}")
+    assert 0 < d <= 2e-3, d        # > 0: the other path really ran
+
+
 def test_unpadded_run_equals_padded_run(golden_dir, small):
     """The variable-length (valid rows only) schedule and the padded one give the same losses, scores and
     gradients: padding rows are inert (SURVEY.md 7 'hard parts': they never reach a loss or a valid row)."""

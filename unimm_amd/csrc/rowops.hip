@@ -772,6 +772,44 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __rest
   }
 }
 
+// dst[c][r] = src[r][c], both bf16: src [R, C] with row stride lds, dst [C, ldd] (columns R..ldd-1 zero-filled).
+// 64 x 64 tiles through LDS, 16-byte global accesses on both sides.  (The gradient of the decoder logits, [rows, vocab],
+// is needed reduction-major by the weight-gradient kernel when it computes a few hundred rows x 768 over 30,522
+// reduction steps: see Engine._decoder_dx.)
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
+                                                             int R, int C, int lds, int ldd) {
+  __shared__ bf16_t tile[64][72];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {                     // 64 rows x 8 chunks of 8 columns
+    const int id = t + 256 * k, r = id >> 3, cc = (id & 7) * 8;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (r0 + r < R) {
+      const bf16_t* sp = src + (size_t)(r0 + r) * lds + c0 + cc;
+      if (c0 + cc + 7 < C) {
+        v = *reinterpret_cast<const u32x4*>(sp);
+      } else {
+        bf16_t e[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) e[i] = (c0 + cc + i < C) ? sp[i] : (bf16_t)0;
+        v = *reinterpret_cast<const u32x4*>(e);
+      }
+    }
+    *reinterpret_cast<u32x4*>(&tile[r][cc]) = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {                     // 64 output rows (source columns) x 8 chunks of 8 source rows
+    const int id = t + 256 * k, c = id >> 3, rr = (id & 7) * 8;
+    if (c0 + c >= C || r0 + rr >= ldd) continue;
+    bf16_t e[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) e[i] = tile[rr + i][c];
+    *reinterpret_cast<u32x4*>(dst + (size_t)(c0 + c) * ldd + r0 + rr) = *reinterpret_cast<const u32x4*>(e);
+  }
+}
+
 // the same for a table of matrices in ONE launch (all transposed weight copies after an optimizer step:
 // ~190 launches of a few microseconds each otherwise).  Block b belongs to the last entry with tile0 <= b.
 __global__ __launch_bounds__(256) void transpose_cast_grouped_kernel(const unimm_transpose_desc* __restrict__ tab, int count) {
@@ -1071,6 +1109,15 @@ extern "C" int unimm_transpose_cast(const float* src, void* dst, int32_t R, int3
   if (!src || !dst || R <= 0 || C <= 0 || ldd < R) return UNIMM_E_ARG;
   hipLaunchKernelGGL(transpose_cast_kernel, dim3((C + 31) / 32, (ldd + 31) / 32), dim3(256), 0, (hipStream_t)stream, src,
                      (bf16_t*)dst, R, C, ldd);
+  UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
+}
+
+extern "C" int unimm_transpose_bf16(const void* src, void* dst, int32_t R, int32_t C, int32_t lds, int32_t ldd, void* stream) {
+  if (!src || !dst || R <= 0 || C <= 0 || lds < C || ldd < R) return UNIMM_E_ARG;
+  if ((lds % 8) || (ldd % 8) || (((uintptr_t)src | (uintptr_t)dst) & 15)) return UNIMM_E_ALIGN;
+  hipLaunchKernelGGL(transpose_bf16_kernel, dim3((C + 63) / 64, (ldd + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)src, (bf16_t*)dst, R, C, lds, ldd);
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;
 }

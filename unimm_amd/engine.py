@@ -118,6 +118,7 @@ class Engine:
         self._inject_header = None       # header values of the step, read ahead of a graph capture (see _forward, graphs.py)
         self.graphs = None               # unimm_amd.graphs.StepGraphs once enable_graphs() was called
         self._dims = None                # (int32 [8], fp32 [8]) device words: {valid rows, decoded rows, regions}, {1/decoded, 1/regions}
+        self.skinny_dx_rows = 3072       # decoded-row count up to which the decoder's input gradient runs as a split reduction (_decoder_dx)
         self._pending = []               # gradient buckets whose weight gradients are still queued: (group, #text, #image queued)
         self._nq = [0, 0]                # weight-gradient problems ever queued (text side, image side) ...
         self._nf = [0, 0]                # ... and launched
@@ -440,6 +441,23 @@ class Engine:
         kdim = lin.wt.shape[1]
         L.gemm_nt(dy, lin.wt, dx, bias=None, epilogue=epi, aux=aux, M=M, N=lin.K, K=kdim, tile=self.gemm_tile)
         return dx
+
+    def _decoder_dx(self, dlog, dec, n, V):
+        """dhn[n, H] = dlog[n, V] @ E[V, H] for FEW decoded rows (the per-GPU share of a split batch: ~630 rows at 30
+        sequences).  As an NT GEMM this is 10 x 6 tiles of 64 x 128, each with a 477-step reduction over the vocabulary:
+        60 workgroups on 256 CUs, 348 us -- 3.5 % of the 30-sequence step for 29 GFLOP.  The reduction axis is the long
+        one, so it runs on the weight-gradient kernel instead (dW[N, K] += dY[M, N]^T X[M, K] with M = vocabulary,
+        dY = dlog^T, X = the bf16 embedding table itself): 9 tiles of 256 x 256, the reduction split ~28 ways over the
+        chip, fp32 atomics into a zeroed [n, H] buffer.  Costs a bf16 transpose of dlog (38 MB) and a cast."""
+        H = dec.K
+        ldT = _rup(n, 64)
+        dlogT = torch.empty((V, ldT), dtype=BF16, device=dlog.device)
+        L.transpose_bf16(dlog, dlogT, n, V)
+        dhn32 = torch.zeros((ldT, H), dtype=F32, device=dlog.device)
+        L.gemm_tn_grouped([(dlogT, dec.w, dhn32, V, ldT, H, None)], shared=self._dual())
+        dhn = torch.empty((n, H), dtype=BF16, device=dlog.device)
+        L.cast_f32_bf16(dhn32, dhn, n * H)
+        return dhn
 
     def _layernorm(self, x, key, save, drop=L.NO_DROP, want32=True, lazy=False):
         """x: fp32 pre-LayerNorm sum -> (y32 residual stream | None, y16 GEMM operand, mean, rstd).
@@ -1150,7 +1168,12 @@ class Engine:
             nd = lm.get("n_dev")                                              # n is a capacity: the real count lives on the device
             L.lm_loss_bwd(lm["logits"], lm["labels"], lm["weights"], lm["lse"], gvec(g_lm), 1.0 / n, dlog, n, V, n_dev=nd,
                           inv_dev=lm.get("inv_dev"))
-            dhn = self._linear_bwd(dlog, lm["hn"], dec, M=n, N=V, m_dev=nd)   # dE += dlog^T hn ; dbias ; dhn = dlog @ E
+            # dE += dlog^T hn ; dbias ; dhn = dlog @ E
+            if n <= self.skinny_dx_rows:
+                self._linear_bwd(dlog, lm["hn"], dec, M=n, N=V, m_dev=nd, need_dx=False)
+                dhn = self._decoder_dx(dlog, dec, n, V)
+            else:
+                dhn = self._linear_bwd(dlog, lm["hn"], dec, M=n, N=V, m_dev=nd)
             dt1, _ = self._layernorm_bwd(dhn, lm["t1"], lm["mean"], lm["rstd"], "lmtr", m_dev=nd)
             du = torch.empty_like(dt1)
             L.gelu_bwd(dt1, lm["u"], du, du.numel())

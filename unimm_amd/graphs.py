@@ -17,8 +17,16 @@ The host still reads ONE header per step (valid lengths, decoded rows: `Engine.c
 signature is captured the second time it is seen (the first time runs eagerly) and at most `max_entries` signatures are
 kept (each owns its activations: ~0.19 GB per sequence at the full config).
 
+Data parallelism: the gradient exchange is issued per bucket from INSIDE backward (Engine._bucket_done -> the wrapper's
+hook -> a collective on the comm stream), i.e. between launches.  With a hook registered the backward is therefore captured
+as a CHAIN of graphs cut at the points where buckets are handed over (6-8 per step, since the weight-gradient launches are
+grouped over blocks): a replayed step is `graph, hook(s), graph, hook(s), ...` in capture order -- the collectives stay
+ordinary eager calls of whatever backend the wrapper uses.  At a cut both streams are joined (the eager path joins them
+there too: the exchange reads what the image side produced) and the image stream is forked back in at the start of the
+next segment.
+
 Not covered (falls back to the eager path): inputs on the host, mask descriptors (`DialogMaskSpec`), dense LM scores
-(`output_lm_scores=True`), the data-parallel wrapper's per-bucket hooks (collectives between the launches of backward)."""
+(`output_lm_scores=True`)."""
 from __future__ import annotations
 
 from collections import OrderedDict
@@ -38,7 +46,7 @@ def _rup(x, m):
 
 
 class _Entry:
-    __slots__ = ("pool", "sin", "gF", "out", "losses", "nsp", "gB", "gin", "gkey", "stream")
+    __slots__ = ("pool", "sin", "gF", "out", "losses", "nsp", "gB", "gin", "gkey", "stream", "lvec", "lshape")
 
 
 class StepGraphs:
@@ -54,7 +62,7 @@ class StepGraphs:
     # ------------------------------------------------------------------------------------------
     def eligible(self, inp, opts):
         eng = self.eng
-        if opts.get("want_seq") or eng.grad_bucket_hook is not None or eng.wgrad_stream or eng.text_priority:
+        if opts.get("want_seq") or eng.text_priority:
             return False
         for k in _TENSOR_KEYS:
             v = inp.get(k)
@@ -95,7 +103,8 @@ class StepGraphs:
         Mv, n_lm = sum(hh[:B]), sum(hh[B:2 * B])
         Mcap = min(_rup(Mv, self.row_bucket), B * T)
         ncap = _rup(n_lm, self.lm_bucket) if n_lm > 0 else 0
-        sig = self._key0(inp, opts) + (Mcap, ncap, eng.dual_stream, eng.unpad, eng.lazy_ln, eng.gemm_tile, eng.wgrad_group_rounds)
+        sig = self._key0(inp, opts) + (Mcap, ncap, eng.dual_stream, eng.unpad, eng.lazy_ln, eng.gemm_tile, eng.wgrad_group_rounds,
+                                         eng.grad_bucket_hook is not None, eng.wgrad_stream)   # with a hook the backward is a chain of graphs
         ent = self.entries.get(sig)
         if ent is None:
             n = self.seen.get(sig, 0)
@@ -112,8 +121,8 @@ class StepGraphs:
         self._set_salt()
         ent.gF.replay()
         self.stats["replays"] += 1
-        ls = ent.losses
-        return ls["lm_loss"].clone(), ls["img_loss"].clone(), ls["nsp_loss"].clone(), ent.nsp.clone(), ent
+        ls = ent.lvec.clone()                                  # one copy out of the static buffers (the next replay overwrites them)
+        return ls[0].reshape(ent.lshape), ls[1].reshape(ent.lshape), ls[2].reshape(ent.lshape), ent.nsp.clone(), ent
 
     def _capture_forward(self, sig, inp, opts, hh):
         eng = self.eng
@@ -144,6 +153,9 @@ class StepGraphs:
                 ent.out = eng.forward(ent.sin, train=opts["train"], save=True, lm_rows="labelled", want_pred_v=True)
                 ent.losses = eng.losses(ent.out, ent.sin)
                 ent.nsp = ent.out["nsp"]
+                ls = ent.losses
+                ent.lshape = tuple(ls["lm_loss"].shape)
+                ent.lvec = torch.stack([ls["lm_loss"].reshape(()), ls["img_loss"].reshape(()), ls["nsp_loss"].reshape(())])
         finally:
             eng.row_bucket, eng.lm_bucket, eng.salt_word, eng._inject_header = was
         self.entries[sig] = ent
@@ -151,30 +163,78 @@ class StepGraphs:
         return ent
 
     # ------------------------------------------------------------------------------------------
+    def _capture_backward(self, ent):
+        """-> the backward as a program: [graph] without a bucket hook, else [graph, (group, more), ..., graph, ...]."""
+        eng = self.eng
+        prog, cur = [], [None]
+        hook = eng.grad_bucket_hook
+
+        def begin():
+            g = torch.cuda.CUDAGraph()
+            g.capture_begin(pool=ent.pool)
+            cur[0] = g
+
+        def end():
+            cur[0].capture_end()
+            prog.append(cur[0])
+            cur[0] = None
+
+        def cut(group, more=False):
+            # Engine._bucket_done has joined the image stream into the text stream (the capturing one) just before
+            if cur[0] is not None:
+                end()
+            prog.append((group, more))
+            if not more and group != "text_embeddings":       # the last bucket: nothing is enqueued after it
+                begin()
+                eng._to_img()                                  # the image stream rejoins the capture
+
+        was = (eng.row_bucket, eng.lm_bucket, eng.salt_word)
+        eng.row_bucket, eng.lm_bucket, eng.salt_word = self.row_bucket, self.lm_bucket, self.salt
+        if hook is not None:
+            eng.grad_bucket_hook = cut
+        try:
+            torch.cuda.synchronize()
+            ent.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(ent.stream):
+                begin()
+                try:
+                    eng.backward(ent.out, *ent.gin)
+                finally:
+                    if cur[0] is not None:
+                        end()
+            torch.cuda.current_stream().wait_stream(ent.stream)
+        finally:
+            eng.row_bucket, eng.lm_bucket, eng.salt_word = was
+            eng.grad_bucket_hook = hook
+        if hook is not None and not any(isinstance(i, tuple) and i[0] == "text_embeddings" for i in prog):
+            raise RuntimeError("graph capture of backward: the last gradient bucket was never handed over")
+        return prog
+
     def backward(self, ent, g_lm, g_img, g_nsp, g_scores):
         eng = self.eng
         dev = eng.arena.device
         grads = (g_lm, g_img, g_nsp, g_scores)
         gkey = tuple(None if g is None else tuple(g.shape) for g in grads)
+        eng.arena.attach_grads()        # BEFORE a capture: it zeroes the arena when .grad was dropped, which must not be replayed
         if ent.gB is None or ent.gkey != gkey:
             ent.gkey = gkey
             ent.gin = [None if g is None else torch.zeros(g.shape, dtype=torch.float32, device=dev) for g in grads]
             for s, g in zip(ent.gin, grads):
                 if s is not None:
                     s.copy_(g.detach().to(torch.float32))
-            was = (eng.row_bucket, eng.lm_bucket, eng.salt_word)
-            eng.row_bucket, eng.lm_bucket, eng.salt_word = self.row_bucket, self.lm_bucket, self.salt
-            try:
-                torch.cuda.synchronize()
-                ent.gB = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ent.gB, pool=ent.pool, stream=ent.stream):
-                    eng.backward(ent.out, *ent.gin)
-            finally:
-                eng.row_bucket, eng.lm_bucket, eng.salt_word = was
+            ent.gB = self._capture_backward(ent)
             self.stats["captures"] += 1
         else:
-            for s, g in zip(ent.gin, grads):
-                if s is not None:
-                    s.copy_(g.detach(), non_blocking=True)
-        eng.arena.attach_grads()
-        ent.gB.replay()
+            pairs = [(s, g.detach()) for s, g in zip(ent.gin, grads) if s is not None]
+            if all(g.dtype == torch.float32 and g.shape == s.shape for s, g in pairs):
+                torch._foreach_copy_([s for s, _ in pairs], [g for _, g in pairs])     # one launch
+            else:
+                for s, g in pairs:
+                    s.copy_(g, non_blocking=True)
+        hook = eng.grad_bucket_hook
+        for item in ent.gB:                                    # graph segments and, between them, the bucket hand-overs
+            if isinstance(item, tuple):
+                if hook is not None:
+                    hook(*item)
+            else:
+                item.replay()
