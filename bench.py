@@ -403,7 +403,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    use_graphs = (args.graphs == "on" or (args.graphs == "auto" and per_gpu <= 120)) and args.workload == "train" \
+    use_graphs = (args.graphs == "on" or (args.graphs == "auto" and per_gpu <= 90)) and args.workload == "train" \
         and not args.compact_inputs and not args.host_profile
     gx = None
     if use_graphs:

@@ -290,6 +290,10 @@ int unimm_transpose_cast(const float* src, void* dst, int32_t R, int32_t C, int3
  * models/vilbert_dialog.py:1023-1026 reduction-major so that its input gradient (a few hundred rows x 768 over the
  * 30,522-long vocabulary axis) can run as a split reduction on unimm_gemm_tn_grouped. */
 int unimm_transpose_bf16(const void* src, void* dst, int32_t R, int32_t C, int32_t lds, int32_t ldd, void* stream);
+/* out[i] (bf16) = slabs[0][i] + slabs[1][i] + ... + slabs[count-1][i] (fp32, in that order), i < n; slab s starts at
+ * slabs + s * stride.  n a multiple of 8, stride of 4, 16-byte aligned pointers.  The fixed-order reduction of the
+ * per-chunk partial sums of the split decoder input gradient (see unimm_transpose_bf16). */
+int unimm_sum_slabs_bf16(const float* slabs, int32_t count, int64_t stride, void* out, int64_t n, void* stream);
 /* The same for `count` matrices in one launch.  `table` is a DEVICE array; entry i owns blocks
  * [tile0_i, tile0_{i+1}) with ceil(C/32) * ceil(ldd/32) blocks each (tile0 ascending, tile0_0 = 0);
  * total_tiles = their sum.  Used after the optimizer step to rebuild every transposed weight copy. */

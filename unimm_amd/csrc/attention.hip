@@ -228,13 +228,14 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnParams p) {
 
   if (p.drop.thr != 0u) {
     // one hash per two neighbouring keys (registers e, e+1 with e even hold keys k, k+1 with k even)
-    const uint32_t wb = drop_wbase(((uint32_t)b * p.H + head) * p.Tq + (uint32_t)qrow, (uint32_t)p.Tk, 0u);
+    // linear stage of the hash: per-lane constant (query row, lane half) + a compile-time multiple of M1 per (tile, register pair)
+    const uint32_t wl = drop_lin(p.drop, drop_wbase(((uint32_t)b * p.H + head) * p.Tq + (uint32_t)qrow, (uint32_t)p.Tk, 0u) + 2u * (uint32_t)h);
 #pragma unroll
     for (int t = 0; t < NKT; ++t) {
       if (32 * t >= Tk_b) continue;
 #pragma unroll
       for (int e = 0; e < 16; e += 2) {
-        const uint32_t w = drop_word(p.drop, wb + (uint32_t)((32 * t + key_of_reg(e, h)) >> 1));
+        const uint32_t w = drop_fin(p.drop, wl + (uint32_t)((32 * t + key_of_reg(e, 0)) >> 1) * DROP_M1);
         s[t][e] = drop_keep(p.drop, w, 0u) ? s[t][e] : 0.0f;
         s[t][e + 1] = drop_keep(p.drop, w, 1u) ? s[t][e + 1] : 0.0f;
       }
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
   f32x16 dq[D / 32];
 #pragma unroll
   for (int dt = 0; dt < D / 32; ++dt) dq[dt] = f32x16{};
-  const uint32_t dwb = drop_wbase(((uint32_t)b * p.H + head) * p.Tq + (uint32_t)qrow, (uint32_t)p.Tk, 0u);
+  const uint32_t dwl = drop_lin(p.drop, drop_wbase(((uint32_t)b * p.H + head) * p.Tq + (uint32_t)qrow, (uint32_t)p.Tk, 0u) + 2u * (uint32_t)h);
 
   // Per score (same log2-domain form as the forward): arg = s * c1 + (masked ? -10000 log2 e : 0) - lse log2 e is one
   // fma, because -lse / scale is what the S accumulator STARTS from; the dropout select carries 1 / (1 - p) and feeds an
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
     uint32_t dw[8];   // dropout words: one hash per two neighbouring keys
     if (dropping) {
 #pragma unroll
-      for (int e2 = 0; e2 < 8; ++e2) dw[e2] = drop_word(p.drop, dwb + (uint32_t)((32 * t + key_of_reg(2 * e2, h)) >> 1));
+      for (int e2 = 0; e2 < 8; ++e2) dw[e2] = drop_fin(p.drop, dwl + (uint32_t)((32 * t + key_of_reg(2 * e2, 0)) >> 1) * DROP_M1);
     } else {
 #pragma unroll
       for (int e2 = 0; e2 < 8; ++e2) dw[e2] = 0u;          // with thr16 = 0 every field "keeps", at scale 1
@@ -500,6 +501,8 @@ __global__ __launch_bounds__(MAXT, MAXT == 256 ? 1 : 2) void attn_bwd_dkv_kernel
   for (int dt = 0; dt < D / 32; ++dt) { dk[dt] = f32x16{}; dv[dt] = f32x16{}; }
   const uint32_t* mrow = mw_s + wt * QPAD;
   const uint32_t hbase = ((uint32_t)b * p.H + head) * (uint32_t)p.Tq;
+  const uint32_t halfw = ((uint32_t)p.Tk + 1u) >> 1, halfm = halfw * DROP_M1;      // D = 64 dropout words (see below)
+  const uint32_t dlane = drop_lin(p.drop, (4u * (uint32_t)h + ((uint32_t)r & 1u)) * halfw + ((uint32_t)(wt * 32 + r) >> 1));
   const float c1 = p.scale * LOG2E;
   constexpr float MOFF = -10000.0f * LOG2E;
   const bool dropping = p.drop.thr != 0u;
@@ -531,11 +534,12 @@ __global__ __launch_bounds__(MAXT, MAXT == 256 ? 1 : 2) void attn_bwd_dkv_kernel
       if constexpr (D == 64) {
         odd = (uint32_t)r & 1u;
         if (dropping) {
-          const uint32_t kw = (uint32_t)(wt * 32 + r) >> 1;
-          const uint32_t half = ((uint32_t)p.Tk + 1u) >> 1;
+          // word index (hbase + qb + par [+ 2]) * half + kw, qb = 32 qt + 8 g4 + 4 h: the lane's part of the hash's linear
+          // stage (h, par, kw) is loop-invariant, the rest is wave-uniform (scalar multiply)
           const uint32_t par = (uint32_t)r & 1u;
-          const uint32_t wa = drop_word(p.drop, (hbase + (uint32_t)qb + par) * half + kw);
-          const uint32_t wb = drop_word(p.drop, (hbase + (uint32_t)qb + par + 2u) * half + kw);
+          const uint32_t ua = (hbase + (uint32_t)(32 * qt + 8 * g4)) * halfm;
+          const uint32_t wa = drop_fin(p.drop, dlane + ua);
+          const uint32_t wb = drop_fin(p.drop, dlane + ua + 2u * halfm);
           const uint32_t oa = (uint32_t)__builtin_amdgcn_mov_dpp((int)wa, 0xB1, 0xF, 0xF, true);
           const uint32_t ob = (uint32_t)__builtin_amdgcn_mov_dpp((int)wb, 0xB1, 0xF, 0xF, true);
           dwv[0] = par ? oa : wa; dwv[1] = par ? wa : oa; dwv[2] = par ? ob : wb; dwv[3] = par ? wb : ob;

@@ -105,36 +105,46 @@ __device__ __forceinline__ void gelu_and_grad2(f32x2v x, f32x2v& y, f32x2v& dy) 
 // Counter-based dropout.  Element (row, col) of a [rows, ncols] activation is kept iff the 16-bit field
 // (col & 1) of  drop_word(key, row * ceil(ncols / 2) + (col >> 1))  is >= thr >> 16, key = per-(step, site)
 // word built on the host (unimm_amd/dropout.py mirrors this bit for bit so the oracle can replay the
-// masks).  One hash serves two neighbouring columns: the two 32-bit multiplies of mix32 were 25 % of the
-// text-attention forward and a third of the dropout GEMM epilogue.  p is resolved to 2^-16.
+// masks).  One hash serves two neighbouring columns.  p is resolved to 2^-16.
+//
+// The hash is a LINEAR stage followed by one xorshift-multiply-xorshift round:
+//     drop_lin(w) = w * M1 + key                      (a bijection of w for every key; affine in w)
+//     drop_fin(x) = x ^= x >> 15; x ^= key * GOLD; x *= M2; x ^= x >> 16
+// Affine means drop_lin(a + b) = drop_lin(a) + b * M1: a kernel forms the linear stage of the element it visits from a
+// per-lane constant (computed once), a wave-uniform term (scalar unit) and compile-time constants with ONE vector add,
+// and pays one 32-bit multiply (quarter rate on this ISA) per hash instead of three (index, and the two of the
+// mix32-style hash of rounds 1-2: 40 % of the vector work of the attention backward kernels).  The key enters twice,
+// additively and -- through another odd multiple -- by XOR before the multiply: with the addition alone the mask of key k2
+// would be the mask of key k1 shifted by (k2 - k1) / M1 words.
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU;
   x ^= x >> 15; x *= 0x846ca68bU;
   x ^= x >> 16;
   return x;
 }
+constexpr uint32_t DROP_M1 = 0x7feb352dU, DROP_M2 = 0x846ca68bU;
 struct DropoutArg {
   uint32_t key;    // 0 with thr == 0 => disabled
   uint32_t thr;    // p * 2^32 (the kernels compare 16-bit fields against thr >> 16)
   float scale;     // 1 / (1 - p)
   const uint32_t* salt;   // or NULL: device word XORed into the key at kernel entry.  Replayed launch sequences freeze their
                           // arguments, so the per-(seed, site) key is the argument and the per-step part lives in memory.
+  uint32_t key2;   // key * GOLD, filled in by drop_resolve
 };
 // effective key of this launch (call once at kernel entry, on the kernel's own copy of its parameters)
 __device__ __forceinline__ void drop_resolve(DropoutArg& d) {
   if (d.salt != nullptr) { d.key ^= d.salt[0]; d.salt = nullptr; }
+  d.key2 = d.key * 0x9E3779B1u;
 }
-// The key enters twice: XORed into the index and, multiplied by an odd constant (uniform: one scalar multiply per kernel),
-// added between the two multiplies.  With the XOR alone the mask of key k2 is the mask of key k1 read at index ^ k1 ^ k2:
-// every site and step would see an index permutation of ONE bit pattern.
-__device__ __forceinline__ uint32_t drop_word(const DropoutArg& d, uint32_t widx) {
-  uint32_t x = widx ^ d.key;
-  x ^= x >> 16; x *= 0x7feb352dU;
-  x += d.key * 0x9E3779B1u;
-  x ^= x >> 15; x *= 0x846ca68bU;
+__device__ __forceinline__ uint32_t drop_lin(const DropoutArg& d, uint32_t widx) { return widx * DROP_M1 + d.key; }
+__device__ __forceinline__ uint32_t drop_fin(const DropoutArg& d, uint32_t x) {
+  x ^= x >> 15;
+  x ^= d.key2;
+  x *= DROP_M2;
   x ^= x >> 16;
   return x;
 }
+__device__ __forceinline__ uint32_t drop_word(const DropoutArg& d, uint32_t widx) { return drop_fin(d, drop_lin(d, widx)); }
 __device__ __forceinline__ uint32_t drop_wbase(uint32_t row, uint32_t ncols, uint32_t col) { return row * ((ncols + 1u) >> 1) + (col >> 1); }
 __device__ __forceinline__ bool drop_keep(const DropoutArg& d, uint32_t w, uint32_t odd) {
   return (odd ? (w >> 16) : (w & 0xffffu)) >= (d.thr >> 16);
@@ -148,11 +158,11 @@ __device__ __forceinline__ float drop_apply(const DropoutArg& d, uint32_t row, u
 }
 // keep bits of 8 consecutive columns col0 .. col0+7 (col0 % 8 == 0): 4 hashes
 __device__ __forceinline__ uint32_t drop_bits8(const DropoutArg& d, uint32_t row, uint32_t ncols, uint32_t col0) {
-  const uint32_t wb = drop_wbase(row, ncols, col0), t16 = d.thr >> 16;
+  const uint32_t l0 = drop_lin(d, drop_wbase(row, ncols, col0)), t16 = d.thr >> 16;
   uint32_t bits = 0;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const uint32_t w = drop_word(d, wb + q);
+    const uint32_t w = drop_fin(d, l0 + (uint32_t)q * DROP_M1);
     bits |= ((w & 0xffffu) >= t16 ? 1u : 0u) << (2 * q);
     bits |= ((w >> 16) >= t16 ? 1u : 0u) << (2 * q + 1);
   }

@@ -810,6 +810,22 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
   }
 }
 
+// out[i] (bf16) = slabs[0][i] + slabs[1][i] + ... in that order (fp32), i < n: the fixed-order sum of the per-chunk partial
+// results of Engine._decoder_dx (a sum whose order does not depend on which workgroup finished first).
+__global__ __launch_bounds__(256) void sum_slabs_bf16_kernel(const float* __restrict__ slabs, int S, size_t stride,
+                                                             bf16_t* __restrict__ out, size_t n8) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+    for (int s = 0; s < S; ++s) {
+      const f32x4* p = reinterpret_cast<const f32x4*>(slabs + (size_t)s * stride) + 2 * i;
+      const f32x4 v0 = p[0], v1 = p[1];
+      a0 += v0; a1 += v1;
+    }
+    u32x4 o = {pack2bf(a0[0], a0[1]), pack2bf(a0[2], a0[3]), pack2bf(a1[0], a1[1]), pack2bf(a1[2], a1[3])};
+    *reinterpret_cast<u32x4*>(out + 8 * i) = o;
+  }
+}
+
 // the same for a table of matrices in ONE launch (all transposed weight copies after an optimizer step:
 // ~190 launches of a few microseconds each otherwise).  Block b belongs to the last entry with tile0 <= b.
 __global__ __launch_bounds__(256) void transpose_cast_grouped_kernel(const unimm_transpose_desc* __restrict__ tab, int count) {
@@ -928,7 +944,7 @@ __global__ void gather_rows_kernel(const bf16_t* __restrict__ src, const int32_t
 }
 
 inline DropoutArg mk_drop(uint32_t key, uint32_t thr, float scale, const uint32_t* salt = nullptr) {
-  DropoutArg d; d.key = key; d.thr = thr; d.scale = scale; d.salt = salt; return d;
+  DropoutArg d; d.key = key; d.thr = thr; d.scale = scale; d.salt = salt; d.key2 = 0u; return d;
 }
 
 }  // namespace
@@ -1118,6 +1134,17 @@ extern "C" int unimm_transpose_bf16(const void* src, void* dst, int32_t R, int32
   if ((lds % 8) || (ldd % 8) || (((uintptr_t)src | (uintptr_t)dst) & 15)) return UNIMM_E_ALIGN;
   hipLaunchKernelGGL(transpose_bf16_kernel, dim3((C + 63) / 64, (ldd + 63) / 64), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)src, (bf16_t*)dst, R, C, lds, ldd);
+  UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
+}
+
+extern "C" int unimm_sum_slabs_bf16(const float* slabs, int32_t count, int64_t stride, void* out, int64_t n, void* stream) {
+  if (!slabs || !out || count <= 0 || n <= 0 || stride < n) return UNIMM_E_ARG;
+  if ((n % 8) || (stride % 4) || (((uintptr_t)slabs | (uintptr_t)out) & 15)) return UNIMM_E_ALIGN;
+  int64_t blocks = (n / 8 + 255) / 256;
+  blocks = blocks > 2048 ? 2048 : blocks;
+  hipLaunchKernelGGL(sum_slabs_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, slabs, count,
+                     (size_t)stride, (bf16_t*)out, (size_t)(n / 8));
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;
 }

@@ -1,4 +1,4 @@
-"""Counter-based dropout shared by every kernel (one mix32 hash per two neighbouring columns).
+"""Counter-based dropout shared by every kernel (one hash per two neighbouring columns).
 
 The kernels never store a mask: the backward pass regenerates it from (key, thr).  `key` is one
 32-bit word per (seed, step, site); `keep_mask` is the bit-exact host mirror of the device hash
@@ -46,16 +46,17 @@ def drop_arg(p: float, key: int):
 
 def keep_mask2d(key: int, thr: int, rows: int, cols: int) -> np.ndarray:
     """Host mirror of the device rule (unimm_amd/csrc/common.h): element (row, col) of a [rows, cols]
-    activation is kept iff the 16-bit field (col & 1) of drop_word(key, row * ceil(cols / 2) + (col >> 1)) -- mix32 with the key
-    XORed into the index and key * 0x9E3779B1 added between its two multiplies -- is >= thr >> 16.  Returns a boolean [rows, cols] array."""
+    activation is kept iff the 16-bit field (col & 1) of drop_word(key, w = row * ceil(cols / 2) + (col >> 1)) -- the affine stage
+    w * M1 + key followed by one xorshift / multiply / xorshift round with key * 0x9E3779B1 XORed in before the multiply -- is
+    >= thr >> 16.  Returns a boolean [rows, cols] array."""
     half = (cols + 1) // 2
     r = np.arange(rows, dtype=np.uint64)[:, None]
     c = np.arange(cols, dtype=np.uint64)[None, :]
-    x = ((r * np.uint64(half) + (c >> np.uint64(1))) & np.uint64(0xFFFFFFFF)) ^ np.uint64(key)
-    x ^= x >> np.uint64(16)
-    x = (x * np.uint64(_M1)) & np.uint64(0xFFFFFFFF)
-    x = (x + np.uint64((key * 0x9E3779B1) & 0xFFFFFFFF)) & np.uint64(0xFFFFFFFF)   # the key's second entry (common.h: drop_word)
-    x ^= x >> np.uint64(15)
+    key &= 0xFFFFFFFF
+    w = (r * np.uint64(half) + (c >> np.uint64(1))) & np.uint64(0xFFFFFFFF)
+    x = (w * np.uint64(_M1) + np.uint64(key)) & np.uint64(0xFFFFFFFF)             # drop_lin: affine in the word index
+    x ^= x >> np.uint64(15)                                                         # drop_fin
+    x ^= np.uint64((key * 0x9E3779B1) & 0xFFFFFFFF)                                 # the key's second entry
     x = (x * np.uint64(_M2)) & np.uint64(0xFFFFFFFF)
     x ^= x >> np.uint64(16)
     field = np.where((c & np.uint64(1)) == 1, x >> np.uint64(16), x & np.uint64(0xFFFF))

@@ -447,17 +447,27 @@ class Engine:
         sequences).  As an NT GEMM this is 10 x 6 tiles of 64 x 128, each with a 477-step reduction over the vocabulary:
         60 workgroups on 256 CUs, 348 us -- 3.5 % of the 30-sequence step for 29 GFLOP.  The reduction axis is the long
         one, so it runs on the weight-gradient kernel instead (dW[N, K] += dY[M, N]^T X[M, K] with M = vocabulary,
-        dY = dlog^T, X = the bf16 embedding table itself): 9 tiles of 256 x 256, the reduction split ~28 ways over the
-        chip, fp32 atomics into a zeroed [n, H] buffer.  Costs a bf16 transpose of dlog (38 MB) and a cast."""
+        dY = dlog^T, X = the bf16 embedding table itself): the vocabulary is cut into S chunks, chunk s is ONE problem of a
+        grouped launch with its own zeroed fp32 slab [n, H] (9 tiles of 256 x 256 per chunk, S ~ 27: one round of the chip,
+        every tile reduced by one workgroup and written once), and the slabs are added in chunk order and rounded to bf16 by
+        one small kernel -- the result does not depend on which workgroup finishes first (atomics into one buffer did:
+        rounded to bf16 that showed up as 4e-3 of the gradient scale between two schedules of the same step).
+        Costs a bf16 transpose of dlog (38 MB), the slabs (S x 2 MB) and the reduction."""
         H = dec.K
         ldT = _rup(n, 64)
         dlogT = torch.empty((V, ldT), dtype=BF16, device=dlog.device)
         L.transpose_bf16(dlog, dlogT, n, V)
-        dhn32 = torch.zeros((ldT, H), dtype=F32, device=dlog.device)
-        L.gemm_tn_grouped([(dlogT, dec.w, dhn32, V, ldT, H, None)], shared=self._dual())
-        dhn = torch.empty((n, H), dtype=BF16, device=dlog.device)
-        L.cast_f32_bf16(dhn32, dhn, n * H)
-        return dhn
+        tiles = ((ldT + 255) // 256) * ((H + 255) // 256)
+        S = max(1, min(48, 256 // tiles, V // 1024))
+        chunk = _rup((V + S - 1) // S, 64)
+        S = max(1, V // chunk)                                 # the last chunk takes the remainder (< 2 chunks long)
+        slabs = torch.zeros((S, ldT, H), dtype=F32, device=dlog.device)
+        ends = [(s + 1) * chunk for s in range(S - 1)] + [V]
+        L.gemm_tn_grouped([(dlogT[e0:e1], dec.w[e0:e1], slabs[s], e1 - e0, ldT, H, None)
+                           for s, (e0, e1) in enumerate(zip([0] + ends[:-1], ends))], shared=0)
+        dhn = torch.empty((ldT, H), dtype=BF16, device=dlog.device)
+        L.sum_slabs_bf16(slabs, dhn, ldT * H)
+        return dhn[:n]
 
     def _layernorm(self, x, key, save, drop=L.NO_DROP, want32=True, lazy=False):
         """x: fp32 pre-LayerNorm sum -> (y32 residual stream | None, y16 GEMM operand, mean, rstd).

@@ -13,7 +13,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libunimm_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROP_RESID, EPI_BIAS_RELU, EPI_DGELU, EPI_ADD, EPI_MUL, EPI_BIAS_GELU_DG = range(8)
 
@@ -86,7 +86,7 @@ SYMBOLS = ["unimm_version", "unimm_arch", "unimm_gemm_nt", "unimm_gemm_tn", "uni
            "unimm_pack_image", "unimm_mul_dropout", "unimm_mul_dropout_bwd", "unimm_lm_loss_fwd",
            "unimm_lm_loss_bwd", "unimm_kl_loss_fwd", "unimm_kl_loss_bwd", "unimm_nsp_loss_fwd",
            "unimm_nsp_loss_bwd", "unimm_reduce_sum", "unimm_segment_sum", "unimm_gelu_bwd", "unimm_gather_rows", "unimm_prof_enable", "unimm_prof_collect", "unimm_adamw_step", "unimm_transpose_cast_grouped", "unimm_mask_synth", "unimm_neural_ndcg", "unimm_plan_lengths", "unimm_plan_build", "unimm_layernorm_bwd_partials",
-           "unimm_colpartials_finish_grouped", "unimm_gemm_tn_grouped_ws", "unimm_linear_f32", "unimm_rows_add_f32", "unimm_transpose_bf16"]
+           "unimm_colpartials_finish_grouped", "unimm_gemm_tn_grouped_ws", "unimm_linear_f32", "unimm_rows_add_f32", "unimm_transpose_bf16", "unimm_sum_slabs_bf16"]
 
 
 def _check(rc, what):
@@ -482,6 +482,13 @@ def transpose_bf16(src, dst, R, C_):
     _dev(src, dst)
     _check(lib().unimm_transpose_bf16(_ptr(src), _ptr(dst), C.c_int32(R), C.c_int32(C_), C.c_int32(src.stride(0)),
                                       C.c_int32(dst.stride(0)), _stream()), "unimm_transpose_bf16")
+
+
+def sum_slabs_bf16(slabs, out, n):
+    """out[:n] (bf16) = slabs.sum(0) in slab order; slabs: fp32 [S, ...] contiguous, n a multiple of 8."""
+    _dev(slabs, out)
+    _check(lib().unimm_sum_slabs_bf16(_ptr(slabs), C.c_int32(slabs.shape[0]), C.c_int64(slabs.stride(0)), _ptr(out),
+                                      C.c_int64(n), _stream()), "unimm_sum_slabs_bf16")
 
 
 class TransposeDesc(C.Structure):
