@@ -121,3 +121,29 @@ def test_dropout_masks_of_two_keys_are_not_index_permutations_of_one_pattern():
     assert agree < 0.9, agree                        # independent masks agree on ~0.82 of the positions, a permutation on all
     c = np.corrcoef(a.astype(np.float64), b.astype(np.float64))[0, 1]
     assert abs(c) < 2e-2, c
+    # the hash's first stage is affine in the word index (w * M1 + key): a key that is d * M1 further on makes that stage
+    # a d-word shift of the first key's -- the second entry of the key (XOR before the multiply) must break the relation
+    for dwords in (1, 5, 1000):
+        k3 = (k1 + dwords * 0x7FEB352D) & 0xFFFFFFFF
+        e = DR.keep_mask(k3, thr, 2 * n)
+        f = DR.keep_mask(k1, thr, 2 * (n + dwords))
+        agree = float((e == f[2 * dwords:]).mean())
+        assert agree < 0.85, (dwords, agree)
+
+
+def test_dropout_mask_statistics_of_the_affine_stage_hash():
+    """Keep rate, neighbour correlations (columns, rows) and row-count dispersion of the host mirror over several keys,
+    including degenerate ones."""
+    from unimm_amd import dropout as DR
+    for key in (0, 1, 0xFFFFFFFF, DR.make_key(7, 0, 0), DR.make_key(7, 1, 0), DR.make_key(8, 0, 5)):
+        _, thr, _ = DR.drop_arg(0.1, key)
+        m = DR.keep_mask2d(key, thr, 2048, 256).astype(np.float64)
+        rate = m.mean()
+        assert abs(rate - 0.9) < 3e-3, (key, rate)
+        d = m - rate
+        v = d.var()
+        for name, cc in (("cols", (d[:, :-1] * d[:, 1:]).mean() / v), ("rows", (d[:-1] * d[1:]).mean() / v),
+                         ("cols2", (d[:, :-2] * d[:, 2:]).mean() / v), ("diag", (d[:-1, :-1] * d[1:, 1:]).mean() / v)):
+            assert abs(cc) < 6e-3, (key, name, cc)
+        disp = m.sum(1).var() / (256 * rate * (1 - rate))          # binomial dispersion of the per-row keep counts
+        assert 0.85 < disp < 1.15, (key, disp)
