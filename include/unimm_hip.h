@@ -154,6 +154,12 @@ typedef struct {
 
 int unimm_attn_fwd(const unimm_attn_args* args, void* stream);
 
+/* The attention probabilities themselves, fp32 [B, H, Tq, Tk] (after dropout, as models/vilbert_dialog.py:401-405 /
+ * :690-717 return them and BertEncoder collects them under output_all_attention_masks, :855-929).  Fixed layout only
+ * (q_off .. k_len NULL); v / out / lse of the argument struct are ignored.  A diagnostic output, not part of the hot path:
+ * unimm_attn_fwd never materialises them. */
+int unimm_attn_probs(const unimm_attn_args* args, float* probs, void* stream);
+
 /* Backward of unimm_attn_fwd (autograd of models/vilbert_dialog.py:390-410 / 519-539 / 681-721):
  * two launches on `stream` -- dQ (+ delta = rowsum(dO o O), fp32 [B,H,Tq] scratch) then dK/dV.
  * P is recomputed from Q, K and lse; the dropout mask is re-generated from (key, thr).

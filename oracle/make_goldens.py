@@ -88,6 +88,33 @@ def save(name, **arrs):
 
 
 # ---------------------------------------------------------------------------------------------
+def gen_attn(vd):
+    """The attention probabilities the reference returns under output_all_attention_masks=True (inference branch,
+    models/vilbert_dialog.py:855-929, :1626), for the batch of small_mixed.npz: per text layer / image layer / connection
+    layer (both directions), sequences 0 (gen) and 3 (dis)."""
+    cfg = R.make_config(SMALL_CFG)
+    sd = R.init_state_dict(cfg, seed=11)
+    model = build_reference_model(vd, SMALL_CFG, sd)
+    modes, negs = ["gen", "dis", "gen", "dis", "gen", "gen"], [0, 1, 1, 0, 1, 1]
+    rng = np.random.Generator(np.random.PCG64(100 + 3))            # == the "mixed" case of gen_small
+    b = make_batch(rng, SMALL_CFG, len(modes), 64, 37, modes, negs, share_image=True, type_ext=False)
+    kw = dict(token_type_ids=T_(b["token_type_ids"]), position_ids=T_(b["position_ids"]),
+              attention_mask=T_(b["attention_mask"]), image_attention_mask=T_(b["image_attention_mask"]),
+              co_attention_mask=T_(b["co_attention_mask"]), output_all_attention_masks=True)
+    with torch.no_grad():
+        _, _, _, _, (att_t, att_v, att_c) = model(T_(b["input_ids"]), T_(b["image_feat"]), T_(b["image_loc"]), **kw)
+    sel = [0, 3]
+    out = {"sel": np.array(sel), "n_t": len(att_t), "n_v": len(att_v), "n_c": len(att_c)}
+    for i, p in enumerate(att_t):
+        out[f"t{i}"] = p[sel]
+    for i, p in enumerate(att_v):
+        out[f"v{i}"] = p[sel]
+    for i, (p1, p2) in enumerate(att_c):
+        out[f"c{i}_1"] = p1[sel]
+        out[f"c{i}_2"] = p2[sel]
+    save("small_attn.npz", **out)
+
+
 def gen_small(vd):
     """G1 + G2: small (HIP-shaped) config end to end, eval mode, all five branches + gradients."""
     cfg = R.make_config(SMALL_CFG)
@@ -393,11 +420,12 @@ def gen_rankloss(vm):
 
 
 if __name__ == "__main__":
-    groups = sys.argv[1:] or ["masks", "ranks", "small", "blocks", "losses", "full", "sched", "rankloss", "fullgrad"]
+    groups = sys.argv[1:] or ["masks", "ranks", "small", "blocks", "losses", "full", "sched", "rankloss", "fullgrad", "attn"]
     vd, du, vm = import_reference()
     torch.manual_seed(0)
     torch.set_num_threads(8)
     for g in groups:
         {"masks": lambda: gen_masks(du), "ranks": lambda: gen_ranks(vm), "small": lambda: gen_small(vd),
          "blocks": lambda: gen_blocks(vd), "losses": lambda: gen_losses(vd), "full": lambda: gen_full(vd),
-         "sched": gen_sched, "rankloss": lambda: gen_rankloss(vm), "fullgrad": lambda: gen_fullgrad(vd)}[g]()
+         "sched": gen_sched, "rankloss": lambda: gen_rankloss(vm), "fullgrad": lambda: gen_fullgrad(vd),
+         "attn": lambda: gen_attn(vd)}[g]()

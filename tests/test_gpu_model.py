@@ -266,6 +266,37 @@ def test_row_capacities_with_device_side_counts_equal_exact_sizes(golden_dir, sm
     assert d <= 1e-5, d                          # fp32 summation order of the weight gradients (split count follows the capacity)
 
 
+def test_attention_probabilities_match_reference_golden(golden_dir, small):
+    """output_all_attention_masks=True (models/vilbert_dialog.py:855-929, :1626): the per-layer attention probabilities the
+    inference branch returns, against those of the reference itself (tests/golden/small_attn.npz, oracle/make_goldens.py
+    `attn`): text self-attention, image self-attention and both directions of every connection layer, padding rows
+    included (the reference computes softmax over raw scores there)."""
+    model, _, _ = small
+    model.eval()
+    g = np.load(os.path.join(golden_dir, "small_mixed.npz"))
+    want = np.load(os.path.join(golden_dir, "small_attn.npz"))
+    args, kw = kwargs_from(g, train=False)
+    with torch.no_grad():
+        plain = model(*args, **kw)
+        pred_t, pred_v, nsp, seq_t, (att_t, att_v, att_c) = model(*args, **kw, output_all_attention_masks=True)
+    assert plain[4] == ([], [], [])
+    assert len(att_t) == int(want["n_t"]) and len(att_v) == int(want["n_v"]) and len(att_c) == int(want["n_c"])
+    close(nsp, plain[2].detach().cpu().numpy(), what="nsp (padded one-stream schedule vs default)")
+    sel = torch.from_numpy(want["sel"]).cuda()
+    worst = 0.0
+    for i, p in enumerate(att_t):
+        assert p.shape[1:] == (model.config.num_attention_heads, 64, 64)
+        worst = max(worst, close(p[sel], want[f"t{i}"], what=f"text layer {i} probabilities"))
+    for i, p in enumerate(att_v):
+        worst = max(worst, close(p[sel], want[f"v{i}"], what=f"image layer {i} probabilities"))
+    for i, (p1, p2) in enumerate(att_c):
+        worst = max(worst, close(p1[sel], want[f"c{i}_1"], what=f"connection {i}: text attends regions"))
+        worst = max(worst, close(p2[sel], want[f"c{i}_2"], what=f"connection {i}: regions attend text"))
+    for p in att_t + att_v:
+        assert (p.sum(-1) - 1).abs().max() < 1e-4
+    print(f"\nattention probabilities vs reference: worst |err| {worst:.2e}")
+
+
 def test_decoder_input_gradient_as_split_reduction_equals_nt_gemm(golden_dir, small):
     """For few decoded rows the decoder's input gradient (dlog @ E, a 30,522-long reduction for a few hundred rows) runs on
     the weight-gradient kernel as a split reduction over the vocabulary (Engine._decoder_dx); it must equal the NT GEMM it

@@ -687,6 +687,74 @@ int launch_fwd(const AttnParams& p, hipStream_t s) {
   return UNIMM_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// attention probabilities as a tensor (models/vilbert_dialog.py:401-405 returns them; the encoder collects them when
+// output_all_attention_masks is set, :855-929).  Not on the hot path: the fused kernels above never materialise P.
+// One wave per (sequence, head, query) row of the fixed layout; a lane owns keys lane, lane + 64, ...; fp32
+// softmax(q . k * scale + additive mask) from the bf16 operands, then the SAME dropout words as attn_fwd.
+// ------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void attn_probs_kernel(AttnParams p, float* __restrict__ probs) {
+  drop_resolve(p.drop);
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);           // (b * H + head) * Tq + q
+  const long nrows = (long)p.B * p.H * p.Tq;
+  if (row >= nrows) return;
+  const int q = (int)(row % p.Tq);
+  const int bh = (int)(row / p.Tq), head = bh % p.H, b = bh / p.H;
+  const bf16_t* qg = p.q + ((size_t)b * p.Tq + q) * p.ldq + head * D;
+  float qv[D];
+#pragma unroll
+  for (int c = 0; c < D / 8; ++c) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(qg + 8 * c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { qv[8 * c + 2 * e] = __uint_as_float(v[e] << 16); qv[8 * c + 2 * e + 1] = __uint_as_float(v[e] & 0xffff0000u); }
+  }
+  const uint32_t* mrow = p.mask + (size_t)b * p.mask_b_stride + (size_t)q * p.mask_q_stride;
+  float sc[4];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int key = lane + 64 * j;
+    sc[j] = -INFINITY;
+    if (key < p.Tk) {
+      const bf16_t* kg = p.k + ((size_t)b * p.Tk + key) * p.ldk + head * D;
+      float acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < D / 8; ++c) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(kg + 8 * c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc = fmaf(qv[8 * c + 2 * e], __uint_as_float(v[e] << 16), acc);
+          acc = fmaf(qv[8 * c + 2 * e + 1], __uint_as_float(v[e] & 0xffff0000u), acc);
+        }
+      }
+      const bool ok = (mrow[key >> 5] >> (key & 31)) & 1u;
+      sc[j] = acc * p.scale + (ok ? 0.f : -10000.0f);
+      mx = fmaxf(mx, sc[j]);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    sc[j] = (lane + 64 * j) < p.Tk ? __expf(sc[j] - mx) : 0.f;
+    sum += sc[j];
+  }
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+  float* out = probs + (size_t)row * p.Tk;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int key = lane + 64 * j;
+    if (key >= p.Tk) continue;
+    float v = sc[j] * inv;
+    if (p.drop.thr != 0u) v = drop_apply(p.drop, (uint32_t)row, (uint32_t)p.Tk, (uint32_t)key, v);
+    out[key] = v;
+  }
+}
+
 }  // namespace
 
 extern "C" int unimm_attn_fwd(const unimm_attn_args* a, void* stream) {
@@ -709,6 +777,28 @@ extern "C" int unimm_attn_fwd(const unimm_attn_args* a, void* stream) {
   const bool small_k = a->Tk <= 64;
   if (a->D == 64) return small_k ? launch_fwd<64, 2>(p, s) : launch_fwd<64, 8>(p, s);
   return small_k ? launch_fwd<128, 2>(p, s) : launch_fwd<128, 8>(p, s);
+}
+
+extern "C" int unimm_attn_probs(const unimm_attn_args* a, float* probs, void* stream) {
+  if (a == nullptr || !a->q || !a->k || !a->mask || !probs) return UNIMM_E_ARG;
+  if (a->q_off || a->q_len || a->k_off || a->k_len) return UNIMM_E_ARG;          // fixed layout only
+  if (a->B <= 0 || a->H <= 0 || a->Tq <= 0 || a->Tk <= 0 || a->Tq > 256 || a->Tk > 256) return UNIMM_E_SHAPE;
+  if (a->D != 64 && a->D != 128) return UNIMM_E_SHAPE;
+  if ((a->ldq % 8) || (a->ldk % 8) || (((uintptr_t)a->q | (uintptr_t)a->k) & 15)) return UNIMM_E_ALIGN;
+  AttnParams p;
+  p.q = (const bf16_t*)a->q; p.k = (const bf16_t*)a->k; p.v = nullptr; p.o = nullptr; p.lse = nullptr; p.mask = a->mask;
+  p.q_off = p.q_len = p.k_off = p.k_len = nullptr;
+  p.B = a->B; p.H = a->H; p.Tq = a->Tq; p.Tk = a->Tk;
+  p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = 0; p.ldo = 0;
+  p.mask_q_stride = a->mask_q_stride; p.mask_b_stride = a->mask_b_stride; p.parts = 1;
+  p.scale = a->scale;
+  p.drop.key = a->drop_key; p.drop.thr = a->drop_thr; p.drop.scale = a->drop_scale; p.drop.salt = a->drop_salt; p.drop.key2 = 0u;
+  const long rows = (long)a->B * a->H * a->Tq;
+  const unsigned blocks = (unsigned)((rows + 3) / 4);
+  if (a->D == 64) hipLaunchKernelGGL(attn_probs_kernel<64>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, probs);
+  else hipLaunchKernelGGL(attn_probs_kernel<128>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, probs);
+  UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
 }
 
 extern "C" int unimm_attn_bwd(const unimm_attn_bwd_args* a, void* stream) {

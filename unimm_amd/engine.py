@@ -118,6 +118,7 @@ class Engine:
         self._inject_header = None       # header values of the step, read ahead of a graph capture (see _forward, graphs.py)
         self.graphs = None               # unimm_amd.graphs.StepGraphs once enable_graphs() was called
         self._dims = None                # (int32 [8], fp32 [8]) device words: {valid rows, decoded rows, regions}, {1/decoded, 1/regions}
+        self.attn_sink = None            # dict while a forward collects attention probabilities (forward_with_attention)
         self.skinny_dx_rows = 3072       # decoded-row count up to which the decoder's input gradient runs as a split reduction (_decoder_dx)
         self._pending = []               # gradient buckets whose weight gradients are still queued: (group, #text, #image queued)
         self._nq = [0, 0]                # weight-gradient problems ever queued (text side, image side) ...
@@ -588,11 +589,17 @@ class Engine:
     # ------------------------------------------------------------------------------------------
     # blocks
     # ------------------------------------------------------------------------------------------
-    def _attn(self, q, k, v, mask, B, H, Tq, Tk, D, drop, save, qvar=None, kvar=None):
+    def _attn(self, q, k, v, mask, B, H, Tq, Tk, D, drop, save, qvar=None, kvar=None, tag=None):
         out = torch.empty((q.shape[0], H * D), dtype=BF16, device=q.device)
         lse = torch.empty((B, H, Tq), dtype=F32, device=q.device) if save else None
         words, mq, mb = mask
         L.attn_fwd(q, k, v, out, lse, words, B, H, Tq, Tk, D, 1.0 / math.sqrt(D), mq, mb, drop, qvar=qvar, kvar=kvar)
+        if self.attn_sink is not None:          # output_all_attention_masks: the probabilities as tensors (diagnostic, padded layout)
+            if qvar is not None or kvar is not None:
+                raise RuntimeError("attention probabilities are collected on the padded schedule only")
+            probs = torch.empty((B, H, Tq, Tk), dtype=F32, device=q.device)
+            L.attn_probs(q, k, probs, words, B, H, Tq, Tk, D, 1.0 / math.sqrt(D), mq, mb, drop)
+            self.attn_sink[tag] = probs
         return out, lse
 
     def _self_block(self, key, x32, x, mask, B, T, heads, pname, p_attn, p_hid, st, var=None):
@@ -606,7 +613,7 @@ class Engine:
         qkv = self._linear(x, qkv_l)
         q, k, v = qkv[:, :Hd], qkv[:, Hd:2 * Hd], qkv[:, 2 * Hd:]
         d_attn = self._drop(pname + "attn", p_attn, train)
-        ctx, lse = self._attn(q, k, v, mask, B, heads, T, T, D, d_attn, save, qvar=var, kvar=var)
+        ctx, lse = self._attn(q, k, v, mask, B, heads, T, T, D, d_attn, save, qvar=var, kvar=var, tag=key)
         d_so = self._drop(pname + "so", p_hid, train)
         pre1 = self._linear(ctx, so, L.EPI_BIAS_DROP_RESID, aux=x32, drop=d_so, out_f32=True)
         x1_32, x1, m1, r1 = self._layernorm(pre1, key + ".ln1", save, lazy=True)
@@ -658,7 +665,7 @@ class Engine:
         dvo = self._drop(pn + "vout", cfg.v_hidden_dropout_prob, train)
         dto = self._drop(pn + "tout", cfg.hidden_dropout_prob, train)
         with self._img():
-            ctx_v, lse_v = self._attn(q1, k2, v2, comask, B, nh, R, T, D, da2, save, kvar=var)    # regions attend text (:701-721)
+            ctx_v, lse_v = self._attn(q1, k2, v2, comask, B, nh, R, T, D, da2, save, kvar=var, tag=key + "/2")    # regions attend text (:701-721)
             prev = self._linear(ctx_v, d1, L.EPI_BIAS_DROP_RESID, aux=xv32, drop=db1, out_f32=True)   # BertBiOutput (:744-754, call order :775)
             av32, av, mv1, rv1 = self._layernorm(prev, key + ".lnb1", save, lazy=True)
             if save:
@@ -667,7 +674,7 @@ class Engine:
                 hv, uv = self._linear(av, vff1, L.EPI_BIAS_GELU), None
             prev2 = self._linear(hv, vff2, L.EPI_BIAS_DROP_RESID, aux=av32, drop=dvo, out_f32=True)
             ov32, ov, mv2, rv2 = self._layernorm(prev2, key + ".lnv", save, lazy=True)
-        ctx_t, lse_t = self._attn(q2, k1, v1, vmask, B, nh, T, R, D, da1, save, qvar=var)     # text attends regions (:681-698)
+        ctx_t, lse_t = self._attn(q2, k1, v1, vmask, B, nh, T, R, D, da1, save, qvar=var, tag=key + "/1")     # text attends regions (:681-698)
         pret = self._linear(ctx_t, d2, L.EPI_BIAS_DROP_RESID, aux=xt32, drop=db2, out_f32=True)
         at32, at, mt1, rt1 = self._layernorm(pret, key + ".lnb2", save, lazy=True)
         if save:
@@ -807,6 +814,28 @@ class Engine:
 
     def forward(self, inp: dict, train: bool, save: bool, lm_rows: str, want_pred_v: bool):
         return self._on_text_stream(self._forward, inp, train, save, lm_rows, want_pred_v)
+
+    def forward_with_attention(self, inp, train, lm_rows, want_pred_v):
+        """Inference forward that also returns the attention probabilities of every layer as the reference's encoder
+        collects them under output_all_attention_masks (models/vilbert_dialog.py:834-937): (text layers, image layers,
+        connection layers as (text-attends-regions, regions-attend-text)), each fp32 [B, heads, Tq, Tk].  Runs the padded,
+        one-stream schedule (the probabilities of padding rows are part of what the reference returns)."""
+        was = (self.unpad, self.dual_stream, self.attn_sink)
+        self.unpad, self.dual_stream, self.attn_sink = False, False, {}
+        try:
+            out = self.forward(inp, train=train, save=False, lm_rows=lm_rows, want_pred_v=want_pred_v)
+            sink = self.attn_sink
+        finally:
+            self.unpad, self.dual_stream, self.attn_sink = was
+
+        def order(prefix):
+            ks = [k for k in sink if k.startswith(prefix) and "/" not in k]
+            return sorted(ks, key=lambda k: int("".join(ch for ch in k if ch.isdigit())))
+        att_t = [sink[k] for k in order("t")]
+        att_v = [sink[k] for k in order("v")]
+        cs = sorted({k.split("/")[0] for k in sink if "/" in k}, key=lambda k: int("".join(ch for ch in k if ch.isdigit())))
+        att_c = [(sink[k + "/1"], sink[k + "/2"]) for k in cs]
+        return out, (att_t, att_v, att_c)
 
     def backward(self, out, g_lm, g_img, g_nsp, g_nsp_scores=None):
         return self._on_text_stream(self._backward, out, g_lm, g_img, g_nsp, g_nsp_scores)

@@ -13,7 +13,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libunimm_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROP_RESID, EPI_BIAS_RELU, EPI_DGELU, EPI_ADD, EPI_MUL, EPI_BIAS_GELU_DG = range(8)
 
@@ -69,6 +69,7 @@ def lib():
     L.unimm_gemm_nt.argtypes = [VP, VP]
     L.unimm_attn_fwd.argtypes = [VP, VP]
     L.unimm_attn_bwd.argtypes = [VP, VP]
+    L.unimm_attn_probs.argtypes = [VP, VP, VP]
     L.unimm_gemm_tn_grouped.argtypes = [VP, I32, VP]
     L.unimm_gemm_tn_grouped_ws.argtypes = [VP, I32, I32, VP, I64, VP]
     L.unimm_colpartials_finish_grouped.argtypes = [VP, I32, VP]
@@ -86,7 +87,7 @@ SYMBOLS = ["unimm_version", "unimm_arch", "unimm_gemm_nt", "unimm_gemm_tn", "uni
            "unimm_pack_image", "unimm_mul_dropout", "unimm_mul_dropout_bwd", "unimm_lm_loss_fwd",
            "unimm_lm_loss_bwd", "unimm_kl_loss_fwd", "unimm_kl_loss_bwd", "unimm_nsp_loss_fwd",
            "unimm_nsp_loss_bwd", "unimm_reduce_sum", "unimm_segment_sum", "unimm_gelu_bwd", "unimm_gather_rows", "unimm_prof_enable", "unimm_prof_collect", "unimm_adamw_step", "unimm_transpose_cast_grouped", "unimm_mask_synth", "unimm_neural_ndcg", "unimm_plan_lengths", "unimm_plan_build", "unimm_layernorm_bwd_partials",
-           "unimm_colpartials_finish_grouped", "unimm_gemm_tn_grouped_ws", "unimm_linear_f32", "unimm_rows_add_f32", "unimm_transpose_bf16", "unimm_sum_slabs_bf16"]
+           "unimm_colpartials_finish_grouped", "unimm_gemm_tn_grouped_ws", "unimm_linear_f32", "unimm_rows_add_f32", "unimm_transpose_bf16", "unimm_sum_slabs_bf16", "unimm_attn_probs"]
 
 
 def _check(rc, what):
@@ -276,6 +277,20 @@ def attn_fwd(q, k, v, out, lse, mask, B, H, Tq, Tk, D, scale, mask_q_stride, mas
     rc = fn(addr, _stream())
     if rc != 0:
         _check(rc, "unimm_attn_fwd")
+
+
+def attn_probs(q, k, probs, mask, B, H, Tq, Tk, D, scale, mask_q_stride, mask_b_stride, drop=NO_DROP):
+    """probs: fp32 [B, H, Tq, Tk] = dropout(softmax(q k^T scale + additive mask)); fixed row layout (diagnostic output)."""
+    _dev(q, k, probs, mask)
+    a = AttnArgs()
+    a.q, a.k, a.v, a.out, a.lse, a.mask = q.data_ptr(), k.data_ptr(), None, None, None, mask.data_ptr()
+    a.q_off = a.q_len = a.k_off = a.k_len = None
+    a.B, a.H, a.Tq, a.Tk, a.D = B, H, Tq, Tk, D
+    a.ldq, a.ldk, a.ldv, a.ldo = q.stride(0), k.stride(0), 0, 0
+    a.mask_q_stride, a.mask_b_stride, a.scale = mask_q_stride, mask_b_stride, scale
+    a.drop_key, a.drop_thr, a.drop_scale = drop[:3]
+    a.drop_salt = _salt(drop)
+    _check(lib().unimm_attn_probs(C.byref(a), _ptr(probs), _stream()), "unimm_attn_probs")
 
 
 def attn_bwd(q, k, v, out, dout, lse, delta, dq, dk, dv, mask, B, H, Tq, Tk, D, scale, mask_q_stride,

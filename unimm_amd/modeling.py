@@ -180,8 +180,6 @@ class BertForMultiModalPreTraining(nn.Module):
         Extensions (unimm_amd/inputs.py): `attention_mask` may be a `DialogMaskSpec`
         (then `co_attention_mask` must be None) and `image_feat` / `image_loc` / `image_target` may hold one
         entry per IMAGE with `image_index` [B] mapping sequences to them."""
-        if output_all_attention_masks:
-            raise NotImplementedError("attention probabilities are never materialised on the HIP path")
         eng = self._engine
         dev = self._device()
         eng.ensure(dev)
@@ -212,11 +210,16 @@ class BertForMultiModalPreTraining(nn.Module):
                     seq_t = seq_raw[0].view(B, T, H)
                     pred_t = eng.decode_rows(seq_raw[1], B * T).view(B, T, -1)[:, :, :V]
             return lm_loss, img_loss, nsp_loss, seq_t, pred_t, nsp
+        att = ([], [], [])
         with torch.no_grad():
-            out = eng.forward(inp, train=self.training, save=False, lm_rows="all" if _want_lm_scores else "none",
-                              want_pred_v=_want_pred_v)
+            if output_all_attention_masks:     # :855-929, :1626 -- diagnostic output, padded one-stream schedule
+                out, att = eng.forward_with_attention(inp, train=self.training, lm_rows="all" if _want_lm_scores else "none",
+                                                      want_pred_v=_want_pred_v)
+            else:
+                out = eng.forward(inp, train=self.training, save=False, lm_rows="all" if _want_lm_scores else "none",
+                                  want_pred_v=_want_pred_v)
         seq_t = eng.padded(out, out["seq32_t"]).view(B, T, H)
-        return out.get("pred_t"), out.get("pred_v"), out["nsp"], seq_t, ([], [], [])
+        return out.get("pred_t"), out.get("pred_v"), out["nsp"], seq_t, att
 
     def _device(self):
         return self.bert.embeddings.word_embeddings.weight.device
