@@ -718,23 +718,23 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(AttnBwdParams p)
     kf[ks] = *reinterpret_cast<const bf16x8*>(kg + 16 * ks + 8 * h);
     vf[ks] = *reinterpret_cast<const bf16x8*>(vg + 16 * ks + 8 * h);
   }
-  // K^T fragments of the wave's tile for dQ: element j of lane (r, h), fragment (dt, ss) = K[32 wt + 16 ss + 8 (j >> 2) + 4 h + (j & 3)][32 dt + r]
+  // K^T fragments of the wave's tile for dQ (fragment (dt, ss): element j of lane (r, h) = K[32 wt + 16 ss + 8 (j >> 2) + 4 h +
+  // (j & 3)][32 dt + r]): the row fragments just loaded go through a wave-private image in the (still unused) accumulator
+  // area and come back as transposed fragments; rows of keys past the end are written as zeros, so whatever those lanes
+  // compute as dS never reaches dQ.  No barrier: a wave's LDS accesses execute in order, and every wave is done with this
+  // before the barrier below, after which the area becomes the accumulator.
   bf16x8 ktf[2][2];
   {
-    typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+    char* kt = reinterpret_cast<char*>(acc) + wave * (32 * 2 * D);
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks) {
+      const u32x4 v = kvalid ? __builtin_bit_cast(u32x4, kf[ks]) : u32x4{0u, 0u, 0u, 0u};
+      *reinterpret_cast<u32x4*>(kt + r * (2 * D) + (((2 * ks + h) ^ swz<D>(r)) << 4)) = v;
+    }
 #pragma unroll
     for (int ss = 0; ss < 2; ++ss) {
-      u16x8 t0, t1;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int key = wt * 32 + 16 * ss + 8 * (j >> 2) + 4 * h + (j & 3);
-        const bool ok = key < Tk_b;
-        const bf16_t* kp = p.k + (kbase + (ok ? key : 0)) * p.ldk + head * D + r;
-        t0[j] = ok ? kp[0] : (bf16_t)0;
-        t1[j] = ok ? kp[32] : (bf16_t)0;
-      }
-      ktf[0][ss] = __builtin_bit_cast(bf16x8, t0);
-      ktf[1][ss] = __builtin_bit_cast(bf16x8, t1);
+      ktf[0][ss] = read_tr_frag<D>(kt, 16 * ss, 0, lane);
+      ktf[1][ss] = read_tr_frag<D>(kt, 16 * ss, 32, lane);
     }
   }
   stage_wait();
