@@ -461,8 +461,8 @@ def main():
         ex = lib.prof_collect()
         lib.prof_enable(False)
         model.engine.dual_stream = True
-        if "gemm_tn" in ex:
-            ems, efl, ecnt = ex["gemm_tn"]
+        if "gemm_tn_pp" in ex:
+            ems, efl, ecnt = ex["gemm_tn_pp"]
             exclusive = dict(achieved=round(efl / (ems * 1e-3) / 1e12, 1), avg_launch_us=round(ems * 1e3 / ecnt, 2),
                              launches_per_step=ecnt // 2, frac=round(efl / (ems * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                              note="2 extra steps after the timed region with everything on one stream")
@@ -595,7 +595,7 @@ def main():
                          "traffic_unit": "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE)", "traffic_source": traffic_src,
                          "traffic_measured_at_commit": traffic_commit,
                          "launches_per_step": cnt // args.steps, "avg_launch_us": round(ms * 1e3 / cnt, 2),
-                         "event_timed_launches": "every GEMM" if prof_all else "gemm_tn only (in the timed region); every GEMM in 2 extra steps",
+                         "event_timed_launches": "every GEMM" if prof_all else "the weight-gradient kernels only (in the timed region); every GEMM in 2 extra steps",
                          "whole_step_executed_gemm_tflops": round(exec_fl_step / (dt / args.steps) / 1e12, 1),
                          "whole_step_frac": round(exec_fl_step / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
                          "gemm_kernels_by_time": [{"kernel": k, "ms_per_step": round(kms, 3), "tflops": round(kfl / (kms * 1e-3) / 1e12, 1) if kms > 0 else None,

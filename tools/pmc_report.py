@@ -38,7 +38,7 @@ for r in rows[:28]:
     print(f"{r['kernel'][:88]:88s} {r['launches']:8d} {r['fetch_kb_raw']:13.1f} {r['read_mb']:13.1f} {r['write_kb']:10.1f} {mu}")
 if len(sys.argv) > 4:
     dom = next((r for r in rows if "gemm_tn_pp_kernel" in r["kernel"]), None) or next(r for r in rows if "gemm_tn_kernel" in r["kernel"])
-    json.dump({"kernel": "gemm_tn", "source": sys.argv[4 + 1] if len(sys.argv) > 5 else "",
+    json.dump({"kernel": "gemm_tn_pp", "source": sys.argv[4 + 1] if len(sys.argv) > 5 else "",
                "fetch_kb_raw_per_launch": dom["fetch_kb_raw"], "write_kb_per_launch": dom["write_kb"],
                "bytes_per_launch_corrected": dom["bytes_per_launch"], "mfma_busy_fraction": dom["mfma_util"],
                "launches_profiled": dom["launches"]}, open(sys.argv[4], "w"), indent=1)

@@ -14,6 +14,9 @@ python tools/pmc_report.py $out/pmc_fetch $out/pmc_write $out/pmc_sq $out/traffi
 python bench.py --batch 30 --steps 30 --no-cpu-baseline --no-padded > $out/bench_b30.json 2> $out/bench_b30.err
 python bench.py --batch 30 --steps 30 --no-cpu-baseline --no-padded --graphs off > $out/bench_b30_eager.json 2> $out/bench_b30_eager.err
 python bench.py --batch 60 --steps 20 --no-cpu-baseline --no-padded > $out/bench_b60.json 2> $out/bench_b60.err
+python bench.py --batch 120 --steps 16 --no-cpu-baseline --no-padded > $out/bench_b120.json 2> $out/bench_b120.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats30g -o run -- python bench.py --batch 30 --steps 12 --warmup 2 --graphs on --no-cpu-baseline --no-padded > $out/bench_b30_graphs_under_rocprof.json 2> $out/stats30g.err
+python tools/queue_breakdown.py $(find $out/stats30g -name "*kernel_trace.csv" | head -1) 12 > $out/b30_graphs_step_breakdown.txt 2>&1
 TN_BLOCKS=7 python tools/bench_tn_group.py > $out/tn_group7.log 2>&1
 TN_BLOCKS=1 python tools/bench_tn_group.py > $out/tn_group1.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $out/pmc_tn7 -o run -- python tools/bench_tn_group.py > /dev/null 2> $out/pmc_tn7.err

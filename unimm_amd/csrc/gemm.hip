@@ -1355,7 +1355,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmTnGroup grp) {
 // ------------------------------------------------------------------------------------------------
 struct ProfRec { hipEvent_t a, b; int variant; double flops; };
 constexpr int PROF_MAX = 1 << 16;
-constexpr int PROF_VARIANTS = 20;   // 0..15: gemm_nt epi*2+out_f32 ; 16: gemm_tn
+// One variant per kernel SYMBOL (what rocprofv3 --stats lists): gemm_nt / gemm_ntp x tile x epilogue x output type, and
+// the three weight-gradient kernels.  NT: ((persistent * 16 + tile code) * 8 + epilogue) * 2 + out_f32 (tile code = the
+// unimm_gemm_nt_args.tile code of the configuration: 1, 3, 6, 7, 8); TN: 512 = gemm_tn_pp, 513 = gemm_tn<2,4,8> (the
+// lock-step loop, tools only), 514 = gemm_tn<2,2,4>.
+constexpr int PROF_VARIANTS = 516;
+constexpr int PROF_TN0 = 512;
+template <class C> constexpr int nt_tile_code() {
+  return C::PP ? 8 : (C::MT == 8 ? 3 : (C::MT == 6 ? 6 : (C::MT == 2 ? 7 : 1)));
+}
 bool g_prof_on = false;
 bool g_prof_tn_only = false;        // unimm_prof_enable(2): only the weight-gradient launches (2 event records per launch
                                     // are host time; a rank whose step is launch-rate-bound should not pay them 340 times)
@@ -1363,7 +1371,7 @@ ProfRec* g_prof = nullptr;
 int g_prof_n = 0;
 
 inline ProfRec* prof_begin(int variant, double flops, hipStream_t s) {
-  if (!g_prof_on || g_prof_n >= PROF_MAX || (g_prof_tn_only && variant != 16)) return nullptr;
+  if (!g_prof_on || g_prof_n >= PROF_MAX || (g_prof_tn_only && variant < PROF_TN0)) return nullptr;
   ProfRec* r = &g_prof[g_prof_n];
   if (r->a == nullptr) {
     if (hipEventCreate(&r->a) != hipSuccess || hipEventCreate(&r->b) != hipSuccess) return nullptr;
@@ -1430,7 +1438,7 @@ int launch_nt_cfg(const GemmNtParams& p, bool out_f32, int want_persist, hipStre
           pdone = true;
         }
       }
-      ProfRec* pr = prof_begin(EPI * 2 + (out_f32 ? 1 : 0), 2.0 * p.M * (double)p.N * p.K, s);
+      ProfRec* pr = prof_begin(((16 + nt_tile_code<C>()) * 8 + EPI) * 2 + (out_f32 ? 1 : 0), 2.0 * p.M * (double)p.N * p.K, s);
       if (out_f32) hipLaunchKernelGGL(p32, dim3(slots), dim3(C::THREADS), C::LDS, s, p, nwg);
       else hipLaunchKernelGGL(p16, dim3(slots), dim3(C::THREADS), C::LDS, s, p, nwg);
       prof_end(pr, s);
@@ -1438,7 +1446,7 @@ int launch_nt_cfg(const GemmNtParams& p, bool out_f32, int want_persist, hipStre
       return UNIMM_OK;
     }
   }
-  ProfRec* pr = prof_begin(EPI * 2 + (out_f32 ? 1 : 0), 2.0 * p.M * (double)p.N * p.K, s);
+  ProfRec* pr = prof_begin((nt_tile_code<C>() * 8 + EPI) * 2 + (out_f32 ? 1 : 0), 2.0 * p.M * (double)p.N * p.K, s);
   if (out_f32) hipLaunchKernelGGL(k32, dim3(nwg), dim3(C::THREADS), C::LDS, s, p);
   else hipLaunchKernelGGL(k16, dim3(nwg), dim3(C::THREADS), C::LDS, s, p);
   prof_end(pr, s);
@@ -1600,7 +1608,7 @@ int launch_tn_group(const unimm_gemm_tn_args* const* a, int count, bool big, boo
       g.slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + cbytes);
     }
   }
-  ProfRec* pr = prof_begin(16, flops, s);
+  ProfRec* pr = prof_begin(PROF_TN0 + (big ? (legacy_loop ? 1 : 0) : 2), flops, s);
   if (big) {
     auto kern = legacy_loop ? gemm_tn_kernel<2, 4, 8> : gemm_tn_pp_kernel;
     static bool attr_done[2] = {false, false};
@@ -1681,6 +1689,7 @@ extern "C" int unimm_prof_collect(double* ms, double* flops, int32_t* count, int
     if (hipEventSynchronize(r.b) != hipSuccess) return UNIMM_E_HIP;
     float t = 0.f;
     if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) return UNIMM_E_HIP;
+    if (r.variant < 0 || r.variant >= nvar) return UNIMM_E_ARG;
     ms[r.variant] += t; flops[r.variant] += r.flops; count[r.variant] += 1;
   }
   g_prof_n = 0;

@@ -646,9 +646,17 @@ def gather_rows(src, idx, dst, n, H, scatter=False, n_dev=None):
                                    C.c_int32(1 if scatter else 0), _ptr(n_dev), _stream()), "unimm_gather_rows")
 
 
-GEMM_VARIANTS = {0: "gemm_nt<BIAS,bf16>", 1: "gemm_nt<BIAS,f32>", 2: "gemm_nt<BIAS_GELU,bf16>", 3: "gemm_nt<BIAS_GELU,f32>",
-                 5: "gemm_nt<BIAS_DROP_RESID,f32>", 6: "gemm_nt<BIAS_RELU,bf16>", 8: "gemm_nt<DGELU,bf16>",
-                 10: "gemm_nt<ADD,bf16>", 12: "gemm_nt<MUL,bf16>", 14: "gemm_nt<BIAS_GELU_DG,bf16>", 16: "gemm_tn"}
+_EPI_NAMES = ["BIAS", "BIAS_GELU", "BIAS_DROP_RESID", "BIAS_RELU", "DGELU", "ADD", "MUL", "BIAS_GELU_DG"]
+_TILE_NAMES = {1: "128x128", 3: "256x256", 6: "192x256", 7: "64x128", 8: "256x256pp"}
+PROF_VARIANTS = 516
+
+
+def gemm_variant_name(i):
+    """Name of a profiler variant = one kernel symbol (csrc/gemm.hip: PROF_VARIANTS): the persistent form is gemm_ntp."""
+    if i >= 512:
+        return {512: "gemm_tn_pp", 513: "gemm_tn<256x256 lock-step>", 514: "gemm_tn<128x128>"}.get(i, f"variant{i}")
+    f32, epi, tile, persist = i & 1, (i >> 1) & 7, (i >> 4) & 15, i >> 8
+    return f"gemm_nt{'p' if persist else ''}<{_TILE_NAMES.get(tile, tile)},{_EPI_NAMES[epi]},{'f32' if f32 else 'bf16'}>"
 
 
 ADAMW_MAX_GROUPS = 8
@@ -719,7 +727,7 @@ def prof_enable(on):
 
 def prof_collect():
     """-> {variant name: (total_ms, total_flops, launches)} for the launches since prof_enable(True)."""
-    n = 20
+    n = PROF_VARIANTS
     ms, fl, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_int32 * n)()
     _check(lib().unimm_prof_collect(ms, fl, cnt, C.c_int32(n)), "unimm_prof_collect")
-    return {GEMM_VARIANTS.get(i, f"variant{i}"): (ms[i], fl[i], cnt[i]) for i in range(n) if cnt[i] > 0}
+    return {gemm_variant_name(i): (ms[i], fl[i], cnt[i]) for i in range(n) if cnt[i] > 0}
