@@ -118,6 +118,7 @@ class Engine:
         self._inject_header = None       # header values of the step, read ahead of a graph capture (see _forward, graphs.py)
         self.graphs = None               # unimm_amd.graphs.StepGraphs once enable_graphs() was called
         self._dims = None                # (int32 [8], fp32 [8]) device words: {valid rows, decoded rows, regions}, {1/decoded, 1/regions}
+        self.image_head_side = True      # image prediction head (forward and backward) on the image stream, beside the MLM head
         self.attn_sink = None            # dict while a forward collects attention probabilities (forward_with_attention)
         self.skinny_dx_rows = 3072       # decoded-row count up to which the decoder's input gradient runs as a split reduction (_decoder_dx)
         self._pending = []               # gradient buckets whose weight gradients are still queued: (group, #text, #image queued)
@@ -546,6 +547,14 @@ class Engine:
         finally:
             torch.cuda.set_stream(main)
             self._on_side = was
+
+    @contextmanager
+    def _img_if(self, flag):
+        if flag:
+            with self._img():
+                yield
+        else:
+            yield
 
     def _to_img(self, *reads):
         """Everything enqueued on the main (text) stream so far happens before whatever the image-side stream is
@@ -1034,12 +1043,30 @@ class Engine:
                 xv32, xv, xt32, xt = self._conn_block(f"c{i}", i, xv32, xv, xt32, xt, B, R, T, vmask, comask, st, var=var)
                 if save:
                     tape[-1] = ("c", tape[-1][0], tape[-1][1])
-        self._to_txt(xv32, xv)                # the heads read both streams
+        # ---- image head (:1001-1005, :1085-1088; its masked KL :1569-1574 is in _losses): on the image stream, beside the
+        # text side's last layers and the MLM head
+        img = None
+        pred_v_out = None
+        if want_pred_v or inp.get("image_target") is not None:
+            with self._img_if(self.image_head_side):
+                itr, idec = self.lin["imgtr"], self.lin["imgdec"]
+                C = cfg.v_target_size
+                if save:
+                    tv, uvh = self._linear(xv, itr, L.EPI_BIAS_GELU, want_u=True, out_f32=True)
+                else:
+                    tv, uvh = self._linear(xv, itr, L.EPI_BIAS_GELU, out_f32=True), None
+                _, hvn, mh, rh = self._layernorm(tv, "imgtr", save, want32=False)
+                pred_v = self._linear(hvn, idec, out_f32=True, ldo=_rup(C, 4))
+            pred_v_out = pred_v.view(B, R, -1)[:, :, :C]
+            img = dict(tv=tv, u=uvh, hn=hvn, mean=mh, rstd=rh, pred=pred_v)
+        self._to_txt(xv32, xv, img["pred"] if img is not None else None)                # the heads read both streams
         seq_t, seq_v = xt, xv
 
         xt32, xv32 = self._dense32(xt32), self._dense32(xv32)      # the final residual stream is an output
         out = dict(seq_out_t=seq_t, seq_out_v=seq_v, seq32_t=xt32, seq32_v=xv32, B=B, T=T, R=R, plan=plan, Mt=Mt,
-                   nsp_weight_host=st_nspw, n_img=n_img, img_label32=il32, dyn=dyn)
+                   nsp_weight_host=st_nspw, n_img=n_img, img_label32=il32, dyn=dyn, img=img)
+        if pred_v_out is not None:
+            out["pred_v"] = pred_v_out
         # ---- poolers + NSP (models/vilbert_dialog.py:946-967, 1064-1070) -------------------------
         cls_idx_t = var[0] if var is not None else torch.arange(0, B * T, T, dtype=torch.int32, device=dev)
         cls_idx_v = torch.arange(0, B * R, R, dtype=torch.int32, device=dev)
@@ -1074,21 +1101,6 @@ class Engine:
             out["lm"] = lm
         elif lm_rows == "all":
             out["pred_t"] = self.decode_rows(self.padded(out, seq_t), B * T).view(B, T, Vp)[:, :, :V]
-
-        # ---- image head (:1001-1005, :1085-1088) + masked KL (:1569-1574) --------------------------
-        img = None
-        if want_pred_v or inp.get("image_target") is not None:
-            itr, idec = self.lin["imgtr"], self.lin["imgdec"]
-            C = cfg.v_target_size
-            if save:
-                tv, uvh = self._linear(seq_v, itr, L.EPI_BIAS_GELU, want_u=True, out_f32=True)
-            else:
-                tv, uvh = self._linear(seq_v, itr, L.EPI_BIAS_GELU, out_f32=True), None
-            _, hvn, mh, rh = self._layernorm(tv, "imgtr", save, want32=False)
-            pred_v = self._linear(hvn, idec, out_f32=True, ldo=_rup(C, 4))
-            out["pred_v"] = pred_v.view(B, R, -1)[:, :, :C]
-            img = dict(tv=tv, u=uvh, hn=hvn, mean=mh, rstd=rh, pred=pred_v)
-        out["img"] = img
 
         if save:
             out["bwd"] = dict(tape=tape, embt=bwd_embt, embv=bwd_embv, pooled_t=pooled_t, pooled_v=pooled_v, fused=fused,
@@ -1197,6 +1209,22 @@ class Engine:
             return torch.zeros(1, dtype=F32, device=dev) if g is None else g.detach().to(F32).reshape(1).contiguous()
 
         dseq_t = torch.zeros((out["Mt"], H), dtype=BF16, device=dev)
+        # ---- image head: on the image stream, beside the MLM head's backward -------------------------
+        img = out["img"]
+        C = cfg.v_target_size
+        itr, idec = self.lin["imgtr"], self.lin["imgdec"]
+        Cp = idec.wt.shape[1]
+        gimg = gvec(g_img)
+        self._to_img(gimg, img["target"], img["lse"], img["label"])
+        with self._img_if(self.image_head_side):
+            dpred = torch.empty((B * R, Cp), dtype=BF16, device=dev)
+            L.kl_loss_bwd(img["pred"], img["target"], img["label"], img["lse"], gimg, img["inv"], dpred, B * R, C,
+                          inv_dev=img.get("inv_dev"))
+            dhn_v = self._linear_bwd(dpred, img["hn"], idec, M=B * R, N=C)
+            dtv, _ = self._layernorm_bwd(dhn_v, img["tv"], img["mean"], img["rstd"], "imgtr")
+            duv = torch.empty_like(dtv)
+            L.gelu_bwd(dtv, img["u"], duv, duv.numel())
+            dseq_v = self._linear_bwd(duv, seq_v, itr)
         # ---- MLM head ---------------------------------------------------------------------------
         lm = out.get("lm")
         if lm is not None:
@@ -1218,19 +1246,6 @@ class Engine:
             L.gelu_bwd(dt1, lm["u"], du, du.numel())
             dxs = self._linear_bwd(du, lm["xs"], lmtr, m_dev=nd)
             L.gather_rows(dxs, lm["idx"], dseq_t, n, H, scatter=True, n_dev=nd)
-        # ---- image head --------------------------------------------------------------------------
-        img = out["img"]
-        C = cfg.v_target_size
-        itr, idec = self.lin["imgtr"], self.lin["imgdec"]
-        Cp = idec.wt.shape[1]
-        dpred = torch.empty((B * R, Cp), dtype=BF16, device=dev)
-        L.kl_loss_bwd(img["pred"], img["target"], img["label"], img["lse"], gvec(g_img), img["inv"], dpred, B * R, C,
-                      inv_dev=img.get("inv_dev"))
-        dhn = self._linear_bwd(dpred, img["hn"], idec, M=B * R, N=C)
-        dtv, _ = self._layernorm_bwd(dhn, img["tv"], img["mean"], img["rstd"], "imgtr")
-        duv = torch.empty_like(dtv)
-        L.gelu_bwd(dtv, img["u"], duv, duv.numel())
-        dseq_v = self._linear_bwd(duv, seq_v, itr)
         # ---- NSP + poolers ------------------------------------------------------------------------
         nlab, w0, w1 = out["nsp_state"]
         dnsp = torch.empty((B, 2), dtype=F32, device=dev)
@@ -1242,15 +1257,18 @@ class Engine:
         dpt, dpv = torch.empty_like(dfused), torch.empty_like(dfused)
         L.mul_dropout_bwd(bw["pooled_t"], bw["pooled_v"], dfused, dpt, dpv, dfused.numel(), bw["d_fuse"])
         # pooler input gradients land on the first-token rows
-        for dp, key, cls, dseq, cidx in ((dpt, "tpool", bw["cls_t"], dseq_t, bw["cls_idx_t"]),
-                                         (dpv, "vpool", bw["cls_v"], dseq_v, bw["cls_idx_v"])):
-            dcls = self._linear32_bwd(dp, cls, key)
-            L.rows_add_f32(dseq, cidx, dcls, B, dcls.shape[1])
+        dcls_t = self._linear32_bwd(dpt, bw["cls_t"], "tpool")
+        L.rows_add_f32(dseq_t, bw["cls_idx_t"], dcls_t, B, dcls_t.shape[1])
+        dcls_v = self._linear32_bwd(dpv, bw["cls_v"], "vpool")
+        self._to_img(dcls_v)                     # the image pooler's input gradient joins the image head's on the image stream
+        with self._img_if(self.image_head_side):
+            L.rows_add_f32(dseq_v, bw["cls_idx_v"], dcls_v, B, dcls_v.shape[1])
         self._bucket_done("heads")
         # ---- encoder blocks in reverse -------------------------------------------------------------
         gt, gv = dseq_t, dseq_v
         entries = list(reversed(bw["tape"]))
-        self._to_img(gv)                         # the heads' gradient of the image stream was produced on the main stream
+        if not self.image_head_side:
+            self._to_img(gv)                     # the heads' gradient of the image stream was produced on the main stream
         pos = 0
         while pos < len(entries):
             seg = []
