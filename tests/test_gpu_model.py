@@ -391,6 +391,24 @@ def test_data_parallel_wrapper_over_rccl_single_rank(golden_dir):
             lm, img, nsp_l, _, _, _ = dp(*args, **kw, _want_lm_scores=False)
             (lm + img + nsp_l).sum().backward()
             assert len(seen) == n0
+        # the same exchange under the graph executor: RCCL collectives are issued between the replayed segments of the
+        # backward (with the process group's watchdog thread alive during the captures)
+        dargs = tuple(a.cuda() for a in args)
+        dkw = {k: (v.cuda() if (torch.is_tensor(v) and k != "nsp_weight") else v) for k, v in kw.items()}
+        gx = model.engine.enable_graphs(capture_after=0, row_bucket=64, lm_bucket=16)
+        try:
+            for it in range(3):
+                del seen[:]
+                model.engine.arena.zero_grads()
+                lm, img, nsp_l, _, _, _ = dp(*dargs, **dkw, _want_lm_scores=False)
+                (lm + img + nsp_l).sum().backward()
+                torch.cuda.synchronize()
+                assert sum(n for _, _, n in seen) == len(model.engine.arena.buckets), (it, seen)
+                got = model.engine.arena.grad_flat
+                assert (got - want).abs().max() <= 1e-2 * want.abs().max(), it
+            assert gx.stats["replays"] == 3 and gx.stats["eager"] == 0, gx.stats
+        finally:
+            model.engine.enable_graphs(False)
     finally:
         model.engine.grad_bucket_hook = None
         dist.destroy_process_group()

@@ -149,7 +149,7 @@ class StepGraphs:
             torch.cuda.current_stream().wait_stream(ent.stream)
             torch.cuda.synchronize()
             ent.gF = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ent.gF, pool=ent.pool, stream=ent.stream):
+            with torch.cuda.graph(ent.gF, pool=ent.pool, stream=ent.stream, capture_error_mode="thread_local"):
                 ent.out = eng.forward(ent.sin, train=opts["train"], save=True, lm_rows="labelled", want_pred_v=True)
                 ent.losses = eng.losses(ent.out, ent.sin)
                 ent.nsp = ent.out["nsp"]
@@ -171,7 +171,7 @@ class StepGraphs:
 
         def begin():
             g = torch.cuda.CUDAGraph()
-            g.capture_begin(pool=ent.pool)
+            g.capture_begin(pool=ent.pool, capture_error_mode="thread_local")   # other threads (a process group's watchdog) may touch the device
             cur[0] = g
 
         def end():
