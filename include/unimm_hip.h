@@ -161,7 +161,9 @@ int unimm_attn_fwd(const unimm_attn_args* args, void* stream);
 int unimm_attn_probs(const unimm_attn_args* args, float* probs, void* stream);
 
 /* Backward of unimm_attn_fwd (autograd of models/vilbert_dialog.py:390-410 / 519-539 / 681-721):
- * two launches on `stream` -- dQ (+ delta = rowsum(dO o O), fp32 [B,H,Tq] scratch) then dK/dV.
+ * ONE launch for the text self-attention shape (D = 64, Tq and Tk above 64: dQ comes out of the dK / dV walk, `delta` is
+ * then formed inside the kernel and the argument is left untouched); two launches on `stream` for the other shapes --
+ * dQ (+ delta = rowsum(dO o O), fp32 [B,H,Tq] scratch) then dK/dV.
  * P is recomputed from Q, K and lse; the dropout mask is re-generated from (key, thr).
  * dq/dk/dv are bf16 strided views like q/k/v (typically into one [rows, 3*H*D] buffer). */
 typedef struct {

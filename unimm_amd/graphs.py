@@ -19,7 +19,7 @@ kept (each owns its activations: ~0.19 GB per sequence at the full config).
 
 Data parallelism: the gradient exchange is issued per bucket from INSIDE backward (Engine._bucket_done -> the wrapper's
 hook -> a collective on the comm stream), i.e. between launches.  With a hook registered the backward is therefore captured
-as a CHAIN of graphs cut at the points where buckets are handed over (6-8 per step, since the weight-gradient launches are
+as a CHAIN of graphs cut at the points where buckets are handed over (~11 per step, since the weight-gradient launches are
 grouped over blocks): a replayed step is `graph, hook(s), graph, hook(s), ...` in capture order -- the collectives stay
 ordinary eager calls of whatever backend the wrapper uses.  At a cut both streams are joined (the eager path joins them
 there too: the exchange reads what the image side produced) and the image stream is forked back in at the start of the
