@@ -35,3 +35,26 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert 0 < rf["whole_step_frac"] < 1 and abs(rf["whole_step_frac"] - rf["whole_step_executed_gemm_tflops"] / rf["peak"]) < 1e-3
     assert rf["gemm_kernels_by_time"] and rf["gemm_kernels_by_time"][0]["kernel"] == rf["kernel"]
     assert j["config"]["padded_schedule_value"] > 0
+
+
+def test_bench_two_ranks_rehearsal_with_the_graph_executor():
+    """The N > 1 path of bench.py as the driver launches it (torch.distributed.run, one JSON line from rank 0), rehearsed on
+    one GPU: UNIMM_BENCH_REHEARSAL=1 puts both ranks on device 0 and exchanges over gloo (RCCL refuses two ranks on one
+    device).  A small global batch, the graph executor forced on: the data-parallel hooks between the replayed segments of
+    backward, the bucket bookkeeping assert of the timed region, the `comm` block."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, UNIMM_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "24", "--graphs", "on", "--no-cpu-baseline", "--no-padded"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 24 and j["config"]["per_gpu_batch"] == 12
+    assert j["config"]["executor"].startswith("hipGraph replay"), j["config"]["executor"]
+    c = j["comm"]
+    assert c["buckets_per_step"] > 0 and 0 < c["collectives_per_step"] <= c["buckets_per_step"]
+    assert c["bytes_per_step"] > 0 and c["exchange_alone_ms"] > 0
