@@ -411,15 +411,19 @@ def main():
     gx = None
     if use_graphs:
         gx = model.engine.enable_graphs(True)
+        done = 0
         try:
             for _ in range(3):                  # eager once more, capture, first replay
                 step()
+                done += 1
             torch.cuda.synchronize()
         except Exception as e:                  # never lose a run to the executor: the eager path computes the same step
             log(f"graph executor unavailable ({type(e).__name__}: {e}); continuing with eager launches")
             model.engine.enable_graphs(False)
             use_graphs, gx = False, None
-            model.engine.arena.zero_grads()
+            for _ in range(3 - done):           # the other ranks' collectives of these steps still need their partners
+                step()
+            torch.cuda.synchronize()
     if world > 1:                               # every rank runs the same executor (their collectives pair up either way)
         flag = torch.tensor([1 if use_graphs else 0], device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
