@@ -71,3 +71,27 @@ def test_graph_executor_falls_back_when_not_eligible(golden_dir):
     b = synth.make_batch(n_seq=6, T=64, R=37, cfg=m.config, seed=3, device="cpu")
     _step(m, b)
     assert graphs.stats["replays"] == 0 and graphs.stats["captures"] == 0
+
+
+def test_graph_entries_are_evicted_and_recaptured(golden_dir):
+    """max_entries = 1: two signatures alternate, so every second step evicts the other signature's graphs (and their private
+    activation pool) and captures again; results stay equal to the eager steps."""
+    from unimm_amd import synth
+    ref, gm = _build(golden_dir), _build(golden_dir)
+    for m in (ref, gm):
+        m.train(True)
+        m.set_dropout_seed(77)
+    cfg = ref.config
+    b1 = synth.make_batch(n_seq=12, T=64, R=37, cfg=cfg, seed=5, device="cuda")
+    b2 = synth.make_batch(n_seq=6, T=64, R=37, cfg=cfg, seed=6, device="cuda")      # another batch size = another signature
+    order = [b1, b2, b1, b2, b1]
+    want = [_step(ref, b) for b in order]
+    g = gm.engine
+    g.ensure(torch.device("cuda", 0))
+    graphs = g.enable_graphs(row_bucket=64, lm_bucket=16, capture_after=0, max_entries=1)
+    got = [_step(gm, b) for b in order]
+    assert len(graphs.entries) == 1 and graphs.stats["captures"] >= 8, graphs.stats      # forward + backward per step after the first
+    for i, (w, h) in enumerate(zip(want, got)):
+        assert (w[0] - h[0]).abs().max() <= 2e-6 * max(1.0, float(w[0].abs().max())), i
+        d = float((w[2] - h[2]).abs().max() / w[2].abs().max())
+        assert d <= 2e-5, (i, d)

@@ -969,7 +969,10 @@ class Engine:
             # capacities: what the launches are sized for (= the real counts unless the graph executor set buckets)
             Mcap = min(_rup(Mv, self.row_bucket), B * T)
             ncap = _rup(n_lm, self.lm_bucket) if n_lm > 0 else 0
-            unpadded = self.unpad and Mcap < B * T
+            # (with row capacities -- the graph executor -- the layout must not depend on whether the bucket happens to reach
+            #  B * T: packed even then, with the identity as row map, so that every replay of a signature and the eager step of
+            #  the same batch number their rows, and therefore draw their dropout masks, alike)
+            unpadded = self.unpad and (Mv < B * T or self.row_bucket > 1)
             if self._dims is None:
                 self._dims = (torch.zeros(8, dtype=torch.int32, device=dev), torch.zeros(8, dtype=F32, device=dev))
             di, df = self._dims
