@@ -95,3 +95,44 @@ def test_graph_entries_are_evicted_and_recaptured(golden_dir):
         assert (w[0] - h[0]).abs().max() <= 2e-6 * max(1.0, float(w[0].abs().max())), i
         d = float((w[2] - h[2]).abs().max() / w[2].abs().max())
         assert d <= 2e-5, (i, d)
+
+
+def test_graph_replays_follow_optimizer_steps(golden_dir):
+    """Weights change between replays (FusedAdamW updates the arena in place, the engine re-casts its bf16 copies before the
+    next replay): six optimizer steps over two alternating batches under the graph executor reproduce the eager run's losses
+    and final weights."""
+    from unimm_amd import synth
+    from unimm_amd.optim import FusedAdamW
+    ref, gm = _build(golden_dir), _build(golden_dir)
+    cfg = ref.config
+    batches = [synth.make_batch(n_seq=12, T=64, R=37, cfg=cfg, seed=s, device="cuda") for s in (5, 6)]
+    res = []
+    for m, use_graphs in ((ref, False), (gm, True)):
+        m.train(True)
+        m.set_dropout_seed(11)
+        m.engine.ensure(torch.device("cuda", 0))
+        opt = FusedAdamW([dict(params=[p for p in m.parameters()], lr=1e-3, weight_decay=0.01)], m.engine, lr=1e-3)
+        if use_graphs:
+            gx = m.engine.enable_graphs(row_bucket=64, lm_bucket=16, capture_after=0)
+        losses = []
+        for it in range(6):
+            b = batches[it % 2]
+            opt.zero_grad()
+            lm, img, nsp_l, _, _, _ = m(
+                b["input_ids"], b["image_feat"], b["image_loc"], token_type_ids=b["token_type_ids"], position_ids=b["token_position_ids"],
+                attention_mask=b["attention_mask"], image_attention_mask=b["image_attention_mask"], co_attention_mask=b["co_attention_mask"],
+                masked_lm_labels=b["masked_lm_labels"], image_label=b["image_label"], image_target=b["image_target"],
+                next_sentence_label=b["next_sentence_label"], nsp_weight=b["nsp_weight"], lm_weight=b["lm_weight"], _want_lm_scores=False)
+            (lm + img + nsp_l).sum().backward()
+            opt.step()
+            losses.append(torch.stack([lm, img, nsp_l]).flatten().detach().clone())
+        torch.cuda.synchronize()
+        res.append((torch.stack(losses), m.engine.arena.flat.detach().clone()))
+    assert gx.stats["replays"] == 6 and gx.stats["eager"] == 0, gx.stats
+    (l0, w0), (l1, w1) = res
+    assert float((l0[0] - l0[-2]).abs().max()) > 1e-3                      # the weights really moved between replays of one batch
+    assert (l0 - l1).abs().max() <= 2e-4 * l0.abs().max(), (l0, l1)
+    # weights: Adam normalises every gradient element, so where the two runs' gradients differ in their last bits around zero a
+    # step may go the other way -- bounded by the step size per update, and rare
+    dw = (w0 - w1).abs()
+    assert float(dw.max()) <= 6 * 1.01e-3 and float(dw.mean()) <= 2e-5, (float(dw.max()), float(dw.mean()))
