@@ -8,8 +8,15 @@ opt = FusedAdamW(reference_param_groups(enc, 2e-5, 2e-5, default_language_weight
 sch = WarmupLinearScheduleNonZero(opt, 100, 1000)
 losses = []
 t0 = time.time()
-for it in range(40):
-    b = synth.make_batch(n_seq=240, cfg=enc.bert_pretrained.config, seed=it % 4, device=dev)   # 4 batches cycled: loss must fall
+# python tools/soak.py [steps=40] [sequences=240] [graphs: 0 | 1]
+STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+NSEQ = int(sys.argv[2]) if len(sys.argv) > 2 else 240
+if len(sys.argv) > 3 and sys.argv[3] == "1":
+    enc.bert_pretrained.engine.ensure(dev)
+    enc.bert_pretrained.engine.enable_graphs()
+batches = [synth.make_batch(n_seq=NSEQ, cfg=enc.bert_pretrained.config, seed=s, device=dev) for s in range(4)]
+for it in range(STEPS):
+    b = dict(batches[it % 4])                                                                  # 4 batches cycled: loss must fall
     nw = b.pop("nsp_weight")
     opt.zero_grad()
     lm, img, nsp = enc(b["input_ids"], b["image_feat"], b["image_loc"], sep_indices=b["sep_indices"], sep_len=b["sep_len"],
@@ -19,7 +26,7 @@ for it in range(40):
                        image_label=b["image_label"], image_target=b["image_target"], nsp_weight=nw, lm_weight=b["lm_weight"])
     loss = lm.mean() + nsp.mean() + img.mean()
     loss.backward(); opt.step(); sch.step()
-    if it % 5 == 0 or it == 39:
+    if it % max(1, STEPS // 8) == 0 or it == STEPS - 1:
         torch.cuda.synchronize()
         print(it, round(float(loss.detach()), 4), "alloc GB", round(torch.cuda.memory_allocated() / 2**30, 2), "reserved GB", round(torch.cuda.memory_reserved() / 2**30, 2), flush=True)
 print("done", round(time.time() - t0, 1), "s")
