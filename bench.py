@@ -81,6 +81,8 @@ def parse():
                     help="A/B: decoded-row count up to which the decoder's input gradient runs as a split reduction over the "
                          "vocabulary (Engine._decoder_dx); 0 = always the NT GEMM; -1 = the engine's default")
     ap.add_argument("--image-head-main", action="store_true", help="A/B: image prediction head on the text stream (round-2 schedule)")
+    ap.add_argument("--image-tile", type=int, default=-1, help="A/B: tile code of the image side's GEMMs at large batches "
+                    "(0 = the kernel library's choice; -1 = the engine's default, the 256x256 ping-pong tile)")
     ap.add_argument("--graphs", choices=["auto", "on", "off"], default="auto",
                     help="run the step as replayed hipGraphs (unimm_amd/graphs.py: two graph launches per step instead of ~650 "
                          "host calls; N = 1 only; auto = on for <= 120 sequences per GPU, where the host would otherwise bound the "
@@ -377,6 +379,8 @@ def main():
         model.engine.wgrad_group_rounds = args.wgrad_rounds
     if args.image_head_main:
         model.engine.image_head_side = False
+    if args.image_tile >= 0:
+        model.engine.image_tile = args.image_tile
     if args.decoder_dx_rows >= 0:
         model.engine.skinny_dx_rows = args.decoder_dx_rows
     model.engine.ensure(dev)

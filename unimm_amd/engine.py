@@ -118,6 +118,7 @@ class Engine:
         self._inject_header = None       # header values of the step, read ahead of a graph capture (see _forward, graphs.py)
         self.graphs = None               # unimm_amd.graphs.StepGraphs once enable_graphs() was called
         self._dims = None                # (int32 [8], fp32 [8]) device words: {valid rows, decoded rows, regions}, {1/decoded, 1/regions}
+        self.image_tile = 8              # tile code of the image side's GEMMs in the large-batch regime (0 = the library's choice; see _tile)
         self.small_rows = 12000          # text rows per step below which the encoder GEMMs take the small-batch tile rule (_tile)
         self._step_rows = None           # text rows of the running step (set by _forward)
         self.image_head_side = True      # image prediction head (forward and backward) on the image stream, beside the MLM head
@@ -336,8 +337,14 @@ class Engine:
         side by side all the time; there the 128x128 tile (64 KiB of LDS, two workgroups per CU, 15 KiB staged per MFLOP) beats
         both the one-per-CU tiles (112-128 KiB of LDS: nothing of the other stream fits beside them) and, on the image side,
         the 64x128 tile (twice the workgroups, 23 KiB per MFLOP): +3 % at 60 sequences; the text side's N = 768 GEMMs at ~4k rows
-        (fewer than 256 tiles of 128x128) stay on 64x128 (-1.7 % otherwise at 30 sequences)."""
+        (fewer than 256 tiles of 128x128) stay on 64x128 (-1.7 % otherwise at 30 sequences).
+        In the large-batch regime the text side's launches fill the chip with one-per-CU workgroups, and what the image side's
+        launches (M = 37 rows per sequence: a fraction of a round) cost the step is the CUs they keep from the text side: the
+        256x256 ping-pong tile puts an image GEMM on 140 CUs instead of the 188 of the library's own choice (192x256, faster
+        alone): +0.8 % at 240 sequences, neutral at 120."""
         if self.gemm_tile != 0 or self._step_rows is None or self._step_rows >= self.small_rows:
+            if self._on_side and self.image_tile:
+                return self.image_tile
             return self.gemm_tile
         if self._on_side:
             return 1
