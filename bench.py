@@ -36,6 +36,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+GRAPHS_AUTO_MAX_SEQ = 90           # --graphs auto: replayed hipGraphs up to this many sequences per GPU (DESIGN.md thresholds table)
 PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak, MI355X (MI355X_MICROARCH.md: ~2.5 PF dense)
 F_FWD_BASE_GF = 76.808             # GFLOP / sequence forward without the vocab decoder
 F_DEC_ROW_GF = 0.04688             # GFLOP per decoded row (768 x 30522)
@@ -85,7 +86,7 @@ def parse():
                     "(0 = the kernel library's choice; -1 = the engine's default, the 256x256 ping-pong tile)")
     ap.add_argument("--graphs", choices=["auto", "on", "off"], default="auto",
                     help="run the step as replayed hipGraphs (unimm_amd/graphs.py: two graph launches per step instead of ~650 "
-                         "host calls; N = 1 only; auto = on for <= 120 sequences per GPU, where the host would otherwise bound the "
+                         "host calls; auto = on for <= %d sequences per GPU, where the host would otherwise bound the " % GRAPHS_AUTO_MAX_SEQ +
                          "step). The timed region then has no per-launch events: the roofline block comes from eager steps after it.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-tile", type=int, default=0, metavar="CODE",
@@ -410,7 +411,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    use_graphs = (args.graphs == "on" or (args.graphs == "auto" and per_gpu <= 90)) and args.workload == "train" \
+    use_graphs = (args.graphs == "on" or (args.graphs == "auto" and per_gpu <= GRAPHS_AUTO_MAX_SEQ)) and args.workload == "train" \
         and not args.compact_inputs and not args.host_profile
     gx = None
     if use_graphs:
@@ -449,11 +450,13 @@ def main():
         st_timed = net.comm_stats()
         assert st_timed["buckets"] == st_timed["n_buckets_expected"] * args.steps, st_timed
     graph_stats = dict(model.engine.graphs.stats) if use_graphs else None
+    prof_steps = args.steps                    # steps the launch profile `prof` covers
     if use_graphs:                             # the per-kernel figures below come from eager steps
         model.engine.graphs = None
         lib.prof_enable(2)
         step(); step()
         torch.cuda.synchronize()
+        prof_steps = 2
     prof = lib.prof_collect()
     lib.prof_enable(False)
     loss_val = float(loss.detach())
@@ -557,15 +560,19 @@ def main():
             # the kernel timed in situ is not the one that takes the most time: report the measured dominant kernel
             # from the two extra steps instead (same schedule, outside the timed region)
             k, kms, kfl, kcnt = ranking[0]
-            name, ms, fl, cnt = k, kms * args.steps, kfl * args.steps, kcnt * args.steps
+            name, ms, fl, cnt = k, kms * prof_steps, kfl * prof_steps, kcnt * prof_steps
             achieved = fl / (ms * 1e-3) / 1e12
         traffic, traffic_src, traffic_commit = None, None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_dominant_kernel.json")
         if os.path.exists(tpath) and args.workload == "train" and per_gpu == 240:   # HBM bytes per launch from the committed rocprofv3 --pmc passes
             tj = json.load(open(tpath))    # (PMC counters cannot be read from inside the process)
-            if tj.get("kernel") == name:
+            import hashlib
+            sha = hashlib.sha256(open(os.path.join(ROOT, "unimm_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()
+            if tj.get("kernel") == name and tj.get("gemm_hip_sha256") == sha:   # a PMC figure of ANOTHER kernel source is stale: null
                 traffic, traffic_src = round(tj["bytes_per_launch_corrected"]), tj["source"]
                 traffic_commit = tj.get("commit")      # the commit the PMC passes were taken at
+            elif tj.get("kernel") == name:
+                traffic_src = "stale: csrc/gemm.hip changed since " + str(tj.get("commit")) + " (re-run tools/profile_round.sh)"
         f_fwd = F_FWD_BASE_GF + F_DEC_ROW_GF * n_lm_rows / per_gpu     # reference-equivalent (padded to 256 tokens)
         plan = plan_default
         valid_rows = plan["Mv"] if plan is not None else per_gpu * 256
@@ -605,7 +612,7 @@ def main():
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE)", "traffic_source": traffic_src,
                          "traffic_measured_at_commit": traffic_commit,
-                         "launches_per_step": cnt // args.steps, "avg_launch_us": round(ms * 1e3 / cnt, 2),
+                         "launches_per_step": cnt // prof_steps, "avg_launch_us": round(ms * 1e3 / cnt, 2),
                          "event_timed_launches": "every GEMM" if prof_all else "the weight-gradient kernels only (in the timed region); every GEMM in 2 extra steps",
                          "whole_step_executed_gemm_tflops": round(exec_fl_step / (dt / args.steps) / 1e12, 1),
                          "whole_step_frac": round(exec_fl_step / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
@@ -618,8 +625,8 @@ def main():
         }
         if prof_all:
             out["roofline"].update(all_gemm_tflops=round(gemm_fl / (gemm_ms * 1e-3) / 1e12, 1),
-                                   gemm_share_of_step=round(gemm_ms * 1e-3 / dt, 3),
-                                   whole_step_executed_gemm_tflops=round(gemm_fl / dt / 1e12, 1))
+                                   gemm_share_of_step=round(gemm_ms * 1e-3 / prof_steps / (dt / args.steps), 3),
+                                   whole_step_executed_gemm_tflops=round(gemm_fl / prof_steps / (dt / args.steps) / 1e12, 1))
         if comm is not None:
             out["comm"] = comm
         if not args.no_cpu_baseline and world == 1:

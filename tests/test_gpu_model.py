@@ -222,7 +222,7 @@ def test_full_config_b6_matches_reference_golden(golden_dir):
 
 def test_row_capacities_with_device_side_counts_equal_exact_sizes(golden_dir, small):
     """The graph executor sizes every launch for a CAPACITY (valid rows / decoded rows rounded up to a bucket) and the
-    kernels read the real counts from device memory (unimm_plan_build -> Engine._dims).  Run eagerly with buckets
+    kernels read the real counts from device memory (unimm_plan_build -> the step's `out["dyn"]` words).  Run eagerly with buckets
     of 64 rows / 16 decoded rows, the step must equal the exact-size step: the surplus rows hold garbage (here: NaN-filled
     allocations) and must never reach a loss, a column sum or a weight gradient."""
     model, _, _ = small

@@ -110,14 +110,13 @@ class Engine:
         # fill about `wgrad_group_rounds` rounds of the chip; a data-parallel wrapper may lower it (smaller, earlier buckets).
         self.wgrad_group_rounds = 4
         # Row-count capacities.  Launch arguments hold CAPACITIES (the step's valid text rows / decoded rows rounded up to
-        # these buckets); kernels whose result depends on the surplus rows read the real counts from `_dims` (written on
-        # the device by unimm_plan_build).  1 = exact sizes (default); the graph executor (unimm_amd/graphs.py) raises them
+        # these buckets); kernels whose result depends on the surplus rows read the real counts from the step's own device
+        # words (`out["dyn"]`, written by unimm_plan_build; allocated per forward).  1 = exact sizes (default); the graph executor (unimm_amd/graphs.py) raises them
         # so that steps with nearby row counts replay one captured launch sequence.
         self.row_bucket, self.lm_bucket = 1, 1
         self.salt_word = None            # int32 [1] device tensor holding dropout.step_salt(seed, step), or None (see _drop)
         self._inject_header = None       # header values of the step, read ahead of a graph capture (see _forward, graphs.py)
         self.graphs = None               # unimm_amd.graphs.StepGraphs once enable_graphs() was called
-        self._dims = None                # (int32 [8], fp32 [8]) device words: {valid rows, decoded rows, regions}, {1/decoded, 1/regions}
         self.image_tile = 8              # tile code of the image side's GEMMs in the large-batch regime (0 = the library's choice; see _tile)
         self.small_rows = 12000          # text rows per step below which the encoder GEMMs take the small-batch tile rule (_tile)
         self._step_rows = None           # text rows of the running step (set by _forward)
@@ -342,10 +341,12 @@ class Engine:
         launches (M = 37 rows per sequence: a fraction of a round) cost the step is the CUs they keep from the text side: the
         256x256 ping-pong tile puts an image GEMM on 140 CUs instead of the 188 of the library's own choice (192x256, faster
         alone): +0.8 % at 240 sequences, neutral at 120."""
-        if self.gemm_tile != 0 or self._step_rows is None or self._step_rows >= self.small_rows:
-            if self._on_side and self.image_tile:
-                return self.image_tile
+        if self.gemm_tile != 0:                   # an explicit tuning code reaches both sides (A/B runs: bench.py --gemm-tile)
             return self.gemm_tile
+        if self._step_rows is None:               # outside a step: the library's own choice
+            return 0
+        if self._step_rows >= self.small_rows:
+            return self.image_tile if (self._on_side and self.image_tile) else 0
         if self._on_side:
             return 1
         t128 = ((M + 127) // 128) * ((N + 127) // 128)
@@ -997,11 +998,12 @@ class Engine:
             #  B * T: packed even then, with the identity as row map, so that every replay of a signature and the eager step of
             #  the same batch number their rows, and therefore draw their dropout masks, alike)
             unpadded = self.unpad and (Mv < B * T or self.row_bucket > 1)
-            if self._dims is None:
-                self._dims = (torch.zeros(8, dtype=torch.int32, device=dev), torch.zeros(8, dtype=F32, device=dev))
-            di, df = self._dims
+            # the device words of THIS forward (never shared between forwards: a backward reads the counts of its own step
+            # even when other forwards -- an eval pass, a second micro-batch -- ran in between); under a graph capture they come
+            # from the graph's pool, i.e. they are static per captured entry
+            di, df = torch.zeros(8, dtype=torch.int32, device=dev), torch.zeros(8, dtype=F32, device=dev)
             built = L.plan_build(header, lab32 if want_sel else None, w32 if want_sel else None, B, T, Mcap if unpadded else Mv,
-                                 ncap, want_rows=unpadded, dims=self._dims)
+                                 ncap, want_rows=unpadded, dims=(di, df))
             dyn = dict(m=di[0:1], n_lm=di[1:2], n_img=di[2:3], inv_lm=df[0:1], inv_img=df[1:2])
             if unpadded:
                 plan = dict(Mv=Mcap, lens_h=lens_h, rows=built["rows"], inv=built["inv"],
@@ -1232,6 +1234,7 @@ class Engine:
         H, Hv = cfg.hidden_size, cfg.v_hidden_size
         seq_t, seq_v = out["seq_out_t"], out["seq_out_v"]
         self.arena.attach_grads()
+        self._step_rows = out["Mt"]              # the tile rule follows THIS step's rows (another forward may have run since)
 
         def gvec(g):
             return torch.zeros(1, dtype=F32, device=dev) if g is None else g.detach().to(F32).reshape(1).contiguous()

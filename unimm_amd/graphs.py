@@ -8,7 +8,7 @@ events, every `torch.empty` of the step comes from the graph's private pool = a 
 two `hipGraphLaunch` calls per step.  What a replay cannot take from frozen launch arguments lives in device memory:
 
   * row counts: launches are sized for CAPACITIES (valid text rows / decoded rows rounded up to `row_bucket` /
-    `lm_bucket`), kernels that reduce over rows read the real counts written by unimm_plan_build (Engine._dims);
+    `lm_bucket`), kernels that reduce over rows read the real counts written by unimm_plan_build (the step's own device words, `out["dyn"]`);
   * loss denominators (1 / decoded rows, 1 / masked regions): the same words;
   * dropout: the launch argument is the per-(seed, site) key, the per-step salt is one device word (Engine.salt_word);
   * inputs: copied into static buffers before the replay; gradients of the three losses likewise.
@@ -46,7 +46,13 @@ def _rup(x, m):
 
 
 class _Entry:
-    __slots__ = ("pool", "sin", "gF", "out", "losses", "nsp", "gB", "gin", "gkey", "stream", "lvec", "lshape")
+    __slots__ = ("pool", "sin", "gF", "out", "losses", "nsp", "gB", "gin", "gkey", "stream", "lvec", "lshape", "inflight", "salt_val")
+
+
+class _Token:
+    """Lives on the autograd context of a replayed forward until its backward ran (or the autograd graph was dropped): while
+    it is alive the entry's static inputs and activations belong to that step and must not be overwritten."""
+    __slots__ = ("__weakref__",)
 
 
 class StepGraphs:
@@ -57,7 +63,8 @@ class StepGraphs:
         self.entries = OrderedDict()
         self.seen = {}
         self.salt = None
-        self.stats = dict(replays=0, captures=0, eager=0)
+        self._salt_val = None
+        self.stats = dict(replays=0, captures=0, eager=0, busy=0)
 
     # ------------------------------------------------------------------------------------------
     def eligible(self, inp, opts):
@@ -86,12 +93,18 @@ class StepGraphs:
         parts.append(None if nw is None else tuple(float(x) for x in nw.reshape(-1).tolist()))
         return tuple(parts)
 
-    def _set_salt(self):
+    def _set_salt(self, v=None):
+        """The per-step dropout salt word.  v = None: the salt of the engine's current step; otherwise the value a replayed
+        forward used (its backward regenerates the masks from the same word, whatever ran in between)."""
         eng = self.eng
         if self.salt is None:
             self.salt = torch.zeros(1, dtype=torch.int32, device=eng.arena.device)
-        v = DR.step_salt(eng.seed, eng.step)
-        self.salt.fill_(v - (1 << 32) if v >= (1 << 31) else v)
+        if v is None:
+            v = DR.step_salt(eng.seed, eng.step)
+        if v != self._salt_val:
+            self.salt.fill_(v - (1 << 32) if v >= (1 << 31) else v)
+            self._salt_val = v
+        return v
 
     # ------------------------------------------------------------------------------------------
     def forward(self, inp, opts):
@@ -106,6 +119,12 @@ class StepGraphs:
         sig = self._key0(inp, opts) + (Mcap, ncap, eng.dual_stream, eng.unpad, eng.lazy_ln, eng.gemm_tile, eng.wgrad_group_rounds,
                                          eng.grad_bucket_hook is not None, eng.wgrad_stream)   # with a hook the backward is a chain of graphs
         ent = self.entries.get(sig)
+        if ent is not None and ent.inflight is not None and ent.inflight() is not None:
+            # the previous forward of this signature has not been back-propagated yet (two losses summed before .backward(),
+            # interleaved micro-batches): its activations live in the entry's static buffers -> this step runs eagerly
+            self.stats["busy"] += 1
+            self.stats["eager"] += 1
+            return None
         if ent is None:
             n = self.seen.get(sig, 0)
             self.seen[sig] = n + 1
@@ -118,9 +137,13 @@ class StepGraphs:
             for k, t in ent.sin.items():
                 if torch.is_tensor(t):
                     t.copy_(inp[k], non_blocking=True)
-        self._set_salt()
+        ent.salt_val = self._set_salt()
         ent.gF.replay()
         self.stats["replays"] += 1
+        import weakref
+        tok = _Token()
+        ent.inflight = weakref.ref(tok)
+        ent.out["_token"] = tok                                # handed to the autograd context by _HotPath.forward
         ls = ent.lvec.clone()                                  # one copy out of the static buffers (the next replay overwrites them)
         return ls[0].reshape(ent.lshape), ls[1].reshape(ent.lshape), ls[2].reshape(ent.lshape), ent.nsp.clone(), ent
 
@@ -133,6 +156,7 @@ class StepGraphs:
         ent.pool = torch.cuda.graph_pool_handle()
         ent.sin = {k: (v.clone() if torch.is_tensor(v) and v.is_cuda else v) for k, v in inp.items()}
         ent.gB, ent.gin, ent.gkey = None, None, None
+        ent.inflight, ent.salt_val = None, None
         ent.stream = torch.cuda.Stream(device=dev)
         was = (eng.row_bucket, eng.lm_bucket, eng.salt_word, eng._inject_header)
         if self.salt is None:
@@ -216,6 +240,7 @@ class StepGraphs:
         grads = (g_lm, g_img, g_nsp, g_scores)
         gkey = tuple(None if g is None else tuple(g.shape) for g in grads)
         eng.arena.attach_grads()        # BEFORE a capture: it zeroes the arena when .grad was dropped, which must not be replayed
+        self._set_salt(ent.salt_val)    # the masks of THIS step's forward (another replay may have re-salted since)
         if ent.gB is None or ent.gkey != gkey:
             ent.gkey = gkey
             ent.gin = [None if g is None else torch.zeros(g.shape, dtype=torch.float32, device=dev) for g in grads]

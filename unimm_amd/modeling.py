@@ -96,6 +96,7 @@ class _HotPath(torch.autograd.Function):
             res = engine.graphs.forward(inp, opts)
             if res is not None:
                 ctx.engine, ctx.out, ctx.graph_entry = engine, None, res[4]
+                ctx.graph_token = res[4].out.pop("_token", None)   # alive until backward ran: the entry is not replayed meanwhile
                 engine.last_seq_t = (None, None)
                 return res[0], res[1], res[2], res[3]
         out = engine.forward(inp, train=opts["train"], save=True, lm_rows="labelled", want_pred_v=True)
@@ -112,6 +113,7 @@ class _HotPath(torch.autograd.Function):
         ctx.out = None
         if ctx.graph_entry is not None:
             engine.graphs.backward(ctx.graph_entry, g_lm, g_img, g_nsp, g_scores)
+            ctx.graph_token = None
             return None, None, None, None
         engine.backward(out, g_lm, g_img, g_nsp, g_scores)
         return None, None, None, None
