@@ -267,6 +267,14 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
+    rccl_ranks = 1
+    if world > 1:                                 # "did the backend see N ranks": an all-reduce of ones, reported in `comm`
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        rccl_ranks = int(ones.item())
+        if rccl_ranks != world:
+            raise SystemExit(f"process group reduced ones to {rccl_ranks}, expected {world}")
+
     from unimm_amd import VisualDialogEncoder, lib, synth
     from unimm_amd.parallel import DataParallelRCCL
 
@@ -532,7 +540,8 @@ def main():
         model.engine.graphs = None
         wire = flat.numel() * (2 if net.wire_dtype == "bf16" else 4)
         busbw = wire * 2 * (world - 1) / world / t_ar / 1e9
-        comm = {"wire_dtype": net.wire_dtype, "algorithm": net.algorithm, "bytes_per_step": wire,
+        comm = {"backend": dist.get_backend(), "rccl_ranks": rccl_ranks, "world_size": dist.get_world_size(),
+                "wire_dtype": net.wire_dtype, "algorithm": net.algorithm, "bytes_per_step": wire,
                 "bucket_bytes": st["bucket_bytes"], "buckets_per_step": len(st["bucket_bytes"]),
                 "collectives_per_step": st_timed["calls"] // max(1, args.steps),
                 "exchange_alone_ms": round(t_ar * 1e3, 3), "busbw_GBps": round(busbw, 1),

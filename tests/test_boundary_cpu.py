@@ -147,3 +147,33 @@ def test_dropout_mask_statistics_of_the_affine_stage_hash():
             assert abs(cc) < 6e-3, (key, name, cc)
         disp = m.sum(1).var() / (256 * rate * (1 - rate))          # binomial dispersion of the per-row keep counts
         assert 0.85 < disp < 1.15, (key, disp)
+
+
+def test_bert_config_constructor_forms_and_json_round_trip(tmp_path):
+    """BertConfig(int | path) / from_dict / to_dict / to_json_string (models/vilbert_dialog.py:131-274)."""
+    c = BertConfig(30522)
+    assert c.vocab_size == 30522 and c.hidden_size == 768 and c.fusion_method == "mul" and c.with_coattention is True
+    assert c.v_biattention_id == [0, 1] and c.t_biattention_id == [10, 11]
+    c2 = BertConfig(30522, v_num_hidden_layers=6, v_biattention_id=[0, 1, 2], t_biattention_id=[9, 10, 11], bi_hidden_size=512)
+    assert c2.bi_hidden_size == 512 and c2.v_biattention_id == [0, 1, 2]
+    with pytest.raises(AssertionError):               # the reference's constructor asserts (:196-198)
+        BertConfig(30522, v_biattention_id=[0, 1, 2])
+    with pytest.raises(ValueError, match="First argument must be either a vocabulary size"):
+        BertConfig(3.5)
+    s = c2.to_json_string()
+    assert s.endswith("\n") and json.loads(s) == c2.to_dict()
+    assert list(json.loads(s)) == sorted(json.loads(s))          # sort_keys=True, indent=2 as the reference prints it
+    p = tmp_path / "cfg.json"
+    p.write_text(s)
+    for back in (BertConfig.from_json_file(str(p)), BertConfig(str(p)), BertConfig.from_dict(json.loads(s))):
+        assert back.to_dict() == c2.to_dict()
+    assert repr(c2) == s
+    d = c2.to_dict()
+    d["v_biattention_id"].append(99)                            # to_dict is a deep copy
+    assert c2.v_biattention_id == [0, 1, 2]
+    # from_json_file = constructor defaults overwritten by the JSON keys (:257-262)
+    shipped = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "unimm_amd", "config",
+                           "bert_base_6layer_6conect.json")
+    full = BertConfig.from_json_file(shipped)
+    assert full.vocab_size == 30522 and full.v_hidden_size == 1024 and full.bi_num_attention_heads == 8
+    assert full.fusion_method == "mul" and full.predict_feature is False and full.fast_mode is False

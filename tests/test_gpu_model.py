@@ -16,7 +16,7 @@ def T_(x):
     return torch.from_numpy(np.ascontiguousarray(x))
 
 
-def close(got, want, tol=TOL, what="", scale_rel=False):
+def close(got, want, tol=TOL, what="", scale_rel=False, min_share=None, max_ratio=None):
     """allclose form |err| <= tol + tol*|want|; scale_rel: |err| <= tol * max(1, max|want|) instead
     (used for the full-depth MLM logits, where 24 blocks of bf16 operands give ~0.6 % of the logit scale)."""
     got = got.detach().float().cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
@@ -29,6 +29,11 @@ def close(got, want, tol=TOL, what="", scale_rel=False):
         ratio = diff / (tol + tol * np.abs(want))
         print(f"\n{what}: max |err| {diff.max():.4g} on scale {np.abs(want).max():.3g} (gate {tol:g} x scale); allclose form "
               f"|err| <= {tol:g} + {tol:g} |want|: {100.0 * float((ratio <= 1).mean()):.2f} % of the elements inside, worst ratio {ratio.max():.2f}")
+        # ... and asserted: measured 99.90 % / worst ratio 1.40 (MLM logits) and 99.08 % / 2.73 (hidden states) in round 4
+        if min_share is not None:
+            assert float((ratio <= 1).mean()) >= min_share, f"{what}: only {100.0 * float((ratio <= 1).mean()):.2f} % inside the allclose form"
+        if max_ratio is not None:
+            assert float(ratio.max()) <= max_ratio, f"{what}: worst |err| / (tol + tol |want|) = {ratio.max():.2f}"
     assert excess.max() <= 0, f"{what}: max |err| {diff.max():.4g}, worst excess {excess.max():.4g} (tol {tol})"
     return diff.max()
 
@@ -210,8 +215,9 @@ def test_full_config_b6_matches_reference_golden(golden_dir):
     close(lm, g["lm_loss"], what="lm_loss"); close(img, g["img_loss"], what="img_loss"); close(nsp_l, g["nsp_loss"], what="nsp_loss")
     close(nsp, g["nsp"], what="nsp")
     rows = T_(g["rows"]).cuda()
-    close(pred_t.reshape(-1, pred_t.shape[-1])[rows][:, ::16], g["pred_t_rows"], what="MLM logits", scale_rel=True)
-    close(seq_t.reshape(-1, 768)[rows], g["seq_out_t_rows"], what="seq_out_t", scale_rel=True)
+    close(pred_t.reshape(-1, pred_t.shape[-1])[rows][:, ::16], g["pred_t_rows"], what="MLM logits", scale_rel=True,
+          min_share=0.995, max_ratio=2.0)
+    close(seq_t.reshape(-1, 768)[rows], g["seq_out_t_rows"], what="seq_out_t", scale_rel=True, min_share=0.98, max_ratio=4.0)
     # candidate log-likelihoods and their ranks (val_lm.py:131-149)
     want_ll = g["seq_loglik"]
     got = scores.cpu().numpy()
@@ -558,3 +564,36 @@ def test_scores_to_ranks_on_the_device_matches_reference_fixture_with_ties(golde
     g = np.load(os.path.join(golden_dir, "ranks.npz"))
     got = scores_to_ranks(T_(g["scores"]).cuda())
     assert got.is_cuda and torch.equal(got.cpu(), T_(g["ranks"]))
+
+
+def test_mask_rank_errors_and_default_masks(golden_dir, small):
+    """Boundary behaviour of BertModel.forward (models/vilbert_dialog.py:1374-1408): masks of rank other than 2 / 3 raise the
+    reference's ValueError, a co-attention mask must be 3-D (assert :1387), and attention_mask / image_attention_mask /
+    co_attention_mask / token_type_ids left at None mean all-ones masks and all-zero type ids (:1374-1385)."""
+    model, _, _ = small
+    model.eval()
+    g = np.load(os.path.join(golden_dir, "small_dis.npz"))
+    (ids, feat, loc), kw = kwargs_from(g, train=False)
+    B, T = ids.shape
+    R = feat.shape[1]
+    with torch.no_grad():
+        with pytest.raises(ValueError, match="Wrong shape for txt input_ids"):
+            model(ids, feat, loc, **{**kw, "attention_mask": torch.ones(B, 1, T, T, dtype=torch.int64)})
+        with pytest.raises(ValueError, match="Wrong shape for img input_ids"):
+            model(ids, feat, loc, **{**kw, "image_attention_mask": torch.ones(B, dtype=torch.int64)})
+        with pytest.raises(AssertionError):
+            model(ids, feat, loc, **{**kw, "co_attention_mask": torch.ones(B, T, dtype=torch.int64)})
+        none = model(ids, feat, loc, position_ids=kw["position_ids"])
+        ones = model(ids, feat, loc, position_ids=kw["position_ids"], token_type_ids=torch.zeros_like(ids),
+                     attention_mask=torch.ones_like(ids), image_attention_mask=torch.ones(B, R, dtype=torch.int64),
+                     co_attention_mask=torch.ones(B, R, T, dtype=torch.int64))
+    for a, b, what in zip(none[:4], ones[:4], ("pred_t", "pred_v", "nsp", "seq_out_t")):
+        assert torch.equal(a, b), what
+    # ... and the oracle (pinned to the reference) agrees with the defaults
+    from oracle import vilbert_ref as R_
+    _, ocfg, sd = small
+    leaves = dict(sd)
+    leaves[R_.TIED[0]] = leaves[R_.TIED[1]]
+    with torch.no_grad():
+        want = R_.forward(leaves, ocfg, ids, feat, loc, position_ids=kw["position_ids"])
+    close(none[2], want["nsp"].numpy(), what="nsp with default masks")

@@ -1,0 +1,96 @@
+#!/usr/bin/env python
+"""Self-check of a multi-GPU bench line against DESIGN.md section 6's predictions.
+
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ... > line.json
+    python tools/check_scale.py line.json [more.json ...]        (or: ... | python tools/check_scale.py -)
+
+No N > 1 box was available to this build in any round, so the first real RCCL run has to check itself: the line must say
+that RCCL really saw N ranks (`comm.rccl_ranks`, an all-reduce of ones), that every gradient bucket was exchanged once per
+step in the predicted number of collectives, and that the step time and the exposed (non-overlapped) exchange time are
+within 25 % (+ an absolute slack for sub-millisecond figures) of DESIGN.md 6's table.  Exit code 1 on any deviation, with
+one line per finding -- a deviation is a finding about the model of section 6, not necessarily a bug.
+
+Expected values ("Expected at N x (240 / N) sequences"; 1-GPU figures measured in round 3, strong scaling of
+the global batch of 240):
+  N  per-GPU  step without exchange   collectives/step   exposed exchange (fp32 wire)
+  1    240        43.7 ms                   0                  0
+  2    120        24.3 ms (eager)           11                 <= 1.0 ms  (last grouped launch's buckets, ~270 MB at 2 rounds... ring of 2)
+  4     60        14.4 ms (graph replay)    11                 <= 1.2 ms
+  8     30         9.9 ms (graph replay)    11                 ~0.9 ms (1.6 ms with 4-round grouping)
+"""
+import json
+import sys
+
+EXPECT = {   # n_gpus: (step_ms_without_exchange, collectives_per_step, exposed_exchange_ms)
+    1: (43.7, 0, 0.0),
+    2: (24.3, 11, 1.0),
+    4: (14.4, 11, 1.2),
+    8: (9.9, 11, 0.9),
+}
+REL = 0.25
+ABS_MS = 0.6          # slack for the sub-millisecond exposed-exchange figures
+
+
+def check(line):
+    msgs = []
+    n = int(line["n_gpus"])
+    if line.get("scaling") != "strong" or line.get("config", {}).get("global_batch") != 240:
+        return [f"n_gpus={n}: not the strong-scaling bs=240 line (scaling={line.get('scaling')}, global_batch="
+                f"{line.get('config', {}).get('global_batch')}): nothing to compare against"]
+    exp = EXPECT.get(n)
+    if exp is None:
+        return [f"n_gpus={n}: no prediction in DESIGN.md 6 (have {sorted(EXPECT)})"]
+    step_exp, coll_exp, exposed_exp = exp
+    comm = line.get("comm")
+    if n > 1:
+        if comm is None:
+            return [f"n_gpus={n}: the line has no `comm` block"]
+        if int(comm.get("rccl_ranks", -1)) != n:
+            msgs.append(f"n_gpus={n}: RCCL saw {comm.get('rccl_ranks')} ranks, not {n} (backend {comm.get('backend')})")
+        if comm.get("backend") != "nccl":
+            msgs.append(f"n_gpus={n}: process-group backend is {comm.get('backend')!r}, not 'nccl' (= RCCL); rehearsal runs are not measurements")
+        c = int(comm.get("collectives_per_step", -1))
+        if abs(c - coll_exp) > REL * coll_exp:
+            msgs.append(f"n_gpus={n}: {c} collectives per step, predicted {coll_exp}")
+        ex = float(comm.get("exposed_exchange_ms", -1.0))
+        if ex > exposed_exp * (1 + REL) + ABS_MS:
+            msgs.append(f"n_gpus={n}: exposed exchange {ex:.2f} ms, predicted <= {exposed_exp:.2f} ms (+25 % + {ABS_MS} ms)")
+        base = float(comm.get("step_ms_without_exchange", -1.0))
+        if abs(base - step_exp) > REL * step_exp:
+            msgs.append(f"n_gpus={n}: step without exchange {base:.2f} ms, predicted {step_exp:.2f} ms")
+        if float(comm.get("busbw_frac_of_xgmi", 0.0)) > 1.0:
+            msgs.append(f"n_gpus={n}: bus bandwidth above the 7 x 153 GB/s xGMI budget: timing is wrong")
+    total = float(line["ms_per_step"])
+    pred = step_exp + (exposed_exp if n > 1 else 0.0)
+    if abs(total - pred) > REL * pred + (ABS_MS if n > 1 else 0.0):
+        msgs.append(f"n_gpus={n}: {total:.2f} ms per step, predicted {pred:.2f} ms")
+    val = float(line["value"])
+    if abs(val - 240.0 / (total * 1e-3)) > 0.02 * val:
+        msgs.append(f"n_gpus={n}: value {val:.1f} seq/s is not global_batch / ms_per_step ({240.0 / (total * 1e-3):.1f})")
+    return msgs
+
+
+def main(argv):
+    lines = []
+    for a in argv or ["-"]:
+        txt = sys.stdin.read() if a == "-" else open(a).read()
+        for ln in txt.splitlines():
+            ln = ln.strip()
+            if ln.startswith("{") and '"metric"' in ln:
+                lines.append(json.loads(ln))
+    if not lines:
+        print("check_scale: no bench line found", file=sys.stderr)
+        return 2
+    bad = 0
+    for line in lines:
+        msgs = check(line)
+        for m in msgs:
+            print("DEVIATION " + m)
+        bad += len(msgs)
+        if not msgs:
+            print(f"ok n_gpus={line['n_gpus']}: {line['value']} seq/s, {line['ms_per_step']} ms per step")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]))
