@@ -441,6 +441,61 @@ typedef struct {
 
 int unimm_neural_ndcg(const unimm_ndcg_args* args, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * fp32-accuracy compute mode ("fp32x3", csrc/x3ops.hip).  The reference's dense-annotation fine-tune calls the model
+ * WITHOUT autocast (dense_annotation_finetuning.py:253: fp32 end to end; north_star gates fp32 results at 1e-3).  gfx950
+ * has no fast fp32 matrix path, so this mode runs every nn.Linear of the path on the SAME bf16 MFMA kernels
+ * (unimm_gemm_nt / unimm_gemm_tn_grouped) over SPLIT operands, x = hi + lo, hi = bf16(x), lo = bf16(x - hi):
+ *   activation operand ("x-type")  X3[M, 3 Kp] = [ hi(X) | lo(X) | hi(X) ]
+ *   weight operand     ("w-type")  W3[N, 3 Kp] = [ hi(W) | hi(W) | lo(W) ]        Kp = K rounded up to 64, padding zero
+ *   unimm_gemm_nt(x = X3, w = W3, K = 3 Kp, out fp32)  =  hi hi + lo hi + hi lo   (fp32 accumulate; lo lo ~ 2^-16 dropped)
+ * and a weight gradient as three problems of unimm_gemm_tn_grouped over column planes of two x-type buffers
+ * (dY.hi, X.hi), (dY.lo, X.hi), (dY.hi, X.lo), all accumulating into the same fp32 gradient.  Between two GEMMs
+ * everything is fp32; the entry points below produce the next split operand from fp32 results, run LayerNorm / loss
+ * backward on fp32 gradients, and compute the attention cores (models/vilbert_dialog.py:390-410, :519-539, :681-721)
+ * in fp32 on the vector ALUs.
+ * ------------------------------------------------------------------------------------------- */
+enum { UNIMM_X3_COPY = 0, UNIMM_X3_ADD = 1, UNIMM_X3_GELU = 2, UNIMM_X3_MUL_DGELU = 3 };
+typedef struct {
+  const float* a;  /* [rows, cols] fp32, row stride lda */
+  const float* b;  /* second operand of ADD / MUL_DGELU (row stride ldb) or NULL */
+  float* out32;    /* or NULL: y as fp32 [rows, cols], row stride ld32 */
+  void* out3;      /* or NULL: y as a split operand, bf16 [rows, 3 cp] (columns cols .. cp-1 of every plane zero) */
+  int64_t rows;
+  int32_t cols, cp;          /* cp % 64 == 0, cp >= cols */
+  int32_t lda, ldb, ld32;
+  int32_t op;                /* y = a | a + b | erf-GELU(a) (:115-121) | a * GELU'(b) */
+  int32_t wtype;             /* 0: x-type planes (hi, lo, hi); 1: w-type planes (hi, hi, lo) */
+} unimm_x3_split_args;
+int unimm_x3_split(const unimm_x3_split_args* args, void* stream);
+/* transposed w-type split of a weight: src fp32 [R, C] (row stride lds) -> dst bf16 [C, 3 Rp], dst[c][p Rp + r]; columns
+ * r in [R, Rp) of every plane are not written (zero-fill dst once).  The operand of the input-gradient GEMMs. */
+int unimm_x3_split_wt(const float* src, void* dst, int32_t R, int32_t C, int32_t lds, int32_t Rp, void* stream);
+/* unimm_layernorm_bwd_partials on fp32 gradients: dy fp32 [M, H]; dx32 (or NULL) = fp32 gradient w.r.t. the pre-LayerNorm
+ * sum; dxd3 (or NULL) = its dropout-masked copy as an x-type split operand [M, 3 H]; partials / blocks_out as there
+ * (reduced by unimm_colpartials_finish_grouped).  H % 64 == 0. */
+int unimm_x3_layernorm_bwd_partials(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                    float* dx32, void* dxd3, float* partials, int32_t M, int32_t H, uint32_t drop_key,
+                                    uint32_t drop_thr, float drop_scale, uint32_t odrop_key, uint32_t odrop_thr,
+                                    float odrop_scale, int32_t* blocks_out, const int32_t* m_dev, const uint32_t* drop_salt,
+                                    void* stream);
+/* unimm_embed_bwd with an fp32 upstream gradient */
+int unimm_embed_bwd_f32(const unimm_embed_args* args, const float* dy, float* dword, float* dpos, float* dtype, float* dext,
+                        float* dgamma, float* dbeta, float* partials, void* stream);
+/* unimm_lm_loss_bwd / unimm_kl_loss_bwd writing x-type split operands [rows, 3 cp] (cp % 64 == 0, cp >= V / C) */
+int unimm_x3_lm_loss_bwd(const float* logits, const int32_t* labels, const int32_t* weights, const float* lse, const float* g,
+                         float inv_denom, void* out3, int32_t n, int32_t V, int32_t ld, int32_t cp, const int32_t* n_dev,
+                         const float* inv_dev, void* stream);
+int unimm_x3_kl_loss_bwd(const float* pred, const float* target, const int32_t* label, const float* lse, const float* g,
+                         float inv_denom, void* out3, int32_t rows, int32_t C, int32_t ld, int32_t cp, const float* inv_dev,
+                         void* stream);
+/* dst[idx[r], :] += src[r, :], both fp32 (unimm_rows_add_f32 for an fp32 gradient stream) */
+int unimm_x3_rows_add(float* dst, const int32_t* idx, const float* src, int32_t n, int32_t H, int32_t ldd, void* stream);
+/* unimm_attn_fwd / unimm_attn_bwd with fp32 q / k / v / out / dout / dq / dk / dv (same argument structs, row strides in
+ * fp32 elements, multiples of 4; every other field -- masks, lse, variable-length offsets, dropout -- as there). */
+int unimm_x3_attn_fwd(const unimm_attn_args* args, void* stream);
+int unimm_x3_attn_bwd(const unimm_attn_bwd_args* args, void* stream);
+
 /* Launch profiler for bench.py's `roofline` block: HIP events around every GEMM launch on its own
  * stream while enabled.  Variant index: 0..11 = unimm_gemm_nt (epilogue * 2 + out_f32), 12 = unimm_gemm_tn.
  * unimm_prof_collect synchronises the events and returns per-variant summed milliseconds, algorithmic

@@ -1,0 +1,310 @@
+"""GPU parity of the fp32-accuracy mode (compute_dtype="fp32x3": unimm_amd/engine_x3.py, csrc/x3ops.hip) behind the drop-in
+API, against the goldens produced by the REFERENCE's own modules (fp32 CPU) and against the CPU oracle.
+
+This is north_star's fp32 gate: outputs within 1e-3 in allclose form, |got - want| <= 1e-3 + 1e-3 |want| -- NSP logits, MLM
+logits, hidden states, losses, candidate log-likelihoods (and identical ranks); gradients within 1e-3 of each tensor's scale.
+The reference runs this arithmetic in dense_annotation_finetuning.py:253 (no autocast)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG_PATH = os.path.join(ROOT, "unimm_amd", "config", "bert_base_6layer_6conect.json")
+
+
+def T_(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def close(got, want, tol=TOL, what=""):
+    got = got.detach().float().cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
+    want = want.detach().cpu().numpy() if torch.is_tensor(want) else np.asarray(want)
+    want = want.astype(np.float64)
+    diff = np.abs(got.astype(np.float64) - want)
+    ratio = float((diff / (tol + tol * np.abs(want))).max())
+    print(f"  {what}: max |err| {diff.max():.3e} on scale {np.abs(want).max():.3g}; worst |err| / ({tol:g} + {tol:g} |want|) = {ratio:.3f}")
+    assert ratio <= 1.0, f"{what}: max |err| {diff.max():.4g} (tol {tol}, worst ratio {ratio:.2f})"
+    return ratio
+
+
+def build_small(golden_dir):
+    from oracle import vilbert_ref as R
+    from unimm_amd import BertConfig, BertForMultiModalPreTraining
+    cfgd = json.load(open(os.path.join(golden_dir, "small_config.json")))
+    model = BertForMultiModalPreTraining(BertConfig.from_dict(cfgd), compute_dtype="fp32x3")
+    ocfg = R.make_config(cfgd)
+    sd = R.init_state_dict(ocfg, seed=11)
+    model.load_state_dict(sd, strict=True)
+    return model.cuda(), ocfg, sd
+
+
+def kwargs_from(g, train=True, use_lm_weight=True, device=None):
+    i = lambda k: (T_(g["in::" + k]).to(device) if device else T_(g["in::" + k]))
+    kw = dict(token_type_ids=i("token_type_ids"), position_ids=i("position_ids"), attention_mask=i("attention_mask"),
+              image_attention_mask=i("image_attention_mask"), co_attention_mask=i("co_attention_mask"))
+    if train:
+        kw.update(masked_lm_labels=i("masked_lm_labels"), image_label=i("image_label"), image_target=i("image_target"),
+                  next_sentence_label=i("next_sentence_label"), nsp_weight=i("nsp_weight"),
+                  lm_weight=i("lm_weight") if use_lm_weight else None)
+    return (i("input_ids"), i("image_feat"), i("image_loc")), kw
+
+
+@pytest.fixture(scope="module")
+def small(golden_dir):
+    return build_small(golden_dir)
+
+
+@pytest.mark.parametrize("case", ["dis", "genpos", "genneg", "mixed"])
+def test_small_config_matches_reference_golden_fp32(golden_dir, small, case):
+    model, ocfg, _ = small
+    assert type(model.engine).__name__ == "EngineX3"
+    model.eval()
+    g = np.load(os.path.join(golden_dir, f"small_{case}.npz"))
+    args, kw = kwargs_from(g)
+    print()
+    with torch.no_grad():
+        lm, img, nsp_l, seq_t, pred_t, nsp = model(*args, **kw)
+    close(lm, g["lm_loss"], what="lm_loss"); close(img, g["img_loss"], what="img_loss"); close(nsp_l, g["nsp_loss"], what="nsp_loss")
+    close(nsp, g["nsp"], what="nsp scores")
+    V = ocfg.vocab_size
+    close(pred_t.reshape(-1, V)[T_(g["pred_rows"]).cuda()], g["pred_t_rows"], what="pred_t")
+    valid = g["in::attention_mask"].reshape(-1, g["in::attention_mask"].shape[-1]).any(-1) if g["in::attention_mask"].ndim == 3 else None
+    st = seq_t.reshape(-1, seq_t.shape[-1]).cpu().numpy()
+    want = g["seq_out_t"].reshape(st.shape)
+    close(st[valid], want[valid], what="seq_out_t")
+    assert np.isfinite(st).all()
+    args, kw = kwargs_from(g, train=False, device="cuda")
+    with torch.no_grad():
+        p_t, p_v, nsp2, _, _ = model(*args, **kw)
+    close(p_v, g["inf_pred_v"], what="pred_v"); close(nsp2, g["inf_nsp"], what="inference nsp")
+    args, kw = kwargs_from(g, use_lm_weight=False)
+    with torch.no_grad():
+        lm_ce = model(*args, **kw, _want_lm_scores=False)[0]
+    close(lm_ce, g["lm_loss_ce"], what="CE fallback")
+
+
+def test_small_config_gradients_match_reference_golden_fp32(golden_dir, small):
+    model, _, _ = small
+    model.eval()
+    g = np.load(os.path.join(golden_dir, "small_mixed.npz"))
+    args, kw = kwargs_from(g)
+    model.zero_grad(set_to_none=True)
+    lm, img, nsp_l, _, _, _ = model(*args, **kw, _want_lm_scores=False)
+    (lm + img + nsp_l).sum().backward()
+    torch.cuda.synchronize()
+    params = dict(model.named_parameters())
+    names, norms = [str(n) for n in g["grad_names"]], g["grad_norms"]
+    worst_n = worst_e = 0.0
+    for n, want in zip(names, norms):
+        p = params[n]
+        if want < 0:
+            assert p.grad is None, f"{n} is never used by forward: grad must stay None"
+            continue
+        got = float(p.grad.double().norm())
+        rel = abs(got - want) / max(want, 1e-4)
+        worst_n = max(worst_n, rel)
+        assert rel < 1e-3, (n, got, want)
+    for k in g.files:
+        if k.startswith("grad::"):
+            want = g[k]
+            got = params[k[6:]].grad.cpu().numpy()
+            err = np.abs(got - want).max() / max(np.abs(want).max(), 1e-5)
+            worst_e = max(worst_e, err)
+            assert err <= 1e-3, (k, err)
+    want = g["grad_rows::word_embeddings"]
+    got = params["bert.embeddings.word_embeddings.weight"].grad[:64].cpu().numpy()
+    assert np.abs(got - want).max() <= 1e-3 * np.abs(want).max()
+    print(f"\nfp32x3 small-config gradients vs the reference: worst norm error {worst_n:.2e}, worst element error / scale {worst_e:.2e}")
+
+
+def test_training_mode_dropout_matches_oracle_with_replayed_masks_fp32(golden_dir, small):
+    """Train mode: the oracle re-plays the kernels' counter-based dropout masks site by site (same sites and counters as the
+    bf16 engine)."""
+    import zlib
+    from oracle import vilbert_ref as R
+    from unimm_amd import dropout as DR
+    model, ocfg, sd = small
+    g = np.load(os.path.join(golden_dir, "small_mixed.npz"))
+    args, kw = kwargs_from(g)
+    model.train()
+    model.set_dropout_seed(77, step=4)
+    model.zero_grad(set_to_none=True)
+    lm, img, nsp_l, _, _, nsp = model(*args, **kw, _want_lm_scores=False)
+    plan = model.engine.last_plan
+    (lm + img + nsp_l).sum().backward()
+    torch.cuda.synchronize()
+    assert plan is not None and plan["Mv"] < g["in::input_ids"].size
+    rows = plan["rows"].cpu()
+
+    def drop_fn(site, x, p):
+        key = DR.make_key(77, 5, zlib.crc32(site.encode()) & 0xFFFFFFFF)
+        _, thr, scale = DR.drop_arg(p, key)
+        text_rowwise = site == "emb_t" or (site.startswith("bert.encoder.layer.") and site.endswith((".so", ".out"))) \
+            or site.endswith((".bo2", ".tout"))
+        if text_rowwise:
+            n = x.shape[-1]
+            keep_p = torch.from_numpy(DR.keep_mask2d(key, thr, rows.numel(), n))
+            keep = torch.ones((x.shape[0] * x.shape[1], n), dtype=torch.bool)
+            keep[rows] = keep_p
+            keep = keep.view(x.shape)
+        else:
+            keep = torch.from_numpy(DR.keep_mask_nd(key, thr, tuple(x.shape)))
+        return x * keep * scale
+
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != R.TIED[0]}
+    leaves[R.TIED[0]] = leaves[R.TIED[1]]
+    out = R.forward(leaves, ocfg, *args, **kw, drop_fn=drop_fn)
+    (out["lm_loss"] + out["img_loss"] + out["nsp_loss"]).sum().backward()
+    print()
+    close(lm, out["lm_loss"].detach(), what="lm_loss (train)")
+    close(img, out["img_loss"].detach(), what="img_loss (train)")
+    close(nsp_l, out["nsp_loss"].detach(), what="nsp_loss (train)")
+    close(nsp, out["nsp"].detach(), what="nsp (train)")
+    worst = 0.0
+    for n, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        want = leaves[n].grad
+        err = float((p.grad.cpu() - want).abs().max() / want.abs().max().clamp_min(1e-6))
+        worst = max(worst, err)
+        assert err <= 2e-3, (n, err)
+    print(f"  train-mode gradients vs the oracle with replayed masks: worst element error / scale {worst:.2e}")
+    model.eval()
+
+
+def test_unpadded_equals_padded_fp32(golden_dir, small):
+    model, _, _ = small
+    model.eval()
+    eng = model.engine
+    g = np.load(os.path.join(golden_dir, "small_mixed.npz"))
+    args, kw = kwargs_from(g)
+    res = {}
+    try:
+        for unpad in (True, False):
+            eng.unpad = unpad
+            model.zero_grad(set_to_none=True)
+            lm, img, nsp_l, _, _, nsp = model(*args, **kw, _want_lm_scores=False)
+            (lm + img + nsp_l).sum().backward()
+            torch.cuda.synchronize()
+            res[unpad] = (torch.stack([lm, img, nsp_l]).flatten().detach().clone(), nsp.detach().clone(), eng.arena.grad_flat.clone())
+    finally:
+        eng.unpad = True
+    a, b = res[True], res[False]
+    assert (a[0] - b[0]).abs().max() <= 2e-6 and (a[1] - b[1]).abs().max() <= 2e-6
+    d = float((a[2] - b[2]).abs().max() / a[2].abs().max())
+    assert d <= 2e-5, d
+
+
+def _build_full(seed):
+    from oracle import vilbert_ref as R
+    from unimm_amd import BertConfig, BertForMultiModalPreTraining
+    model = BertForMultiModalPreTraining(BertConfig.from_json_file(CFG_PATH), compute_dtype="fp32x3")
+    model.load_state_dict(R.init_state_dict(R.make_config(CFG_PATH), seed=seed), strict=True)
+    return model.cuda().eval()
+
+
+def _full_b6_call(g):
+    i = lambda k: T_(g["in::" + k])
+    n = g["in::input_ids"].shape[0]
+    rep = lambda x: x.expand(n, *x.shape[1:])
+    args = (i("input_ids"), rep(i("image_feat")), rep(i("image_loc")))
+    kw = dict(token_type_ids=i("token_type_ids"), position_ids=i("position_ids"), attention_mask=i("attention_mask"),
+              image_attention_mask=i("image_attention_mask"), co_attention_mask=i("co_attention_mask").expand(n, 37, 256),
+              masked_lm_labels=i("masked_lm_labels"), image_label=i("image_label"), image_target=rep(i("image_target")),
+              next_sentence_label=i("next_sentence_label"), nsp_weight=i("nsp_weight"), lm_weight=i("lm_weight"))
+    return args, kw
+
+
+@pytest.fixture(scope="module")
+def full5():
+    return _build_full(seed=5)
+
+
+def test_full_config_b6_matches_reference_golden_fp32(golden_dir, full5):
+    """BASELINE config 1 on the GPU in the fp32-accuracy mode: full model, 1 image x 6 sequences x 256 tokens x 37 regions,
+    every output in allclose form at 1e-3 (north_star's fp32 tolerance)."""
+    from oracle import vilbert_ref as R
+    g = np.load(os.path.join(golden_dir, "full_b6.npz"))
+    model = full5
+    args, kw = _full_b6_call(g)
+    with torch.no_grad():
+        lm, img, nsp_l, seq_t, pred_t, nsp = model(*args, **kw)
+        kw2 = {k: kw[k] for k in ("token_type_ids", "position_ids", "attention_mask", "image_attention_mask", "co_attention_mask")}
+        scores, _ = model.sequence_log_likelihood(*args, kw["masked_lm_labels"], **kw2)
+    print()
+    close(lm, g["lm_loss"], what="lm_loss"); close(img, g["img_loss"], what="img_loss"); close(nsp_l, g["nsp_loss"], what="nsp_loss")
+    close(nsp, g["nsp"], what="nsp")
+    rows = T_(g["rows"]).cuda()
+    close(pred_t.reshape(-1, pred_t.shape[-1])[rows][:, ::16], g["pred_t_rows"], what="MLM logits")
+    close(seq_t.reshape(-1, 768)[rows], g["seq_out_t_rows"], what="seq_out_t")
+    close(scores, g["seq_loglik"], what="candidate log-likelihoods")
+    from unimm_amd.harness import scores_to_ranks
+    assert torch.equal(scores_to_ranks(scores.view(1, 1, -1)).cpu(), R.scores_to_ranks(T_(g["seq_loglik"]).view(1, 1, -1)))
+
+
+def test_full_config_b6_backward_matches_reference_golden_fp32(golden_dir, full5):
+    """The whole model's backward against the REFERENCE's gradients (tests/golden/full_b6_grads.npz), with NO exceptions for
+    the poolers / the top connection block: in this mode the ReLU units of the pooled rows no longer switch on bf16 noise."""
+    from oracle.cases import grad_sample_index
+    g = np.load(os.path.join(golden_dir, "full_b6.npz"))
+    gg = np.load(os.path.join(golden_dir, "full_b6_grads.npz"))
+    model = full5
+    args, kw = _full_b6_call(g)
+    model.zero_grad(set_to_none=True)
+    lm, img, nsp_l, _, _, _ = model(*args, **kw, _want_lm_scores=False)
+    (lm + img + nsp_l).sum().backward()
+    torch.cuda.synchronize()
+    for name, got in (("lm_loss", lm), ("img_loss", img), ("nsp_loss", nsp_l)):
+        assert abs(float(got.detach()) - float(gg[name].item())) <= 1e-3 * (1 + abs(float(gg[name].item()))), name
+    params = dict(model.named_parameters())
+    names = [str(n) for n in gg["grad_names"]]
+    norms, amax = gg["grad_norms"], gg["grad_absmax"]
+    gmax = float(amax.max())
+    worst_n, checked = 0.0, 0
+    for n, want, am in zip(names, norms, amax):
+        p = params[n]
+        if want < 0:
+            assert p.grad is None, n
+            continue
+        got = float(p.grad.double().norm())
+        if am < 1e-6 * gmax:
+            assert got <= 1e-3 * float(norms.max()), (n, got)
+            continue
+        rel = abs(got - want) / want
+        worst_n = max(worst_n, rel)
+        assert rel <= 1e-3, (n, got, want, rel)
+        checked += 1
+    assert checked > 450
+    worst_l2 = worst_max = 0.0
+    worst_name = ""
+    nslices = 0
+    for k in gg.files:
+        if not k.startswith("grad::"):
+            continue
+        n = k[6:]
+        want = gg[k]
+        gr = params[n].grad
+        if n.endswith("word_embeddings.weight"):
+            got = gr[T_(gg["grad_rowidx::" + n]).cuda()][:, ::4]
+        elif gr.dim() == 1:
+            got = gr[::4]
+        else:
+            got = gr[T_(grad_sample_index(tuple(gr.shape))[0]).cuda()][:, ::4]
+        if np.abs(want).max() < 1e-6 * gmax:
+            continue
+        gn = got.detach().double().cpu().numpy()
+        r = float(np.abs(gn - want).max() / np.abs(want).max())
+        l2 = float(np.linalg.norm(gn - want) / max(np.linalg.norm(want), 1e-30))
+        if l2 > worst_l2:
+            worst_name = n
+        worst_l2, worst_max = max(worst_l2, l2), max(worst_max, r)
+        assert l2 <= 2e-3 and r <= 2e-3, (n, l2, r)
+        nslices += 1
+    assert nslices > 100
+    print(f"\nfp32x3 full-config backward vs the reference: worst norm error {worst_n:.2e}; sampled slices: worst L2 {worst_l2:.2e} "
+          f"({worst_name}), worst element / scale {worst_max:.2e}")

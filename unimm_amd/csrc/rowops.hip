@@ -3,11 +3,9 @@
 // copies, region-feature packing.  All are one-wave-per-row or flat streaming kernels
 // with 16-byte vector accesses; none is MFMA work, their roofline is HBM bandwidth.
 #include "common.h"
+#include "rows.h"
 
 namespace {
-
-constexpr int MAXC = 2;          // 8-element chunks per lane: hidden sizes up to 1024
-constexpr int RED_BLOCKS = 512;  // row-kernel grid for kernels that emit per-block column partials
 
 // ------------------------------------------------------------------------------------------------
 // mask pack: any 0/1 mask tensor [rows, T] -> bit words [rows, ceil(T/32)]   (SURVEY K13;
@@ -245,84 +243,6 @@ __global__ __launch_bounds__(256) void plan_build_kernel(const int32_t* __restri
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// row helpers: a wave owns one row of H elements as 8-element (16-byte) chunks, chunk c = lane + 64*i
-// ------------------------------------------------------------------------------------------------
-struct Row8 { float v[MAXC][8]; };
-
-__device__ __forceinline__ void load_row_bf16(const bf16_t* __restrict__ p, int H, int lane, Row8& r) {
-#pragma unroll
-  for (int i = 0; i < MAXC; ++i) {
-    const int c = lane + 64 * i;
-    if (c * 8 < H) {
-      const u32x4 raw = *reinterpret_cast<const u32x4*>(p + c * 8);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        r.v[i][2 * j] = __uint_as_float(raw[j] << 16);
-        r.v[i][2 * j + 1] = __uint_as_float(raw[j] & 0xffff0000u);
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) r.v[i][j] = 0.f;
-    }
-  }
-}
-
-__device__ __forceinline__ void store_row_bf16(bf16_t* __restrict__ p, int H, int lane, const Row8& r) {
-#pragma unroll
-  for (int i = 0; i < MAXC; ++i) {
-    const int c = lane + 64 * i;
-    if (c * 8 < H)
-      *reinterpret_cast<u32x4*>(p + c * 8) = u32x4{pack2bf(r.v[i][0], r.v[i][1]), pack2bf(r.v[i][2], r.v[i][3]),
-                                                   pack2bf(r.v[i][4], r.v[i][5]), pack2bf(r.v[i][6], r.v[i][7])};
-  }
-}
-
-__device__ __forceinline__ void store_row_f32(float* __restrict__ p, int H, int lane, const Row8& r) {
-#pragma unroll
-  for (int i = 0; i < MAXC; ++i) {
-    const int c = lane + 64 * i;
-    if (c * 8 < H) {
-      *reinterpret_cast<f32x4*>(p + c * 8) = f32x4{r.v[i][0], r.v[i][1], r.v[i][2], r.v[i][3]};
-      *reinterpret_cast<f32x4*>(p + c * 8 + 4) = f32x4{r.v[i][4], r.v[i][5], r.v[i][6], r.v[i][7]};
-    }
-  }
-}
-
-__device__ __forceinline__ void load_vec_f32(const float* __restrict__ p, int H, int lane, Row8& r) {
-#pragma unroll
-  for (int i = 0; i < MAXC; ++i) {
-    const int c = lane + 64 * i;
-    if (c * 8 < H) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(p + c * 8);
-      const f32x4 b = *reinterpret_cast<const f32x4*>(p + c * 8 + 4);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { r.v[i][j] = a[j]; r.v[i][4 + j] = b[j]; }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) r.v[i][j] = 0.f;
-    }
-  }
-}
-
-__device__ __forceinline__ void row_stats(const Row8& x, int H, float& mean, float& rstd, float eps) {
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < MAXC; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) s += x.v[i][j];
-  mean = wave_sum(s) / (float)H;
-  float q = 0.f;
-#pragma unroll
-  for (int i = 0; i < MAXC; ++i) {
-    const int c = (threadIdx.x & 63) + 64 * i;
-    if (c * 8 < H) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { const float d = x.v[i][j] - mean; q += d * d; }
-    }
-  }
-  rstd = rsqrtf(wave_sum(q) / (float)H + eps);
-}
 
 // ------------------------------------------------------------------------------------------------
 // LayerNorm forward (torch.nn.LayerNorm, eps 1e-12; models/vilbert_dialog.py:279,425,468,...)
@@ -621,7 +541,8 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(EmbArgs a, float* __rest
 
 // backward: re-gathers x (nothing was saved), LayerNorm backward, scatter-add into the fp32 tables.
 // The two regular type rows receive a colsum from every token -> per-block partials, not atomics.
-__global__ __launch_bounds__(256) void embed_bwd_kernel(EmbArgs a, const bf16_t* __restrict__ dy, float* __restrict__ dword,
+template <typename DY>      // bf16_t (the bf16 path) or float (the fp32x3 mode's gradient stream)
+__global__ __launch_bounds__(256) void embed_bwd_kernel(EmbArgs a, const DY* __restrict__ dy, float* __restrict__ dword,
                                                         float* __restrict__ dpos, float* __restrict__ dext,
                                                         float* __restrict__ partials) {
   __shared__ float red[4 * 1024];
@@ -644,7 +565,8 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbArgs a, const bf16_t*
     emb_gather(a, row, lane, x, id, pid, tt);
     float mean, rstd;
     row_stats(x, a.H, mean, rstd, a.eps);
-    load_row_bf16(dy + (size_t)row * a.H, a.H, lane, dyv);
+    if constexpr (sizeof(DY) == 4) load_vec_f32(reinterpret_cast<const float*>(dy) + (size_t)row * a.H, a.H, lane, dyv);
+    else load_row_bf16(reinterpret_cast<const bf16_t*>(dy) + (size_t)row * a.H, a.H, lane, dyv);
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXC; ++i)
@@ -1051,8 +973,21 @@ extern "C" int unimm_embed_fwd(const unimm_embed_args* a, float* y32, void* y, v
   return UNIMM_OK;
 }
 
+namespace {
+int embed_bwd_any(const unimm_embed_args* a, const void* dy, bool dy_f32, float* dword, float* dpos, float* dtype,
+                  float* dext, float* dgamma, float* dbeta, float* partials, void* stream);
+}
 extern "C" int unimm_embed_bwd(const unimm_embed_args* a, const void* dy, float* dword, float* dpos, float* dtype,
                                float* dext, float* dgamma, float* dbeta, float* partials, void* stream) {
+  return embed_bwd_any(a, dy, false, dword, dpos, dtype, dext, dgamma, dbeta, partials, stream);
+}
+extern "C" int unimm_embed_bwd_f32(const unimm_embed_args* a, const float* dy, float* dword, float* dpos, float* dtype,
+                                   float* dext, float* dgamma, float* dbeta, float* partials, void* stream) {
+  return embed_bwd_any(a, dy, true, dword, dpos, dtype, dext, dgamma, dbeta, partials, stream);
+}
+namespace {
+int embed_bwd_any(const unimm_embed_args* a, const void* dy, bool dy_f32, float* dword, float* dpos, float* dtype,
+                  float* dext, float* dgamma, float* dbeta, float* partials, void* stream) {
   if (!a || !dy || !dword || !dpos || !dtype || !dext || !dgamma || !dbeta || !partials) return UNIMM_E_ARG;
   if (a->M <= 0 || a->H <= 0 || a->H > MAXC * 512 || (a->H % 8) || a->type_vocab != 2) return UNIMM_E_SHAPE;
   EmbArgs e;
@@ -1065,13 +1000,15 @@ extern "C" int unimm_embed_bwd(const unimm_embed_args* a, const void* dy, float*
   int blocks = (a->M + 3) / 4;
   blocks = blocks > RED_BLOCKS ? RED_BLOCKS : blocks;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3(blocks), dim3(256), 0, s, e, (const bf16_t*)dy, dword, dpos, dext, partials);
+  if (dy_f32) hipLaunchKernelGGL(embed_bwd_kernel<float>, dim3(blocks), dim3(256), 0, s, e, (const float*)dy, dword, dpos, dext, partials);
+  else hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, e, (const bf16_t*)dy, dword, dpos, dext, partials);
   UNIMM_CHECK_LAUNCH();
   hipLaunchKernelGGL(colpartials_finish_kernel, dim3((a->H + 63) / 64, 4), dim3(1024), 0, s, partials, blocks, 4, a->H,
                      dgamma, dbeta, dtype, dtype + a->H);
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;
 }
+}  // namespace
 
 extern "C" int unimm_plan_lengths(const uint32_t* text_words, int32_t t_q_stride, int32_t t_b_stride, const uint32_t* co_words,
                                   int32_t c_q_stride, int32_t c_b_stride, int32_t R, const int32_t* labels, const int32_t* weights,

@@ -1,0 +1,686 @@
+// The fp32-accuracy compute mode ("fp32x3") of the UniMM-UL hot path on gfx950.
+//
+// The reference's dense-annotation fine-tune runs WITHOUT autocast (dense_annotation_finetuning.py:253: fp32 end to
+// end) and BASELINE.json's north_star gates fp32 results at 1e-3.  CDNA4 has no fast fp32 matrix path
+// (v_mfma_f32_16x16x4_f32 runs at 1/16 of the bf16 rate), so this mode keeps the bf16 MFMA GEMM kernels and feeds them
+// SPLIT operands: x = hi + lo with hi = bf16(x), lo = bf16(x - hi), and
+//     x . w  ~=  hi(x) hi(w) + lo(x) hi(w) + hi(x) lo(w)          (the dropped lo.lo term is 2^-16 relative)
+// accumulated in fp32 by the same kernel -- as ONE product over a reduction axis that is three planes long:
+//     activation operand  X3[M, 3 Kp] = [ hi(X) | lo(X) | hi(X) ]        ("x-type" planes)
+//     weight operand      W3[N, 3 Kp] = [ hi(W) | hi(W) | lo(W) ]        ("w-type" planes)
+//     X3 . W3^T = hi hi + lo hi + hi lo.         Kp = K rounded up to 64, padding columns are zero.
+// Weight gradients dW += dY^T X become three problems of the grouped TN launch over column planes of the x-type
+// buffers ((hi, hi), (lo, hi), (hi, lo)), accumulating into the same fp32 gradient.  Everything between two GEMMs is
+// fp32: the GEMMs write fp32, and the kernels of this file turn fp32 results into the next split operand (with the
+// elementwise op that the bf16 path fuses into its epilogues), run LayerNorm / embedding / loss backward on fp32
+// gradients, and compute the attention cores in fp32 on the vector ALUs (K / V rows broadcast out of LDS; ~1.3 % of
+// the model's FLOPs).  Same dropout counters, mask words, row maps and device-side row counts as the bf16 kernels.
+#include "common.h"
+#include "rows.h"
+
+namespace {
+
+__device__ __forceinline__ void split2(float x, float& hi, float& lo) {
+  hi = bf2f(f2bf(x));
+  lo = x - hi;            // exact in fp32; rounded to bf16 when packed
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32 -> split operand, with the elementwise op of the bf16 path's GEMM epilogues in front
+// ------------------------------------------------------------------------------------------------
+struct SplitParams {
+  const float* a; const float* b; float* out32; bf16_t* out3;
+  long rows; int cols, cp, lda, ldb, ld32, op, wtype;
+};
+
+__device__ __forceinline__ float ew_op(int op, float a, float b) {
+  switch (op) {
+    case UNIMM_X3_ADD: return a + b;
+    case UNIMM_X3_GELU: return gelu_erf(a);
+    case UNIMM_X3_MUL_DGELU: return a * gelu_erf_grad(b);
+    default: return a;
+  }
+}
+
+__global__ __launch_bounds__(256) void x3_split_kernel(SplitParams p) {
+  const int nch = p.cp >> 3;                                  // 8-column chunks per plane (cp % 64 == 0)
+  const long total = p.rows * nch;
+  const bool veca = (p.lda & 3) == 0 && (((uintptr_t)p.a) & 15) == 0;
+  const bool vecb = p.b == nullptr || ((p.ldb & 3) == 0 && (((uintptr_t)p.b) & 15) == 0);
+  const bool veco = p.out32 == nullptr || ((p.ld32 & 3) == 0 && (((uintptr_t)p.out32) & 15) == 0);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / nch;
+    const int c0 = (int)(i - r * nch) * 8;
+    float y[8];
+    const float* ar = p.a + (size_t)r * p.lda;
+    const float* br = p.b != nullptr ? p.b + (size_t)r * p.ldb : nullptr;
+    if (c0 + 8 <= p.cols && veca && vecb) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(ar + c0), a1 = *reinterpret_cast<const f32x4*>(ar + c0 + 4);
+      f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+      if (br != nullptr) { b0 = *reinterpret_cast<const f32x4*>(br + c0); b1 = *reinterpret_cast<const f32x4*>(br + c0 + 4); }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { y[e] = ew_op(p.op, a0[e], b0[e]); y[4 + e] = ew_op(p.op, a1[e], b1[e]); }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = c0 + e;
+        y[e] = c < p.cols ? ew_op(p.op, ar[c], br != nullptr ? br[c] : 0.f) : 0.f;
+      }
+    }
+    if (p.out32 != nullptr) {
+      float* o = p.out32 + (size_t)r * p.ld32;
+      if (c0 + 8 <= p.cols && veco) {
+        *reinterpret_cast<f32x4*>(o + c0) = f32x4{y[0], y[1], y[2], y[3]};
+        *reinterpret_cast<f32x4*>(o + c0 + 4) = f32x4{y[4], y[5], y[6], y[7]};
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (c0 + e < p.cols) o[c0 + e] = y[e];
+      }
+    }
+    if (p.out3 != nullptr) {
+      float hi[8], lo[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) split2(y[e], hi[e], lo[e]);
+      const u32x4 H = u32x4{pack2bf(hi[0], hi[1]), pack2bf(hi[2], hi[3]), pack2bf(hi[4], hi[5]), pack2bf(hi[6], hi[7])};
+      const u32x4 L = u32x4{pack2bf(lo[0], lo[1]), pack2bf(lo[2], lo[3]), pack2bf(lo[4], lo[5]), pack2bf(lo[6], lo[7])};
+      bf16_t* o = p.out3 + (size_t)r * 3 * p.cp + c0;
+      *reinterpret_cast<u32x4*>(o) = H;
+      *reinterpret_cast<u32x4*>(o + p.cp) = p.wtype ? H : L;
+      *reinterpret_cast<u32x4*>(o + 2 * p.cp) = p.wtype ? L : H;
+    }
+  }
+}
+
+// transposed w-type split of a weight matrix: src fp32 [R, C] (row stride lds) -> dst bf16 [C, 3 Rp]:
+// dst[c][p * Rp + r] = plane_p(src[r][c]); columns r in [R, Rp) are left untouched (the caller zero-fills once).
+__global__ __launch_bounds__(256) void x3_split_wt_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int R, int C,
+                                                           int lds, int Rp) {
+  __shared__ float tile[32][33];
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+  for (int k = ty; k < 32; k += 8) {
+    const int r = r0 + k, c = c0 + tx;
+    tile[k][tx] = (r < R && c < C) ? src[(size_t)r * lds + c] : 0.f;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int c = c0 + k, r = r0 + tx;
+    if (c < C && r < R) {
+      float hi, lo;
+      split2(tile[tx][k], hi, lo);
+      bf16_t* o = dst + (size_t)c * 3 * Rp + r;
+      o[0] = f2bf(hi); o[Rp] = f2bf(hi); o[2 * Rp] = f2bf(lo);
+    }
+  }
+}
+
+__device__ __forceinline__ void store_row_split3(bf16_t* __restrict__ p, int cp, int H, int lane, const Row8& r) {
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c * 8 < H) {
+      float hi[8], lo[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) split2(r.v[i][e], hi[e], lo[e]);
+      const u32x4 Hh = u32x4{pack2bf(hi[0], hi[1]), pack2bf(hi[2], hi[3]), pack2bf(hi[4], hi[5]), pack2bf(hi[6], hi[7])};
+      const u32x4 Ll = u32x4{pack2bf(lo[0], lo[1]), pack2bf(lo[2], lo[3]), pack2bf(lo[4], lo[5]), pack2bf(lo[6], lo[7])};
+      *reinterpret_cast<u32x4*>(p + c * 8) = Hh;
+      *reinterpret_cast<u32x4*>(p + cp + c * 8) = Ll;
+      *reinterpret_cast<u32x4*>(p + 2 * cp + c * 8) = Hh;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm backward on fp32 gradients (same arithmetic and partials layout as layernorm_bwd_kernel of rowops.hip):
+// dx32 = gradient w.r.t. the pre-LayerNorm sum (fp32, the residual branch), dxd3 = its dropout-masked copy as an
+// x-type split operand (the dY of the dense branch: dgrad GEMM operand and weight-gradient operand).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void x3_layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                               const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+                                                               const float* __restrict__ gamma, float* __restrict__ dx32,
+                                                               bf16_t* __restrict__ dxd3, float* __restrict__ partials, int M, int H,
+                                                               DropoutArg drop, DropoutArg out_drop,
+                                                               const int32_t* __restrict__ m_dev) {
+  __shared__ float red[4 * 1024];
+  drop_resolve(drop);
+  drop_resolve(out_drop);
+  if (m_dev != nullptr) M = min(M, m_dev[0]);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wave = blockIdx.x * 4 + wv;
+  const int nwaves = gridDim.x * 4;
+  Row8 g;
+  load_vec_f32(gamma, H, lane, g);
+  Row8 dg, db, dbias;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { dg.v[i][j] = 0.f; db.v[i][j] = 0.f; dbias.v[i][j] = 0.f; }
+  const float invH = 1.0f / (float)H;
+  for (int row = wave; row < M; row += nwaves) {
+    Row8 dyv, xv;
+    load_vec_f32(dy + (size_t)row * H, H, lane, dyv);
+    load_vec_f32(x + (size_t)row * H, H, lane, xv);
+    const float mean = mean_i[row], rstd = rstd_i[row];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const uint32_t kbo = out_drop.thr != 0u ? drop_bits8(out_drop, (uint32_t)row, (uint32_t)H, (uint32_t)((lane + 64 * i) * 8)) : 0u;
+      const bool in = (lane + 64 * i) * 8 < H;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float d = dyv.v[i][j];
+        if (out_drop.thr != 0u) d = ((kbo >> j) & 1u) ? d * out_drop.scale : 0.f;
+        const float xh = in ? (xv.v[i][j] - mean) * rstd : 0.f;
+        const float gg = d * g.v[i][j];
+        dg.v[i][j] += d * xh;
+        db.v[i][j] += d;
+        s1 += gg;
+        s2 += gg * xh;
+        dyv.v[i][j] = gg;
+        xv.v[i][j] = xh;
+      }
+    }
+    s1 = wave_sum(s1) * invH;
+    s2 = wave_sum(s2) * invH;
+    Row8 dd;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const uint32_t kb = drop.thr != 0u ? drop_bits8(drop, (uint32_t)row, (uint32_t)H, (uint32_t)((lane + 64 * i) * 8)) : 0u;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = rstd * (dyv.v[i][j] - s1 - xv.v[i][j] * s2);
+        dyv.v[i][j] = v;
+        float vd = v;
+        if (drop.thr != 0u) vd = ((kb >> j) & 1u) ? v * drop.scale : 0.f;
+        dd.v[i][j] = vd;
+        dbias.v[i][j] += vd;
+      }
+    }
+    if (dx32 != nullptr) store_row_f32(dx32 + (size_t)row * H, H, lane, dyv);
+    if (dxd3 != nullptr) store_row_split3(dxd3 + (size_t)row * 3 * H, H, H, lane, dd);
+  }
+  for (int qn = 0; qn < 3; ++qn) {
+    const Row8& src = qn == 0 ? dg : (qn == 1 ? db : dbias);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int col = (lane + 64 * i) * 8 + j;
+        if (col < H) red[wv * 1024 + col] = src.v[i][j];
+      }
+    __syncthreads();
+    for (int col = threadIdx.x; col < H; col += 256)
+      partials[((size_t)blockIdx.x * 3 + qn) * H + col] = red[col] + red[1024 + col] + red[2048 + col] + red[3072 + col];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// loss backward straight into x-type split operands (dlogits is both the dgrad GEMM's operand and the dY of the
+// decoder's weight gradient)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void store8_split3(bf16_t* o, int cp, const float* v) {
+  float hi[8], lo[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) split2(v[e], hi[e], lo[e]);
+  const u32x4 H = u32x4{pack2bf(hi[0], hi[1]), pack2bf(hi[2], hi[3]), pack2bf(hi[4], hi[5]), pack2bf(hi[6], hi[7])};
+  const u32x4 L = u32x4{pack2bf(lo[0], lo[1]), pack2bf(lo[2], lo[3]), pack2bf(lo[4], lo[5]), pack2bf(lo[6], lo[7])};
+  *reinterpret_cast<u32x4*>(o) = H;
+  *reinterpret_cast<u32x4*>(o + cp) = L;
+  *reinterpret_cast<u32x4*>(o + 2 * cp) = H;
+}
+
+__global__ __launch_bounds__(256) void x3_lm_loss_bwd_kernel(const float* __restrict__ logits, const int32_t* __restrict__ labels,
+                                                             const int32_t* __restrict__ weights, const float* __restrict__ lse_i,
+                                                             const float* __restrict__ g, float inv_denom, bf16_t* __restrict__ out3,
+                                                             int V, int ld, int cp, float clamp_min,
+                                                             const int32_t* __restrict__ n_dev, const float* __restrict__ inv_dev) {
+  const int row = blockIdx.x;
+  bf16_t* dz = out3 + (size_t)row * 3 * cp;
+  const bool live = n_dev == nullptr || row < n_dev[0];
+  if (inv_dev != nullptr) inv_denom = inv_dev[0];
+  const float* z = logits + (size_t)row * ld;
+  float coef = 0.f, lse = 0.f;
+  int y = -1;
+  if (live) {
+    y = labels[row];
+    const int w = weights[row];
+    lse = lse_i[row];
+    if (y >= 0) {
+      const float gs = g[0] * inv_denom;
+      if (w > 0) coef = gs * (float)w;
+      else if (w == -1) {
+        const float py = expf(z[y] - lse);
+        const float om = 1.0f - py;
+        coef = om >= clamp_min ? -gs * py / om : 0.f;
+      }
+    }
+  }
+  for (int i = threadIdx.x; i < (cp >> 3); i += 256) {
+    const int c0 = 8 * i;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = c0 + e;
+      v[e] = (live && coef != 0.f && c < V) ? coef * (expf(z[c] - lse) - (c == y ? 1.0f : 0.0f)) : 0.f;
+    }
+    store8_split3(dz + c0, cp, v);
+  }
+}
+
+__global__ __launch_bounds__(256) void x3_kl_loss_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                             const int32_t* __restrict__ label, const float* __restrict__ lse_i,
+                                                             const float* __restrict__ g, float inv_denom, bf16_t* __restrict__ out3,
+                                                             int C, int ld, int cp, const float* __restrict__ inv_dev) {
+  __shared__ float red[4];
+  const int row = blockIdx.x;
+  if (inv_dev != nullptr) inv_denom = inv_dev[0];
+  const float* z = pred + (size_t)row * ld;
+  const float* t = target + (size_t)row * C;
+  bf16_t* dz = out3 + (size_t)row * 3 * cp;
+  const bool on = label[row] == 1;
+  float ts = 0.f;
+  if (on)
+    for (int i = threadIdx.x; i < C; i += 256) ts += t[i];
+  ts = wave_sum(ts);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ts;
+  __syncthreads();
+  ts = red[0] + red[1] + red[2] + red[3];
+  const float gs = on ? g[0] * inv_denom : 0.f;
+  const float lse = lse_i[row];
+  for (int i = threadIdx.x; i < (cp >> 3); i += 256) {
+    const int c0 = 8 * i;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = c0 + e;
+      v[e] = (on && c < C) ? gs * (expf(z[c] - lse) * ts - t[c]) : 0.f;
+    }
+    store8_split3(dz + c0, cp, v);
+  }
+}
+
+// dst[idx[r], :] += src[r, :], fp32 both (idx unique)
+__global__ void x3_rows_add_kernel(float* __restrict__ dst, const int32_t* __restrict__ idx, const float* __restrict__ src, int n,
+                                   int H, int ldd) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)n * H) return;
+  const int r = (int)(i / H), c = (int)(i - (long)r * H);
+  dst[(size_t)idx[r] * ldd + c] += src[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Attention cores in fp32 (models/vilbert_dialog.py:390-410, :519-539, :681-721 and their autograd).
+// One lane owns 64 of a row's D dimensions (D = 64: a lane per row; D = 128: two neighbouring lanes per row whose
+// partial dot products meet in one cross-lane add); the other side's rows are staged in LDS in chunks of 32 and read
+// as broadcasts.  Online softmax over the keys in the forward; the backward recomputes P from the saved log-sum-exp,
+// dQ with a lane per query, dK / dV with a lane per key.  Masks, additive -10000, dropout counters, variable-length
+// offsets: exactly the bf16 kernels' conventions (csrc/attention.hip).
+// ------------------------------------------------------------------------------------------------
+struct AttnF32 {
+  const float* q; const float* k; const float* v; const float* o; const float* dout;
+  float* out; float* lse; float* delta; float* dq; float* dk; float* dv;
+  const uint32_t* mask;
+  const int* q_off; const int* q_len; const int* k_off; const int* k_len;
+  int B, H, Tq, Tk;
+  int ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
+  int mqs, mbs;
+  float scale;
+  DropoutArg drop;
+};
+
+constexpr int XA_T = 128;     // threads per workgroup
+constexpr int XA_C = 32;      // staged rows per chunk (= one mask word)
+constexpr int XA_HS = 68;     // floats per staged half row: 64 + 4 (the two halves of a D = 128 row land on different banks)
+
+__device__ __forceinline__ void xa_load64(const float* __restrict__ g, float* r) {
+#pragma unroll
+  for (int c = 0; c < 64; c += 4) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(g + c);
+    r[c] = t[0]; r[c + 1] = t[1]; r[c + 2] = t[2]; r[c + 3] = t[3];
+  }
+}
+__device__ __forceinline__ void xa_store64(float* __restrict__ g, const float* r, float s) {
+#pragma unroll
+  for (int c = 0; c < 64; c += 4) *reinterpret_cast<f32x4*>(g + c) = f32x4{r[c] * s, r[c + 1] * s, r[c + 2] * s, r[c + 3] * s};
+}
+__device__ __forceinline__ float xa_dot64(const float* r, const float* __restrict__ lds) {
+  float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+  for (int c = 0; c < 64; c += 8) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(lds + c), b = *reinterpret_cast<const f32x4*>(lds + c + 4);
+    d0 = fmaf(r[c], a[0], d0); d0 = fmaf(r[c + 1], a[1], d0); d0 = fmaf(r[c + 2], a[2], d0); d0 = fmaf(r[c + 3], a[3], d0);
+    d1 = fmaf(r[c + 4], b[0], d1); d1 = fmaf(r[c + 5], b[1], d1); d1 = fmaf(r[c + 6], b[2], d1); d1 = fmaf(r[c + 7], b[3], d1);
+  }
+  return d0 + d1;
+}
+__device__ __forceinline__ void xa_axpy64(float* acc, float a, const float* __restrict__ lds) {
+#pragma unroll
+  for (int c = 0; c < 64; c += 4) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(lds + c);
+    acc[c] = fmaf(a, t[0], acc[c]); acc[c + 1] = fmaf(a, t[1], acc[c + 1]);
+    acc[c + 2] = fmaf(a, t[2], acc[c + 2]); acc[c + 3] = fmaf(a, t[3], acc[c + 3]);
+  }
+}
+// stage rows [r0, r0 + XA_C) (zeros past `len`) of a [.., ld] fp32 matrix, D columns from column `col0`, into LDS
+template <int D>
+__device__ __forceinline__ void xa_stage(float* __restrict__ lds, const float* __restrict__ g, int row_base, int r0, int len, int ld,
+                                         int col0) {
+  constexpr int RS = (D / 64) * XA_HS;
+  for (int i = threadIdx.x; i < XA_C * (D / 4); i += XA_T) {
+    const int r = i / (D / 4), c = (i - r * (D / 4)) * 4;
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    if (r0 + r < len) t = *reinterpret_cast<const f32x4*>(g + (size_t)(row_base + r0 + r) * ld + col0 + c);
+    *reinterpret_cast<f32x4*>(lds + r * RS + (c >> 6) * XA_HS + (c & 63)) = t;
+  }
+}
+__device__ __forceinline__ bool xa_keep(const DropoutArg& d, uint32_t hrow, uint32_t Tk, uint32_t key) {
+  if (d.thr == 0u) return true;
+  const uint32_t w = drop_word(d, drop_wbase(hrow, Tk, key));
+  return ((key & 1u) ? (w >> 16) : (w & 0xffffu)) >= (d.thr >> 16);
+}
+
+template <int D>
+__global__ __launch_bounds__(XA_T) void x3_attn_fwd_kernel(AttnF32 p) {
+  constexpr int LPR = D / 64, RPW = XA_T / LPR, RS = LPR * XA_HS;
+  __shared__ __attribute__((aligned(16))) float Ks[XA_C * RS];
+  __shared__ __attribute__((aligned(16))) float Vs[XA_C * RS];
+  drop_resolve(p.drop);
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int qlen = p.q_len != nullptr ? p.q_len[b] : p.Tq, qoff = p.q_off != nullptr ? p.q_off[b] : b * p.Tq;
+  const int klen = p.k_len != nullptr ? p.k_len[b] : p.Tk, koff = p.k_off != nullptr ? p.k_off[b] : b * p.Tk;
+  const int r0 = blockIdx.x * RPW;
+  if (r0 >= qlen) return;                                  // workgroup-uniform
+  const int rl = threadIdx.x / LPR, half = threadIdx.x % LPR;
+  const bool valid = r0 + rl < qlen;
+  const int qr = valid ? r0 + rl : qlen - 1;
+  float qv[64], acc[64];
+  xa_load64(p.q + (size_t)(qoff + qr) * p.ldq + head * D + half * 64, qv);
+#pragma unroll
+  for (int c = 0; c < 64; ++c) acc[c] = 0.f;
+  float m = -INFINITY, l = 0.f;
+  const uint32_t* mrow = p.mask + (size_t)b * p.mbs + (size_t)qr * p.mqs;
+  const uint32_t hrow = ((uint32_t)b * p.H + head) * p.Tq + (uint32_t)qr;
+  for (int k0 = 0; k0 < klen; k0 += XA_C) {
+    __syncthreads();
+    xa_stage<D>(Ks, p.k, koff, k0, klen, p.ldk, head * D);
+    xa_stage<D>(Vs, p.v, koff, k0, klen, p.ldv, head * D);
+    __syncthreads();
+    const uint32_t mw = mrow[k0 >> 5];
+    const int nk = min(XA_C, klen - k0);
+    for (int j = 0; j < nk; ++j) {
+      float d = xa_dot64(qv, Ks + j * RS + half * XA_HS);
+      if (LPR == 2) d += __shfl_xor(d, 1, 64);
+      const float sv = d * p.scale + (((mw >> j) & 1u) ? 0.f : -10000.0f);
+      if (sv > m) {
+        const float corr = __expf(m - sv);                 // first key: exp(-inf) = 0
+        l *= corr;
+#pragma unroll
+        for (int c = 0; c < 64; ++c) acc[c] *= corr;
+        m = sv;
+      }
+      const float e = __expf(sv - m);
+      l += e;
+      const float pe = xa_keep(p.drop, hrow, (uint32_t)p.Tk, (uint32_t)(k0 + j)) ? e : 0.f;
+      xa_axpy64(acc, pe, Vs + j * RS + half * XA_HS);
+    }
+  }
+  if (!valid) return;
+  const float inv = (p.drop.thr != 0u ? p.drop.scale : 1.0f) / l;
+  xa_store64(p.out + (size_t)(qoff + qr) * p.ldo + head * D + half * 64, acc, inv);
+  if (p.lse != nullptr && half == 0) p.lse[((size_t)b * p.H + head) * p.Tq + qr] = m + __logf(l);
+}
+
+// dQ (+ delta = rowsum(dO o O)): a lane per query, keys staged
+template <int D>
+__global__ __launch_bounds__(XA_T) void x3_attn_bwd_dq_kernel(AttnF32 p) {
+  constexpr int LPR = D / 64, RPW = XA_T / LPR, RS = LPR * XA_HS;
+  __shared__ __attribute__((aligned(16))) float Ks[XA_C * RS];
+  __shared__ __attribute__((aligned(16))) float Vs[XA_C * RS];
+  drop_resolve(p.drop);
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int qlen = p.q_len != nullptr ? p.q_len[b] : p.Tq, qoff = p.q_off != nullptr ? p.q_off[b] : b * p.Tq;
+  const int klen = p.k_len != nullptr ? p.k_len[b] : p.Tk, koff = p.k_off != nullptr ? p.k_off[b] : b * p.Tk;
+  const int r0 = blockIdx.x * RPW;
+  if (r0 >= qlen) return;
+  const int rl = threadIdx.x / LPR, half = threadIdx.x % LPR;
+  const bool valid = r0 + rl < qlen;
+  const int qr = valid ? r0 + rl : qlen - 1;
+  float qv[64], dov[64], dq[64];
+  xa_load64(p.q + (size_t)(qoff + qr) * p.ldq + head * D + half * 64, qv);
+  xa_load64(p.dout + (size_t)(qoff + qr) * p.lddo + head * D + half * 64, dov);
+  float delta = 0.f;
+  {
+    const float* og = p.o + (size_t)(qoff + qr) * p.ldo + head * D + half * 64;
+#pragma unroll
+    for (int c = 0; c < 64; c += 4) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(og + c);
+      delta = fmaf(dov[c], t[0], delta); delta = fmaf(dov[c + 1], t[1], delta);
+      delta = fmaf(dov[c + 2], t[2], delta); delta = fmaf(dov[c + 3], t[3], delta);
+    }
+    if (LPR == 2) delta += __shfl_xor(delta, 1, 64);
+  }
+  const size_t li = ((size_t)b * p.H + head) * p.Tq + qr;
+  const float lse = p.lse[li];
+  if (valid && half == 0) p.delta[li] = delta;
+#pragma unroll
+  for (int c = 0; c < 64; ++c) dq[c] = 0.f;
+  const uint32_t* mrow = p.mask + (size_t)b * p.mbs + (size_t)qr * p.mqs;
+  const uint32_t hrow = ((uint32_t)b * p.H + head) * p.Tq + (uint32_t)qr;
+  const float dsc = p.drop.thr != 0u ? p.drop.scale : 1.0f;
+  for (int k0 = 0; k0 < klen; k0 += XA_C) {
+    __syncthreads();
+    xa_stage<D>(Ks, p.k, koff, k0, klen, p.ldk, head * D);
+    xa_stage<D>(Vs, p.v, koff, k0, klen, p.ldv, head * D);
+    __syncthreads();
+    const uint32_t mw = mrow[k0 >> 5];
+    const int nk = min(XA_C, klen - k0);
+    for (int j = 0; j < nk; ++j) {
+      const float* kr = Ks + j * RS + half * XA_HS;
+      float d = xa_dot64(qv, kr);
+      float dpv = xa_dot64(dov, Vs + j * RS + half * XA_HS);
+      if (LPR == 2) { d += __shfl_xor(d, 1, 64); dpv += __shfl_xor(dpv, 1, 64); }
+      const float pr = __expf(d * p.scale + (((mw >> j) & 1u) ? 0.f : -10000.0f) - lse);
+      const float dP = xa_keep(p.drop, hrow, (uint32_t)p.Tk, (uint32_t)(k0 + j)) ? dpv * dsc : 0.f;
+      const float dS = pr * (dP - delta) * p.scale;
+      xa_axpy64(dq, dS, kr);
+    }
+  }
+  if (valid) xa_store64(p.dq + (size_t)(qoff + qr) * p.lddq + head * D + half * 64, dq, 1.0f);
+}
+
+// dK, dV: a lane per key, queries staged (Q, dO rows + their lse / delta / mask words)
+template <int D>
+__global__ __launch_bounds__(XA_T) void x3_attn_bwd_dkv_kernel(AttnF32 p) {
+  constexpr int LPR = D / 64, RPW = XA_T / LPR, RS = LPR * XA_HS;
+  __shared__ __attribute__((aligned(16))) float Qs[XA_C * RS];
+  __shared__ __attribute__((aligned(16))) float Os[XA_C * RS];
+  __shared__ float Ls[XA_C], Ds[XA_C];
+  __shared__ uint32_t Ms[XA_C * 8];
+  drop_resolve(p.drop);
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int qlen = p.q_len != nullptr ? p.q_len[b] : p.Tq, qoff = p.q_off != nullptr ? p.q_off[b] : b * p.Tq;
+  const int klen = p.k_len != nullptr ? p.k_len[b] : p.Tk, koff = p.k_off != nullptr ? p.k_off[b] : b * p.Tk;
+  const int r0 = blockIdx.x * RPW;
+  if (r0 >= klen) return;
+  const int rl = threadIdx.x / LPR, half = threadIdx.x % LPR;
+  const bool valid = r0 + rl < klen;
+  const int key = valid ? r0 + rl : klen - 1;
+  float kv[64], vv[64], dk[64], dv[64];
+  xa_load64(p.k + (size_t)(koff + key) * p.ldk + head * D + half * 64, kv);
+  xa_load64(p.v + (size_t)(koff + key) * p.ldv + head * D + half * 64, vv);
+#pragma unroll
+  for (int c = 0; c < 64; ++c) { dk[c] = 0.f; dv[c] = 0.f; }
+  const int nw = (p.Tk + 31) >> 5;
+  const uint32_t hbase = ((uint32_t)b * p.H + head) * p.Tq;
+  const float dsc = p.drop.thr != 0u ? p.drop.scale : 1.0f;
+  const size_t lbase = ((size_t)b * p.H + head) * p.Tq;
+  for (int q0 = 0; q0 < qlen; q0 += XA_C) {
+    __syncthreads();
+    xa_stage<D>(Qs, p.q, qoff, q0, qlen, p.ldq, head * D);
+    xa_stage<D>(Os, p.dout, qoff, q0, qlen, p.lddo, head * D);
+    const int nq = min(XA_C, qlen - q0);
+    if (threadIdx.x < nq) { Ls[threadIdx.x] = p.lse[lbase + q0 + threadIdx.x]; Ds[threadIdx.x] = p.delta[lbase + q0 + threadIdx.x]; }
+    for (int i = threadIdx.x; i < nq * nw; i += XA_T) {
+      const int r = i / nw, w = i - r * nw;
+      Ms[r * 8 + w] = p.mask[(size_t)b * p.mbs + (size_t)(q0 + r) * p.mqs + w];
+    }
+    __syncthreads();
+    for (int j = 0; j < nq; ++j) {
+      const float* qr_ = Qs + j * RS + half * XA_HS;
+      const float* or_ = Os + j * RS + half * XA_HS;
+      float d = xa_dot64(kv, qr_);
+      float dpv = xa_dot64(vv, or_);
+      if (LPR == 2) { d += __shfl_xor(d, 1, 64); dpv += __shfl_xor(dpv, 1, 64); }
+      const uint32_t mw = Ms[j * 8 + (key >> 5)];
+      const float pr = __expf(d * p.scale + (((mw >> (key & 31)) & 1u) ? 0.f : -10000.0f) - Ls[j]);
+      const bool keep = xa_keep(p.drop, hbase + (uint32_t)(q0 + j), (uint32_t)p.Tk, (uint32_t)key);
+      const float pd = keep ? pr * dsc : 0.f;
+      const float dP = keep ? dpv * dsc : 0.f;
+      const float dS = pr * (dP - Ds[j]) * p.scale;
+      xa_axpy64(dv, pd, or_);
+      xa_axpy64(dk, dS, qr_);
+    }
+  }
+  if (!valid) return;
+  xa_store64(p.dk + (size_t)(koff + key) * p.lddk + head * D + half * 64, dk, 1.0f);
+  xa_store64(p.dv + (size_t)(koff + key) * p.lddv + head * D + half * 64, dv, 1.0f);
+}
+
+int fill_attn(const unimm_attn_args* a, AttnF32& p) {
+  if (a == nullptr || !a->q || !a->k || !a->v || !a->out || !a->mask) return UNIMM_E_ARG;
+  if (a->B <= 0 || a->H <= 0 || a->Tq <= 0 || a->Tk <= 0 || a->Tq > 256 || a->Tk > 256) return UNIMM_E_SHAPE;
+  if (a->D != 64 && a->D != 128) return UNIMM_E_SHAPE;
+  if ((a->ldq % 4) || (a->ldk % 4) || (a->ldv % 4) || (a->ldo % 4)) return UNIMM_E_ALIGN;
+  if (((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v | (uintptr_t)a->out) & 15) return UNIMM_E_ALIGN;
+  if ((a->q_off == nullptr) != (a->q_len == nullptr) || (a->k_off == nullptr) != (a->k_len == nullptr)) return UNIMM_E_ARG;
+  p = AttnF32{};
+  p.q = (const float*)a->q; p.k = (const float*)a->k; p.v = (const float*)a->v; p.out = (float*)a->out; p.lse = a->lse;
+  p.mask = a->mask; p.q_off = a->q_off; p.q_len = a->q_len; p.k_off = a->k_off; p.k_len = a->k_len;
+  p.B = a->B; p.H = a->H; p.Tq = a->Tq; p.Tk = a->Tk;
+  p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo;
+  p.mqs = a->mask_q_stride; p.mbs = a->mask_b_stride; p.scale = a->scale;
+  p.drop.key = a->drop_key; p.drop.thr = a->drop_thr; p.drop.scale = a->drop_scale; p.drop.salt = a->drop_salt; p.drop.key2 = 0u;
+  return UNIMM_OK;
+}
+
+}  // namespace
+
+extern "C" int unimm_x3_split(const unimm_x3_split_args* a, void* stream) {
+  if (a == nullptr || a->a == nullptr || (a->out32 == nullptr && a->out3 == nullptr)) return UNIMM_E_ARG;
+  if (a->rows <= 0 || a->cols <= 0 || a->cp < a->cols || (a->cp % 64) != 0 || a->lda < a->cols) return UNIMM_E_SHAPE;
+  if (a->op < 0 || a->op > UNIMM_X3_MUL_DGELU) return UNIMM_E_ARG;
+  if ((a->op == UNIMM_X3_ADD || a->op == UNIMM_X3_MUL_DGELU) && (a->b == nullptr || a->ldb < a->cols)) return UNIMM_E_ARG;
+  if (a->out32 != nullptr && a->ld32 < a->cols) return UNIMM_E_SHAPE;
+  if (a->out3 != nullptr && (((uintptr_t)a->out3) & 15)) return UNIMM_E_ALIGN;
+  SplitParams p;
+  p.a = a->a; p.b = (a->op == UNIMM_X3_ADD || a->op == UNIMM_X3_MUL_DGELU) ? a->b : nullptr;
+  p.out32 = a->out32; p.out3 = (bf16_t*)a->out3;
+  p.rows = a->rows; p.cols = a->cols; p.cp = a->cp; p.lda = a->lda; p.ldb = a->ldb; p.ld32 = a->ld32; p.op = a->op;
+  p.wtype = a->wtype != 0;
+  const long total = p.rows * (p.cp >> 3);
+  const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(x3_split_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
+}
+
+extern "C" int unimm_x3_split_wt(const float* src, void* dst, int32_t R, int32_t C, int32_t lds, int32_t Rp, void* stream) {
+  if (src == nullptr || dst == nullptr) return UNIMM_E_ARG;
+  if (R <= 0 || C <= 0 || lds < C || Rp < R || (Rp % 64) != 0) return UNIMM_E_SHAPE;
+  hipLaunchKernelGGL(x3_split_wt_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, (hipStream_t)stream, src,
+                     (bf16_t*)dst, R, C, lds, Rp);
+  UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
+}
+
+extern "C" int unimm_x3_layernorm_bwd_partials(const float* dy, const float* x, const float* mean, const float* rstd,
+                                               const float* gamma, float* dx32, void* dxd3, float* partials, int32_t M,
+                                               int32_t H, uint32_t drop_key, uint32_t drop_thr, float drop_scale,
+                                               uint32_t odrop_key, uint32_t odrop_thr, float odrop_scale, int32_t* blocks_out,
+                                               const int32_t* m_dev, const uint32_t* drop_salt, void* stream) {
+  if (!dy || !x || !mean || !rstd || !gamma || !partials || !blocks_out || (!dx32 && !dxd3)) return UNIMM_E_ARG;
+  if (M <= 0 || H <= 0 || H > 1024 || (H % 64) != 0) return UNIMM_E_SHAPE;
+  DropoutArg d{drop_key, drop_thr, drop_scale, drop_salt, 0u}, od{odrop_key, odrop_thr, odrop_scale, drop_salt, 0u};
+  int blocks = (M + 3) / 4;
+  blocks = blocks < RED_BLOCKS ? blocks : RED_BLOCKS;
+  *blocks_out = blocks;
+  hipLaunchKernelGGL(x3_layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, dx32,
+                     (bf16_t*)dxd3, partials, M, H, d, od, m_dev);
+  UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
+}
+
+extern "C" int unimm_x3_lm_loss_bwd(const float* logits, const int32_t* labels, const int32_t* weights, const float* lse,
+                                    const float* g, float inv_denom, void* out3, int32_t n, int32_t V, int32_t ld, int32_t cp,
+                                    const int32_t* n_dev, const float* inv_dev, void* stream) {
+  if (!logits || !labels || !weights || !lse || !g || !out3) return UNIMM_E_ARG;
+  if (n <= 0 || V <= 0 || ld < V || cp < V || (cp % 64)) return UNIMM_E_SHAPE;
+  hipLaunchKernelGGL(x3_lm_loss_bwd_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, logits, labels, weights, lse, g,
+                     inv_denom, (bf16_t*)out3, V, ld, cp, 1e-6f, n_dev, inv_dev);
+  UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
+}
+
+extern "C" int unimm_x3_kl_loss_bwd(const float* pred, const float* target, const int32_t* label, const float* lse,
+                                    const float* g, float inv_denom, void* out3, int32_t rows, int32_t C, int32_t ld, int32_t cp,
+                                    const float* inv_dev, void* stream) {
+  if (!pred || !target || !label || !lse || !g || !out3) return UNIMM_E_ARG;
+  if (rows <= 0 || C <= 0 || ld < C || cp < C || (cp % 64)) return UNIMM_E_SHAPE;
+  hipLaunchKernelGGL(x3_kl_loss_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, pred, target, label, lse, g,
+                     inv_denom, (bf16_t*)out3, C, ld, cp, inv_dev);
+  UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
+}
+
+extern "C" int unimm_x3_rows_add(float* dst, const int32_t* idx, const float* src, int32_t n, int32_t H, int32_t ldd, void* stream) {
+  if (!dst || !idx || !src || n <= 0 || H <= 0 || ldd < H) return UNIMM_E_ARG;
+  const long total = (long)n * H;
+  hipLaunchKernelGGL(x3_rows_add_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dst, idx, src,
+                     n, H, ldd);
+  UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
+}
+
+extern "C" int unimm_x3_attn_fwd(const unimm_attn_args* a, void* stream) {
+  AttnF32 p;
+  const int rc = fill_attn(a, p);
+  if (rc != UNIMM_OK) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (a->D == 64) hipLaunchKernelGGL(x3_attn_fwd_kernel<64>, dim3((a->Tq + 127) / 128, a->H, a->B), dim3(XA_T), 0, s, p);
+  else hipLaunchKernelGGL(x3_attn_fwd_kernel<128>, dim3((a->Tq + 63) / 64, a->H, a->B), dim3(XA_T), 0, s, p);
+  UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
+}
+
+extern "C" int unimm_x3_attn_bwd(const unimm_attn_bwd_args* a, void* stream) {
+  if (a == nullptr || !a->out || !a->dout || !a->lse || !a->delta || !a->dq || !a->dk || !a->dv) return UNIMM_E_ARG;
+  unimm_attn_args f{};
+  f.q = a->q; f.k = a->k; f.v = a->v; f.out = (void*)a->out; f.lse = (float*)a->lse; f.mask = a->mask;
+  f.q_off = a->q_off; f.q_len = a->q_len; f.k_off = a->k_off; f.k_len = a->k_len;
+  f.B = a->B; f.H = a->H; f.Tq = a->Tq; f.Tk = a->Tk; f.D = a->D;
+  f.ldq = a->ldq; f.ldk = a->ldk; f.ldv = a->ldv; f.ldo = a->ldo;
+  f.mask_q_stride = a->mask_q_stride; f.mask_b_stride = a->mask_b_stride; f.scale = a->scale;
+  f.drop_key = a->drop_key; f.drop_thr = a->drop_thr; f.drop_scale = a->drop_scale; f.drop_salt = a->drop_salt;
+  AttnF32 p;
+  const int rc = fill_attn(&f, p);
+  if (rc != UNIMM_OK) return rc;
+  if ((a->lddo % 4) || (a->lddq % 4) || (a->lddk % 4) || (a->lddv % 4)) return UNIMM_E_ALIGN;
+  if (((uintptr_t)a->dout | (uintptr_t)a->dq | (uintptr_t)a->dk | (uintptr_t)a->dv) & 15) return UNIMM_E_ALIGN;
+  p.o = (const float*)a->out; p.out = nullptr; p.dout = (const float*)a->dout; p.delta = a->delta;
+  p.dq = (float*)a->dq; p.dk = (float*)a->dk; p.dv = (float*)a->dv;
+  p.lddo = a->lddo; p.lddq = a->lddq; p.lddk = a->lddk; p.lddv = a->lddv;
+  hipStream_t s = (hipStream_t)stream;
+  if (a->D == 64) {
+    hipLaunchKernelGGL(x3_attn_bwd_dq_kernel<64>, dim3((a->Tq + 127) / 128, a->H, a->B), dim3(XA_T), 0, s, p);
+    hipLaunchKernelGGL(x3_attn_bwd_dkv_kernel<64>, dim3((a->Tk + 127) / 128, a->H, a->B), dim3(XA_T), 0, s, p);
+  } else {
+    hipLaunchKernelGGL(x3_attn_bwd_dq_kernel<128>, dim3((a->Tq + 63) / 64, a->H, a->B), dim3(XA_T), 0, s, p);
+    hipLaunchKernelGGL(x3_attn_bwd_dkv_kernel<128>, dim3((a->Tk + 63) / 64, a->H, a->B), dim3(XA_T), 0, s, p);
+  }
+  UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
+}

@@ -877,29 +877,9 @@ class Engine:
     def losses(self, out, inp):
         return self._on_text_stream(self._losses, out, inp)
 
-    def _forward(self, inp: dict, train: bool, save: bool, lm_rows: str, want_pred_v: bool):
-        """Runs the trunk + heads.  Returns a dict of outputs and (when save) the tape for backward.
-        lm_rows: 'labelled' (decode only rows that carry a label / weight), 'all', or 'none'."""
-        cfg = self.cfg
-        dev = self.arena.device
-        self.refresh_weights()
-        ids = inp["input_ids"]
-        B, T = ids.shape
-        feat = inp["image_feat"]
-        R = feat.shape[1]
-        img_idx = inp.get("image_index")
-        if img_idx is not None:
-            img_idx = img_idx.to(dev, dtype=torch.int64, non_blocking=True).reshape(-1)
-            if img_idx.numel() != B:
-                raise ValueError("image_index needs one entry per sequence")
-        elif feat.shape[0] != B:
-            raise ValueError(f"image_feat has {feat.shape[0]} rows for {B} sequences and no image_index was given")
-        if T > 256 or R > 256:
-            raise ValueError("sequence / region count above 256 is not supported by the attention kernels")
-        H, Hv = cfg.hidden_size, cfg.v_hidden_size
-        st = dict(train=train, tape=[] if save else None)
-        tape = st["tape"]
-
+    def _prep_masks(self, inp, B, T, R, dev):
+        """Packed attention masks of the step: (text mask, image key mask, co-attention mask), each (words, q stride, b stride)."""
+        ids, feat = inp["input_ids"], inp["image_feat"]
         # ---- masks (models/vilbert_dialog.py:1374-1431) ------------------------------------------
         am = inp.get("attention_mask")
         spec = am if isinstance(am, DialogMaskSpec) else None
@@ -935,34 +915,12 @@ class Engine:
             vmask = self._pack_mask(im, dev, R)
             comask = self._pack_mask(cm, dev, R)
         self._dev_masks = []
-        # ---- image embedding first: it does not depend on the plan, so the image stream already has work while the
-        # host waits for the header below (models/vilbert_dialog.py:360-383)
-        A = self.arena
-        F = cfg.v_feature_size
-        self._to_img()                        # masks are packed (and the previous step is behind us): the image side may start
-        with self._img():                     # image embedding: beside the first text layers
-            featd = feat.to(dev, dtype=F32, non_blocking=True)
-            locd = inp["image_loc"].to(dev, dtype=F32, non_blocking=True)
-            if img_idx is not None:             # one entry per image on the wire, expanded on the device (train.py:413-432)
-                featd, locd = featd.index_select(0, img_idx), locd.index_select(0, img_idx)
-            featd, locd = featd.contiguous().view(B * R, F), locd.contiguous().view(B * R, 5)
-            packed = torch.empty((B * R, self.vemb_k), dtype=BF16, device=dev)
-            L.pack_image(featd, locd, packed, B * R, F, self.vemb_k)
-            prev = torch.empty((B * R, Hv), dtype=F32, device=dev)
-            L.gemm_nt(packed, self.vemb_w, prev, bias=self.vemb_b, M=B * R, N=Hv, K=self.vemb_k)
-            d_embv = self._drop("emb_v", cfg.hidden_dropout_prob, train)
-            xv32, xv, mv, rv = self._layernorm(prev, "emb_v", save, drop=d_embv)
-            if save:
-                v = "bert.v_embeddings."
+        return tmask, vmask, comask
 
-                def bwd_embv(dxv):
-                    dbias = A.grad(v + "image_embeddings.bias")
-                    before = dbias.clone()
-                    dpre, _ = self._layernorm_bwd(dxv, prev, mv, rv, "emb_v", dbias=dbias, out_drop=d_embv, defer=False)
-                    A.grad(v + "image_location_embeddings.bias").add_(dbias - before)
-                    self._wgrad(dpre, packed, A.grad(v + "image_embeddings.weight"), B * R, Hv, F)
-                    self._wgrad(dpre, packed[:, F:], A.grad(v + "image_location_embeddings.weight"), B * R, Hv, 5)
-
+    def _prep_plan(self, inp, B, T, R, tmask, comask, lm_rows, dev):
+        """Input conversions + the plan of the step (one device->host copy): valid prefix lengths of the unpadded schedule,
+        the rows the MLM head decodes, loss denominators as device words.  Returns a dict."""
+        ids = inp["input_ids"]
         # ---- plan of the step: everything the host has to know, in ONE device->host copy ------------------
         # (valid prefix lengths for the unpadded schedule, the number of rows the MLM head decodes, the NSP class
         # weights when they live on the device); row maps and the decoded rows' index lists are then built on the
@@ -1023,6 +981,64 @@ class Engine:
         Mt = plan["Mv"] if plan is not None else B * T      # text rows actually computed
         self._step_rows = Mt
 
+        return dict(ids32=ids32, typ32=typ32, pos32=pos32, labels=labels, lab32=lab32, w32=w32, il32=il32, plan=plan, sel=sel,
+                    n_img=n_img, dyn=dyn, st_nspw=st_nspw, var=var, Mt=Mt)
+
+    def _forward(self, inp: dict, train: bool, save: bool, lm_rows: str, want_pred_v: bool):
+        """Runs the trunk + heads.  Returns a dict of outputs and (when save) the tape for backward.
+        lm_rows: 'labelled' (decode only rows that carry a label / weight), 'all', or 'none'."""
+        cfg = self.cfg
+        dev = self.arena.device
+        self.refresh_weights()
+        ids = inp["input_ids"]
+        B, T = ids.shape
+        feat = inp["image_feat"]
+        R = feat.shape[1]
+        img_idx = inp.get("image_index")
+        if img_idx is not None:
+            img_idx = img_idx.to(dev, dtype=torch.int64, non_blocking=True).reshape(-1)
+            if img_idx.numel() != B:
+                raise ValueError("image_index needs one entry per sequence")
+        elif feat.shape[0] != B:
+            raise ValueError(f"image_feat has {feat.shape[0]} rows for {B} sequences and no image_index was given")
+        if T > 256 or R > 256:
+            raise ValueError("sequence / region count above 256 is not supported by the attention kernels")
+        H, Hv = cfg.hidden_size, cfg.v_hidden_size
+        st = dict(train=train, tape=[] if save else None)
+        tape = st["tape"]
+
+        tmask, vmask, comask = self._prep_masks(inp, B, T, R, dev)
+        # ---- image embedding first: it does not depend on the plan, so the image stream already has work while the
+        # host waits for the header below (models/vilbert_dialog.py:360-383)
+        A = self.arena
+        F = cfg.v_feature_size
+        self._to_img()                        # masks are packed (and the previous step is behind us): the image side may start
+        with self._img():                     # image embedding: beside the first text layers
+            featd = feat.to(dev, dtype=F32, non_blocking=True)
+            locd = inp["image_loc"].to(dev, dtype=F32, non_blocking=True)
+            if img_idx is not None:             # one entry per image on the wire, expanded on the device (train.py:413-432)
+                featd, locd = featd.index_select(0, img_idx), locd.index_select(0, img_idx)
+            featd, locd = featd.contiguous().view(B * R, F), locd.contiguous().view(B * R, 5)
+            packed = torch.empty((B * R, self.vemb_k), dtype=BF16, device=dev)
+            L.pack_image(featd, locd, packed, B * R, F, self.vemb_k)
+            prev = torch.empty((B * R, Hv), dtype=F32, device=dev)
+            L.gemm_nt(packed, self.vemb_w, prev, bias=self.vemb_b, M=B * R, N=Hv, K=self.vemb_k)
+            d_embv = self._drop("emb_v", cfg.hidden_dropout_prob, train)
+            xv32, xv, mv, rv = self._layernorm(prev, "emb_v", save, drop=d_embv)
+            if save:
+                v = "bert.v_embeddings."
+
+                def bwd_embv(dxv):
+                    dbias = A.grad(v + "image_embeddings.bias")
+                    before = dbias.clone()
+                    dpre, _ = self._layernorm_bwd(dxv, prev, mv, rv, "emb_v", dbias=dbias, out_drop=d_embv, defer=False)
+                    A.grad(v + "image_location_embeddings.bias").add_(dbias - before)
+                    self._wgrad(dpre, packed, A.grad(v + "image_embeddings.weight"), B * R, Hv, F)
+                    self._wgrad(dpre, packed[:, F:], A.grad(v + "image_location_embeddings.weight"), B * R, Hv, 5)
+
+        pl = self._prep_plan(inp, B, T, R, tmask, comask, lm_rows, dev)
+        ids32, typ32, pos32, labels = pl["ids32"], pl["typ32"], pl["pos32"], pl["labels"]
+        il32, plan, sel, n_img, dyn, st_nspw, var, Mt = (pl[k] for k in ("il32", "plan", "sel", "n_img", "dyn", "st_nspw", "var", "Mt"))
         # ---- embeddings --------------------------------------------------------------------------
         erows = plan["rows"] if plan is not None else None      # packed row -> padded row (the kernels gather through it)
         emd = plan["var"][2] if plan is not None else None

@@ -13,7 +13,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libunimm_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROP_RESID, EPI_BIAS_RELU, EPI_DGELU, EPI_ADD, EPI_MUL, EPI_BIAS_GELU_DG = range(8)
 
@@ -69,6 +69,9 @@ def lib():
     L.unimm_gemm_nt.argtypes = [VP, VP]
     L.unimm_attn_fwd.argtypes = [VP, VP]
     L.unimm_attn_bwd.argtypes = [VP, VP]
+    L.unimm_x3_split.argtypes = [VP, VP]
+    L.unimm_x3_attn_fwd.argtypes = [VP, VP]
+    L.unimm_x3_attn_bwd.argtypes = [VP, VP]
     L.unimm_attn_probs.argtypes = [VP, VP, VP]
     L.unimm_gemm_tn_grouped.argtypes = [VP, I32, VP]
     L.unimm_gemm_tn_grouped_ws.argtypes = [VP, I32, I32, VP, I64, VP]
@@ -87,7 +90,10 @@ SYMBOLS = ["unimm_version", "unimm_arch", "unimm_gemm_nt", "unimm_gemm_tn", "uni
            "unimm_pack_image", "unimm_mul_dropout", "unimm_mul_dropout_bwd", "unimm_lm_loss_fwd",
            "unimm_lm_loss_bwd", "unimm_kl_loss_fwd", "unimm_kl_loss_bwd", "unimm_nsp_loss_fwd",
            "unimm_nsp_loss_bwd", "unimm_reduce_sum", "unimm_segment_sum", "unimm_gelu_bwd", "unimm_gather_rows", "unimm_prof_enable", "unimm_prof_collect", "unimm_adamw_step", "unimm_transpose_cast_grouped", "unimm_mask_synth", "unimm_neural_ndcg", "unimm_plan_lengths", "unimm_plan_build", "unimm_layernorm_bwd_partials",
-           "unimm_colpartials_finish_grouped", "unimm_gemm_tn_grouped_ws", "unimm_linear_f32", "unimm_rows_add_f32", "unimm_transpose_bf16", "unimm_sum_slabs_bf16", "unimm_attn_probs"]
+           "unimm_colpartials_finish_grouped", "unimm_gemm_tn_grouped_ws", "unimm_linear_f32", "unimm_rows_add_f32", "unimm_transpose_bf16", "unimm_sum_slabs_bf16", "unimm_attn_probs",
+           # the fp32-accuracy mode (csrc/x3ops.hip)
+           "unimm_x3_split", "unimm_x3_split_wt", "unimm_x3_layernorm_bwd_partials", "unimm_embed_bwd_f32", "unimm_x3_lm_loss_bwd",
+           "unimm_x3_kl_loss_bwd", "unimm_x3_rows_add", "unimm_x3_attn_fwd", "unimm_x3_attn_bwd"]
 
 
 def _check(rc, what):
@@ -731,3 +737,115 @@ def prof_collect():
     ms, fl, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_int32 * n)()
     _check(lib().unimm_prof_collect(ms, fl, cnt, C.c_int32(n)), "unimm_prof_collect")
     return {gemm_variant_name(i): (ms[i], fl[i], cnt[i]) for i in range(n) if cnt[i] > 0}
+
+
+# ---------------------------------------------------------------------------------------------
+# fp32-accuracy mode (csrc/x3ops.hip; include/unimm_hip.h "fp32x3")
+# ---------------------------------------------------------------------------------------------
+X3_COPY, X3_ADD, X3_GELU, X3_MUL_DGELU = range(4)
+
+
+class X3SplitArgs(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("out32", C.c_void_p), ("out3", C.c_void_p), ("rows", C.c_int64),
+                ("cols", C.c_int32), ("cp", C.c_int32), ("lda", C.c_int32), ("ldb", C.c_int32), ("ld32", C.c_int32),
+                ("op", C.c_int32), ("wtype", C.c_int32)]
+
+
+def x3_split(a, out3=None, out32=None, op=X3_COPY, b=None, rows=None, cols=None, cp=None, wtype=False):
+    """y = op(a, b) (fp32 [rows, cols]) -> out32 (fp32) and / or out3 (split operand, bf16 [rows, 3 cp])."""
+    _dev(a, b, out32, out3)
+    st = getattr(_tls, "x3s", None)
+    if st is None:
+        s = X3SplitArgs()
+        st = _tls.x3s = (s, C.addressof(s), lib().unimm_x3_split)
+    s, addr, fn = st
+    s.a, s.b, s.out32, s.out3 = a.data_ptr(), _P(b), _P(out32), _P(out3)
+    s.rows = a.shape[0] if rows is None else rows
+    s.cols = a.shape[1] if cols is None else cols
+    s.cp = (out3.shape[1] // 3) if cp is None else cp
+    s.lda, s.ldb, s.ld32 = a.stride(0), (b.stride(0) if b is not None else 0), (out32.stride(0) if out32 is not None else 0)
+    s.op, s.wtype = op, 1 if wtype else 0
+    rc = fn(addr, _stream())
+    if rc != 0:
+        _check(rc, "unimm_x3_split")
+
+
+def x3_split_wt(src, dst, R, C_, Rp):
+    """transposed w-type split: src fp32 [R, C] -> dst bf16 [C, 3 Rp] (zero-filled by the caller once)."""
+    _dev(src, dst)
+    _check(lib().unimm_x3_split_wt(_ptr(src), _ptr(dst), C.c_int32(R), C.c_int32(C_), C.c_int32(src.stride(0)), C.c_int32(Rp),
+                                   _stream()), "unimm_x3_split_wt")
+
+
+def x3_layernorm_bwd_partials(dy, x, mean, rstd, gamma, dx32, dxd3, partials, M, H, drop=None, out_drop=None, m_dev=None):
+    drop = drop or NO_DROP
+    out_drop = out_drop or NO_DROP
+    _dev(dy, x, mean, rstd, gamma, dx32, dxd3, partials)
+    blocks = C.c_int32(0)
+    _check(lib().unimm_x3_layernorm_bwd_partials(
+        _ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(dx32), _ptr(dxd3), _ptr(partials), C.c_int32(M), C.c_int32(H),
+        C.c_uint32(drop[0]), C.c_uint32(drop[1]), C.c_float(drop[2]), C.c_uint32(out_drop[0]), C.c_uint32(out_drop[1]),
+        C.c_float(out_drop[2]), C.byref(blocks), _ptr(m_dev), C.c_void_p(_salt(drop, out_drop)), _stream()),
+        "unimm_x3_layernorm_bwd_partials")
+    return blocks.value
+
+
+def embed_bwd_f32(ids, pos, typ, word, post, type_, ext, gamma, beta, dy, dword, dpos, dtype, dext, dgamma, dbeta,
+                  partials, M, H, type_vocab=2, eps=1e-12, drop=NO_DROP, m_dev=None, rows=None):
+    a = _embed_args(ids, pos, typ, word, post, type_, ext, gamma, beta, M, H, type_vocab, eps, drop, m_dev, rows)
+    _dev(dy, dword, dpos, dtype, dext, dgamma, dbeta, partials)
+    _check(lib().unimm_embed_bwd_f32(C.byref(a), _ptr(dy), _ptr(dword), _ptr(dpos), _ptr(dtype), _ptr(dext), _ptr(dgamma),
+                                     _ptr(dbeta), _ptr(partials), _stream()), "unimm_embed_bwd_f32")
+
+
+def x3_lm_loss_bwd(logits, labels, weights, lse, g, inv_denom, out3, n, V, n_dev=None, inv_dev=None):
+    _dev(logits, labels, weights, lse, g, out3)
+    _check(lib().unimm_x3_lm_loss_bwd(_ptr(logits), _ptr(labels), _ptr(weights), _ptr(lse), _ptr(g), C.c_float(inv_denom),
+                                      _ptr(out3), C.c_int32(n), C.c_int32(V), C.c_int32(logits.stride(0)),
+                                      C.c_int32(out3.shape[1] // 3), _ptr(n_dev), _ptr(inv_dev), _stream()), "unimm_x3_lm_loss_bwd")
+
+
+def x3_kl_loss_bwd(pred, target, label, lse, g, inv_denom, out3, rows, Cn, inv_dev=None):
+    _dev(pred, target, label, lse, g, out3)
+    _check(lib().unimm_x3_kl_loss_bwd(_ptr(pred), _ptr(target), _ptr(label), _ptr(lse), _ptr(g), C.c_float(inv_denom),
+                                      _ptr(out3), C.c_int32(rows), C.c_int32(Cn), C.c_int32(pred.stride(0)),
+                                      C.c_int32(out3.shape[1] // 3), _ptr(inv_dev), _stream()), "unimm_x3_kl_loss_bwd")
+
+
+def x3_rows_add(dst, idx, src, n, H):
+    _dev(dst, idx, src)
+    _check(lib().unimm_x3_rows_add(_ptr(dst), _ptr(idx), _ptr(src), C.c_int32(n), C.c_int32(H), C.c_int32(dst.stride(0)),
+                                   _stream()), "unimm_x3_rows_add")
+
+
+def x3_attn_fwd(q, k, v, out, lse, mask, B, H, Tq, Tk, D, scale, mask_q_stride, mask_b_stride, drop=NO_DROP, qvar=None, kvar=None):
+    """unimm_attn_fwd on fp32 q / k / v / out (2-D views, row stride = stride(0))."""
+    _dev(q, k, v, out, lse, mask)
+    a = AttnArgs()
+    a.q, a.k, a.v, a.out, a.lse, a.mask = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _P(lse), mask.data_ptr()
+    a.q_off, a.q_len = (qvar[0].data_ptr(), qvar[1].data_ptr()) if qvar is not None else (None, None)
+    a.k_off, a.k_len = (kvar[0].data_ptr(), kvar[1].data_ptr()) if kvar is not None else (None, None)
+    a.B, a.H, a.Tq, a.Tk, a.D = B, H, Tq, Tk, D
+    a.ldq, a.ldk, a.ldv, a.ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
+    a.mask_q_stride, a.mask_b_stride, a.scale = mask_q_stride, mask_b_stride, scale
+    a.drop_key, a.drop_thr, a.drop_scale = drop[:3]
+    a.drop_salt = _salt(drop)
+    _check(lib().unimm_x3_attn_fwd(C.byref(a), _stream()), "unimm_x3_attn_fwd")
+
+
+def x3_attn_bwd(q, k, v, out, dout, lse, delta, dq, dk, dv, mask, B, H, Tq, Tk, D, scale, mask_q_stride, mask_b_stride,
+                drop=NO_DROP, qvar=None, kvar=None):
+    _dev(q, k, v, out, dout, lse, delta, dq, dk, dv, mask)
+    a = AttnBwdArgs()
+    a.q_off, a.q_len = (qvar[0].data_ptr(), qvar[1].data_ptr()) if qvar is not None else (None, None)
+    a.k_off, a.k_len = (kvar[0].data_ptr(), kvar[1].data_ptr()) if kvar is not None else (None, None)
+    a.q, a.k, a.v, a.out, a.dout = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr()
+    a.lse, a.delta, a.dq, a.dk, a.dv, a.mask = (lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
+                                                mask.data_ptr())
+    a.B, a.H, a.Tq, a.Tk, a.D = B, H, Tq, Tk, D
+    a.ldq, a.ldk, a.ldv, a.ldo, a.lddo = q.stride(0), k.stride(0), v.stride(0), out.stride(0), dout.stride(0)
+    a.lddq, a.lddk, a.lddv = dq.stride(0), dk.stride(0), dv.stride(0)
+    a.mask_q_stride, a.mask_b_stride, a.scale = mask_q_stride, mask_b_stride, scale
+    a.drop_key, a.drop_thr, a.drop_scale = drop[:3]
+    a.drop_salt = _salt(drop)
+    _check(lib().unimm_x3_attn_bwd(C.byref(a), _stream()), "unimm_x3_attn_bwd")

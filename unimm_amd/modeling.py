@@ -122,7 +122,11 @@ class _HotPath(torch.autograd.Function):
 class BertForMultiModalPreTraining(nn.Module):
     """BERT model with multi modal pre-training heads (drop-in for models/vilbert_dialog.py:1496)."""
 
-    def __init__(self, config):
+    def __init__(self, config, compute_dtype="bf16"):
+        """`compute_dtype` (an extension of the reference's one-argument constructor): "bf16" = the reference's autocast
+        class (train.py:445: half-precision matmuls, fp32 LayerNorm / softmax / losses) on the bf16 MFMA engine; "fp32x3" =
+        fp32-grade arithmetic end to end for callers that run WITHOUT autocast (dense_annotation_finetuning.py:253), on the
+        same GEMM kernels over split operands (unimm_amd/engine_x3.py)."""
         super().__init__()
         if not isinstance(config, BertConfig):
             raise ValueError(
@@ -131,7 +135,14 @@ class BertForMultiModalPreTraining(nn.Module):
         self.config = config
         _build_param_tree(self, config)
         self.predict_feature = config.predict_feature
-        self._engine = Engine(self, config)
+        if compute_dtype not in ("bf16", "fp32x3"):
+            raise ValueError(f"compute_dtype must be 'bf16' or 'fp32x3', got {compute_dtype!r}")
+        self.compute_dtype = compute_dtype
+        if compute_dtype == "fp32x3":
+            from .engine_x3 import EngineX3
+            self._engine = EngineX3(self, config)
+        else:
+            self._engine = Engine(self, config)
         # values loaded into the Parameters must reach the engine's bf16 / transposed weight copies
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._engine.invalidate_weights())
 
@@ -252,12 +263,12 @@ class BertForMultiModalPreTraining(nn.Module):
 class VisualDialogEncoder(nn.Module):
     """Drop-in for models/visual_dialog_encoder.py:8-50 (what train.py / val_lm.py instantiate)."""
 
-    def __init__(self, config_path, pretrained="bert-base-uncased"):
+    def __init__(self, config_path, pretrained="bert-base-uncased", compute_dtype="bf16"):
         super().__init__()
         config = BertConfig.from_json_file(config_path)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            self.bert_pretrained = BertForMultiModalPreTraining.from_pretrained(pretrained, config)
+            self.bert_pretrained = BertForMultiModalPreTraining.from_pretrained(pretrained, config, compute_dtype=compute_dtype)
         self.bert_pretrained.train()
 
     def forward(self, input_ids, image_feat, image_loc, sep_indices=None, sep_len=None, token_type_ids=None,
