@@ -88,6 +88,10 @@ def parse():
                     help="run the step as replayed hipGraphs (unimm_amd/graphs.py: two graph launches per step instead of ~650 "
                          "host calls; auto = on for <= %d sequences per GPU, where the host would otherwise bound the " % GRAPHS_AUTO_MAX_SEQ +
                          "step). The timed region then has no per-launch events: the roofline block comes from eager steps after it.")
+    ap.add_argument("--compute", choices=["bf16", "fp32x3"], default="bf16",
+                    help="bf16 (default, the headline: the reference's autocast class) or fp32x3 = the fp32-accuracy engine "
+                         "(unimm_amd/engine_x3.py: bf16 MFMA GEMMs over split operands hi/lo, fp32 attention and gradient "
+                         "stream): the arithmetic dense_annotation_finetuning.py:253 runs in (no autocast)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-tile", type=int, default=0, metavar="CODE",
                     help="tuning: unimm_gemm_nt_args.tile = CODE for every launch of the run (1000 x tile columns per group + 100 x {1 persistent, "
@@ -279,7 +283,7 @@ def main():
     from unimm_amd.parallel import DataParallelRCCL
 
     torch.manual_seed(1234)                       # identical init on every rank (+ broadcast in the wrapper)
-    enc = VisualDialogEncoder(args.config).to(dev)
+    enc = VisualDialogEncoder(args.config, compute_dtype=args.compute).to(dev)
     enc.train()
     model = enc.bert_pretrained
     model.set_dropout_seed(1234 + rank)
@@ -420,7 +424,7 @@ def main():
         torch.cuda.synchronize()
 
     use_graphs = (args.graphs == "on" or (args.graphs == "auto" and per_gpu <= GRAPHS_AUTO_MAX_SEQ)) and args.workload == "train" \
-        and not args.compact_inputs and not args.host_profile
+        and not args.compact_inputs and not args.host_profile and args.compute == "bf16"
     gx = None
     if use_graphs:
         gx = model.engine.enable_graphs(True)
@@ -589,7 +593,7 @@ def main():
         if args.workload == "dense":
             metric = f"dialog-sequences/sec (fwd+bwd) dense-annotation fine-tune micro-step at bs={per_gpu} seq=256 regions=36(+1 <IMG>)"
             wl = ("dense-annotation fine-tune micro-step (BASELINE configs[3]): bert_base_6layer_6conect, discriminative inputs, "
-                  "sequences_per_image=2, nsp_loss_coeff=0, batch_multiply=16 (gradient exchange every 16th step), bf16, "
+                  "sequences_per_image=2, nsp_loss_coeff=0, batch_multiply=16 (gradient exchange every 16th step), " + args.compute + ", "
                   "fwd+bwd, " + ("objective = NeuralNDCG^T over the step's options + LM loss (dense_annotation_finetuning.py:263-293), "
                               "optimizer not included" if args.dense_objective == "ranking"
                               else "LM + region-KL proxy objective, ranking loss and optimizer not included"))
@@ -605,8 +609,10 @@ def main():
             "metric": metric,
             "value": round(value, 2), "unit": "dialog-sequences/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": args.scaling, "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": wl,
+            "scaling": args.scaling, "vs_baseline": None,
+            "dtype": "bf16" if args.compute == "bf16" else "fp32x3 (bf16 MFMA over split operands hi+lo, fp32 accumulate; fp32 attention / activations / gradients)",
+            "data": "synthetic",
+            "config": {"workload": wl + ("" if args.compute == "bf16" else "; compute_dtype=fp32x3 (the reference's no-autocast arithmetic class)"),
                        "global_batch": global_batch, "per_gpu_batch": per_gpu, "seq_len": 256, "regions": 37,
                        "parallelism": f"dp{world}", "lm_rows_decoded_per_seq": round(n_lm_rows / per_gpu, 2),
                        "executor": ("hipGraph replay (unimm_amd/graphs.py): " + json.dumps(graph_stats)) if graph_stats else "eager launches",
@@ -632,6 +638,9 @@ def main():
                          "exclusive": exclusive,
                          "padded_equivalent_tflops": round(3 * f_fwd * 1e9 * value / 1e12, 1)},
         }
+        if args.compute != "bf16":
+            out["roofline"]["note"] = ("fp32x3: every GEMM runs over three bf16 planes (hi hi + lo hi + hi lo): the FLOPs priced here are the "
+                                       "EXECUTED bf16 MFMA FLOPs, 3x the algorithmic fp32 FLOPs of the layer")
         if prof_all:
             out["roofline"].update(all_gemm_tflops=round(gemm_fl / (gemm_ms * 1e-3) / 1e12, 1),
                                    gemm_share_of_step=round(gemm_ms * 1e-3 / prof_steps / (dt / args.steps), 3),
