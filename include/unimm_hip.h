@@ -504,6 +504,12 @@ int unimm_x3_attn_bwd(const unimm_attn_bwd_args* args, void* stream);
  * launch-rate-bound step should not pay for all ~340 GEMM launches); 0 = off. */
 int unimm_prof_enable(int32_t on);
 int unimm_prof_collect(double* ms, double* flops, int32_t* count, int32_t nvar);
+/* Caller-side tag (0 .. 7, default 0) carried by the unimm_gemm_nt launches that follow; unimm_prof_tagged returns, per tag, the
+ * summed milliseconds / FLOPs / launch counts of the records the LAST unimm_prof_collect consumed.  The engine tags the launches
+ * it issues from inside a BertConnectionLayer (models/vilbert_dialog.py:655-783) with 1: bench.py's
+ * `roofline.coattention_gemms`, the figure north_star's ">= 40 % MFMA utilisation on the co-attention GEMMs" is judged by. */
+int unimm_prof_tag(int32_t tag);
+int unimm_prof_tagged(double* ms, double* flops, int32_t* count, int32_t ntags);
 
 #ifdef __cplusplus
 }

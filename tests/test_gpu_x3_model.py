@@ -308,3 +308,48 @@ def test_full_config_b6_backward_matches_reference_golden_fp32(golden_dir, full5
     assert nslices > 100
     print(f"\nfp32x3 full-config backward vs the reference: worst norm error {worst_n:.2e}; sampled slices: worst L2 {worst_l2:.2e} "
           f"({worst_name}), worst element / scale {worst_max:.2e}")
+
+
+def test_optimizer_step_and_ranking_gradient_in_fp32_mode(golden_dir):
+    """The rest of the dense fine-tune iteration around the fp32-accuracy engine: a gradient arriving through the returned NSP
+    scores (the NeuralNDCG^T term of dense_annotation_finetuning.py:286-293) and a FusedAdamW step whose updated weights must
+    reach the split weight copies (the next forward equals the oracle's forward on the updated state dict)."""
+    from oracle import vilbert_ref as R
+    from unimm_amd.optim import FusedAdamW
+    model, ocfg, sd = build_small(golden_dir)
+    model.eval()
+    g = np.load(os.path.join(golden_dir, "small_dis.npz"))
+    args, kw = kwargs_from(g)
+    eng = model.engine
+    eng.ensure(torch.device("cuda", 0))
+    opt = FusedAdamW([dict(params=list(model.parameters()), lr=1e-3, weight_decay=0.01)], eng, lr=1e-3)
+    opt.zero_grad()
+    lm, img, nsp_l, _, _, nsp = model(*args, **kw, _want_lm_scores=False)
+    wvec = torch.linspace(-1.0, 1.0, nsp.numel(), device=nsp.device).view_as(nsp)
+    (lm.sum() + (torch.softmax(nsp, -1) * wvec).sum()).backward()          # a loss on the scores + the LM loss, no NSP / image term
+    torch.cuda.synchronize()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != R.TIED[0]}
+    leaves[R.TIED[0]] = leaves[R.TIED[1]]
+    out = R.forward(leaves, ocfg, *args, **kw)
+    (out["lm_loss"].sum() + (torch.softmax(out["nsp"], -1) * wvec.cpu()).sum()).backward()
+    worst = 0.0
+    for n, p in model.named_parameters():
+        if p.grad is None:
+            assert leaves[n].grad is None or float(leaves[n].grad.abs().max()) == 0.0, n
+            continue
+        want = leaves[n].grad
+        if want is None:
+            assert float(p.grad.abs().max()) == 0.0, n
+            continue
+        worst = max(worst, float((p.grad.cpu() - want).abs().max() / want.abs().max().clamp_min(1e-6)))
+    assert worst <= 1e-3, worst
+    opt.step()
+    with torch.no_grad():
+        lm2, _, _, _, _, nsp2 = model(*args, **kw, _want_lm_scores=False)
+        new_sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        new_sd[R.TIED[0]] = new_sd[R.TIED[1]]
+        ref2 = R.forward(new_sd, ocfg, *args, **kw)
+    assert abs(float(lm2) - float(lm)) > 1e-3                 # the step really changed the model
+    print()
+    close(lm2, ref2["lm_loss"], what="lm_loss after one AdamW step")
+    close(nsp2, ref2["nsp"], what="nsp after one AdamW step")

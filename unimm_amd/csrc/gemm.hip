@@ -1353,7 +1353,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmTnGroup grp) {
 // events on the launch stream; unimm_prof_collect() sums elapsed time and algorithmic FLOPs per kernel
 // variant.  Off by default (no events, no overhead).
 // ------------------------------------------------------------------------------------------------
-struct ProfRec { hipEvent_t a, b; int variant; double flops; };
+struct ProfRec { hipEvent_t a, b; int variant; int tag; double flops; };
 constexpr int PROF_MAX = 1 << 16;
 // One variant per kernel SYMBOL (what rocprofv3 --stats lists): gemm_nt / gemm_ntp x tile x epilogue x output type, and
 // the three weight-gradient kernels.  NT: ((persistent * 16 + tile code) * 8 + epilogue) * 2 + out_f32 (tile code = the
@@ -1369,6 +1369,12 @@ bool g_prof_tn_only = false;        // unimm_prof_enable(2): only the weight-gra
                                     // are host time; a rank whose step is launch-rate-bound should not pay them 340 times)
 ProfRec* g_prof = nullptr;
 int g_prof_n = 0;
+// Caller-side tag of the launches that follow (unimm_prof_tag): bench.py's `roofline.coattention_gemms` = the GEMM launches
+// the engine issues from inside a BertConnectionLayer (models/vilbert_dialog.py:655-783), forward and backward.
+constexpr int PROF_TAGS = 8;
+int g_prof_tag = 0;
+double g_tag_ms[PROF_TAGS], g_tag_flops[PROF_TAGS];
+int g_tag_count[PROF_TAGS];
 
 inline ProfRec* prof_begin(int variant, double flops, hipStream_t s) {
   if (!g_prof_on || g_prof_n >= PROF_MAX || (g_prof_tn_only && variant < PROF_TN0)) return nullptr;
@@ -1376,7 +1382,7 @@ inline ProfRec* prof_begin(int variant, double flops, hipStream_t s) {
   if (r->a == nullptr) {
     if (hipEventCreate(&r->a) != hipSuccess || hipEventCreate(&r->b) != hipSuccess) return nullptr;
   }
-  r->variant = variant; r->flops = flops;
+  r->variant = variant; r->flops = flops; r->tag = g_prof_tag;
   hipEventRecord(r->a, s);
   ++g_prof_n;
   return r;
@@ -1684,6 +1690,7 @@ extern "C" int unimm_prof_enable(int32_t on) {
 extern "C" int unimm_prof_collect(double* ms, double* flops, int32_t* count, int32_t nvar) {
   if (!ms || !flops || !count || nvar < PROF_VARIANTS) return UNIMM_E_ARG;
   for (int v = 0; v < nvar; ++v) { ms[v] = 0.0; flops[v] = 0.0; count[v] = 0; }
+  for (int t = 0; t < PROF_TAGS; ++t) { g_tag_ms[t] = 0.0; g_tag_flops[t] = 0.0; g_tag_count[t] = 0; }
   for (int i = 0; i < g_prof_n; ++i) {
     ProfRec& r = g_prof[i];
     if (hipEventSynchronize(r.b) != hipSuccess) return UNIMM_E_HIP;
@@ -1691,7 +1698,24 @@ extern "C" int unimm_prof_collect(double* ms, double* flops, int32_t* count, int
     if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) return UNIMM_E_HIP;
     if (r.variant < 0 || r.variant >= nvar) return UNIMM_E_ARG;
     ms[r.variant] += t; flops[r.variant] += r.flops; count[r.variant] += 1;
+    if (r.variant < PROF_TN0 && r.tag >= 0 && r.tag < PROF_TAGS) {      // NT launches only: grouped TN launches mix layers
+      g_tag_ms[r.tag] += t; g_tag_flops[r.tag] += r.flops; g_tag_count[r.tag] += 1;
+    }
   }
   g_prof_n = 0;
+  return UNIMM_OK;
+}
+
+extern "C" int unimm_prof_tag(int32_t tag) {
+  if (tag < 0 || tag >= PROF_TAGS) return UNIMM_E_ARG;
+  g_prof_tag = tag;
+  return UNIMM_OK;
+}
+
+extern "C" int unimm_prof_tagged(double* ms, double* flops, int32_t* count, int32_t ntags) {
+  if (!ms || !flops || !count || ntags < 1) return UNIMM_E_ARG;
+  for (int t = 0; t < ntags; ++t) {
+    ms[t] = t < PROF_TAGS ? g_tag_ms[t] : 0.0; flops[t] = t < PROF_TAGS ? g_tag_flops[t] : 0.0; count[t] = t < PROF_TAGS ? g_tag_count[t] : 0;
+  }
   return UNIMM_OK;
 }

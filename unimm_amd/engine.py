@@ -123,6 +123,7 @@ class Engine:
         self.image_head_side = True      # image prediction head (forward and backward) on the image stream, beside the MLM head
         self.attn_sink = None            # dict while a forward collects attention probabilities (forward_with_attention)
         self.skinny_dx_rows = 3072       # decoded-row count up to which the decoder's input gradient runs as a split reduction (_decoder_dx)
+        self.prof_conn = None            # bench.py: dict while the launch profiler tags the connection layers' GEMMs (see _conn_tag)
         self._pending = []               # gradient buckets whose weight gradients are still queued: (group, #text, #image queued)
         self._nq = [0, 0]                # weight-gradient problems ever queued (text side, image side) ...
         self._nf = [0, 0]                # ... and launched
@@ -376,6 +377,27 @@ class Engine:
         (`_flush_due` says when).  dy / x stay referenced by the queue until then."""
         (self._wq_img if self._on_side else self._wq).append((dy, x, gw, M, N, K, dbias, m_dev))
         self._nq[1 if self._on_side else 0] += 1
+        if self.prof_conn is not None:            # FLOPs of the weight gradients queued from inside / outside a connection layer
+            MM = dy.shape[0] if M is None else M
+            NN = dy.shape[1] if N is None else N
+            KK = x.shape[1] if K is None else K
+            self.prof_conn["tn_conn" if self.prof_conn["in"] else "tn_other"] += 2.0 * MM * NN * KK
+
+    @contextmanager
+    def _conn_tag(self):
+        """While bench.py profiles (`prof_conn` is a dict): the GEMM launches issued inside the block carry tag 1 in the launch
+        profiler and the weight gradients queued inside it are counted as connection-layer FLOPs -- `roofline.coattention_gemms`,
+        the projections and FFNs of models/vilbert_dialog.py:655-783, forward and backward."""
+        if self.prof_conn is None:
+            yield
+            return
+        L.prof_tag(1)
+        self.prof_conn["in"] = True
+        try:
+            yield
+        finally:
+            self.prof_conn["in"] = False
+            L.prof_tag(0)
 
     @staticmethod
     def _big_tiles(queue):
@@ -1086,7 +1108,8 @@ class Engine:
             if pos < len(sched):
                 i = sched[pos][1]
                 pos += 1
-                xv32, xv, xt32, xt = self._conn_block(f"c{i}", i, xv32, xv, xt32, xt, B, R, T, vmask, comask, st, var=var)
+                with self._conn_tag():
+                    xv32, xv, xt32, xt = self._conn_block(f"c{i}", i, xv32, xv, xt32, xt, B, R, T, vmask, comask, st, var=var)
                 if save:
                     tape[-1] = ("c", tape[-1][0], tape[-1][1])
         # ---- image head (:1001-1005, :1085-1088; its masked KL :1569-1574 is in _losses): on the image stream, beside the
@@ -1334,7 +1357,8 @@ class Engine:
             if pos < len(entries):
                 _, key, fn = entries[pos]
                 pos += 1
-                gv, gt = fn(gv, gt)                          # exchanges between the streams happen inside
+                with self._conn_tag():
+                    gv, gt = fn(gv, gt)                      # exchanges between the streams happen inside
                 self._bucket_done(key)
         with self._img():
             bw["embv"](gv)

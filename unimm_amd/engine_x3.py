@@ -357,7 +357,8 @@ class EngineX3(Engine):
                 xt32, xt3 = self._self_block(f"t{i}", xt32, xt3, tmask, B, T, cfg.num_attention_heads, f"bert.encoder.layer.{i}.",
                                              cfg.attention_probs_dropout_prob, cfg.hidden_dropout_prob, st, var=var)
             else:
-                xv32, xv3, xt32, xt3 = self._conn_block(f"c{i}", i, xv32, xv3, xt32, xt3, B, R, T, vmask, comask, st, var=var)
+                with self._conn_tag():
+                    xv32, xv3, xt32, xt3 = self._conn_block(f"c{i}", i, xv32, xv3, xt32, xt3, B, R, T, vmask, comask, st, var=var)
             if save:
                 tape[-1] = (kind, tape[-1][0], tape[-1][1])
 
@@ -507,7 +508,8 @@ class EngineX3(Engine):
             if pos < len(entries):
                 _, key, fn = entries[pos]
                 pos += 1
-                gv, gt = fn(gv, gt)
+                with self._conn_tag():
+                    gv, gt = fn(gv, gt)
                 self._bucket_done(key)
         bw["embv"](gv)
         self._bucket_done("image_embeddings")

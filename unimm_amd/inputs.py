@@ -65,3 +65,66 @@ class DialogMaskSpec:
             txt[b, np.arange(L, L + k), np.arange(L, L + k)] = True
             co[b, 1:c] = True
         return torch.from_numpy(txt), torch.from_numpy(co)
+
+
+class DevicePrefetcher:
+    """Host-resident batches -> device-resident batches, one batch ahead, on a copy stream of its own.
+
+    The reference's callers hand CPU tensors to `forward` (train.py:113-129: the `.to(device)` lines are commented out; the
+    DataParallel wrapper scatters them, utils/data_parallel.py:123-124) -- ~270 MB per 240 sequences in the reference's layout
+    (int64 [256, 256] text masks, per-sequence copies of the region features), ~25 MB with compact inputs.  Passing CPU
+    tensors to this build's `forward` works too, but then the copies sit in front of the step on the compute stream.  This
+    iterator pins each host batch once, issues the host->device copies of batch i+1 on a side stream while step i computes,
+    and makes the consumer's stream wait for exactly those copies (an event, no host synchronisation).
+
+        for batch in DevicePrefetcher(loader, device):       # dict values: tensors, DialogMaskSpec, or anything else (passed through)
+            loss = step(batch)
+    """
+
+    def __init__(self, batches, device, pin=True):
+        self.it = iter(batches)
+        self.device = torch.device(device)
+        self.pin = pin
+        self.stream = torch.cuda.Stream(device=self.device)
+        self._pinned = {}                        # id(host tensor) -> pinned copy (a cycled list of batches is pinned once)
+        self._next = self._issue()
+
+    def _host(self, t):
+        if not self.pin or t.is_pinned():
+            return t
+        p = self._pinned.get(id(t))
+        if p is None:
+            p = self._pinned[id(t)] = (t, t.pin_memory())      # keep `t` alive: its id is the key
+        return p[1]
+
+    def _issue(self):
+        try:
+            hb = next(self.it)
+        except StopIteration:
+            return None
+        db = {}
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))      # buffers freed by the consumer may be reused here
+        with torch.cuda.stream(self.stream):
+            for k, v in hb.items():
+                if torch.is_tensor(v) and not v.is_cuda:
+                    db[k] = self._host(v).to(self.device, non_blocking=True)
+                else:
+                    db[k] = v
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        return db, ev
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self._next is None:
+            raise StopIteration
+        db, ev = self._next
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(ev)
+        for v in db.values():
+            if torch.is_tensor(v) and v.is_cuda:
+                v.record_stream(cur)              # allocated on the copy stream, consumed on the compute stream
+        self._next = self._issue()
+        return db

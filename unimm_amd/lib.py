@@ -93,7 +93,7 @@ SYMBOLS = ["unimm_version", "unimm_arch", "unimm_gemm_nt", "unimm_gemm_tn", "uni
            "unimm_colpartials_finish_grouped", "unimm_gemm_tn_grouped_ws", "unimm_linear_f32", "unimm_rows_add_f32", "unimm_transpose_bf16", "unimm_sum_slabs_bf16", "unimm_attn_probs",
            # the fp32-accuracy mode (csrc/x3ops.hip)
            "unimm_x3_split", "unimm_x3_split_wt", "unimm_x3_layernorm_bwd_partials", "unimm_embed_bwd_f32", "unimm_x3_lm_loss_bwd",
-           "unimm_x3_kl_loss_bwd", "unimm_x3_rows_add", "unimm_x3_attn_fwd", "unimm_x3_attn_bwd"]
+           "unimm_x3_kl_loss_bwd", "unimm_x3_rows_add", "unimm_x3_attn_fwd", "unimm_x3_attn_bwd", "unimm_prof_tag", "unimm_prof_tagged"]
 
 
 def _check(rc, what):
@@ -737,6 +737,18 @@ def prof_collect():
     ms, fl, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_int32 * n)()
     _check(lib().unimm_prof_collect(ms, fl, cnt, C.c_int32(n)), "unimm_prof_collect")
     return {gemm_variant_name(i): (ms[i], fl[i], cnt[i]) for i in range(n) if cnt[i] > 0}
+
+
+def prof_tag(tag):
+    """Tag (0 .. 7) of the GEMM launches that follow (see include/unimm_hip.h: unimm_prof_tag)."""
+    lib().unimm_prof_tag(C.c_int32(int(tag)))
+
+
+def prof_tagged(ntags=8):
+    """-> {tag: (total_ms, total_flops, launches)} of the NT launches the last prof_collect() consumed."""
+    ms, fl, cnt = (C.c_double * ntags)(), (C.c_double * ntags)(), (C.c_int32 * ntags)()
+    _check(lib().unimm_prof_tagged(ms, fl, cnt, C.c_int32(ntags)), "unimm_prof_tagged")
+    return {t: (ms[t], fl[t], cnt[t]) for t in range(ntags)}
 
 
 # ---------------------------------------------------------------------------------------------
