@@ -323,6 +323,13 @@ int unimm_mul_dropout(const float* a, const float* b, float* out, int64_t n, uin
 int unimm_mul_dropout_bwd(const float* a, const float* b, const float* dout, float* da, float* db, int64_t n,
                           uint32_t drop_key, uint32_t drop_thr, float drop_scale, const uint32_t* drop_salt, void* stream);
 
+/* The same for fusion_method = 'sum' (models/vilbert_dialog.py:1062-1063): out = dropout(a + b); da = [a>0] drop(dout),
+ * db = [b>0] drop(dout). */
+int unimm_sum_dropout(const float* a, const float* b, float* out, int64_t n, uint32_t drop_key, uint32_t drop_thr,
+                      float drop_scale, const uint32_t* drop_salt, void* stream);
+int unimm_sum_dropout_bwd(const float* a, const float* b, const float* dout, float* da, float* db, int64_t n,
+                          uint32_t drop_key, uint32_t drop_thr, float drop_scale, const uint32_t* drop_salt, void* stream);
+
 /* fp32 linear algebra of the heads on top of the network (the two poolers :946-967, the NSP head :1070) and their
  * backward, on the exact-fp32 matrix instruction v_mfma_f32_16x16x4_f32, straight from the fp32 master weights:
  *   OUT[m, n] (+)= act( sum_k A(m, k) * B(k, n) + bias[n] ),  A(m, k) = a[m * sa_m + k * sa_k],  B(k, n) = b[k * sb_k + n * sb_n]
@@ -371,6 +378,14 @@ int unimm_kl_loss_fwd(const float* pred, const float* target, const int32_t* lab
 int unimm_kl_loss_bwd(const float* pred, const float* target, const int32_t* label, const float* lse,
                       const float* g, float inv_denom, void* dpred, int32_t rows, int32_t C, int32_t ld,
                       int32_t ldd, const float* inv_dev, void* stream);
+/* Masked-region MSE, the predict_feature = True branch (models/vilbert_dialog.py:1562-1566): rowloss = [label==1] *
+ * sum_j (pred_j - target_j)^2 / C (the reference divides the sum over selected ELEMENTS by their count; the caller divides the
+ * sum of rowloss by max(#selected rows, 1)).  Backward: dpred = [label==1] g inv_denom 2 (pred - target) / C as bf16 [rows, ldd]
+ * (out_split == 0, columns >= C zero) or as an x-type split operand [rows, 3 ldd] (out_split != 0, the fp32-accuracy mode). */
+int unimm_mse_loss_fwd(const float* pred, const float* target, const int32_t* label, float* rowloss, int32_t rows, int32_t C,
+                       int32_t ld, void* stream);
+int unimm_mse_loss_bwd(const float* pred, const float* target, const int32_t* label, const float* g, float inv_denom,
+                       void* dpred, int32_t rows, int32_t C, int32_t ld, int32_t ldd, int32_t out_split, void* stream);
 /* Weighted 2-way cross-entropy, reduction 'mean' = sum w_y l / sum w_y (models/vilbert_dialog.py:1617-1621);
  * w0, w1 already divided by w0 (:1608). */
 int unimm_nsp_loss_fwd(const float* logits, const int32_t* labels, float w0, float w1, float* loss, int32_t B,

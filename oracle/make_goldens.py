@@ -160,6 +160,35 @@ def gen_small(vd):
         save(f"small_{cname}.npz", **{("in::" + k): v for k, v in b.items()}, **out)
 
 
+def gen_switches(vd):
+    """Config switches that are off in bert_base_6layer_6conect.json but honoured by the reference: fusion_method='sum'
+    (models/vilbert_dialog.py:1062-1063) and predict_feature=True (the MSE branch of the image loss, :1562-1566).  Small config,
+    eval mode: losses, NSP scores, region predictions, gradient norms of every tensor and a few gradients."""
+    cfgd = dict(SMALL_CFG, fusion_method="sum", predict_feature=True)
+    cfg = R.make_config(cfgd)
+    sd = R.init_state_dict(cfg, seed=11)
+    model = build_reference_model(vd, cfgd, sd)
+    modes, negs = ["gen", "dis", "gen", "dis"], [0, 1, 1, 0]
+    rng = np.random.Generator(np.random.PCG64(200))
+    b = make_batch(rng, cfgd, len(modes), 64, 37, modes, negs, share_image=False)
+    b["image_target"] = rng.standard_normal(b["image_target"].shape).astype(np.float32)      # regression targets (features)
+    model.zero_grad()
+    lm, img, nsp_l, seq_t, pred_t, nsp = run_reference(model, b, train=True)
+    (lm + img + nsp_l).sum().backward()
+    names = [n for n, _ in model.named_parameters()]
+    out = dict(lm_loss=lm, img_loss=img, nsp_loss=nsp_l, nsp=nsp, grad_names=np.array(names),
+               grad_norms=np.array([float(p.grad.norm()) if p.grad is not None else -1.0 for _, p in model.named_parameters()],
+                                   dtype=np.float64))
+    for n, p in model.named_parameters():
+        if p.grad is not None and any(k in n for k in ("cls.imagePredictions.decoder", "cls.bi_seq_relationship", "t_pooler.dense.bias",
+                                                       "v_pooler.dense.bias", "v_layer.1.output.dense.bias")):
+            out["grad::" + n] = p.grad
+    with torch.no_grad():
+        _, pred_v, nsp2, _, _ = run_reference(model, b, train=False)
+    out.update(inf_pred_v=pred_v, inf_nsp=nsp2)
+    save("small_sumfeat.npz", **{("in::" + k): v for k, v in b.items()}, **out)
+
+
 def gen_blocks(vd):
     """G3: full-size single blocks with seeded inputs (weights from the seeded generator)."""
     cfg = R.make_config(FULL_CFG)
@@ -420,7 +449,7 @@ def gen_rankloss(vm):
 
 
 if __name__ == "__main__":
-    groups = sys.argv[1:] or ["masks", "ranks", "small", "blocks", "losses", "full", "sched", "rankloss", "fullgrad", "attn"]
+    groups = sys.argv[1:] or ["masks", "ranks", "small", "blocks", "losses", "full", "sched", "rankloss", "fullgrad", "attn", "switches"]
     vd, du, vm = import_reference()
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -428,4 +457,4 @@ if __name__ == "__main__":
         {"masks": lambda: gen_masks(du), "ranks": lambda: gen_ranks(vm), "small": lambda: gen_small(vd),
          "blocks": lambda: gen_blocks(vd), "losses": lambda: gen_losses(vd), "full": lambda: gen_full(vd),
          "sched": gen_sched, "rankloss": lambda: gen_rankloss(vm), "fullgrad": lambda: gen_fullgrad(vd),
-         "attn": lambda: gen_attn(vd)}[g]()
+         "attn": lambda: gen_attn(vd), "switches": lambda: gen_switches(vd)}[g]()

@@ -387,6 +387,14 @@ def image_kl_loss(pred_v, image_target, image_label):
     return torch.sum(kl * sel.unsqueeze(2).float()) / max(torch.sum(sel), 0)
 
 
+def image_mse_loss(pred_v, image_target, image_label):
+    """predict_feature branch (models/vilbert_dialog.py:1562-1566): MSE(reduction='none') on the regions with label 1,
+    divided by max(#selected elements, 1)."""
+    mse = F.mse_loss(pred_v, image_target, reduction="none")
+    sel = (image_label == 1).unsqueeze(2)
+    return torch.sum(mse * sel.float()) / max(torch.sum(sel.expand_as(mse)), 1)
+
+
 def nsp_loss(nsp_scores, next_sentence_label, nsp_weight=None):
     """Weighted 2-way CE (models/vilbert_dialog.py:1605-1621)."""
     if nsp_weight is None:
@@ -409,7 +417,8 @@ def forward(sd, cfg, input_ids, image_feat, image_loc, token_type_ids=None, posi
     pred_t, pred_v, nsp = heads(sd, cfg, seq_t, seq_v, pt, pv, drop)
     out = dict(pred_t=pred_t, pred_v=pred_v, nsp=nsp, seq_out_t=seq_t, seq_out_v=seq_v)
     if masked_lm_labels is not None and next_sentence_label is not None and image_target is not None:
-        out["img_loss"] = image_kl_loss(pred_v, image_target, image_label).unsqueeze(0)
+        img_fn = image_mse_loss if getattr(cfg, "predict_feature", False) else image_kl_loss
+        out["img_loss"] = img_fn(pred_v, image_target, image_label).unsqueeze(0)
         out["lm_loss"] = mlm_ul_loss(pred_t, masked_lm_labels, lm_weight).unsqueeze(0)
         out["nsp_loss"] = nsp_loss(nsp, next_sentence_label, nsp_weight).unsqueeze(0)
     return out

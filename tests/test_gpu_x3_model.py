@@ -353,3 +353,42 @@ def test_optimizer_step_and_ranking_gradient_in_fp32_mode(golden_dir):
     print()
     close(lm2, ref2["lm_loss"], what="lm_loss after one AdamW step")
     close(nsp2, ref2["nsp"], what="nsp after one AdamW step")
+
+
+@pytest.mark.parametrize("compute,tol", [("bf16", 1e-2), ("fp32x3", 1e-3)])
+def test_config_switches_sum_fusion_and_predict_feature(golden_dir, compute, tol):
+    """fusion_method='sum' (models/vilbert_dialog.py:1062-1063) and predict_feature=True (masked-region MSE, :1562-1566) against
+    the REFERENCE's output on the small config (tests/golden/small_sumfeat.npz), both engines."""
+    from oracle import vilbert_ref as R
+    from unimm_amd import BertConfig, BertForMultiModalPreTraining
+    cfgd = dict(json.load(open(os.path.join(golden_dir, "small_config.json"))), fusion_method="sum", predict_feature=True)
+    model = BertForMultiModalPreTraining(BertConfig.from_dict(cfgd), compute_dtype=compute)
+    model.load_state_dict(R.init_state_dict(R.make_config(cfgd), seed=11), strict=True)
+    model = model.cuda().eval()
+    g = np.load(os.path.join(golden_dir, "small_sumfeat.npz"))
+    args, kw = kwargs_from(g)
+    model.zero_grad(set_to_none=True)
+    lm, img, nsp_l, _, _, nsp = model(*args, **kw, _want_lm_scores=False)
+    (lm + img + nsp_l).sum().backward()
+    torch.cuda.synchronize()
+    print()
+    close(lm, g["lm_loss"], tol=tol, what="lm_loss"); close(img, g["img_loss"], tol=tol, what="img_loss (MSE)")
+    close(nsp_l, g["nsp_loss"], tol=tol, what="nsp_loss"); close(nsp, g["nsp"], tol=tol, what="nsp (sum fusion)")
+    params = dict(model.named_parameters())
+    gate = 4e-2 if compute == "bf16" else 1e-3
+    for n, want in zip([str(x) for x in g["grad_names"]], g["grad_norms"]):
+        if want < 0:
+            assert params[n].grad is None, n
+            continue
+        got = float(params[n].grad.double().norm())
+        assert abs(got - want) <= gate * max(want, 1e-4), (n, got, want)
+    for k in g.files:
+        if k.startswith("grad::"):
+            want = g[k]
+            err = np.abs(params[k[6:]].grad.cpu().numpy() - want).max() / max(np.abs(want).max(), 1e-6)
+            # (bf16 engine: ReLU units of the 4 pooled rows switch on operand noise -- the pooler gate of test_gpu_fullsize.py)
+            assert err <= (0.35 if (compute == "bf16" and "pooler" in k) else gate), (k, err)
+    args, kw = kwargs_from(g, train=False, device="cuda")
+    with torch.no_grad():
+        _, p_v, nsp2, _, _ = model(*args, **kw)
+    close(p_v, g["inf_pred_v"], tol=tol, what="pred_v"); close(nsp2, g["inf_nsp"], tol=tol, what="inference nsp")

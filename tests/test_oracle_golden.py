@@ -224,3 +224,33 @@ def test_full_config_b6_gradients(golden_dir):
             continue
         err = np.abs(got.numpy() - gg[k]).max()
         assert err <= 2e-4 * np.abs(gg[k]).max(), (k, err)
+
+
+def test_config_switches_sum_fusion_and_predict_feature(golden_dir):
+    """fusion_method='sum' (models/vilbert_dialog.py:1062-1063) and predict_feature=True (MSE image loss, :1562-1566): the oracle's
+    branches against the reference's own output (tests/golden/small_sumfeat.npz, oracle/make_goldens.py::gen_switches)."""
+    cfgd = dict(json.load(open(os.path.join(golden_dir, "small_config.json"))), fusion_method="sum", predict_feature=True)
+    cfg = R.make_config(cfgd)
+    sd = R.init_state_dict(cfg, seed=11)
+    g = np.load(os.path.join(golden_dir, "small_sumfeat.npz"))
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != R.TIED[0]}
+    leaves[R.TIED[0]] = leaves[R.TIED[1]]
+    args, kw = oracle_kwargs(g)
+    out = R.forward(leaves, cfg, *args, **kw)
+    for k in ("lm_loss", "img_loss", "nsp_loss", "nsp"):
+        close(out[k], g[k], what=k)
+    (out["lm_loss"] + out["img_loss"] + out["nsp_loss"]).sum().backward()
+    for n, want in zip([str(x) for x in g["grad_names"]], g["grad_norms"]):
+        if want < 0:
+            assert leaves[n].grad is None or float(leaves[n].grad.abs().max()) == 0.0, n
+            continue
+        got = float(leaves[n].grad.norm())
+        assert abs(got - want) <= 2e-4 * max(want, 1e-3), (n, got, want)
+    for k in g.files:
+        if k.startswith("grad::"):
+            close(leaves[k[6:]].grad, g[k], tol=2e-4, what=k)
+    args, kw = oracle_kwargs(g, train=False)
+    with torch.no_grad():
+        inf = R.forward(sd, cfg, *args, **kw)
+    close(inf["pred_v"], g["inf_pred_v"], what="pred_v")
+    close(inf["nsp"], g["inf_nsp"], what="inf nsp")

@@ -85,6 +85,7 @@ class BertConfig(object):
         need(max(self.hidden_size, self.v_hidden_size) <= 1024, "hidden sizes above 1024 not supported by the row kernels")
         need(self.type_vocab_size == 2, "type_vocab_size must be 2")
         need(self.hidden_act == "gelu" and self.v_hidden_act == "gelu", "only erf-GELU is implemented")
-        need(self.fusion_method in ("mul",), "fusion_method must be 'mul'")
-        need(not (self.predict_feature or self.fast_mode or self.in_batch_pairs), "predict_feature/fast_mode/in_batch_pairs are off on this path")
+        need(self.fusion_method in ("mul", "sum"), "fusion_method must be 'mul' or 'sum' (models/vilbert_dialog.py:1062-1067 asserts on anything else)")
+        need(not (self.fast_mode or self.in_batch_pairs), "fast_mode / in_batch_pairs (every text paired with every image of the batch, "
+             "models/vilbert_dialog.py:876-899) are not built: off in bert_base_6layer_6conect.json and unused by the reference's scripts")
         need(self.fixed_t_layer == 0 and self.fixed_v_layer == 0 and self.with_coattention, "fixed layers / with_coattention=False unsupported")

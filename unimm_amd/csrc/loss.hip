@@ -178,6 +178,46 @@ __global__ __launch_bounds__(256) void kl_loss_bwd_kernel(const float* __restric
   }
 }
 
+// ---- masked-region MSE, the predict_feature branch (models/vilbert_dialog.py:1562-1566) ---------------
+// rowloss = [label == 1] * sum_j (pred_j - target_j)^2 / C  (the caller divides by max(#selected rows, 1): the reference
+// divides by the number of selected ELEMENTS)
+__global__ __launch_bounds__(256) void mse_loss_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                           const int32_t* __restrict__ label, float* __restrict__ rowloss, int C,
+                                                           int ld) {
+  __shared__ float red[4];
+  const int row = blockIdx.x;
+  float acc = 0.f;
+  if (label[row] == 1) {
+    const float* z = pred + (size_t)row * ld;
+    const float* t = target + (size_t)row * C;
+    for (int i = threadIdx.x; i < C; i += 256) { const float d = z[i] - t[i]; acc += d * d; }
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) rowloss[row] = acc / (float)C;
+}
+
+// dpred = [label == 1] * g * inv_denom * 2 (pred - target) / C; out_split == 0: bf16 [rows, ldd] (columns >= C zero),
+// else an x-type split operand [rows, 3 ldd] (the fp32-accuracy mode, csrc/x3ops.hip)
+__global__ __launch_bounds__(256) void mse_loss_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                           const int32_t* __restrict__ label, const float* __restrict__ g,
+                                                           float inv_denom, bf16_t* __restrict__ dpred, int C, int ld, int ldd,
+                                                           int out_split) {
+  const int row = blockIdx.x;
+  const float* z = pred + (size_t)row * ld;
+  const float* t = target + (size_t)row * C;
+  const float gs = label[row] == 1 ? g[0] * inv_denom * 2.0f / (float)C : 0.f;
+  for (int i = threadIdx.x; i < ldd; i += 256) {
+    const float v = (gs != 0.f && i < C) ? gs * (z[i] - t[i]) : 0.f;
+    if (out_split == 0) {
+      dpred[(size_t)row * ldd + i] = f2bf(v);
+    } else {
+      const bf16_t hi = f2bf(v), lo = f2bf(v - bf2f(hi));
+      bf16_t* o = dpred + (size_t)row * 3 * ldd + i;
+      o[0] = hi; o[ldd] = lo; o[2 * ldd] = hi;
+    }
+  }
+}
+
 // ---- weighted NSP cross-entropy (models/vilbert_dialog.py:1605-1621), single workgroup -----------
 __global__ __launch_bounds__(256) void nsp_loss_fwd_kernel(const float* __restrict__ logits, const int32_t* __restrict__ labels,
                                                            float w0, float w1, float* __restrict__ loss, int B, int ld) {
@@ -280,6 +320,25 @@ extern "C" int unimm_kl_loss_bwd(const float* pred, const float* target, const i
   if (rows <= 0 || C <= 0 || ld < C || ldd < C) return UNIMM_E_SHAPE;
   hipLaunchKernelGGL(kl_loss_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, pred, target, label, lse, g,
                      inv_denom, (bf16_t*)dpred, C, ld, ldd, inv_dev);
+  UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
+}
+
+extern "C" int unimm_mse_loss_fwd(const float* pred, const float* target, const int32_t* label, float* rowloss, int32_t rows,
+                                  int32_t C, int32_t ld, void* stream) {
+  if (!pred || !target || !label || !rowloss) return UNIMM_E_ARG;
+  if (rows <= 0 || C <= 0 || ld < C) return UNIMM_E_SHAPE;
+  hipLaunchKernelGGL(mse_loss_fwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, pred, target, label, rowloss, C, ld);
+  UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
+}
+
+extern "C" int unimm_mse_loss_bwd(const float* pred, const float* target, const int32_t* label, const float* g, float inv_denom,
+                                  void* dpred, int32_t rows, int32_t C, int32_t ld, int32_t ldd, int32_t out_split, void* stream) {
+  if (!pred || !target || !label || !g || !dpred) return UNIMM_E_ARG;
+  if (rows <= 0 || C <= 0 || ld < C || ldd < C) return UNIMM_E_SHAPE;
+  hipLaunchKernelGGL(mse_loss_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, pred, target, label, g, inv_denom,
+                     (bf16_t*)dpred, C, ld, ldd, out_split);
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;
 }

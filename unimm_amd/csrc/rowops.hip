@@ -804,17 +804,19 @@ __global__ void pack_image_kernel(const float* __restrict__ feat, const float* _
 }
 
 // out = dropout(a * b)  fp32 [n]   (pooled_t * pooled_v, models/vilbert_dialog.py:1065)
+template <bool SUM>      // fusion_method 'mul' (default) / 'sum' (models/vilbert_dialog.py:1062-1065)
 __global__ void mul_dropout_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
                                    size_t n, DropoutArg drop) {
   drop_resolve(drop);
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  float v = a[i] * b[i];
+  float v = SUM ? a[i] + b[i] : a[i] * b[i];
   if (drop.thr != 0u) v = drop_apply(drop, 0u, (uint32_t)n, (uint32_t)i, v);
   out[i] = v;
 }
 
 // backward of the above given dfused: da = drop(dfused) * b, db = drop(dfused) * a
+template <bool SUM>
 __global__ void mul_dropout_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                        const float* __restrict__ dout, float* __restrict__ da, float* __restrict__ db,
                                        size_t n, DropoutArg drop) {
@@ -825,8 +827,8 @@ __global__ void mul_dropout_bwd_kernel(const float* __restrict__ a, const float*
   if (drop.thr != 0u) d = drop_apply(drop, 0u, (uint32_t)n, (uint32_t)i, d);
   // ReLU of the poolers (:951,:966) is folded in: a, b are post-ReLU, gradient is zero where they are
   const float av = a[i], bv = b[i];
-  da[i] = av > 0.f ? d * bv : 0.f;
-  db[i] = bv > 0.f ? d * av : 0.f;
+  da[i] = av > 0.f ? (SUM ? d : d * bv) : 0.f;
+  db[i] = bv > 0.f ? (SUM ? d : d * av) : 0.f;
 }
 
 // du = dt * GELU'(u)  (backward of the erf-GELU that sits between a dense and a LayerNorm in the two
@@ -1119,7 +1121,7 @@ extern "C" int unimm_pack_image(const float* feat, const float* loc, void* out, 
 extern "C" int unimm_mul_dropout(const float* a, const float* b, float* out, int64_t n, uint32_t drop_key, uint32_t drop_thr,
                                  float drop_scale, const uint32_t* drop_salt, void* stream) {
   if (!a || !b || !out || n <= 0) return UNIMM_E_ARG;
-  hipLaunchKernelGGL(mul_dropout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(mul_dropout_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      a, b, out, (size_t)n, mk_drop(drop_key, drop_thr, drop_scale, drop_salt));
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;
@@ -1129,7 +1131,27 @@ extern "C" int unimm_mul_dropout_bwd(const float* a, const float* b, const float
                                      uint32_t drop_key, uint32_t drop_thr, float drop_scale, const uint32_t* drop_salt,
                                      void* stream) {
   if (!a || !b || !dout || !da || !db || n <= 0) return UNIMM_E_ARG;
-  hipLaunchKernelGGL(mul_dropout_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(mul_dropout_bwd_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     a, b, dout, da, db, (size_t)n,
+                     mk_drop(drop_key, drop_thr, drop_scale, drop_salt));
+  UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
+}
+
+extern "C" int unimm_sum_dropout(const float* a, const float* b, float* out, int64_t n, uint32_t drop_key, uint32_t drop_thr,
+                                 float drop_scale, const uint32_t* drop_salt, void* stream) {
+  if (!a || !b || !out || n <= 0) return UNIMM_E_ARG;
+  hipLaunchKernelGGL(mul_dropout_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     a, b, out, (size_t)n, mk_drop(drop_key, drop_thr, drop_scale, drop_salt));
+  UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
+}
+
+extern "C" int unimm_sum_dropout_bwd(const float* a, const float* b, const float* dout, float* da, float* db, int64_t n,
+                                     uint32_t drop_key, uint32_t drop_thr, float drop_scale, const uint32_t* drop_salt,
+                                     void* stream) {
+  if (!a || !b || !dout || !da || !db || n <= 0) return UNIMM_E_ARG;
+  hipLaunchKernelGGL(mul_dropout_bwd_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      a, b, dout, da, db, (size_t)n,
                      mk_drop(drop_key, drop_thr, drop_scale, drop_salt));
   UNIMM_CHECK_LAUNCH();

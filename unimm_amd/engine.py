@@ -1150,7 +1150,7 @@ class Engine:
         pooled_v = self._linear32(cls_v, "vpool", relu=True)
         d_fuse = self._drop("fuse", 0.1, train)
         fused = torch.empty_like(pooled_t)
-        L.mul_dropout(pooled_t, pooled_v, fused, fused.numel(), d_fuse)
+        L.mul_dropout(pooled_t, pooled_v, fused, fused.numel(), d_fuse, fusion_sum=cfg.fusion_method == "sum")
         nsp = torch.zeros((B, 4), dtype=F32, device=dev)
         self._linear32(fused, "nsp", out=nsp)
         out["nsp"] = nsp[:, :2]
@@ -1241,11 +1241,15 @@ class Engine:
         tgt = tgt.contiguous().view(B * R, C)
         lab32 = out["img_label32"].reshape(-1) if out.get("img_label32") is not None else self._i32(label.reshape(-1), dev)
         rl, lse = torch.empty(B * R, dtype=F32, device=dev), torch.empty(B * R, dtype=F32, device=dev)
-        L.kl_loss_fwd(img["pred"], tgt, lab32, rl, lse, B * R, C)
         img_loss = torch.empty(1, dtype=F32, device=dev)
-        inv_img = 1.0 / n_img if n_img > 0 else float("inf")
-        # (the plan kernels counted the regions: the divisor is then read from the device word, not from a launch argument)
-        inv_img_dev = out["dyn"]["inv_img"] if (out.get("dyn") is not None and out.get("n_img") is not None) else None
+        if cfg.predict_feature:               # MSE on the labelled regions / max(#selected elements, 1) (:1562-1566)
+            L.mse_loss_fwd(img["pred"], tgt, lab32, rl, B * R, C)
+            inv_img, inv_img_dev = 1.0 / max(n_img, 1), None
+        else:
+            L.kl_loss_fwd(img["pred"], tgt, lab32, rl, lse, B * R, C)
+            inv_img = 1.0 / n_img if n_img > 0 else float("inf")
+            # (the plan kernels counted the regions: the divisor is then read from the device word, not from a launch argument)
+            inv_img_dev = out["dyn"]["inv_img"] if (out.get("dyn") is not None and out.get("n_img") is not None) else None
         L.reduce_sum(rl, B * R, img_loss, inv_img, scale_dev=inv_img_dev)
         img.update(target=tgt, label=lab32, lse=lse, inv=inv_img, inv_dev=inv_img_dev)
         res["img_loss"] = img_loss
@@ -1288,8 +1292,11 @@ class Engine:
         self._to_img(gimg, img["target"], img["lse"], img["label"])
         with self._img_if(self.image_head_side):
             dpred = torch.empty((B * R, Cp), dtype=BF16, device=dev)
-            L.kl_loss_bwd(img["pred"], img["target"], img["label"], img["lse"], gimg, img["inv"], dpred, B * R, C,
-                          inv_dev=img.get("inv_dev"))
+            if cfg.predict_feature:
+                L.mse_loss_bwd(img["pred"], img["target"], img["label"], gimg, img["inv"], dpred, B * R, C)
+            else:
+                L.kl_loss_bwd(img["pred"], img["target"], img["label"], img["lse"], gimg, img["inv"], dpred, B * R, C,
+                              inv_dev=img.get("inv_dev"))
             dhn_v = self._linear_bwd(dpred, img["hn"], idec, M=B * R, N=C)
             dtv, _ = self._layernorm_bwd(dhn_v, img["tv"], img["mean"], img["rstd"], "imgtr")
             duv = torch.empty_like(dtv)
@@ -1325,7 +1332,8 @@ class Engine:
         L.nsp_loss_bwd(bw["nsp_pad"], nlab, w0, w1, gvec(g_nsp), dnsp, B, extra=extra)
         dfused = self._linear32_bwd(dnsp, bw["fused"], "nsp")
         dpt, dpv = torch.empty_like(dfused), torch.empty_like(dfused)
-        L.mul_dropout_bwd(bw["pooled_t"], bw["pooled_v"], dfused, dpt, dpv, dfused.numel(), bw["d_fuse"])
+        L.mul_dropout_bwd(bw["pooled_t"], bw["pooled_v"], dfused, dpt, dpv, dfused.numel(), bw["d_fuse"],
+                          fusion_sum=cfg.fusion_method == "sum")
         # pooler input gradients land on the first-token rows
         dcls_t = self._linear32_bwd(dpt, bw["cls_t"], "tpool")
         L.rows_add_f32(dseq_t, bw["cls_idx_t"], dcls_t, B, dcls_t.shape[1])

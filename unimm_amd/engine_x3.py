@@ -389,7 +389,7 @@ class EngineX3(Engine):
         pooled_v = self._linear32(cls_v, "vpool", relu=True)
         d_fuse = self._drop("fuse", 0.1, train)
         fused = torch.empty_like(pooled_t)
-        L.mul_dropout(pooled_t, pooled_v, fused, fused.numel(), d_fuse)
+        L.mul_dropout(pooled_t, pooled_v, fused, fused.numel(), d_fuse, fusion_sum=cfg.fusion_method == "sum")
         nsp = torch.zeros((B, 4), dtype=F32, device=dev)
         self._linear32(fused, "nsp", out=nsp)
         out["nsp"] = nsp[:, :2]
@@ -453,8 +453,11 @@ class EngineX3(Engine):
         C = cfg.v_target_size
         itr, idec = self.lin["imgtr"], self.lin["imgdec"]
         dpred3 = torch.empty((B * R, 3 * idec.Np), dtype=BF16, device=dev)
-        L.x3_kl_loss_bwd(img["pred"], img["target"], img["label"], img["lse"], gvec(g_img), img["inv"], dpred3, B * R, C,
-                         inv_dev=img.get("inv_dev"))
+        if cfg.predict_feature:
+            L.mse_loss_bwd(img["pred"], img["target"], img["label"], gvec(g_img), img["inv"], dpred3, B * R, C, split=True)
+        else:
+            L.x3_kl_loss_bwd(img["pred"], img["target"], img["label"], img["lse"], gvec(g_img), img["inv"], dpred3, B * R, C,
+                             inv_dev=img.get("inv_dev"))
         dhn_v = self._lin3_bwd(dpred3, img["hn"], idec)
         dtv, _ = self._ln3_bwd(dhn_v, img["tv"], img["mean"], img["rstd"], "imgtr", want3=False)
         duv3 = self._op3(dtv, op=L.X3_MUL_DGELU, b=img["u"])[0]
@@ -482,7 +485,8 @@ class EngineX3(Engine):
         L.nsp_loss_bwd(bw["nsp_pad"], nlab, w0, w1, gvec(g_nsp), dnsp, B, extra=extra)
         dfused = self._linear32_bwd(dnsp, bw["fused"], "nsp")
         dpt, dpv = torch.empty_like(dfused), torch.empty_like(dfused)
-        L.mul_dropout_bwd(bw["pooled_t"], bw["pooled_v"], dfused, dpt, dpv, dfused.numel(), bw["d_fuse"])
+        L.mul_dropout_bwd(bw["pooled_t"], bw["pooled_v"], dfused, dpt, dpv, dfused.numel(), bw["d_fuse"],
+                          fusion_sum=cfg.fusion_method == "sum")
         dcls_t = self._linear32_bwd(dpt, bw["cls_t"], "tpool")
         L.x3_rows_add(dseq_t, bw["cls_idx_t"], dcls_t, B, H)
         dcls_v = self._linear32_bwd(dpv, bw["cls_v"], "vpool")

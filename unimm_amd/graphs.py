@@ -69,7 +69,7 @@ class StepGraphs:
     # ------------------------------------------------------------------------------------------
     def eligible(self, inp, opts):
         eng = self.eng
-        if opts.get("want_seq") or eng.text_priority:
+        if opts.get("want_seq") or eng.text_priority or eng.cfg.predict_feature:      # (the MSE branch's divisor is a launch argument)
             return False
         for k in _TENSOR_KEYS:
             v = inp.get(k)

@@ -93,7 +93,8 @@ SYMBOLS = ["unimm_version", "unimm_arch", "unimm_gemm_nt", "unimm_gemm_tn", "uni
            "unimm_colpartials_finish_grouped", "unimm_gemm_tn_grouped_ws", "unimm_linear_f32", "unimm_rows_add_f32", "unimm_transpose_bf16", "unimm_sum_slabs_bf16", "unimm_attn_probs",
            # the fp32-accuracy mode (csrc/x3ops.hip)
            "unimm_x3_split", "unimm_x3_split_wt", "unimm_x3_layernorm_bwd_partials", "unimm_embed_bwd_f32", "unimm_x3_lm_loss_bwd",
-           "unimm_x3_kl_loss_bwd", "unimm_x3_rows_add", "unimm_x3_attn_fwd", "unimm_x3_attn_bwd", "unimm_prof_tag", "unimm_prof_tagged"]
+           "unimm_x3_kl_loss_bwd", "unimm_x3_rows_add", "unimm_x3_attn_fwd", "unimm_x3_attn_bwd", "unimm_prof_tag", "unimm_prof_tagged",
+           "unimm_sum_dropout", "unimm_sum_dropout_bwd", "unimm_mse_loss_fwd", "unimm_mse_loss_bwd"]
 
 
 def _check(rc, what):
@@ -541,15 +542,18 @@ def pack_image(feat, loc, out, rows, F, ld):
                                   _stream()), "unimm_pack_image")
 
 
-def mul_dropout(a, b, out, n, drop=NO_DROP):
+def mul_dropout(a, b, out, n, drop=NO_DROP, fusion_sum=False):
+    """out = dropout(a * b) (fusion_method 'mul') or dropout(a + b) ('sum')."""
     _dev(a, b, out)
-    _check(lib().unimm_mul_dropout(_ptr(a), _ptr(b), _ptr(out), C.c_int64(n), C.c_uint32(drop[0]), C.c_uint32(drop[1]),
+    fn = lib().unimm_sum_dropout if fusion_sum else lib().unimm_mul_dropout
+    _check(fn(_ptr(a), _ptr(b), _ptr(out), C.c_int64(n), C.c_uint32(drop[0]), C.c_uint32(drop[1]),
                                    C.c_float(drop[2]), C.c_void_p(_salt(drop)), _stream()), "unimm_mul_dropout")
 
 
-def mul_dropout_bwd(a, b, dout, da, db, n, drop=NO_DROP):
+def mul_dropout_bwd(a, b, dout, da, db, n, drop=NO_DROP, fusion_sum=False):
     _dev(a, b, dout, da, db)
-    _check(lib().unimm_mul_dropout_bwd(_ptr(a), _ptr(b), _ptr(dout), _ptr(da), _ptr(db), C.c_int64(n),
+    fn = lib().unimm_sum_dropout_bwd if fusion_sum else lib().unimm_mul_dropout_bwd
+    _check(fn(_ptr(a), _ptr(b), _ptr(dout), _ptr(da), _ptr(db), C.c_int64(n),
                                        C.c_uint32(drop[0]), C.c_uint32(drop[1]), C.c_float(drop[2]), C.c_void_p(_salt(drop)),
                                        _stream()), "unimm_mul_dropout_bwd")
 
@@ -582,6 +586,21 @@ def kl_loss_bwd(pred, target, label, lse, g, inv_denom, dpred, rows, Cn, inv_dev
     _check(lib().unimm_kl_loss_bwd(_ptr(pred), _ptr(target), _ptr(label), _ptr(lse), _ptr(g), C.c_float(inv_denom),
                                    _ptr(dpred), C.c_int32(rows), C.c_int32(Cn), C.c_int32(pred.stride(0)),
                                    C.c_int32(dpred.stride(0)), _ptr(inv_dev), _stream()), "unimm_kl_loss_bwd")
+
+
+def mse_loss_fwd(pred, target, label, rowloss, rows, Cn):
+    _dev(pred, target, label, rowloss)
+    _check(lib().unimm_mse_loss_fwd(_ptr(pred), _ptr(target), _ptr(label), _ptr(rowloss), C.c_int32(rows), C.c_int32(Cn),
+                                    C.c_int32(pred.stride(0)), _stream()), "unimm_mse_loss_fwd")
+
+
+def mse_loss_bwd(pred, target, label, g, inv_denom, dpred, rows, Cn, split=False):
+    """dpred: bf16 [rows, ldd], or (split=True) an x-type split operand [rows, 3 ldd]."""
+    _dev(pred, target, label, g, dpred)
+    ldd = dpred.shape[1] // 3 if split else dpred.stride(0)
+    _check(lib().unimm_mse_loss_bwd(_ptr(pred), _ptr(target), _ptr(label), _ptr(g), C.c_float(inv_denom), _ptr(dpred),
+                                    C.c_int32(rows), C.c_int32(Cn), C.c_int32(pred.stride(0)), C.c_int32(ldd),
+                                    C.c_int32(1 if split else 0), _stream()), "unimm_mse_loss_bwd")
 
 
 def nsp_loss_fwd(logits, labels, w0, w1, loss, B):
