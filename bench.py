@@ -98,6 +98,7 @@ def parse():
                     help="bf16 (default, the headline: the reference's autocast class) or fp32x3 = the fp32-accuracy engine "
                          "(unimm_amd/engine_x3.py: bf16 MFMA GEMMs over split operands hi/lo, fp32 attention and gradient "
                          "stream): the arithmetic dense_annotation_finetuning.py:253 runs in (no autocast)")
+    ap.add_argument("--no-splitk", action="store_true", help="A/B: engine.splitk = False (no split-K for the long reductions of small batches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-tile", type=int, default=0, metavar="CODE",
                     help="tuning: unimm_gemm_nt_args.tile = CODE for every launch of the run (1000 x tile columns per group + 100 x {1 persistent, "
@@ -416,6 +417,8 @@ def main():
         return fwd_bwd()
 
     model.engine.gemm_tile = args.gemm_tile      # per-call tuning code of every unimm_gemm_nt launch (0 = automatic)
+    if args.no_splitk:
+        model.engine.splitk = False
     if args.single_stream:
         model.engine.dual_stream = False
     if args.wgrad_stream:

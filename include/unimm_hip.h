@@ -84,6 +84,16 @@ typedef struct {
    * step; unimm_amd/dropout.py: make_key(seed, step, site) = site_key(seed, site) ^ step_salt(seed, step).  Every entry
    * point that takes a dropout triple takes such a word. */
   const uint32_t* drop_salt;
+  /* Split-K for grids that leave the chip under-filled (the ~4-8k rows of a 30-60-sequence share of a split batch against
+   * K = 2304 / 3072: a few hundred tiles, each a 36-48 step dependent chain).  splitk: 0 / 1 = off; 2 .. 8 = at most that many
+   * workgroups per output tile, each reducing a slice of K; -1 = the library's choice (as many as stay resident at once, <= 4,
+   * >= 8 K-steps each).  Partial tiles meet in the caller's workspace and the last arriver of a tile runs the epilogue, so the
+   * fused epilogues work unchanged.  splitk_ws: 256-byte aligned device memory, ZERO-FILLED ONCE by the caller and then private
+   * to launches of ONE stream (the kernel leaves its counters zero); 16 KiB + tiles * splits * tile bytes (a 64 x 128 tile is
+   * 32 KiB); too small for a launch = that launch runs unsplit.  Ring-loop tiles only (64x128, 128x128). */
+  void* splitk_ws;
+  int64_t splitk_ws_bytes;
+  int32_t splitk;
 } unimm_gemm_nt_args;
 
 int unimm_gemm_nt(const unimm_gemm_nt_args* args, void* stream);

@@ -364,3 +364,46 @@ def test_gemm_tn_workspace_reducer_matches_atomic_path():
     lib.gemm_tn_grouped(probs_b, shared=True, ws=small)
     torch.cuda.synchronize()
     assert (probs_b[0][2] - 4 * refs[0]).abs().max().item() <= 3e-3 * 4 * max(1.0, refs[0].abs().max().item())
+
+
+@pytest.mark.parametrize("M,N,K,tile", [(3900, 768, 3072, 7), (3900, 768, 2304, 7), (3900, 768, 3072, 1), (1110, 1024, 3072, 7),
+                                        (777, 200, 1024, 7), (3900, 3072, 768, 7)])
+def test_gemm_nt_split_k_equals_unsplit(M, N, K, tile):
+    """Split-K (unimm_gemm_nt_args.splitk: several workgroups per output tile, partial tiles meet in the caller's workspace, the
+    last arriver runs the fused epilogue) against the unsplit launch, every epilogue of the small-batch regime, repeated launches
+    on one workspace (the counters must come back to zero), forced 2 / 3 / 4 splits and the library's own choice."""
+    from unimm_amd import dropout as DR
+    from unimm_amd import lib
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    x, w = _rand((M, K), g), _rand((N, K), g, 0.05)
+    bias = torch.randn(N, generator=g, device="cuda")
+    aux16 = _rand((M, N), g)
+    aux32 = torch.randn((M, N), generator=g, device="cuda")
+    ws = torch.zeros(64 << 20, dtype=torch.uint8, device="cuda")
+    drop = DR.drop_arg(0.1, DR.make_key(3, 1, 4))
+    cases = [(lib.EPI_BIAS, torch.bfloat16, None, None), (lib.EPI_ADD, torch.bfloat16, aux16, None),
+             (lib.EPI_MUL, torch.bfloat16, aux16, None), (lib.EPI_BIAS_DROP_RESID, torch.float32, aux32, drop),
+             (lib.EPI_BIAS_GELU_DG, torch.bfloat16, None, None)]
+    for epi, dt, aux, dr in cases:
+        def run(splitk):
+            out = torch.full((M, N), float("nan"), device="cuda").to(dt)
+            out2 = torch.full((M, N), float("nan"), device="cuda").to(torch.bfloat16) if epi == lib.EPI_BIAS_GELU_DG else None
+            lib.gemm_nt(x, w, out, bias=bias, epilogue=epi, aux=aux, out2=out2, drop=dr, tile=tile, splitk=splitk, splitk_ws=ws)
+            return out, out2
+        ref, ref2 = run(0)
+        for sk in (2, 3, 4, -1, 2):
+            got, got2 = run(sk)
+            torch.cuda.synchronize()
+            scale = float(ref.float().abs().max())
+            err = float((got.float() - ref.float()).abs().max())
+            # fp32 sums in another order, then (bf16 outputs) one rounding: at most one bf16 ulp of the largest value
+            assert err <= (2e-5 if dt == torch.float32 else 2 ** -7) * scale, (epi, sk, err, scale)
+            if got2 is not None:
+                assert float((got2.float() - ref2.float()).abs().max()) <= 2 ** -7 * float(ref2.float().abs().max())
+    assert int(ws[:16384].view(torch.int32).abs().max()) == 0          # tickets returned to zero
+    # and against fp32 torch for one epilogue
+    want = x.float() @ w.float().t() + bias
+    got = torch.empty((M, N), device="cuda")
+    lib.gemm_nt(x, w, got, bias=bias, tile=tile, splitk=4, splitk_ws=ws)
+    torch.cuda.synchronize()
+    assert float((got - want).abs().max()) <= 2e-3 * float(want.abs().max())

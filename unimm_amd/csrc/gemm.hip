@@ -29,6 +29,9 @@ struct GemmNtParams {
   int gn;            // n-tiles per column group of the tile order (see tile_of)
   DropoutArg drop;
   const float* aux_mean; const float* aux_rstd; const float* aux_gamma; const float* aux_beta;  // DROP_RESID: aux = LayerNorm(aux)
+  // split-K (ring-loop tiles only; see nt_split_join): ksplit workgroups share one output tile, each reduces a slice of K,
+  // partial tiles meet in `slabs` and the last arriver (ticket in `counters`) runs the epilogue.  ksplit <= 1: off.
+  int ksplit; float* slabs; int* counters;
 };
 
 // Tile order.  Logical ids run group by group over the n-tiles (gn tile columns per group), inside a
@@ -656,11 +659,69 @@ __device__ __forceinline__ void nt_mainloop_pp(const GemmNtParams& p, char* smem
 #undef UNIMM_PP_SYNC_READS
 }
 
+// Split-K join.  The small per-GPU batches of a split global batch (30-60 sequences: ~4-8k rows) give a K = 2304 / 3072
+// GEMM a few hundred tiles whose 36-48 step reductions are one dependent chain per workgroup: the chip is half empty and
+// the kernel's time is the chain's.  With ksplit workgroups per tile each reduces 1 / ksplit of K; every one stores its
+// fp32 partial tile to its own slab (register order, fully coalesced) and takes a ticket; the LAST arriver adds the other
+// slabs to the partial it still holds and runs the normal epilogue.  Hand-off (placement-independent; MI355X_MICROARCH.md
+// "inter-workgroup visibility"): write-through slab stores -> every wave's vmcnt(0) -> workgroup barrier -> lane 0: relaxed
+// agent-scope ticket; the last arriver: agent-scope acquire, vmcnt(0), barrier, loads.  Returns false for the
+// workgroups that are done.  Deterministic: the last arriver adds the other slabs in split order onto its own partial --
+// which split arrives last may differ from run to run, so sums can differ in their last bits between runs (like the
+// atomic weight gradients), never between a captured launch and its replays' arithmetic.
+template <class C>
+__device__ __forceinline__ bool nt_split_join(const GemmNtParams& p, f32x4 (&acc)[4][C::MT], char* smem, int tile, int split) {
+  constexpr int MT = C::MT, TILE_F4 = C::NW * 4 * MT * 64;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  f32x4* mine = reinterpret_cast<f32x4*>(p.slabs) + ((size_t)tile * p.ksplit + split) * TILE_F4;
+  // WRITE-THROUGH (sc0 sc1) 16-byte stores: the bytes leave the XCD's L2 as they are written, so the publisher needs no
+  // agent-scope release (buffer_wbl2 writes back EVERY dirty line of the L2, and with a few hundred workgroups publishing
+  // 32 KiB each at the same time that fence cost more than the reduction it saved: 57 vs 33 us for K = 3072 at 3.9k rows).
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      f32x4* dst = mine + ((wave * 4 + i) * MT + j) * 64 + lane;
+      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(acc[i][j]) : "memory");
+    }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                               // (every wave has left the ring: smem[0..3] carries the ticket)
+  int* flag = reinterpret_cast<int*>(smem);
+  if (tid == 0) {
+    const int ticket = __hip_atomic_fetch_add(p.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ticket == p.ksplit - 1) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(p.counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
+    *flag = ticket;
+  }
+  __syncthreads();
+  const bool last = *flag == p.ksplit - 1;                        // workgroup-uniform
+  __syncthreads();                                               // the flag word is part of the epilogue's slab
+  if (!last) return false;
+  const f32x4* base = reinterpret_cast<const f32x4*>(p.slabs) + (size_t)tile * p.ksplit * TILE_F4;
+  for (int sp = 0; sp < p.ksplit; ++sp) {
+    if (sp == split) continue;
+    const f32x4* other = base + (size_t)sp * TILE_F4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        const f32x4 o = other[((wave * 4 + i) * MT + j) * 64 + lane];
+        acc[i][j][0] += o[0]; acc[i][j][1] += o[1]; acc[i][j][2] += o[2]; acc[i][j][3] += o[3];
+      }
+  }
+  return true;
+}
+
 // One output tile (logical tile id `lid`, already XCD-remapped): ring-staged main loop + epilogue.
 template <class C, int EPI, bool OUT_F32>
 __device__ __forceinline__ void nt_tile(const GemmNtParams& p, char* smem, int lid) {
   constexpr int BM = C::BM, BN = C::BN, BK = C::BK, S = C::STAGES, G = C::G, MT = C::MT;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  int split = 0;
+  if (!C::PP && p.ksplit > 1) { split = lid % p.ksplit; lid /= p.ksplit; }   // the splits of a tile are neighbours in the remapped order
   const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
   int tm, tn;
   tile_of(lid, nbm, nbn, p.gn, tm, tn);
@@ -690,7 +751,12 @@ __device__ __forceinline__ void nt_tile(const GemmNtParams& p, char* smem, int l
     nt_epilogue<C, EPI, OUT_F32>(p, acc, smem, m0, n0, wm, wn, wave, lane);
     return;
   }
-  const int nk = p.K / BK;
+  int nk = p.K / BK, kb = 0;                 // this workgroup reduces K-steps [kb, kb + nk)
+  if (p.ksplit > 1) {
+    const int per = (nk + p.ksplit - 1) / p.ksplit;
+    kb = split * per;
+    nk = (nk - kb) < per ? (nk - kb) : per;  // >= 1: the host only splits when (ksplit - 1) * per < K / BK
+  }
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   RingStage<C> rst;
   ring_stage_init<C>(rst, p, n0, m0, (uint32_t)(size_t)(__attribute__((address_space(3))) char*)LDS_PTR(smem), wave, lane);
@@ -702,7 +768,7 @@ __device__ __forceinline__ void nt_tile(const GemmNtParams& p, char* smem, int l
   // prologue: fill S-1 ring slots
 #pragma unroll
   for (int s = 0; s < S - 1; ++s)
-    if (s < nk) ring_stage_step<C>(rst, s * BK, s, wave_u);
+    if (s < nk) ring_stage_step<C>(rst, (kb + s) * BK, s, wave_u);
 
   for (int t = 0; t < nk; ++t) {
     // K-step t has landed once at most min(S-2, nk-1-t) younger steps are still in flight
@@ -713,7 +779,7 @@ __device__ __forceinline__ void nt_tile(const GemmNtParams& p, char* smem, int l
     __builtin_amdgcn_s_barrier();            // every wave's loads of step t landed; step t-1 fully read
     __builtin_amdgcn_sched_barrier(0);
     if (t + S - 1 < nk)                      // refill the slot step t-1 used
-      if constexpr (!SPREAD) ring_stage_step<C>(rst, (t + S - 1) * BK, (t + S - 1) % S, wave_u);
+      if constexpr (!SPREAD) ring_stage_step<C>(rst, (kb + t + S - 1) * BK, (t + S - 1) % S, wave_u);
     const char* tw = smem + (t % S) * C::STAGE_BYTES;
     const char* tx = tw + BN * C::ROWB;
     // Software-pipelined fragment stream.  Left alone, the compiler reads all 12 fragments of a 32-deep
@@ -759,7 +825,7 @@ __device__ __forceinline__ void nt_tile(const GemmNtParams& p, char* smem, int l
           acc[i][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ks_ & 1][i], fx[(u) % 3], acc[i][j_], 0, 0, 0); \
         if constexpr (FragPipe<MT, KS>::AFTER) { UNIMM_PREFETCH(u) }                                         \
         if constexpr (SPREAD && (u) < G) {                                         /* refill, one LDS-DMA per unit */ \
-          if (t + 1 < nk) ring_stage_one<C>(rst, (t + 1) * BK, (t + 1) & 1, wave_u, u);                    \
+          if (t + 1 < nk) ring_stage_one<C>(rst, (kb + t + 1) * BK, (t + 1) & 1, wave_u, u);               \
         }                                                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
       }
@@ -770,6 +836,9 @@ __device__ __forceinline__ void nt_tile(const GemmNtParams& p, char* smem, int l
     }
   }
 
+  if (p.ksplit > 1) {
+    if (!nt_split_join<C>(p, acc, smem, lid, split)) return;
+  }
   nt_epilogue<C, EPI, OUT_F32>(p, acc, smem, m0, n0, wm, wn, wave, lane);
 }
 
@@ -1362,7 +1431,7 @@ constexpr int PROF_MAX = 1 << 16;
 constexpr int PROF_VARIANTS = 516;
 constexpr int PROF_TN0 = 512;
 template <class C> constexpr int nt_tile_code() {
-  return C::PP ? 8 : (C::MT == 8 ? 3 : (C::MT == 6 ? 6 : (C::MT == 2 ? 7 : 1)));
+  return C::PP ? 8 : (C::MT == 8 ? 3 : (C::MT == 6 ? 6 : (C::MT == 2 ? (C::STAGES == 3 ? 9 : 7) : (C::STAGES == 3 ? 10 : 1))));
 }
 bool g_prof_on = false;
 bool g_prof_tn_only = false;        // unimm_prof_enable(2): only the weight-gradient launches (2 event records per launch
@@ -1397,7 +1466,7 @@ inline bool nt_tune_decode(int code, NtTune& t) {
   t.persist = pc == 0 ? -1 : (pc == 1 ? 1 : 0);           // x1xx persistent, x2xx one workgroup per tile, else automatic
   t.cfg = code % 100;
   t.gn = code / 1000;
-  return pc <= 2 && (t.cfg == 0 || t.cfg == 1 || t.cfg == 3 || t.cfg == 6 || t.cfg == 7 || t.cfg == 8);
+  return pc <= 2 && (t.cfg == 0 || t.cfg == 1 || t.cfg == 3 || t.cfg == 6 || t.cfg == 7 || t.cfg == 8 || t.cfg == 9 || t.cfg == 10);
 }
 
 template <class C, int EPI, bool F32> constexpr auto pick_nt_kernel() { return &gemm_nt_kernel<C, EPI, F32>; }
@@ -1414,9 +1483,33 @@ inline int cu_count() {
   return n;
 }
 
+struct NtSplit { int want; void* ws; long ws_bytes; };     // want: 0 / 1 = off, >= 2 = that many splits, -1 = the library's choice
+
 template <class C, int EPI>
-int launch_nt_cfg(const GemmNtParams& p, bool out_f32, int want_persist, hipStream_t s) {
-  const int nwg = ((p.M + C::BM - 1) / C::BM) * ((p.N + C::BN - 1) / C::BN);
+int launch_nt_cfg(const GemmNtParams& p_in, bool out_f32, int want_persist, hipStream_t s, const NtSplit& sk = NtSplit{0, nullptr, 0}) {
+  GemmNtParams p = p_in;
+  int nwg = ((p.M + C::BM - 1) / C::BM) * ((p.N + C::BN - 1) / C::BN);
+  p.ksplit = 1; p.slabs = nullptr; p.counters = nullptr;
+  if (!C::PP && sk.want != 0 && sk.want != 1 && sk.ws != nullptr) {
+    // Split only grids that leave the chip under-filled (every split workgroup resident at once) and reductions long enough
+    // to pay for the join (>= 8 K-steps per split).
+    const int slots = (cu_count() & ~7) * C::WG_PER_CU, nk = p.K / C::BK;
+    int ks = sk.want > 1 ? sk.want : (nwg > 0 ? slots / nwg : 1);
+    ks = ks > 4 ? 4 : ks;
+    while (ks > 1 && nk / ks < 8) --ks;
+    if (ks > 1) {
+      const int per = (nk + ks - 1) / ks;
+      while (ks > 1 && (ks - 1) * per >= nk) --ks;                 // no empty split
+    }
+    constexpr long CBYTES = 16384, TILE_BYTES = (long)C::NW * 4 * C::MT * 64 * 16;
+    if (ks > 1 && nwg <= CBYTES / 4 && CBYTES + (long)nwg * ks * TILE_BYTES <= sk.ws_bytes) {
+      p.ksplit = ks;
+      p.counters = reinterpret_cast<int*>(sk.ws);
+      p.slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(sk.ws) + CBYTES);
+      nwg *= ks;
+      want_persist = 0;
+    }
+  }
   auto k32 = pick_nt_kernel<C, EPI, true>();
   auto k16 = pick_nt_kernel<C, EPI, false>();
   if (C::LDS > 64 * 1024) {
@@ -1461,7 +1554,7 @@ int launch_nt_cfg(const GemmNtParams& p, bool out_f32, int want_persist, hipStre
 }
 
 template <int EPI>
-int launch_nt(const GemmNtParams& p, bool out_f32, const NtTune& tune, hipStream_t s) {
+int launch_nt(const GemmNtParams& p, bool out_f32, const NtTune& tune, hipStream_t s, const NtSplit& sk = NtSplit{0, nullptr, 0}) {
   int cfg = tune.cfg;
   const int wp = tune.persist;
   if (cfg == 0) {
@@ -1498,9 +1591,14 @@ int launch_nt(const GemmNtParams& p, bool out_f32, const NtTune& tune, hipStream
   // (configurations 2, 4, 5 - the BK = 32 rings of 4 and 5 slots, measured slower in round 1 - are not instantiated:
   //  a third of this file's compile time; unimm_gemm_nt rejects them, DESIGN.md 5 has the numbers)
   if (cfg == 6) return launch_nt_cfg<Cfg<2, 4, 6, 64, 2>, EPI>(p, out_f32, wp, s);
-  if (cfg == 7) return launch_nt_cfg<Cfg<2, 2, 2, 64, 2>, EPI>(p, out_f32, wp, s);
+  if (cfg == 7) return launch_nt_cfg<Cfg<2, 2, 2, 64, 2>, EPI>(p, out_f32, wp, s, sk);
+  // 3-slot rings for the small tiles (two K-steps in flight): grids that leave the chip under-filled run one or two
+  // workgroups per CU whose K loop is a chain of exposed L2 round trips (0.69 us per 64-deep step at 3.9k rows, 15 % of a
+  // CU's MFMA rate); 9 = 64x128 (72 KiB: two workgroups per CU), 10 = 128x128 (96 KiB: one per CU)
+  if (cfg == 9) return launch_nt_cfg<Cfg<2, 2, 2, 64, 3>, EPI>(p, out_f32, wp, s, sk);
+  if (cfg == 10) return launch_nt_cfg<Cfg<2, 2, 4, 64, 3>, EPI>(p, out_f32, wp, s, sk);
   if (cfg == 3) return launch_nt_cfg<Cfg<2, 4, 8, 64, 2>, EPI>(p, out_f32, wp, s);
-  return launch_nt_cfg<Cfg<2, 2, 4, 64, 2>, EPI>(p, out_f32, wp, s);
+  return launch_nt_cfg<Cfg<2, 2, 4, 64, 2>, EPI>(p, out_f32, wp, s, sk);
 }
 
 }  // namespace
@@ -1528,15 +1626,20 @@ extern "C" int unimm_gemm_nt(const unimm_gemm_nt_args* a, void* stream) {
   p.gn = tune.gn > 0 ? tune.gn : 4;   // 4 tile columns per group: +1 % at 240 sequences, +5-8 % at 30 over 6 (A/B, two-stream schedule)
   hipStream_t s = (hipStream_t)stream;
   const bool f32 = a->out_f32 != 0;
+  p.ksplit = 1; p.slabs = nullptr; p.counters = nullptr;
+  if (a->splitk != 0 && a->splitk != 1 && (a->splitk_ws == nullptr || a->splitk_ws_bytes < 32768 || ((uintptr_t)a->splitk_ws & 255) ||
+                                           a->splitk > 8 || a->splitk < -1))
+    return UNIMM_E_ARG;
+  const NtSplit sk{a->splitk, a->splitk_ws, (long)a->splitk_ws_bytes};
   switch (a->epilogue) {
-    case UNIMM_EPI_BIAS: return launch_nt<UNIMM_EPI_BIAS>(p, f32, tune, s);
-    case UNIMM_EPI_BIAS_GELU: return launch_nt<UNIMM_EPI_BIAS_GELU>(p, f32, tune, s);
-    case UNIMM_EPI_BIAS_DROP_RESID: return launch_nt<UNIMM_EPI_BIAS_DROP_RESID>(p, f32, tune, s);
-    case UNIMM_EPI_BIAS_RELU: return launch_nt<UNIMM_EPI_BIAS_RELU>(p, f32, tune, s);
-    case UNIMM_EPI_DGELU: return launch_nt<UNIMM_EPI_DGELU>(p, f32, tune, s);
-    case UNIMM_EPI_ADD: return launch_nt<UNIMM_EPI_ADD>(p, f32, tune, s);
-    case UNIMM_EPI_MUL: return launch_nt<UNIMM_EPI_MUL>(p, f32, tune, s);
-    case UNIMM_EPI_BIAS_GELU_DG: return launch_nt<UNIMM_EPI_BIAS_GELU_DG>(p, f32, tune, s);
+    case UNIMM_EPI_BIAS: return launch_nt<UNIMM_EPI_BIAS>(p, f32, tune, s, sk);
+    case UNIMM_EPI_BIAS_GELU: return launch_nt<UNIMM_EPI_BIAS_GELU>(p, f32, tune, s, sk);
+    case UNIMM_EPI_BIAS_DROP_RESID: return launch_nt<UNIMM_EPI_BIAS_DROP_RESID>(p, f32, tune, s, sk);
+    case UNIMM_EPI_BIAS_RELU: return launch_nt<UNIMM_EPI_BIAS_RELU>(p, f32, tune, s, sk);
+    case UNIMM_EPI_DGELU: return launch_nt<UNIMM_EPI_DGELU>(p, f32, tune, s, sk);
+    case UNIMM_EPI_ADD: return launch_nt<UNIMM_EPI_ADD>(p, f32, tune, s, sk);
+    case UNIMM_EPI_MUL: return launch_nt<UNIMM_EPI_MUL>(p, f32, tune, s, sk);
+    case UNIMM_EPI_BIAS_GELU_DG: return launch_nt<UNIMM_EPI_BIAS_GELU_DG>(p, f32, tune, s, sk);
     default: return UNIMM_E_ARG;
   }
 }

@@ -332,49 +332,67 @@ struct AttnF32 {
   DropoutArg drop;
 };
 
+#ifndef UNIMM_X3_ATTN_BWD_DH
+#define UNIMM_X3_ATTN_BWD_DH 32
+#endif
+#ifndef UNIMM_X3_ATTN_FWD_DH
+#define UNIMM_X3_ATTN_FWD_DH 64
+#endif
 constexpr int XA_T = 128;     // threads per workgroup
 constexpr int XA_C = 32;      // staged rows per chunk (= one mask word)
-constexpr int XA_HS = 68;     // floats per staged half row: 64 + 4 (the two halves of a D = 128 row land on different banks)
+// A row of D dimensions is split over LPR = D / DH neighbouring lanes (DH = 64 or 32 dimensions per lane: 32 halves the
+// per-lane operand / accumulator registers, which is what lets the backward kernels keep two waves per SIMD); the partial
+// dot products meet in log2(LPR) cross-lane adds.  Staged rows are stored as segments of DH + 4 floats, so that the lanes of
+// one row read different banks.
 
-__device__ __forceinline__ void xa_load64(const float* __restrict__ g, float* r) {
+template <int DH>
+__device__ __forceinline__ void xa_load(const float* __restrict__ g, float* r) {
 #pragma unroll
-  for (int c = 0; c < 64; c += 4) {
+  for (int c = 0; c < DH; c += 4) {
     const f32x4 t = *reinterpret_cast<const f32x4*>(g + c);
     r[c] = t[0]; r[c + 1] = t[1]; r[c + 2] = t[2]; r[c + 3] = t[3];
   }
 }
-__device__ __forceinline__ void xa_store64(float* __restrict__ g, const float* r, float s) {
+template <int DH>
+__device__ __forceinline__ void xa_store(float* __restrict__ g, const float* r, float s) {
 #pragma unroll
-  for (int c = 0; c < 64; c += 4) *reinterpret_cast<f32x4*>(g + c) = f32x4{r[c] * s, r[c + 1] * s, r[c + 2] * s, r[c + 3] * s};
+  for (int c = 0; c < DH; c += 4) *reinterpret_cast<f32x4*>(g + c) = f32x4{r[c] * s, r[c + 1] * s, r[c + 2] * s, r[c + 3] * s};
 }
-__device__ __forceinline__ float xa_dot64(const float* r, const float* __restrict__ lds) {
+template <int DH>
+__device__ __forceinline__ float xa_dot(const float* r, const float* __restrict__ lds) {
   float d0 = 0.f, d1 = 0.f;
 #pragma unroll
-  for (int c = 0; c < 64; c += 8) {
+  for (int c = 0; c < DH; c += 8) {
     const f32x4 a = *reinterpret_cast<const f32x4*>(lds + c), b = *reinterpret_cast<const f32x4*>(lds + c + 4);
     d0 = fmaf(r[c], a[0], d0); d0 = fmaf(r[c + 1], a[1], d0); d0 = fmaf(r[c + 2], a[2], d0); d0 = fmaf(r[c + 3], a[3], d0);
     d1 = fmaf(r[c + 4], b[0], d1); d1 = fmaf(r[c + 5], b[1], d1); d1 = fmaf(r[c + 6], b[2], d1); d1 = fmaf(r[c + 7], b[3], d1);
   }
   return d0 + d1;
 }
-__device__ __forceinline__ void xa_axpy64(float* acc, float a, const float* __restrict__ lds) {
+template <int DH>
+__device__ __forceinline__ void xa_axpy(float* acc, float a, const float* __restrict__ lds) {
 #pragma unroll
-  for (int c = 0; c < 64; c += 4) {
+  for (int c = 0; c < DH; c += 4) {
     const f32x4 t = *reinterpret_cast<const f32x4*>(lds + c);
     acc[c] = fmaf(a, t[0], acc[c]); acc[c + 1] = fmaf(a, t[1], acc[c + 1]);
     acc[c + 2] = fmaf(a, t[2], acc[c + 2]); acc[c + 3] = fmaf(a, t[3], acc[c + 3]);
   }
 }
 // stage rows [r0, r0 + XA_C) (zeros past `len`) of a [.., ld] fp32 matrix, D columns from column `col0`, into LDS
-template <int D>
+template <int LPR> __device__ __forceinline__ float xa_rowsum(float v) {       // sum over the LPR lanes of a row
+#pragma unroll
+  for (int o = 1; o < LPR; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <int D, int DH>
 __device__ __forceinline__ void xa_stage(float* __restrict__ lds, const float* __restrict__ g, int row_base, int r0, int len, int ld,
                                          int col0) {
-  constexpr int RS = (D / 64) * XA_HS;
+  constexpr int RS = (D / DH) * (DH + 4);
   for (int i = threadIdx.x; i < XA_C * (D / 4); i += XA_T) {
     const int r = i / (D / 4), c = (i - r * (D / 4)) * 4;
     f32x4 t = {0.f, 0.f, 0.f, 0.f};
     if (r0 + r < len) t = *reinterpret_cast<const f32x4*>(g + (size_t)(row_base + r0 + r) * ld + col0 + c);
-    *reinterpret_cast<f32x4*>(lds + r * RS + (c >> 6) * XA_HS + (c & 63)) = t;
+    *reinterpret_cast<f32x4*>(lds + r * RS + (c / DH) * (DH + 4) + (c % DH)) = t;
   }
 }
 __device__ __forceinline__ bool xa_keep(const DropoutArg& d, uint32_t hrow, uint32_t Tk, uint32_t key) {
@@ -383,9 +401,9 @@ __device__ __forceinline__ bool xa_keep(const DropoutArg& d, uint32_t hrow, uint
   return ((key & 1u) ? (w >> 16) : (w & 0xffffu)) >= (d.thr >> 16);
 }
 
-template <int D>
+template <int D, int DH>
 __global__ __launch_bounds__(XA_T) void x3_attn_fwd_kernel(AttnF32 p) {
-  constexpr int LPR = D / 64, RPW = XA_T / LPR, RS = LPR * XA_HS;
+  constexpr int LPR = D / DH, RPW = XA_T / LPR, HS = DH + 4, RS = LPR * HS;
   __shared__ __attribute__((aligned(16))) float Ks[XA_C * RS];
   __shared__ __attribute__((aligned(16))) float Vs[XA_C * RS];
   drop_resolve(p.drop);
@@ -397,47 +415,47 @@ __global__ __launch_bounds__(XA_T) void x3_attn_fwd_kernel(AttnF32 p) {
   const int rl = threadIdx.x / LPR, half = threadIdx.x % LPR;
   const bool valid = r0 + rl < qlen;
   const int qr = valid ? r0 + rl : qlen - 1;
-  float qv[64], acc[64];
-  xa_load64(p.q + (size_t)(qoff + qr) * p.ldq + head * D + half * 64, qv);
+  float qv[DH], acc[DH];
+  xa_load<DH>(p.q + (size_t)(qoff + qr) * p.ldq + head * D + half * DH, qv);
 #pragma unroll
-  for (int c = 0; c < 64; ++c) acc[c] = 0.f;
+  for (int c = 0; c < DH; ++c) acc[c] = 0.f;
   float m = -INFINITY, l = 0.f;
   const uint32_t* mrow = p.mask + (size_t)b * p.mbs + (size_t)qr * p.mqs;
   const uint32_t hrow = ((uint32_t)b * p.H + head) * p.Tq + (uint32_t)qr;
   for (int k0 = 0; k0 < klen; k0 += XA_C) {
     __syncthreads();
-    xa_stage<D>(Ks, p.k, koff, k0, klen, p.ldk, head * D);
-    xa_stage<D>(Vs, p.v, koff, k0, klen, p.ldv, head * D);
+    xa_stage<D, DH>(Ks, p.k, koff, k0, klen, p.ldk, head * D);
+    xa_stage<D, DH>(Vs, p.v, koff, k0, klen, p.ldv, head * D);
     __syncthreads();
     const uint32_t mw = mrow[k0 >> 5];
     const int nk = min(XA_C, klen - k0);
     for (int j = 0; j < nk; ++j) {
-      float d = xa_dot64(qv, Ks + j * RS + half * XA_HS);
-      if (LPR == 2) d += __shfl_xor(d, 1, 64);
+      float d = xa_dot<DH>(qv, Ks + j * RS + half * HS);
+      d = xa_rowsum<LPR>(d);
       const float sv = d * p.scale + (((mw >> j) & 1u) ? 0.f : -10000.0f);
       if (sv > m) {
         const float corr = __expf(m - sv);                 // first key: exp(-inf) = 0
         l *= corr;
 #pragma unroll
-        for (int c = 0; c < 64; ++c) acc[c] *= corr;
+        for (int c = 0; c < DH; ++c) acc[c] *= corr;
         m = sv;
       }
       const float e = __expf(sv - m);
       l += e;
       const float pe = xa_keep(p.drop, hrow, (uint32_t)p.Tk, (uint32_t)(k0 + j)) ? e : 0.f;
-      xa_axpy64(acc, pe, Vs + j * RS + half * XA_HS);
+      xa_axpy<DH>(acc, pe, Vs + j * RS + half * HS);
     }
   }
   if (!valid) return;
   const float inv = (p.drop.thr != 0u ? p.drop.scale : 1.0f) / l;
-  xa_store64(p.out + (size_t)(qoff + qr) * p.ldo + head * D + half * 64, acc, inv);
+  xa_store<DH>(p.out + (size_t)(qoff + qr) * p.ldo + head * D + half * DH, acc, inv);
   if (p.lse != nullptr && half == 0) p.lse[((size_t)b * p.H + head) * p.Tq + qr] = m + __logf(l);
 }
 
 // dQ (+ delta = rowsum(dO o O)): a lane per query, keys staged
-template <int D>
+template <int D, int DH>
 __global__ __launch_bounds__(XA_T) void x3_attn_bwd_dq_kernel(AttnF32 p) {
-  constexpr int LPR = D / 64, RPW = XA_T / LPR, RS = LPR * XA_HS;
+  constexpr int LPR = D / DH, RPW = XA_T / LPR, HS = DH + 4, RS = LPR * HS;
   __shared__ __attribute__((aligned(16))) float Ks[XA_C * RS];
   __shared__ __attribute__((aligned(16))) float Vs[XA_C * RS];
   drop_resolve(p.drop);
@@ -449,53 +467,53 @@ __global__ __launch_bounds__(XA_T) void x3_attn_bwd_dq_kernel(AttnF32 p) {
   const int rl = threadIdx.x / LPR, half = threadIdx.x % LPR;
   const bool valid = r0 + rl < qlen;
   const int qr = valid ? r0 + rl : qlen - 1;
-  float qv[64], dov[64], dq[64];
-  xa_load64(p.q + (size_t)(qoff + qr) * p.ldq + head * D + half * 64, qv);
-  xa_load64(p.dout + (size_t)(qoff + qr) * p.lddo + head * D + half * 64, dov);
+  float qv[DH], dov[DH], dq[DH];
+  xa_load<DH>(p.q + (size_t)(qoff + qr) * p.ldq + head * D + half * DH, qv);
+  xa_load<DH>(p.dout + (size_t)(qoff + qr) * p.lddo + head * D + half * DH, dov);
   float delta = 0.f;
   {
-    const float* og = p.o + (size_t)(qoff + qr) * p.ldo + head * D + half * 64;
+    const float* og = p.o + (size_t)(qoff + qr) * p.ldo + head * D + half * DH;
 #pragma unroll
-    for (int c = 0; c < 64; c += 4) {
+    for (int c = 0; c < DH; c += 4) {
       const f32x4 t = *reinterpret_cast<const f32x4*>(og + c);
       delta = fmaf(dov[c], t[0], delta); delta = fmaf(dov[c + 1], t[1], delta);
       delta = fmaf(dov[c + 2], t[2], delta); delta = fmaf(dov[c + 3], t[3], delta);
     }
-    if (LPR == 2) delta += __shfl_xor(delta, 1, 64);
+    delta = xa_rowsum<LPR>(delta);
   }
   const size_t li = ((size_t)b * p.H + head) * p.Tq + qr;
   const float lse = p.lse[li];
   if (valid && half == 0) p.delta[li] = delta;
 #pragma unroll
-  for (int c = 0; c < 64; ++c) dq[c] = 0.f;
+  for (int c = 0; c < DH; ++c) dq[c] = 0.f;
   const uint32_t* mrow = p.mask + (size_t)b * p.mbs + (size_t)qr * p.mqs;
   const uint32_t hrow = ((uint32_t)b * p.H + head) * p.Tq + (uint32_t)qr;
   const float dsc = p.drop.thr != 0u ? p.drop.scale : 1.0f;
   for (int k0 = 0; k0 < klen; k0 += XA_C) {
     __syncthreads();
-    xa_stage<D>(Ks, p.k, koff, k0, klen, p.ldk, head * D);
-    xa_stage<D>(Vs, p.v, koff, k0, klen, p.ldv, head * D);
+    xa_stage<D, DH>(Ks, p.k, koff, k0, klen, p.ldk, head * D);
+    xa_stage<D, DH>(Vs, p.v, koff, k0, klen, p.ldv, head * D);
     __syncthreads();
     const uint32_t mw = mrow[k0 >> 5];
     const int nk = min(XA_C, klen - k0);
     for (int j = 0; j < nk; ++j) {
-      const float* kr = Ks + j * RS + half * XA_HS;
-      float d = xa_dot64(qv, kr);
-      float dpv = xa_dot64(dov, Vs + j * RS + half * XA_HS);
-      if (LPR == 2) { d += __shfl_xor(d, 1, 64); dpv += __shfl_xor(dpv, 1, 64); }
+      const float* kr = Ks + j * RS + half * HS;
+      float d = xa_dot<DH>(qv, kr);
+      float dpv = xa_dot<DH>(dov, Vs + j * RS + half * HS);
+      d = xa_rowsum<LPR>(d); dpv = xa_rowsum<LPR>(dpv);
       const float pr = __expf(d * p.scale + (((mw >> j) & 1u) ? 0.f : -10000.0f) - lse);
       const float dP = xa_keep(p.drop, hrow, (uint32_t)p.Tk, (uint32_t)(k0 + j)) ? dpv * dsc : 0.f;
       const float dS = pr * (dP - delta) * p.scale;
-      xa_axpy64(dq, dS, kr);
+      xa_axpy<DH>(dq, dS, kr);
     }
   }
-  if (valid) xa_store64(p.dq + (size_t)(qoff + qr) * p.lddq + head * D + half * 64, dq, 1.0f);
+  if (valid) xa_store<DH>(p.dq + (size_t)(qoff + qr) * p.lddq + head * D + half * DH, dq, 1.0f);
 }
 
 // dK, dV: a lane per key, queries staged (Q, dO rows + their lse / delta / mask words)
-template <int D>
+template <int D, int DH>
 __global__ __launch_bounds__(XA_T) void x3_attn_bwd_dkv_kernel(AttnF32 p) {
-  constexpr int LPR = D / 64, RPW = XA_T / LPR, RS = LPR * XA_HS;
+  constexpr int LPR = D / DH, RPW = XA_T / LPR, HS = DH + 4, RS = LPR * HS;
   __shared__ __attribute__((aligned(16))) float Qs[XA_C * RS];
   __shared__ __attribute__((aligned(16))) float Os[XA_C * RS];
   __shared__ float Ls[XA_C], Ds[XA_C];
@@ -509,19 +527,19 @@ __global__ __launch_bounds__(XA_T) void x3_attn_bwd_dkv_kernel(AttnF32 p) {
   const int rl = threadIdx.x / LPR, half = threadIdx.x % LPR;
   const bool valid = r0 + rl < klen;
   const int key = valid ? r0 + rl : klen - 1;
-  float kv[64], vv[64], dk[64], dv[64];
-  xa_load64(p.k + (size_t)(koff + key) * p.ldk + head * D + half * 64, kv);
-  xa_load64(p.v + (size_t)(koff + key) * p.ldv + head * D + half * 64, vv);
+  float kv[DH], vv[DH], dk[DH], dv[DH];
+  xa_load<DH>(p.k + (size_t)(koff + key) * p.ldk + head * D + half * DH, kv);
+  xa_load<DH>(p.v + (size_t)(koff + key) * p.ldv + head * D + half * DH, vv);
 #pragma unroll
-  for (int c = 0; c < 64; ++c) { dk[c] = 0.f; dv[c] = 0.f; }
+  for (int c = 0; c < DH; ++c) { dk[c] = 0.f; dv[c] = 0.f; }
   const int nw = (p.Tk + 31) >> 5;
   const uint32_t hbase = ((uint32_t)b * p.H + head) * p.Tq;
   const float dsc = p.drop.thr != 0u ? p.drop.scale : 1.0f;
   const size_t lbase = ((size_t)b * p.H + head) * p.Tq;
   for (int q0 = 0; q0 < qlen; q0 += XA_C) {
     __syncthreads();
-    xa_stage<D>(Qs, p.q, qoff, q0, qlen, p.ldq, head * D);
-    xa_stage<D>(Os, p.dout, qoff, q0, qlen, p.lddo, head * D);
+    xa_stage<D, DH>(Qs, p.q, qoff, q0, qlen, p.ldq, head * D);
+    xa_stage<D, DH>(Os, p.dout, qoff, q0, qlen, p.lddo, head * D);
     const int nq = min(XA_C, qlen - q0);
     if (threadIdx.x < nq) { Ls[threadIdx.x] = p.lse[lbase + q0 + threadIdx.x]; Ds[threadIdx.x] = p.delta[lbase + q0 + threadIdx.x]; }
     for (int i = threadIdx.x; i < nq * nw; i += XA_T) {
@@ -530,24 +548,24 @@ __global__ __launch_bounds__(XA_T) void x3_attn_bwd_dkv_kernel(AttnF32 p) {
     }
     __syncthreads();
     for (int j = 0; j < nq; ++j) {
-      const float* qr_ = Qs + j * RS + half * XA_HS;
-      const float* or_ = Os + j * RS + half * XA_HS;
-      float d = xa_dot64(kv, qr_);
-      float dpv = xa_dot64(vv, or_);
-      if (LPR == 2) { d += __shfl_xor(d, 1, 64); dpv += __shfl_xor(dpv, 1, 64); }
+      const float* qr_ = Qs + j * RS + half * HS;
+      const float* or_ = Os + j * RS + half * HS;
+      float d = xa_dot<DH>(kv, qr_);
+      float dpv = xa_dot<DH>(vv, or_);
+      d = xa_rowsum<LPR>(d); dpv = xa_rowsum<LPR>(dpv);
       const uint32_t mw = Ms[j * 8 + (key >> 5)];
       const float pr = __expf(d * p.scale + (((mw >> (key & 31)) & 1u) ? 0.f : -10000.0f) - Ls[j]);
       const bool keep = xa_keep(p.drop, hbase + (uint32_t)(q0 + j), (uint32_t)p.Tk, (uint32_t)key);
       const float pd = keep ? pr * dsc : 0.f;
       const float dP = keep ? dpv * dsc : 0.f;
       const float dS = pr * (dP - Ds[j]) * p.scale;
-      xa_axpy64(dv, pd, or_);
-      xa_axpy64(dk, dS, qr_);
+      xa_axpy<DH>(dv, pd, or_);
+      xa_axpy<DH>(dk, dS, qr_);
     }
   }
   if (!valid) return;
-  xa_store64(p.dk + (size_t)(koff + key) * p.lddk + head * D + half * 64, dk, 1.0f);
-  xa_store64(p.dv + (size_t)(koff + key) * p.lddv + head * D + half * 64, dv, 1.0f);
+  xa_store<DH>(p.dk + (size_t)(koff + key) * p.lddk + head * D + half * DH, dk, 1.0f);
+  xa_store<DH>(p.dv + (size_t)(koff + key) * p.lddv + head * D + half * DH, dv, 1.0f);
 }
 
 int fill_attn(const unimm_attn_args* a, AttnF32& p) {
@@ -650,8 +668,11 @@ extern "C" int unimm_x3_attn_fwd(const unimm_attn_args* a, void* stream) {
   const int rc = fill_attn(a, p);
   if (rc != UNIMM_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
-  if (a->D == 64) hipLaunchKernelGGL(x3_attn_fwd_kernel<64>, dim3((a->Tq + 127) / 128, a->H, a->B), dim3(XA_T), 0, s, p);
-  else hipLaunchKernelGGL(x3_attn_fwd_kernel<128>, dim3((a->Tq + 63) / 64, a->H, a->B), dim3(XA_T), 0, s, p);
+  // forward: 64 dimensions per lane (176-184 registers: two waves per SIMD either way, half the cross-lane adds)
+  constexpr int DH = UNIMM_X3_ATTN_FWD_DH;
+  constexpr int R64 = XA_T / (64 / DH), R128 = XA_T / (128 / DH);
+  if (a->D == 64) hipLaunchKernelGGL((x3_attn_fwd_kernel<64, DH>), dim3((a->Tq + R64 - 1) / R64, a->H, a->B), dim3(XA_T), 0, s, p);
+  else hipLaunchKernelGGL((x3_attn_fwd_kernel<128, DH>), dim3((a->Tq + R128 - 1) / R128, a->H, a->B), dim3(XA_T), 0, s, p);
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;
 }
@@ -674,12 +695,17 @@ extern "C" int unimm_x3_attn_bwd(const unimm_attn_bwd_args* a, void* stream) {
   p.dq = (float*)a->dq; p.dk = (float*)a->dk; p.dv = (float*)a->dv;
   p.lddo = a->lddo; p.lddq = a->lddq; p.lddk = a->lddk; p.lddv = a->lddv;
   hipStream_t s = (hipStream_t)stream;
+  // backward: 32 dimensions per lane (the dK / dV kernel holds k, v, dk, dv: 4 x 64 registers at 64 per lane = one wave per SIMD
+  // with nothing to hide the LDS round trips behind)
+  constexpr int DH = UNIMM_X3_ATTN_BWD_DH;
   if (a->D == 64) {
-    hipLaunchKernelGGL(x3_attn_bwd_dq_kernel<64>, dim3((a->Tq + 127) / 128, a->H, a->B), dim3(XA_T), 0, s, p);
-    hipLaunchKernelGGL(x3_attn_bwd_dkv_kernel<64>, dim3((a->Tk + 127) / 128, a->H, a->B), dim3(XA_T), 0, s, p);
+    constexpr int RPW = XA_T / (64 / DH);
+    hipLaunchKernelGGL((x3_attn_bwd_dq_kernel<64, DH>), dim3((a->Tq + RPW - 1) / RPW, a->H, a->B), dim3(XA_T), 0, s, p);
+    hipLaunchKernelGGL((x3_attn_bwd_dkv_kernel<64, DH>), dim3((a->Tk + RPW - 1) / RPW, a->H, a->B), dim3(XA_T), 0, s, p);
   } else {
-    hipLaunchKernelGGL(x3_attn_bwd_dq_kernel<128>, dim3((a->Tq + 63) / 64, a->H, a->B), dim3(XA_T), 0, s, p);
-    hipLaunchKernelGGL(x3_attn_bwd_dkv_kernel<128>, dim3((a->Tk + 63) / 64, a->H, a->B), dim3(XA_T), 0, s, p);
+    constexpr int RPW = XA_T / (128 / DH);
+    hipLaunchKernelGGL((x3_attn_bwd_dq_kernel<128, DH>), dim3((a->Tq + RPW - 1) / RPW, a->H, a->B), dim3(XA_T), 0, s, p);
+    hipLaunchKernelGGL((x3_attn_bwd_dkv_kernel<128, DH>), dim3((a->Tk + RPW - 1) / RPW, a->H, a->B), dim3(XA_T), 0, s, p);
   }
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;

@@ -124,6 +124,10 @@ class Engine:
         self.attn_sink = None            # dict while a forward collects attention probabilities (forward_with_attention)
         self.skinny_dx_rows = 3072       # decoded-row count up to which the decoder's input gradient runs as a split reduction (_decoder_dx)
         self.prof_conn = None            # bench.py: dict while the launch profiler tags the connection layers' GEMMs (see _conn_tag)
+        # Split-K for the long reductions of the small-batch regime (see _splitk): workspace per launch stream, zero-filled once
+        self.splitk = True
+        self.splitk_ws_bytes = 48 << 20
+        self._splitk_ws = {}
         self._pending = []               # gradient buckets whose weight gradients are still queued: (group, #text, #image queued)
         self._nq = [0, 0]                # weight-gradient problems ever queued (text side, image side) ...
         self._nf = [0, 0]                # ... and launched
@@ -326,8 +330,13 @@ class Engine:
         aux_ln = None
         if isinstance(aux, _LazyLN):
             aux, aux_ln = aux.x, (aux.mean, aux.rstd, aux.gamma, aux.beta)
-        L.gemm_nt(x, lin.w, out, bias=lin.bias, epilogue=epi, aux=aux, out2=u, drop=drop, M=M, N=lin.N, K=lin.K, aux_ln=aux_ln,
-                  tile=self._tile(M, lin.N))
+        sk = self._splitk(M, lin.N, lin.K)
+        if sk is not None:
+            L.gemm_nt(x, lin.w, out, bias=lin.bias, epilogue=epi, aux=aux, out2=u, drop=drop, M=M, N=lin.N, K=lin.K, aux_ln=aux_ln,
+                      tile=sk[0], splitk=sk[1], splitk_ws=sk[2])
+        else:
+            L.gemm_nt(x, lin.w, out, bias=lin.bias, epilogue=epi, aux=aux, out2=u, drop=drop, M=M, N=lin.N, K=lin.K, aux_ln=aux_ln,
+                      tile=self._tile(M, lin.N))
         return (out, u) if want_u else out
 
     def _tile(self, M, N):
@@ -352,6 +361,23 @@ class Engine:
             return 1
         t128 = ((M + 127) // 128) * ((N + 127) // 128)
         return 7 if t128 < 256 else 1
+
+    def _splitk(self, M, N, K):
+        """(tile code, splitk, workspace) of a long-reduction GEMM in the small-batch regime, or None.  At ~4k text rows a
+        K = 2304 / 3072, N = 768 GEMM is 366 tiles of 64x128, each a 36-48 step chain, and stages 430 MB through the L2s (the W
+        panel is re-read by 61 row tiles): 128x128 tiles halve the staged bytes but leave 186 workgroups for 256 CUs -- two
+        workgroups per tile, each reducing half of K and meeting in a workspace (unimm_gemm_nt_args.splitk), get both: 30.3
+        against 33.6 us alone (profiles/r4c_small_batch_gemm_microbench.txt)."""
+        if not self.splitk or self._on_side or self.gemm_tile != 0 or self._step_rows is None or self._step_rows >= self.small_rows:
+            return None
+        if K < 2048 or N > 1024 or ((M + 127) // 128) * ((N + 127) // 128) > 256:
+            return None
+        dev = self.arena.flat.device
+        key = "img" if self._on_side else "txt"
+        ws = self._splitk_ws.get(key)
+        if ws is None:
+            ws = self._splitk_ws[key] = torch.zeros(self.splitk_ws_bytes, dtype=torch.uint8, device=dev)
+        return 1, 2, ws
 
     def _linear32(self, x, key, relu=False, out=None):
         """y = act(x W^T + b) in fp32 from the fp32 master weights (poolers, NSP head; models/vilbert_dialog.py:946-967, :1070)."""
@@ -488,7 +514,11 @@ class Engine:
             return None
         dx = torch.empty((M, lin.K), dtype=BF16, device=dy.device)
         kdim = lin.wt.shape[1]
-        L.gemm_nt(dy, lin.wt, dx, bias=None, epilogue=epi, aux=aux, M=M, N=lin.K, K=kdim, tile=self._tile(M, lin.K))
+        sk = self._splitk(M, lin.K, kdim)
+        if sk is not None:
+            L.gemm_nt(dy, lin.wt, dx, bias=None, epilogue=epi, aux=aux, M=M, N=lin.K, K=kdim, tile=sk[0], splitk=sk[1], splitk_ws=sk[2])
+        else:
+            L.gemm_nt(dy, lin.wt, dx, bias=None, epilogue=epi, aux=aux, M=M, N=lin.K, K=kdim, tile=self._tile(M, lin.K))
         return dx
 
     def _decoder_dx(self, dlog, dec, n, V):

@@ -117,7 +117,7 @@ class StepGraphs:
         Mcap = min(_rup(Mv, self.row_bucket), B * T)
         ncap = _rup(n_lm, self.lm_bucket) if n_lm > 0 else 0
         sig = self._key0(inp, opts) + (Mcap, ncap, eng.dual_stream, eng.unpad, eng.lazy_ln, eng.gemm_tile, eng.wgrad_group_rounds,
-                                         eng.grad_bucket_hook is not None, eng.wgrad_stream)   # with a hook the backward is a chain of graphs
+                                         eng.grad_bucket_hook is not None, eng.wgrad_stream, eng.splitk)   # with a hook the backward is a chain of graphs
         ent = self.entries.get(sig)
         if ent is not None and ent.inflight is not None and ent.inflight() is not None:
             # the previous forward of this signature has not been back-propagated yet (two losses summed before .backward(),

@@ -13,7 +13,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libunimm_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROP_RESID, EPI_BIAS_RELU, EPI_DGELU, EPI_ADD, EPI_MUL, EPI_BIAS_GELU_DG = range(8)
 
@@ -32,7 +32,8 @@ class GemmNtArgs(C.Structure):
                 ("epilogue", C.c_int32), ("out_f32", C.c_int32),
                 ("drop_key", C.c_uint32), ("drop_thr", C.c_uint32), ("drop_scale", C.c_float),
                 ("aux_mean", C.c_void_p), ("aux_rstd", C.c_void_p), ("aux_gamma", C.c_void_p), ("aux_beta", C.c_void_p),
-                ("tile", C.c_int32), ("drop_salt", C.c_void_p)]
+                ("tile", C.c_int32), ("drop_salt", C.c_void_p),
+                ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64), ("splitk", C.c_int32)]
 
 
 class GemmTnArgs(C.Structure):
@@ -158,7 +159,8 @@ def _dev(*ts):
             raise UnimmHipError("unimm_amd kernels need device tensors (got a CPU tensor)")
 
 
-def gemm_nt(x, w, out, bias=None, epilogue=EPI_BIAS, aux=None, out2=None, drop=None, M=None, N=None, K=None, aux_ln=None, tile=0):
+def gemm_nt(x, w, out, bias=None, epilogue=EPI_BIAS, aux=None, out2=None, drop=None, M=None, N=None, K=None, aux_ln=None, tile=0,
+            splitk=0, splitk_ws=None):
     """out[M,N] = epi(x[M,K] @ w[N,K]^T).  x/w bf16 2-D (row stride = stride(0)); out bf16 or fp32.
     aux_ln = (mean[M], rstd[M], gamma[N], beta[N]): the DROP_RESID residual is LayerNorm(aux) computed on the fly.
     tile: per-call tuning code (include/unimm_hip.h: unimm_gemm_nt_args.tile); 0 = automatic."""
@@ -184,6 +186,10 @@ def gemm_nt(x, w, out, bias=None, epilogue=EPI_BIAS, aux=None, out2=None, drop=N
     a.out_f32 = 1 if out.dtype == torch.float32 else 0
     a.drop_key, a.drop_thr, a.drop_scale = drop[:3] if drop is not None else (0, 0, 0.0)
     a.drop_salt = _salt(drop)
+    if splitk_ws is not None and splitk not in (0, 1):          # (see include/unimm_hip.h: unimm_gemm_nt_args.splitk)
+        a.splitk, a.splitk_ws, a.splitk_ws_bytes = splitk, splitk_ws.data_ptr(), splitk_ws.numel() * splitk_ws.element_size()
+    else:
+        a.splitk, a.splitk_ws, a.splitk_ws_bytes = 0, None, 0
     if aux_ln is not None:
         _dev(*aux_ln)
         a.aux_mean, a.aux_rstd, a.aux_gamma, a.aux_beta = (t.data_ptr() for t in aux_ln)
@@ -672,7 +678,7 @@ def gather_rows(src, idx, dst, n, H, scatter=False, n_dev=None):
 
 
 _EPI_NAMES = ["BIAS", "BIAS_GELU", "BIAS_DROP_RESID", "BIAS_RELU", "DGELU", "ADD", "MUL", "BIAS_GELU_DG"]
-_TILE_NAMES = {1: "128x128", 3: "256x256", 6: "192x256", 7: "64x128", 8: "256x256pp"}
+_TILE_NAMES = {1: "128x128", 3: "256x256", 6: "192x256", 7: "64x128", 8: "256x256pp", 9: "64x128s3", 10: "128x128s3"}
 PROF_VARIANTS = 516
 
 
