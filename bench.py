@@ -98,6 +98,8 @@ def parse():
                     help="bf16 (default, the headline: the reference's autocast class) or fp32x3 = the fp32-accuracy engine "
                          "(unimm_amd/engine_x3.py: bf16 MFMA GEMMs over split operands hi/lo, fp32 attention and gradient "
                          "stream): the arithmetic dense_annotation_finetuning.py:253 runs in (no autocast)")
+    ap.add_argument("--plain-loss", action="store_true", help="A/B: combine the three losses with the written-out torch arithmetic "
+                    "(c * x.mean() + ...) instead of harness.combine_losses (one autograd node)")
     ap.add_argument("--no-splitk", action="store_true", help="A/B: engine.splitk = False (no split-K for the long reductions of small batches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-tile", type=int, default=0, metavar="CODE",
@@ -286,7 +288,7 @@ def main():
         if rccl_ranks != world:
             raise SystemExit(f"process group reduced ones to {rccl_ranks}, expected {world}")
 
-    from unimm_amd import VisualDialogEncoder, lib, synth
+    from unimm_amd import VisualDialogEncoder, harness, lib, synth
     from unimm_amd.parallel import DataParallelRCCL
 
     torch.manual_seed(1234)                       # identical init on every rank (+ broadcast in the wrapper)
@@ -345,6 +347,11 @@ def main():
         def feed():
             batch.update(next(src))
 
+    def combine(lm, nsp, img):                  # train.py:164-168, as unimm_amd.harness.forward combines them
+        if args.plain_loss:
+            return coeff["lm"] * lm.mean() + coeff["nsp"] * nsp.mean() + coeff["img"] * img.mean()
+        return harness.combine_losses(lm, nsp, img, coeff["lm"], coeff["nsp"], coeff["img"])
+
     def fwd_bwd():
         if args.workload == "dense" and args.dense_objective == "ranking":
             from unimm_amd import ranking
@@ -367,7 +374,7 @@ def main():
                                image_attention_mask=batch["image_attention_mask"], image_label=batch["image_label"],
                                image_target=batch["image_target_unique"], nsp_weight=nsp_w, lm_weight=batch["lm_weight"],
                                image_index=batch["image_index"])
-            loss = coeff["lm"] * lm.mean() + coeff["nsp"] * nsp.mean() + coeff["img"] * img.mean()
+            loss = combine(lm, nsp, img)
             loss.backward()
             return loss
         lm, img, nsp = net(batch["input_ids"], batch["image_feat"], batch["image_loc"], sep_indices=batch["sep_indices"],
@@ -377,7 +384,7 @@ def main():
                            image_attention_mask=batch["image_attention_mask"], co_attention_mask=batch["co_attention_mask"],
                            image_label=batch["image_label"], image_target=batch["image_target"], nsp_weight=nsp_w,
                            lm_weight=batch["lm_weight"])
-        loss = coeff["lm"] * lm.mean() + coeff["nsp"] * nsp.mean() + coeff["img"] * img.mean()   # train.py:164-168
+        loss = combine(lm, nsp, img)
         loss.backward()
         return loss
 

@@ -407,3 +407,40 @@ def test_gemm_nt_split_k_equals_unsplit(M, N, K, tile):
     lib.gemm_nt(x, w, got, bias=bias, tile=tile, splitk=4, splitk_ws=ws)
     torch.cuda.synchronize()
     assert float((got - want).abs().max()) <= 2e-3 * float(want.abs().max())
+
+
+def test_gemm_nt_split_k_hand_off_under_uneven_load():
+    """The split-K hand-off (write-through slab stores -> vmcnt(0) -> barrier -> ticket; last arriver: agent-scope acquire) with
+    another stream keeping part of the chip busy, inputs ALTERNATING between launches on one workspace: a slab read that saw the
+    previous launch's bytes (a stale L1 / L2 line) would be off by O(1), every word of every launch is checked."""
+    from unimm_amd import lib
+    g = torch.Generator(device="cuda").manual_seed(11)
+    M, N, K = 3900, 768, 3072
+    xs = [_rand((M, K), g), _rand((M, K), g, 3.0)]
+    w = _rand((N, K), g, 0.05)
+    aux = _rand((M, N), g)
+    ws = torch.zeros(64 << 20, dtype=torch.uint8, device="cuda")
+    refs = []
+    for x in xs:
+        r = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+        lib.gemm_nt(x, w, r, epilogue=lib.EPI_ADD, aux=aux, tile=1)
+        refs.append(r.float())
+    side = torch.cuda.Stream()
+    xb, wb = _rand((2048, 1024), g), _rand((1024, 1024), g)
+    ob = torch.empty((2048, 1024), device="cuda", dtype=torch.bfloat16)
+    outs = [torch.empty((M, N), device="cuda", dtype=torch.bfloat16) for _ in range(8)]
+    torch.cuda.synchronize()
+    worst = 0.0
+    for it in range(160):
+        with torch.cuda.stream(side), lib.stream_scope(side):            # uneven load: small GEMMs beside the split launches
+            for _ in range(3):
+                lib.gemm_nt(xb, wb, ob, tile=7)
+        o = outs[it % 8]
+        lib.gemm_nt(xs[it % 2], w, o, epilogue=lib.EPI_ADD, aux=aux, tile=1, splitk=2 + (it % 3 == 0), splitk_ws=ws)
+        if it % 8 == 7:
+            torch.cuda.synchronize()
+            for j in range(8):
+                k = it - 7 + j
+                ref = refs[k % 2]
+                worst = max(worst, float((outs[j].float() - ref).abs().max() / ref.abs().max()))
+    assert worst <= 2 ** -7, worst

@@ -525,3 +525,20 @@ def test_transpose_bf16_exact(R, C, lds):
     torch.cuda.synchronize()
     assert torch.equal(dst[:, :R], src[:, :C].t())
     assert (dst[:, R:] == 0).all()
+
+
+def test_combine_losses_equals_the_written_out_arithmetic():
+    """harness.combine_losses (one autograd node for c_lm * lm.mean() + c_nsp * nsp.mean() + c_img * img.mean(), train.py:164-168)."""
+    from unimm_amd import harness
+    vals = [torch.tensor([v], device=DEV, requires_grad=True) for v in (3.25, 0.7, 0.55)]
+    ref = [v.detach().clone().requires_grad_(True) for v in vals]
+    c = (1.0, 0.5, 2.0)
+    got = harness.combine_losses(vals[0], vals[1], vals[2], *c)
+    want = c[0] * ref[0].mean() + c[1] * ref[1].mean() + c[2] * ref[2].mean()
+    (got * 3.0).backward()
+    (want * 3.0).backward()
+    assert got.shape == want.shape and abs(float(got) - float(want)) < 1e-6
+    for a, b in zip(vals, ref):
+        assert a.grad.shape == b.grad.shape and torch.allclose(a.grad, b.grad)
+    cpu = [torch.tensor([1.0, 2.0], requires_grad=True) for _ in range(3)]          # several replicas / CPU: the plain arithmetic
+    assert abs(float(harness.combine_losses(*cpu, 1.0, 1.0, 1.0)) - 4.5) < 1e-6
