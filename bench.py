@@ -560,7 +560,10 @@ def main():
         fl = (tag[1] + share * tn_fl) / nsteps
         ms = (tag[0] + share * tn_ms) / nsteps
         nt_tf = tag[1] / (tag[0] * 1e-3) / 1e12 if tag[0] > 0 else 0.0
+        un = (tag[3] + share * tn_ms) / nsteps       # wall time with >= 1 connection-layer GEMM executing (+ the weight-gradient share, taken as not overlapping)
         return allv, {"gflop_per_step": round(fl / 1e9, 1), "ms_per_step": round(ms, 3),
+                      "wall_ms_per_step_with_a_coattention_gemm_running": round(un, 3),
+                      "frac_over_that_wall_time": round(fl / (un * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if un > 0 else None,
                       "tflops": round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else None,
                       "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if ms > 0 else None,
                       "fwd_and_dgrad": {"launches_per_step": tag[2] // nsteps, "ms_per_step": round(tag[0] / nsteps, 3),

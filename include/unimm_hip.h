@@ -534,7 +534,9 @@ int unimm_prof_collect(double* ms, double* flops, int32_t* count, int32_t nvar);
  * it issues from inside a BertConnectionLayer (models/vilbert_dialog.py:655-783) with 1: bench.py's
  * `roofline.coattention_gemms`, the figure north_star's ">= 40 % MFMA utilisation on the co-attention GEMMs" is judged by. */
 int unimm_prof_tag(int32_t tag);
-int unimm_prof_tagged(double* ms, double* flops, int32_t* count, int32_t ntags);
+/* union_ms (or NULL): per tag > 0, the length of the UNION of the launches' execution intervals on one time axis -- launches
+ * of two streams that ran side by side count once: the wall time during which at least one tagged GEMM was executing. */
+int unimm_prof_tagged(double* ms, double* flops, int32_t* count, double* union_ms, int32_t ntags);
 
 #ifdef __cplusplus
 }

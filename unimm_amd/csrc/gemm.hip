@@ -1442,7 +1442,7 @@ int g_prof_n = 0;
 // the engine issues from inside a BertConnectionLayer (models/vilbert_dialog.py:655-783), forward and backward.
 constexpr int PROF_TAGS = 8;
 int g_prof_tag = 0;
-double g_tag_ms[PROF_TAGS], g_tag_flops[PROF_TAGS];
+double g_tag_ms[PROF_TAGS], g_tag_flops[PROF_TAGS], g_tag_union_ms[PROF_TAGS];
 int g_tag_count[PROF_TAGS];
 
 inline ProfRec* prof_begin(int variant, double flops, hipStream_t s) {
@@ -1793,7 +1793,12 @@ extern "C" int unimm_prof_enable(int32_t on) {
 extern "C" int unimm_prof_collect(double* ms, double* flops, int32_t* count, int32_t nvar) {
   if (!ms || !flops || !count || nvar < PROF_VARIANTS) return UNIMM_E_ARG;
   for (int v = 0; v < nvar; ++v) { ms[v] = 0.0; flops[v] = 0.0; count[v] = 0; }
-  for (int t = 0; t < PROF_TAGS; ++t) { g_tag_ms[t] = 0.0; g_tag_flops[t] = 0.0; g_tag_count[t] = 0; }
+  for (int t = 0; t < PROF_TAGS; ++t) { g_tag_ms[t] = 0.0; g_tag_flops[t] = 0.0; g_tag_count[t] = 0; g_tag_union_ms[t] = 0.0; }
+  // per tag: the UNION of the launches' [start, end] intervals on a common time axis (the first record's start event): launches
+  // of two streams that run side by side are counted once -- the wall time during which at least one tagged GEMM was executing
+  struct Iv { double a, b; int tag; };
+  Iv* iv = g_prof_n > 0 ? (Iv*)malloc(sizeof(Iv) * (size_t)g_prof_n) : nullptr;
+  int niv = 0;
   for (int i = 0; i < g_prof_n; ++i) {
     ProfRec& r = g_prof[i];
     if (hipEventSynchronize(r.b) != hipSuccess) return UNIMM_E_HIP;
@@ -1803,8 +1808,23 @@ extern "C" int unimm_prof_collect(double* ms, double* flops, int32_t* count, int
     ms[r.variant] += t; flops[r.variant] += r.flops; count[r.variant] += 1;
     if (r.variant < PROF_TN0 && r.tag >= 0 && r.tag < PROF_TAGS) {      // NT launches only: grouped TN launches mix layers
       g_tag_ms[r.tag] += t; g_tag_flops[r.tag] += r.flops; g_tag_count[r.tag] += 1;
+      float ta = 0.f;
+      if (iv != nullptr && r.tag > 0 && hipEventElapsedTime(&ta, g_prof[0].a, r.a) == hipSuccess) iv[niv++] = Iv{(double)ta, (double)ta + t, r.tag};
     }
   }
+  for (int tag = 1; tag < PROF_TAGS && niv > 0; ++tag) {               // sort by start (insertion sort per tag: a few hundred records)
+    int m = 0;
+    for (int i = 0; i < niv; ++i) if (iv[i].tag == tag) { Iv x = iv[i]; iv[i] = iv[m]; iv[m] = x; ++m; }
+    for (int i = 1; i < m; ++i) { Iv x = iv[i]; int j = i - 1; while (j >= 0 && iv[j].a > x.a) { iv[j + 1] = iv[j]; --j; } iv[j + 1] = x; }
+    double end = -1e300, total = 0.0;
+    for (int i = 0; i < m; ++i) {
+      if (iv[i].a > end) { total += iv[i].b - iv[i].a; end = iv[i].b; }
+      else if (iv[i].b > end) { total += iv[i].b - end; end = iv[i].b; }
+    }
+    g_tag_union_ms[tag] = total;
+    // (records of other tags stay behind index m: restore nothing, every tag re-partitions the array)
+  }
+  free(iv);
   g_prof_n = 0;
   return UNIMM_OK;
 }
@@ -1815,10 +1835,11 @@ extern "C" int unimm_prof_tag(int32_t tag) {
   return UNIMM_OK;
 }
 
-extern "C" int unimm_prof_tagged(double* ms, double* flops, int32_t* count, int32_t ntags) {
+extern "C" int unimm_prof_tagged(double* ms, double* flops, int32_t* count, double* union_ms, int32_t ntags) {
   if (!ms || !flops || !count || ntags < 1) return UNIMM_E_ARG;
   for (int t = 0; t < ntags; ++t) {
     ms[t] = t < PROF_TAGS ? g_tag_ms[t] : 0.0; flops[t] = t < PROF_TAGS ? g_tag_flops[t] : 0.0; count[t] = t < PROF_TAGS ? g_tag_count[t] : 0;
+    if (union_ms != nullptr) union_ms[t] = t < PROF_TAGS ? g_tag_union_ms[t] : 0.0;
   }
   return UNIMM_OK;
 }

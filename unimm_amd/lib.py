@@ -770,10 +770,11 @@ def prof_tag(tag):
 
 
 def prof_tagged(ntags=8):
-    """-> {tag: (total_ms, total_flops, launches)} of the NT launches the last prof_collect() consumed."""
-    ms, fl, cnt = (C.c_double * ntags)(), (C.c_double * ntags)(), (C.c_int32 * ntags)()
-    _check(lib().unimm_prof_tagged(ms, fl, cnt, C.c_int32(ntags)), "unimm_prof_tagged")
-    return {t: (ms[t], fl[t], cnt[t]) for t in range(ntags)}
+    """-> {tag: (total_ms, total_flops, launches, union_ms)} of the NT launches the last prof_collect() consumed; union_ms = the
+    wall time during which at least one launch of the tag was executing (launches of two streams side by side count once)."""
+    ms, fl, cnt, un = (C.c_double * ntags)(), (C.c_double * ntags)(), (C.c_int32 * ntags)(), (C.c_double * ntags)()
+    _check(lib().unimm_prof_tagged(ms, fl, cnt, un, C.c_int32(ntags)), "unimm_prof_tagged")
+    return {t: (ms[t], fl[t], cnt[t], un[t]) for t in range(ntags)}
 
 
 # ---------------------------------------------------------------------------------------------
