@@ -3,7 +3,7 @@
 `DataParallelRCCL` -> `Engine.grad_bucket_hook` -> per-bucket all-reduce issued from inside backward, on the comm
 stream, with the dual-stream joins of `Engine._bucket_done`.
 
-    python tests/_dp2_worker.py <rank> <world> <port> <out.pt> [bf16|fp32] [allreduce|rs_ag] [gloo|nccl] [eager|graphs]
+    python tests/_dp2_worker.py <rank> <world> <port> <out.pt> [bf16|fp32] [allreduce|rs_ag] [gloo|nccl] [eager|graphs] [bf16|fp32x3]
 (nccl = RCCL, rank r on device r: the path bench.py --gpus N takes; needs as many GPUs as ranks.
  graphs = the step executor of unimm_amd/graphs.py: the backward replayed as a chain of graphs cut at the bucket hand-overs)"""
 import json
@@ -24,6 +24,7 @@ def main():
     algo = sys.argv[6] if len(sys.argv) > 6 else "allreduce"
     backend = sys.argv[7] if len(sys.argv) > 7 else "gloo"
     graphs = len(sys.argv) > 8 and sys.argv[8] == "graphs"
+    compute = sys.argv[9] if len(sys.argv) > 9 else "bf16"          # "fp32x3": the fp32-accuracy engine (unimm_amd/engine_x3.py)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     if backend == "nccl":                                 # real RCCL: one device per rank (needs >= `world` GPUs)
         torch.cuda.set_device(rank)
@@ -36,7 +37,7 @@ def main():
     from unimm_amd.parallel import DataParallelRCCL, shard_range
     gold = os.path.join(ROOT, "tests", "golden")
     cfgd = json.load(open(os.path.join(gold, "small_config.json")))
-    model = BertForMultiModalPreTraining(BertConfig.from_dict(cfgd))
+    model = BertForMultiModalPreTraining(BertConfig.from_dict(cfgd), compute_dtype=compute)
     # a different init on every rank: the wrapper's broadcast must make the replicas equal to rank 0's
     model.load_state_dict(R.init_state_dict(R.make_config(cfgd), seed=11 + 5 * rank), strict=True)
     model = model.cuda().eval()

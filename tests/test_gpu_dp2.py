@@ -38,14 +38,13 @@ def _run_ranks(tmp_path, tag, extra):
     return [torch.load(o) for o in outs]
 
 
-@pytest.fixture(scope="module")
-def single_rank(golden_dir):
+def _single_rank(golden_dir, compute="bf16"):
     """1-rank HIP gradients of each shard (same kernels as the ranks run), and rank 0's initial weights."""
     from oracle import vilbert_ref as R
     from unimm_amd import BertConfig, BertForMultiModalPreTraining
     from unimm_amd.parallel import shard_range
     cfgd = json.load(open(os.path.join(golden_dir, "small_config.json")))
-    model = BertForMultiModalPreTraining(BertConfig.from_dict(cfgd))
+    model = BertForMultiModalPreTraining(BertConfig.from_dict(cfgd), compute_dtype=compute)
     model.load_state_dict(R.init_state_dict(R.make_config(cfgd), seed=11), strict=True)
     model = model.cuda().eval()
     g = np.load(os.path.join(golden_dir, "small_mixed.npz"))
@@ -67,6 +66,11 @@ def single_rank(golden_dir):
         grads.append(model.engine.arena.grad_flat.clone().cpu())
         losses.append([float(lm.detach()), float(img.detach()), float(nsp_l.detach())])
     return dict(grads=grads, losses=losses, flat=model.engine.arena.flat.detach().cpu().clone())
+
+
+@pytest.fixture(scope="module")
+def single_rank(golden_dir):
+    return _single_rank(golden_dir)
 
 
 @pytest.mark.parametrize("wire,algo,tol", [("fp32", "allreduce", 2e-5), ("bf16", "allreduce", 6e-3), ("fp32", "rs_ag", 2e-5)])
@@ -124,4 +128,21 @@ def test_two_engine_ranks_over_rccl(tmp_path, single_rank, wire, algo, tol):
         assert np.allclose(out["losses"], single_rank["losses"][r], rtol=0, atol=2e-5)
         err = float((out["grad"] - want).abs().max())
         assert err <= tol * scale, (r, err, scale)
+        assert out["stats"]["buckets"] == out["stats"]["n_buckets_expected"]
+
+
+def test_two_engine_ranks_of_the_fp32_accuracy_engine(tmp_path, golden_dir):
+    """The same two ranks on `compute_dtype="fp32x3"` (unimm_amd/engine_x3.py: the arithmetic class of the reference's dense
+    fine-tune, which the driver's configs[3] runs data-parallel): bucket order, hooks and `no_sync` are the base engine's."""
+    one = _single_rank(golden_dir, compute="fp32x3")
+    res = _run_ranks(tmp_path, "x3", ["fp32", "allreduce", "gloo", "eager", "fp32x3"])
+    want = 0.5 * (one["grads"][0] + one["grads"][1])
+    scale = float(want.abs().max())
+    for r, out in enumerate(res):
+        assert torch.equal(out["flat"], one["flat"])
+        assert np.allclose(out["losses"], one["losses"][r], rtol=0, atol=2e-5), (out["losses"], one["losses"][r])
+        err = float((out["grad"] - want).abs().max())
+        assert err <= 2e-5 * scale, (r, err, scale)
+        acc_err = float((out["acc"] - (out["grad"] + one["grads"][r])).abs().max())
+        assert acc_err <= 2e-5 * scale, (r, acc_err)
         assert out["stats"]["buckets"] == out["stats"]["n_buckets_expected"]
