@@ -392,3 +392,33 @@ def test_config_switches_sum_fusion_and_predict_feature(golden_dir, compute, tol
     with torch.no_grad():
         _, p_v, nsp2, _, _ = model(*args, **kw)
     close(p_v, g["inf_pred_v"], tol=tol, what="pred_v"); close(nsp2, g["inf_nsp"], tol=tol, what="inference nsp")
+
+
+def test_two_streams_equal_one_stream_fp32(golden_dir, small):
+    """The fp32-accuracy engine on the base engine's two-stream schedule (image side beside the text side) against everything on
+    one stream: same kernels, same order within each stream -> identical losses / scores, gradients equal up to the order of
+    the fp32 atomics of the weight-gradient launches; train mode (dropout keys are per site, not per launch order)."""
+    model, _, _ = small
+    eng = model.engine
+    g = np.load(os.path.join(golden_dir, "small_mixed.npz"))
+    args, kw = kwargs_from(g)
+    res = {}
+    model.train()
+    try:
+        for dual in (True, False, True):
+            eng.dual_stream = dual
+            model.set_dropout_seed(5, step=0)
+            model.zero_grad(set_to_none=True)
+            lm, img, nsp_l, _, _, nsp = model(*args, **kw, _want_lm_scores=False)
+            (lm + img + nsp_l).sum().backward()
+            torch.cuda.synchronize()
+            res.setdefault(dual, []).append((torch.stack([lm, img, nsp_l]).flatten().detach().clone(), nsp.detach().clone(),
+                                             eng.arena.grad_flat.clone()))
+    finally:
+        eng.dual_stream = True
+        model.eval()
+    a, b, a2 = res[True][0], res[False][0], res[True][1]
+    for x, y in ((a, b), (a, a2)):
+        assert torch.equal(x[0], y[0]) and torch.equal(x[1], y[1])
+        d = float((x[2] - y[2]).abs().max() / x[2].abs().max())
+        assert d <= 2e-6, d

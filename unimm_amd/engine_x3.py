@@ -10,8 +10,8 @@ residual-join that the bf16 path fuses into GEMM epilogues), run LayerNorm / emb
 and compute the attention cores in fp32 on the vector ALUs.  Masks, the unpadded schedule, dropout counters, the row-sparse
 decoder, the fp32 pooler / NSP heads, the loss kernels and the flat gradient arena are the base engine's.
 
-One stream, eager launches (no graph executor), no lazy LayerNorm: this is the accuracy mode, ~1/4 of the bf16 engine's
-throughput.  There is no CPU / eager-PyTorch fallback here either."""
+The base engine's two-stream schedule (image side beside the text side), eager launches (no graph executor), no lazy
+LayerNorm: this is the accuracy mode, ~0.3 of the bf16 engine's throughput.  There is no CPU / eager-PyTorch fallback here either."""
 from __future__ import annotations
 
 import math
@@ -41,8 +41,9 @@ class EngineX3(Engine):
 
     def __init__(self, model, cfg):
         super().__init__(model, cfg)
-        self.dual_stream = False
+        self.dual_stream = True           # the base engine's two-stream schedule (image side beside the text side)
         self.lazy_ln = False
+        self.splitk = False
 
     # ------------------------------------------------------------------------------------------
     # weights: split copies instead of the bf16 copies
@@ -146,9 +147,10 @@ class EngineX3(Engine):
         dxd3 = torch.empty((M, 3 * H), dtype=BF16, device=x.device) if want3 else None
         part = torch.empty(self.part[H].numel(), dtype=F32, device=x.device)
         blocks = L.x3_layernorm_bwd_partials(dy, x, mean, rstd, gmm, dx32, dxd3, part, M, H, drop=drop, out_drop=out_drop, m_dev=m_dev)
-        self._fq.append((part, blocks, H, [gg, gb, dbias]))
+        fq = self._fq_img if self._on_side else self._fq
+        fq.append((part, blocks, H, [gg, gb, dbias]))
         if dbias2 is not None:
-            self._fq.append((part, blocks, H, [None, None, dbias2]))
+            fq.append((part, blocks, H, [None, None, dbias2]))
         return dx32, dxd3
 
     def _attn(self, q, k, v, mask, B, H, Tq, Tk, D, drop, save, qvar=None, kvar=None, tag=None):
@@ -217,8 +219,13 @@ class EngineX3(Engine):
         sc = 1.0 / math.sqrt(D)
         lq1, lq2, d1, d2 = (self.lin[key + s] for s in (".qkv1", ".qkv2", ".d1", ".d2"))
         vff1, vff2, tff1, tff2 = (self.lin[key + s] for s in (".vff1", ".vff2", ".tff1", ".tff2"))
-        qkv1 = self._lin3(xv3, lq1)           # image side  [B*R, 3Hb]
+        # The two halves run on their own streams (`_img()` = image side, otherwise the text side); the only exchanges are the
+        # other side's K / V for the two co-attention directions (the base engine's schedule).
+        with self._img():
+            qkv1 = self._lin3(xv3, lq1)       # image side  [B*R, 3Hb]
         qkv2 = self._lin3(xt3, lq2)           # text side   [rows, 3Hb]
+        self._to_txt(qkv1)
+        self._to_img(qkv2)
         q1, k1, v1 = qkv1[:, :Hb], qkv1[:, Hb:2 * Hb], qkv1[:, 2 * Hb:]
         q2, k2, v2 = qkv2[:, :Hb], qkv2[:, Hb:2 * Hb], qkv2[:, 2 * Hb:]
         da1 = self._drop(pn + "attn1", cfg.v_attention_probs_dropout_prob, train)
@@ -228,14 +235,15 @@ class EngineX3(Engine):
         dvo = self._drop(pn + "vout", cfg.v_hidden_dropout_prob, train)
         dto = self._drop(pn + "tout", cfg.hidden_dropout_prob, train)
         # image half: regions attend text (:701-721), BertBiOutput (:744-754, call order :775), image FFN
-        ctx_v, lse_v = self._attn(q1, k2, v2, comask, B, nh, R, T, D, da2, save, kvar=var, tag=key + "/2")
-        ctx_v3 = self._split(ctx_v)
-        prev = self._lin3(ctx_v3, d1, L.EPI_BIAS_DROP_RESID, aux=xv32, drop=db1)
-        av32, av3, mv1, rv1 = self._ln3(prev, key + ".lnb1", save)
-        uv = self._lin3(av3, vff1)
-        hv3 = self._op3(uv, op=L.X3_GELU)[0]
-        prev2 = self._lin3(hv3, vff2, L.EPI_BIAS_DROP_RESID, aux=av32, drop=dvo)
-        ov32, ov3, mv2, rv2 = self._ln3(prev2, key + ".lnv", save)
+        with self._img():
+            ctx_v, lse_v = self._attn(q1, k2, v2, comask, B, nh, R, T, D, da2, save, kvar=var, tag=key + "/2")
+            ctx_v3 = self._split(ctx_v)
+            prev = self._lin3(ctx_v3, d1, L.EPI_BIAS_DROP_RESID, aux=xv32, drop=db1)
+            av32, av3, mv1, rv1 = self._ln3(prev, key + ".lnb1", save)
+            uv = self._lin3(av3, vff1)
+            hv3 = self._op3(uv, op=L.X3_GELU)[0]
+            prev2 = self._lin3(hv3, vff2, L.EPI_BIAS_DROP_RESID, aux=av32, drop=dvo)
+            ov32, ov3, mv2, rv2 = self._ln3(prev2, key + ".lnv", save)
         # text half: text attends regions (:681-698)
         ctx_t, lse_t = self._attn(q2, k1, v1, vmask, B, nh, T, R, D, da1, save, qvar=var, tag=key + "/1")
         ctx_t3 = self._split(ctx_t)
@@ -248,18 +256,23 @@ class EngineX3(Engine):
         md = var[2] if var is not None else None
         if save:
             def bwd(dov, dot):
-                dqkv1 = torch.empty_like(qkv1)
+                # gradient buffers of the two projections: each is written by BOTH attention backward kernels (every slice exactly
+                # once), i.e. from both streams -> allocate first and let each stream see the other's
+                with self._img():
+                    dqkv1 = torch.empty_like(qkv1)
                 dqkv2 = torch.empty_like(qkv2)
-                # image half
-                dp, dpd3 = self._ln3_bwd(dov, prev2, mv2, rv2, key + ".lnv", dbias=vff2.gb, drop=dvo)
-                duv3 = self._op3(self._lin3_bwd(dpd3, hv3, vff2, bias_grad=False), op=L.X3_MUL_DGELU, b=uv)[0]
-                dav = self._add32(self._lin3_bwd(duv3, av3, vff1), dp)
-                dprev, dprevd3 = self._ln3_bwd(dav, prev, mv1, rv1, key + ".lnb1", dbias=d1.gb, drop=db1)
-                dctx_v = self._lin3_bwd(dprevd3, ctx_v3, d1, bias_grad=False)
-                delta_v = torch.empty_like(lse_v)
-                w, mq, mb = comask
-                L.x3_attn_bwd(q1, k2, v2, ctx_v, dctx_v, lse_v, delta_v, dqkv1[:, :Hb], dqkv2[:, Hb:2 * Hb], dqkv2[:, 2 * Hb:],
-                              w, B, nh, R, T, D, sc, mq, mb, da2, kvar=var)
+                self._to_txt(dqkv1)
+                self._to_img(dqkv2)
+                with self._img():                                   # image half
+                    dp, dpd3 = self._ln3_bwd(dov, prev2, mv2, rv2, key + ".lnv", dbias=vff2.gb, drop=dvo)
+                    duv3 = self._op3(self._lin3_bwd(dpd3, hv3, vff2, bias_grad=False), op=L.X3_MUL_DGELU, b=uv)[0]
+                    dav = self._add32(self._lin3_bwd(duv3, av3, vff1), dp)
+                    dprev, dprevd3 = self._ln3_bwd(dav, prev, mv1, rv1, key + ".lnb1", dbias=d1.gb, drop=db1)
+                    dctx_v = self._lin3_bwd(dprevd3, ctx_v3, d1, bias_grad=False)
+                    delta_v = torch.empty_like(lse_v)
+                    w, mq, mb = comask
+                    L.x3_attn_bwd(q1, k2, v2, ctx_v, dctx_v, lse_v, delta_v, dqkv1[:, :Hb], dqkv2[:, Hb:2 * Hb], dqkv2[:, 2 * Hb:],
+                                  w, B, nh, R, T, D, sc, mq, mb, da2, kvar=var)
                 # text half
                 dp, dpd3 = self._ln3_bwd(dot, pret2, mt2, rt2, key + ".lnt", dbias=tff2.gb, drop=dto, m_dev=md)
                 dut3 = self._op3(self._lin3_bwd(dpd3, ht3, tff2, bias_grad=False, m_dev=md), op=L.X3_MUL_DGELU, b=ut)[0]
@@ -270,7 +283,10 @@ class EngineX3(Engine):
                 w, mq, mb = vmask
                 L.x3_attn_bwd(q2, k1, v1, ctx_t, dctx_t, lse_t, delta_t, dqkv2[:, :Hb], dqkv1[:, Hb:2 * Hb], dqkv1[:, 2 * Hb:],
                               w, B, nh, T, R, D, sc, mq, mb, da1, qvar=var)
-                dxv = self._add32(self._lin3_bwd(self._split(dqkv1), xv3, lq1), dprev)
+                self._to_img()                                      # dK1 / dV1 written by the text side
+                self._to_txt()                                      # dK2 / dV2 written by the image side
+                with self._img():
+                    dxv = self._add32(self._lin3_bwd(self._split(dqkv1), xv3, lq1), dprev)
                 dxt = self._add32(self._lin3_bwd(self._split(dqkv2), xt3, lq2, m_dev=md), dpret)
                 return dxv, dxt
             tape.append((key, bwd))
@@ -306,28 +322,30 @@ class EngineX3(Engine):
         A = self.arena
         F = cfg.v_feature_size
 
-        # ---- image embedding (models/vilbert_dialog.py:1487-1493): one GEMM over [feat | loc | 0] --------------------
-        featd = feat.to(dev, dtype=F32, non_blocking=True)
-        locd = inp["image_loc"].to(dev, dtype=F32, non_blocking=True)
-        if img_idx is not None:
-            featd, locd = featd.index_select(0, img_idx), locd.index_select(0, img_idx)
-        packed32 = torch.zeros((B * R, self.vemb_k), dtype=F32, device=dev)
-        packed32[:, :F].copy_(featd.reshape(B * R, F))
-        packed32[:, F:F + 5].copy_(locd.reshape(B * R, 5))
-        packed3 = self._split(packed32)
-        prev = torch.empty((B * R, Hv), dtype=F32, device=dev)
-        L.gemm_nt(packed3, self.vemb_w3, prev, bias=self.vemb_b, M=B * R, N=Hv, K=3 * self.vemb_k)
-        d_embv = self._drop("emb_v", cfg.hidden_dropout_prob, train)
-        xv32, xv3, mv, rv = self._ln3(prev, "emb_v", save, drop=d_embv)
-        if save:
-            v = "bert.v_embeddings."
+        # ---- image embedding (models/vilbert_dialog.py:1487-1493): one GEMM over [feat | loc | 0], on the image stream -
+        self._to_img()                        # masks / plan are enqueued (and the previous step is behind us)
+        with self._img():
+            featd = feat.to(dev, dtype=F32, non_blocking=True)
+            locd = inp["image_loc"].to(dev, dtype=F32, non_blocking=True)
+            if img_idx is not None:
+                featd, locd = featd.index_select(0, img_idx), locd.index_select(0, img_idx)
+            packed32 = torch.zeros((B * R, self.vemb_k), dtype=F32, device=dev)
+            packed32[:, :F].copy_(featd.reshape(B * R, F))
+            packed32[:, F:F + 5].copy_(locd.reshape(B * R, 5))
+            packed3 = self._split(packed32)
+            prev = torch.empty((B * R, Hv), dtype=F32, device=dev)
+            L.gemm_nt(packed3, self.vemb_w3, prev, bias=self.vemb_b, M=B * R, N=Hv, K=3 * self.vemb_k)
+            d_embv = self._drop("emb_v", cfg.hidden_dropout_prob, train)
+            xv32, xv3, mv, rv = self._ln3(prev, "emb_v", save, drop=d_embv)
+            if save:
+                v = "bert.v_embeddings."
 
-            def bwd_embv(dxv):
-                _, dpre3 = self._ln3_bwd(dxv, prev, mv, rv, "emb_v", dbias=A.grad(v + "image_embeddings.bias"), out_drop=d_embv,
-                                         want32=False, dbias2=A.grad(v + "image_location_embeddings.bias"))
-                K3 = self.vemb_k
-                self._wgrad3(dpre3, packed3, A.grad(v + "image_embeddings.weight"), B * R, Hv, F, Hv, K3)
-                self._wgrad3(dpre3, packed3, A.grad(v + "image_location_embeddings.weight"), B * R, Hv, 5, Hv, K3, xcol0=F)
+                def bwd_embv(dxv):
+                    _, dpre3 = self._ln3_bwd(dxv, prev, mv, rv, "emb_v", dbias=A.grad(v + "image_embeddings.bias"), out_drop=d_embv,
+                                             want32=False, dbias2=A.grad(v + "image_location_embeddings.bias"))
+                    K3 = self.vemb_k
+                    self._wgrad3(dpre3, packed3, A.grad(v + "image_embeddings.weight"), B * R, Hv, F, Hv, K3)
+                    self._wgrad3(dpre3, packed3, A.grad(v + "image_location_embeddings.weight"), B * R, Hv, 5, Hv, K3, xcol0=F)
 
         # ---- text embeddings (:326-356) --------------------------------------------------------------------------------
         erows = plan["rows"] if plan is not None else None
@@ -351,8 +369,9 @@ class EngineX3(Engine):
         # ---- encoder (schedule of :842-929) ------------------------------------------------------------------------------
         for kind, i in PM.encoder_schedule(cfg):
             if kind == "v":
-                xv32, xv3 = self._self_block(f"v{i}", xv32, xv3, vmask, B, R, cfg.v_num_attention_heads, f"bert.encoder.v_layer.{i}.",
-                                             cfg.v_attention_probs_dropout_prob, cfg.v_hidden_dropout_prob, st)
+                with self._img():
+                    xv32, xv3 = self._self_block(f"v{i}", xv32, xv3, vmask, B, R, cfg.v_num_attention_heads, f"bert.encoder.v_layer.{i}.",
+                                                 cfg.v_attention_probs_dropout_prob, cfg.v_hidden_dropout_prob, st)
             elif kind == "t":
                 xt32, xt3 = self._self_block(f"t{i}", xt32, xt3, tmask, B, T, cfg.num_attention_heads, f"bert.encoder.layer.{i}.",
                                              cfg.attention_probs_dropout_prob, cfg.hidden_dropout_prob, st, var=var)
@@ -368,12 +387,14 @@ class EngineX3(Engine):
         if want_pred_v or inp.get("image_target") is not None:
             itr, idec = self.lin["imgtr"], self.lin["imgdec"]
             C = cfg.v_target_size
-            uvh = self._lin3(xv3, itr)
-            tv = self._op3(uvh, op=L.X3_GELU, want3=False, want32=True)[1]
-            _, hvn3, mh, rh = self._ln3(tv, "imgtr", save)
-            pred_v = self._lin3(hvn3, idec, ldo=_rup(C, 4))
+            with self._img():
+                uvh = self._lin3(xv3, itr)
+                tv = self._op3(uvh, op=L.X3_GELU, want3=False, want32=True)[1]
+                _, hvn3, mh, rh = self._ln3(tv, "imgtr", save)
+                pred_v = self._lin3(hvn3, idec, ldo=_rup(C, 4))
             pred_v_out = pred_v.view(B, R, -1)[:, :, :C]
             img = dict(tv=tv, u=uvh, hn=hvn3, mean=mh, rstd=rh, pred=pred_v)
+        self._to_txt(xv32, xv3, img["pred"] if img is not None else None)       # the heads read both streams
         out = dict(seq_out_t=xt3, seq_out_v=xv3, seq32_t=xt32, seq32_v=xv32, B=B, T=T, R=R, plan=plan, Mt=Mt,
                    nsp_weight_host=st_nspw, n_img=n_img, img_label32=il32, dyn=dyn, img=img)
         if pred_v_out is not None:
@@ -452,16 +473,19 @@ class EngineX3(Engine):
         img = out["img"]
         C = cfg.v_target_size
         itr, idec = self.lin["imgtr"], self.lin["imgdec"]
-        dpred3 = torch.empty((B * R, 3 * idec.Np), dtype=BF16, device=dev)
-        if cfg.predict_feature:
-            L.mse_loss_bwd(img["pred"], img["target"], img["label"], gvec(g_img), img["inv"], dpred3, B * R, C, split=True)
-        else:
-            L.x3_kl_loss_bwd(img["pred"], img["target"], img["label"], img["lse"], gvec(g_img), img["inv"], dpred3, B * R, C,
-                             inv_dev=img.get("inv_dev"))
-        dhn_v = self._lin3_bwd(dpred3, img["hn"], idec)
-        dtv, _ = self._ln3_bwd(dhn_v, img["tv"], img["mean"], img["rstd"], "imgtr", want3=False)
-        duv3 = self._op3(dtv, op=L.X3_MUL_DGELU, b=img["u"])[0]
-        dseq_v = self._lin3_bwd(duv3, out["seq_out_v"], itr)
+        gimg = gvec(g_img)
+        self._to_img(gimg, img["target"], img["lse"], img["label"])
+        with self._img():                                    # image head: on the image stream, beside the MLM head's backward
+            dpred3 = torch.empty((B * R, 3 * idec.Np), dtype=BF16, device=dev)
+            if cfg.predict_feature:
+                L.mse_loss_bwd(img["pred"], img["target"], img["label"], gimg, img["inv"], dpred3, B * R, C, split=True)
+            else:
+                L.x3_kl_loss_bwd(img["pred"], img["target"], img["label"], img["lse"], gimg, img["inv"], dpred3, B * R, C,
+                                 inv_dev=img.get("inv_dev"))
+            dhn_v = self._lin3_bwd(dpred3, img["hn"], idec)
+            dtv, _ = self._ln3_bwd(dhn_v, img["tv"], img["mean"], img["rstd"], "imgtr", want3=False)
+            duv3 = self._op3(dtv, op=L.X3_MUL_DGELU, b=img["u"])[0]
+            dseq_v = self._lin3_bwd(duv3, out["seq_out_v"], itr)
         # ---- MLM head -----------------------------------------------------------------------------------------------
         lm = out.get("lm")
         if lm is not None:
@@ -490,7 +514,9 @@ class EngineX3(Engine):
         dcls_t = self._linear32_bwd(dpt, bw["cls_t"], "tpool")
         L.x3_rows_add(dseq_t, bw["cls_idx_t"], dcls_t, B, H)
         dcls_v = self._linear32_bwd(dpv, bw["cls_v"], "vpool")
-        L.x3_rows_add(dseq_v, bw["cls_idx_v"], dcls_v, B, Hv)
+        self._to_img(dcls_v)                     # the image pooler's input gradient joins the image head's on the image stream
+        with self._img():
+            L.x3_rows_add(dseq_v, bw["cls_idx_v"], dcls_v, B, Hv)
         self._bucket_done("heads")
         # ---- encoder blocks in reverse --------------------------------------------------------------------------------
         gt, gv = dseq_t, dseq_v
@@ -503,8 +529,9 @@ class EngineX3(Engine):
                 pos += 1
             for kind, key, fn in seg:
                 if kind == "v":
-                    gv = fn(gv)
-                    self._bucket_done(key)
+                    with self._img():
+                        gv = fn(gv)
+                        self._bucket_done(key)
             for kind, key, fn in seg:
                 if kind == "t":
                     gt = fn(gt)
@@ -515,7 +542,9 @@ class EngineX3(Engine):
                 with self._conn_tag():
                     gv, gt = fn(gv, gt)
                 self._bucket_done(key)
-        bw["embv"](gv)
-        self._bucket_done("image_embeddings")
+        with self._img():
+            bw["embv"](gv)
+            self._bucket_done("image_embeddings")
         bw["embt"](gt)
+        self._to_txt()                                       # everything joined before the caller continues
         self._bucket_done("text_embeddings")
