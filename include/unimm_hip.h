@@ -74,7 +74,8 @@ typedef struct {
   /* Per-call tuning (tests and A/B measurements; 0 = everything automatic): tile = gn * 1000 + p * 100 + cfg.
    *   cfg: 0 automatic (a cost model over {256x256, 192x256, 128x128}; 64x128 for grids that do not fill the chip),
    *        1 = 128x128 / 4 waves / 2-slot ring of BK 64 / 2 workgroups per CU,   3 = 256x256 / 8 waves / lock-step ring,
-   *        6 = 192x256 / 8 waves,   7 = 64x128 / 4 waves of 32x64 / 3 workgroups per CU,   8 = 256x256 / ping-pong loop;
+   *        6 = 192x256 / 8 waves,   7 = 64x128 / 4 waves of 32x64 / 3 workgroups per CU,   8 = 256x256 / ping-pong loop,
+   *        9 = 64x128 with a 3-slot ring (two K steps in flight, 2 workgroups per CU),   10 = 128x128 with a 3-slot ring (1 per CU);
    *        anything else is rejected with UNIMM_E_ARG
    *   p:   0 automatic, 1 persistent workgroups (one per CU slot walks several tiles), 2 one workgroup per tile
    *   gn:  n-tiles per column group of the tile order (0 = default 4) */

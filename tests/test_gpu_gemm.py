@@ -317,12 +317,12 @@ def test_gemm_nt_epilogue_layout_against_torch(cfg, epi):
 
 
 def test_gemm_nt_rejects_uninstantiated_tiles():
-    """Tile codes 2, 4, 5 (the BK = 32 rings that are no longer built) and anything above 8 fail at the call, not later."""
+    """Tile codes 2, 4, 5 (the BK = 32 rings that are no longer built) and anything above 10 fail at the call, not later."""
     from unimm_amd import lib
     x = torch.zeros((256, 64), device="cuda", dtype=torch.bfloat16)
     w = torch.zeros((256, 64), device="cuda", dtype=torch.bfloat16)
     out = torch.zeros((256, 256), device="cuda", dtype=torch.bfloat16)
-    for bad in (2, 4, 5, 9, 308, -1):
+    for bad in (2, 4, 5, 11, 308, -1):
         with pytest.raises(lib.UnimmHipError):
             lib.gemm_nt(x, w, out, tile=bad)
 
@@ -444,3 +444,10 @@ def test_gemm_nt_split_k_hand_off_under_uneven_load():
                 ref = refs[k % 2]
                 worst = max(worst, float((outs[j].float() - ref).abs().max() / ref.abs().max()))
     assert worst <= 2 ** -7, worst
+    # ... and with TWO splits (what the engine uses) bit-identical from launch to launch: a + b does not depend on who arrives last
+    a = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+    lib.gemm_nt(xs[0], w, a, epilogue=lib.EPI_ADD, aux=aux, tile=1, splitk=2, splitk_ws=ws)
+    for _ in range(10):
+        b2 = torch.empty_like(a)
+        lib.gemm_nt(xs[0], w, b2, epilogue=lib.EPI_ADD, aux=aux, tile=1, splitk=2, splitk_ws=ws)
+        assert torch.equal(a, b2)

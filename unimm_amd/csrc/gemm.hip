@@ -666,9 +666,7 @@ __device__ __forceinline__ void nt_mainloop_pp(const GemmNtParams& p, char* smem
 // slabs to the partial it still holds and runs the normal epilogue.  Hand-off (placement-independent; MI355X_MICROARCH.md
 // "inter-workgroup visibility"): write-through slab stores -> every wave's vmcnt(0) -> workgroup barrier -> lane 0: relaxed
 // agent-scope ticket; the last arriver: agent-scope acquire, vmcnt(0), barrier, loads.  Returns false for the
-// workgroups that are done.  Deterministic: the last arriver adds the other slabs in split order onto its own partial --
-// which split arrives last may differ from run to run, so sums can differ in their last bits between runs (like the
-// atomic weight gradients), never between a captured launch and its replays' arithmetic.
+// workgroups that are done.
 template <class C>
 __device__ __forceinline__ bool nt_split_join(const GemmNtParams& p, f32x4 (&acc)[4][C::MT], char* smem, int tile, int split) {
   constexpr int MT = C::MT, TILE_F4 = C::NW * 4 * MT * 64;
@@ -700,17 +698,33 @@ __device__ __forceinline__ bool nt_split_join(const GemmNtParams& p, f32x4 (&acc
   const bool last = *flag == p.ksplit - 1;                        // workgroup-uniform
   __syncthreads();                                               // the flag word is part of the epilogue's slab
   if (!last) return false;
+  // The other splits' slabs, in split order, on top of the partial this workgroup still holds in registers.  With two splits
+  // (what the engine asks for) the sum does not depend on who arrived last (fp32 addition commutes); with three or four the
+  // association does, i.e. the last bits may differ between runs, like the atomically accumulated weight gradients.
   const f32x4* base = reinterpret_cast<const f32x4*>(p.slabs) + (size_t)tile * p.ksplit * TILE_F4;
   for (int sp = 0; sp < p.ksplit; ++sp) {
     if (sp == split) continue;
     const f32x4* other = base + (size_t)sp * TILE_F4;
+    // sc0 sc1 loads (L1-bypassing, like the stores that published the bytes): together with the acquire above this is the
+    // guide's "write-through stores and loads on both sides" hand-off as well as its "acquire + loads" one.  Eight loads in
+    // flight per lane, one wait that names their registers (so no use can move above it).
+    static_assert((4 * MT) % 8 == 0, "split-K join: 8 loads per batch");
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int c = 0; c < 4 * MT; c += 8) {
+      f32x4 o[8];
 #pragma unroll
-      for (int j = 0; j < MT; ++j) {
-        const f32x4 o = other[((wave * 4 + i) * MT + j) * 64 + lane];
-        acc[i][j][0] += o[0]; acc[i][j][1] += o[1]; acc[i][j][2] += o[2]; acc[i][j][3] += o[3];
+      for (int e = 0; e < 8; ++e) {
+        const f32x4* src = other + ((wave * 4 + (c + e) / MT) * MT + (c + e) % MT) * 64 + lane;
+        asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(o[e]) : "v"(src) : "memory");
       }
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]), "+v"(o[6]), "+v"(o[7])
+                   :: "memory");
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int i = (c + e) / MT, j = (c + e) % MT;
+        acc[i][j][0] += o[e][0]; acc[i][j][1] += o[e][1]; acc[i][j][2] += o[e][2]; acc[i][j][3] += o[e][3];
+      }
+    }
   }
   return true;
 }

@@ -370,6 +370,8 @@ class Engine:
         against 33.6 us alone (profiles/r4c_small_batch_gemm_microbench.txt)."""
         if not self.splitk or self._on_side or self.gemm_tile != 0 or self._step_rows is None or self._step_rows >= self.small_rows:
             return None
+        if M != self._step_rows:      # the text stream's GEMMs only, whatever stream they run on (one-stream runs must round alike)
+            return None
         if K < 2048 or N > 1024 or ((M + 127) // 128) * ((N + 127) // 128) > 256:
             return None
         dev = self.arena.flat.device
