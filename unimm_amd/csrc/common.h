@@ -169,6 +169,19 @@ __device__ __forceinline__ uint32_t drop_bits8(const DropoutArg& d, uint32_t row
   return bits;
 }
 
+// keep bits of 4 consecutive columns col0 .. col0+3 (col0 % 4 == 0): 2 hashes (the same words drop_bits8 forms for them)
+__device__ __forceinline__ uint32_t drop_bits4(const DropoutArg& d, uint32_t row, uint32_t ncols, uint32_t col0) {
+  const uint32_t l0 = drop_lin(d, drop_wbase(row, ncols, col0)), t16 = d.thr >> 16;
+  uint32_t bits = 0;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const uint32_t w = drop_fin(d, l0 + (uint32_t)q * DROP_M1);
+    bits |= ((w & 0xffffu) >= t16 ? 1u : 0u) << (2 * q);
+    bits |= ((w >> 16) >= t16 ? 1u : 0u) << (2 * q + 1);
+  }
+  return bits;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

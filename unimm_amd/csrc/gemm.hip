@@ -225,6 +225,19 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtParams& p, f32x4 (&acc)[
   const int n = n0 + wn * 64 + c0;
   const bool ncols_ok_ = n < p.N;
   const bool full_ = (n + 7 < p.N);
+  // fp32 outputs: a lane that owns 8 CONSECUTIVE fp32 columns writes them with two 16-byte stores 16 bytes apart, so one
+  // store instruction covers half of every 128-byte line it touches: measured 3.2-3.5 TB/s for a [31k, 768] fp32 matrix
+  // against 6.0 TB/s when every instruction writes whole lines (tools/exp/store_pattern.hip), and +17.6 us for the fp32
+  // output of an N = 768, K = 768 GEMM over its bf16 one (48 MB more at 2.7 TB/s).  In the FAST walk of the plain fp32
+  // epilogues a lane therefore owns columns 4l..4l+3 (group A) and 32+4l..32+4l+3 (group B) of the wave's 64: element e of
+  // the lane's 8 values is column colA + e (e < 4) or colB + e - 4.  Everywhere else colA = n, colB = n + 4 (the old map).
+  constexpr bool SPLITCOL = OUT_F32 && (EPI == UNIMM_EPI_BIAS || EPI == UNIMM_EPI_BIAS_DROP_RESID || EPI == UNIMM_EPI_BIAS_RELU);
+  const bool fastw_ = (n0 + wn * 64 + 64 <= p.N) && ((p.ldo * (OUT_F32 ? 4 : 2)) % 16 == 0) &&
+                      (!(EPI == UNIMM_EPI_BIAS_DROP_RESID || EPI == UNIMM_EPI_DGELU || EPI == UNIMM_EPI_ADD || EPI == UNIMM_EPI_MUL) ||
+                       (p.ldaux * (EPI == UNIMM_EPI_BIAS_DROP_RESID ? 4 : 2)) % 16 == 0);
+  const bool splitc = SPLITCOL && fastw_;                         // wave-uniform
+  const int colA = splitc ? n0 + wn * 64 + (lane & 7) * 4 : n, colB = splitc ? colA + 32 : n + 4;
+  const int cA = colA - (n0 + wn * 64), cB = colB - (n0 + wn * 64);       // the same inside the wave's slab row
   // Residual / multiplier operand: loaded in batches of PF row-walk iterations, one batch ahead of its use (the first
   // before the barrier below; registers: the main loop's fragment registers are dead).  In program order the walk used
   // to reach each load only after the slab reads of its iteration, and because loads and stores share vmcnt (and may
@@ -238,6 +251,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtParams& p, f32x4 (&acc)[
   constexpr int PFN = PF > 0 ? PF : 1;
   const bool pf_on = PF > 0 && p.aux != nullptr && ((p.ldaux * (AUX32 ? 4 : 2)) % 16 == 0);   // uniform
   const int pf_n = full_ ? n : 0;                     // lanes at the ragged N edge take the scalar path; their prefetch is ignored
+  const int pf_a = full_ ? colA : 0, pf_b = full_ ? colB : 4;
   f32x4 pf0[2][PFN], pf1[2][PFN];
   float pfmu[2][PFN], pfrs[2][PFN];
   auto aux_prefetch = [&](int batch, auto sure) {    // requests walk iterations [batch * PF, (batch + 1) * PF)
@@ -250,9 +264,9 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtParams& p, f32x4 (&acc)[
           int m = m0 + wm * 16 * MT + (g / NIT) * 16 * C::JP + row;
           m = m < p.M ? m : p.M - 1;
           if constexpr (AUX32) {
-            const float* ap = reinterpret_cast<const float*>(p.aux) + (size_t)m * p.ldaux + pf_n;
-            pf0[batch & 1][k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ap));
-            pf1[batch & 1][k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ap + 4));
+            const float* ap = reinterpret_cast<const float*>(p.aux) + (size_t)m * p.ldaux;
+            pf0[batch & 1][k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ap + pf_a));
+            pf1[batch & 1][k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ap + pf_b));
             if (p.aux_mean != nullptr) { pfmu[batch & 1][k] = p.aux_mean[m]; pfrs[batch & 1][k] = p.aux_rstd[m]; }
           } else {
             const bf16_t* ap = reinterpret_cast<const bf16_t*>(p.aux) + (size_t)m * p.ldaux + pf_n;
@@ -266,14 +280,18 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtParams& p, f32x4 (&acc)[
   __builtin_amdgcn_s_barrier();                      // all waves finished reading the ring
   float b[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) b[e] = (p.bias != nullptr && n + e < p.N) ? p.bias[n + e] : 0.f;
+  for (int e = 0; e < 8; ++e) {
+    const int c = e < 4 ? colA + e : colB + e - 4;
+    b[e] = (p.bias != nullptr && c < p.N) ? p.bias[c] : 0.f;
+  }
   float lg[8], lb[8];                                // LayerNorm-on-the-fly residual (DROP_RESID only)
   const bool aux_ln = EPI == UNIMM_EPI_BIAS_DROP_RESID && p.aux_mean != nullptr;
   if (aux_ln) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      lg[e] = n + e < p.N ? p.aux_gamma[n + e] : 0.f;
-      lb[e] = n + e < p.N ? p.aux_beta[n + e] : 0.f;
+      const int c = e < 4 ? colA + e : colB + e - 4;
+      lg[e] = c < p.N ? p.aux_gamma[c] : 0.f;
+      lb[e] = c < p.N ? p.aux_beta[c] : 0.f;
     }
   }
   const bool vec_out_ = full_ && ((p.ldo * (OUT_F32 ? 4 : 2)) % 16 == 0);
@@ -298,8 +316,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtParams& p, f32x4 (&acc)[
   // uniform), so no lane ever takes an element-wise path.  Keeping the element-wise loads out of that instance is what
   // lets the batched operand loads above work: with divergent load paths at every join the compiler's conservative
   // vmcnt(0)s also waited for the batch that had just been requested.
-  const bool fastw = (n0 + wn * 64 + 64 <= p.N) && ((p.ldo * (OUT_F32 ? 4 : 2)) % 16 == 0) &&
-                     (!(AUX32 || AUX16) || (p.ldaux * (AUX32 ? 4 : 2)) % 16 == 0);
+  const bool fastw = fastw_;
   auto walk = [&](auto fast_tag) {
   constexpr bool FAST = decltype(fast_tag)::value;
   const bool ncols_ok = FAST ? true : ncols_ok_;
@@ -341,8 +358,8 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtParams& p, f32x4 (&acc)[
     for (int it = 0; it < 2 * JP; ++it) {
       const int row = it * 8 + (lane >> 3);
       const int m = m0 + wm * 16 * MT + pass * 16 * JP + row;
-      const f32x4 lo = *reinterpret_cast<const f32x4*>(slab + row * SLAB_LD + c0);
-      const f32x4 hi = *reinterpret_cast<const f32x4*>(slab + row * SLAB_LD + c0 + 4);
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(slab + row * SLAB_LD + cA);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(slab + row * SLAB_LD + cB);
       const int gw = pass * NIT + it;                  // walk index; at the start of a batch request the next one
       if (PF > 0 && gw % PFN == 0) {
         // drain first (this batch's operands, requested a batch ago), THEN request: with the order reversed the
@@ -384,19 +401,19 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtParams& p, f32x4 (&acc)[
       if constexpr (EPI == UNIMM_EPI_BIAS_DROP_RESID || EPI == UNIMM_EPI_DGELU || EPI == UNIMM_EPI_ADD || EPI == UNIMM_EPI_MUL) {
         float a[8];
         if constexpr (EPI == UNIMM_EPI_BIAS_DROP_RESID) {   // fp32 residual stream
-          const float* ap = reinterpret_cast<const float*>(p.aux) + (size_t)m * p.ldaux + n;
+          const float* ap = reinterpret_cast<const float*>(p.aux) + (size_t)m * p.ldaux;
           if (vec_aux) {
             f32x4 r0, r1;
             if (PF > 0) { r0 = pfa0; r1 = pfa1; }
             else {
-              r0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ap));
-              r1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ap + 4));
+              r0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ap + colA));
+              r1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ap + colB));
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) { a[e] = r0[e]; a[4 + e] = r1[e]; }
           } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) a[e] = (n + e < p.N) ? ap[e] : 0.f;
+            for (int e = 0; e < 8; ++e) a[e] = (n + e < p.N) ? ap[n + e] : 0.f;      // (ragged edge: never the split map)
           }
           if (aux_ln) {
             const bool pfd = PF > 0 && (FAST || pf_on);
@@ -405,7 +422,9 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtParams& p, f32x4 (&acc)[
             for (int e = 0; e < 8; ++e) a[e] = (a[e] - mu) * rs * lg[e] + lb[e];
           }
           if (p.drop.thr != 0u) {
-            const uint32_t kb = drop_bits8(p.drop, (uint32_t)m, (uint32_t)p.N, (uint32_t)n);
+            const uint32_t kb = (SPLITCOL && FAST)
+                ? (drop_bits4(p.drop, (uint32_t)m, (uint32_t)p.N, (uint32_t)colA) | (drop_bits4(p.drop, (uint32_t)m, (uint32_t)p.N, (uint32_t)colB) << 4))
+                : drop_bits8(p.drop, (uint32_t)m, (uint32_t)p.N, (uint32_t)n);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = ((kb >> e) & 1u) ? v[e] * p.drop.scale : 0.f;
           }
@@ -456,12 +475,12 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtParams& p, f32x4 (&acc)[
         for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
       }
       if constexpr (OUT_F32) {
-        float* op = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n;
+        float* op = reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo;
         if (vec_out) {
-          __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(op));
-          __builtin_nontemporal_store(f32x4{v[4], v[5], v[6], v[7]}, reinterpret_cast<f32x4*>(op + 4));
+          __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(op + colA));
+          __builtin_nontemporal_store(f32x4{v[4], v[5], v[6], v[7]}, reinterpret_cast<f32x4*>(op + colB));
         } else {
-          for (int e = 0; e < 8; ++e) if (n + e < p.N) op[e] = v[e];
+          for (int e = 0; e < 8; ++e) if (n + e < p.N) op[n + e] = v[e];
         }
       } else {
         bf16_t* op = reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldo + n;
