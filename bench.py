@@ -98,6 +98,8 @@ def parse():
                     help="bf16 (default, the headline: the reference's autocast class) or fp32x3 = the fp32-accuracy engine "
                          "(unimm_amd/engine_x3.py: bf16 MFMA GEMMs over split operands hi/lo, fp32 attention and gradient "
                          "stream): the arithmetic dense_annotation_finetuning.py:253 runs in (no autocast)")
+    ap.add_argument("--x3-attn", choices=["mfma", "valu"], default="mfma", help="A/B (fp32x3): attention cores on the fp32 matrix "
+                    "instruction (default) or the vector-ALU kernels of the first version (unimm_x3_attn_set_impl)")
     ap.add_argument("--plain-loss", action="store_true", help="A/B: combine the three losses with the written-out torch arithmetic "
                     "(c * x.mean() + ...) instead of harness.combine_losses (one autograd node)")
     ap.add_argument("--no-splitk", action="store_true", help="A/B: engine.splitk = False (no split-K for the long reductions of small batches)")
@@ -293,6 +295,9 @@ def main():
 
     torch.manual_seed(1234)                       # identical init on every rank (+ broadcast in the wrapper)
     enc = VisualDialogEncoder(args.config, compute_dtype=args.compute).to(dev)
+    if args.compute != "bf16":
+        from unimm_amd import lib as _lib
+        _lib.x3_attn_set_impl(1 if args.x3_attn == "mfma" else 0)
     enc.train()
     model = enc.bert_pretrained
     model.set_dropout_seed(1234 + rank)

@@ -521,6 +521,9 @@ int unimm_x3_rows_add(float* dst, const int32_t* idx, const float* src, int32_t 
  * fp32 elements, multiples of 4; every other field -- masks, lse, variable-length offsets, dropout -- as there). */
 int unimm_x3_attn_fwd(const unimm_attn_args* args, void* stream);
 int unimm_x3_attn_bwd(const unimm_attn_bwd_args* args, void* stream);
+/* Which kernels the two entry points above launch: 1 (default) = the fp32 matrix-instruction kernels
+ * (v_mfma_f32_16x16x4_f32, exact fp32 operands), 0 = the vector-ALU kernels of the first version (kept for A/B runs). */
+int unimm_x3_attn_set_impl(int32_t impl);
 
 /* Launch profiler for bench.py's `roofline` block: HIP events around every GEMM launch on its own
  * stream while enabled.  Variant index: 0..11 = unimm_gemm_nt (epilogue * 2 + out_f32), 12 = unimm_gemm_tn.

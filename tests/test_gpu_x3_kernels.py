@@ -197,6 +197,7 @@ def _attn_case(B, H, Tq, Tk, D, dense_mask, seed, p_drop=0.0, varlen=False):
 @pytest.mark.parametrize("B,H,Tq,Tk,D,dense", [
     (2, 2, 256, 256, 64, True), (3, 2, 64, 64, 64, True), (2, 2, 37, 37, 128, False), (2, 2, 256, 37, 128, False),
     (2, 2, 37, 256, 128, True), (1, 1, 100, 200, 64, True), (2, 3, 130, 70, 128, True),
+    (2, 1, 65, 17, 64, True), (1, 2, 16, 129, 128, True), (3, 1, 1, 3, 64, False),      # tile / chunk edges of the matrix kernels
 ])
 def test_fp32_attention_fwd_bwd(B, H, Tq, Tk, D, dense):
     _attn_case(B, H, Tq, Tk, D, dense, seed=Tq + Tk + D)
@@ -207,6 +208,19 @@ def test_fp32_attention_dropout_and_variable_length(B, H, Tq, Tk, D, dense):
     _attn_case(B, H, Tq, Tk, D, dense, seed=3 + Tq, p_drop=0.1)
     if Tq == Tk:
         _attn_case(B, H, Tq, Tk, D, dense, seed=5 + Tq, p_drop=0.1, varlen=True)
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk,D,dense", [(2, 2, 256, 256, 64, True), (2, 3, 130, 70, 128, True)])
+def test_fp32_attention_vector_kernels_still_agree(B, H, Tq, Tk, D, dense):
+    """unimm_x3_attn_set_impl(0): the vector-ALU kernels of the first version (kept for A/B runs) pass the same gates."""
+    from unimm_amd import lib
+    lib.x3_attn_set_impl(0)
+    try:
+        _attn_case(B, H, Tq, Tk, D, dense, seed=11 + Tq, p_drop=0.1)
+        if Tq == Tk:
+            _attn_case(B, H, Tq, Tk, D, dense, seed=13 + Tq, p_drop=0.1, varlen=True)
+    finally:
+        lib.x3_attn_set_impl(1)
 
 
 @pytest.mark.parametrize("M,H", [(1000, 768), (333, 1024), (64, 128)])

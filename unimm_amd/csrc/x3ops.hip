@@ -568,6 +568,427 @@ __global__ __launch_bounds__(XA_T) void x3_attn_bwd_dkv_kernel(AttnF32 p) {
   xa_store<DH>(p.dv + (size_t)(koff + key) * p.lddv + head * D + half * DH, dv, 1.0f);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same attention cores on the fp32 matrix instruction (v_mfma_f32_16x16x4_f32: A[m = lane % 16][k = lane / 16],
+// B[k = lane / 16][n = lane % 16], D[m = 4 (lane / 16) + i][n = lane % 16], i = 0..3).  Its peak equals the packed fp32
+// vector rate, but the vector kernels above are nowhere near that: every FMA takes its second operand from a BROADCAST
+// ds_read_b128, which still moves 64 x 16 bytes through the LDS crossbar (8 cycles per instruction, one per 4 FMAs per
+// wave: the LDS saturates at ~1/4 of the vector rate; 334 us for the text self-attention forward of the dense step =
+// 17 TFLOP/s).  In the matrix form a wave owns 16 rows of its own side as the B operand IN REGISTERS (reduction index
+// permuted so that four k-steps are one 16-byte load: k-step 4 J + jj of lane group g = lane / 16 is dimension
+// 16 J + 4 g + jj), the other side's rows are staged in LDS once per workgroup and read as the A operand (one
+// ds_read_b128 per 4 MFMAs, every lane its own bytes), and a product's result -- lane holds [other-side row 4 g + i]
+// [own row lane % 16] -- IS the B operand of the next product over the other side's rows (k-step i <-> row 4 g + i),
+// whose A operand (the other side transposed: m = dimension, k = row 4 g + i) is a 4-byte LDS read per MFMA.
+// Exact fp32 operands, fp32 accumulation; mask, -10000, dropout counters and variable lengths as above.
+// ------------------------------------------------------------------------------------------------
+constexpr int XM_T = 256;     // 4 waves x 16 own rows
+constexpr int XM_R = 64;      // own rows per workgroup
+#define XM_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+constexpr float XM_LOG2E = 1.4426950408889634f, XM_NEG2 = -10000.0f * 1.4426950408889634f;
+#ifndef UNIMM_X3M_MIN_WAVES
+#define UNIMM_X3M_MIN_WAVES 2
+#endif
+
+// Workgroup -> (row block, head, sequence).  Workgroups go to the 8 XCDs round-robin by their linear id, and every XCD has
+// its own L2: with the plain (row block, head, sequence) grid the row blocks of one (sequence, head) -- which stage the SAME
+// other-side rows -- land on different XCDs and each fetches them from HBM.  Here the 1-D id d is decoded as xcd = d % 8,
+// j = d / 8, row block = j % nblk, pair = (j / nblk) * 8 + xcd: all row blocks of a pair run on one XCD, back to back.
+__device__ __forceinline__ bool xm_decode(int nblk, int H, int B, int& blk, int& head, int& b) {
+  const int d = blockIdx.x, xcd = d & 7, j = d >> 3;
+  blk = j % nblk;
+  const int pair = (j / nblk) * 8 + xcd;
+  b = pair / H;
+  head = pair - b * H;
+  return pair < H * B;
+}
+__host__ inline unsigned xm_grid(int nblk, int H, int B) { return (unsigned)(((H * B + 7) / 8) * nblk * 8); }
+
+__device__ __forceinline__ f32x4 xm_mfma(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// own row `row` (clamped by the caller), D dimensions from column col0, as the B operand: reg[4 J + jj] = x[16 J + 4 g + jj]
+template <int D>
+__device__ __forceinline__ void xm_load_b(const float* __restrict__ g, int grp, float* reg) {
+#pragma unroll
+  for (int J = 0; J < D / 16; ++J) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(g + 16 * J + 4 * grp);
+    reg[4 * J] = t[0]; reg[4 * J + 1] = t[1]; reg[4 * J + 2] = t[2]; reg[4 * J + 3] = t[3];
+  }
+}
+// Staging: rows [r0, r0 + NR) of the other side (zeros past `len`) into LDS rows of D + 4 floats, in two halves, so that a
+// chunk's global loads are in flight while the previous chunk is being multiplied:
+// load() requests rows [r0, r0 + NR) into registers, store() puts them into LDS (between two barriers).
+template <int D, int NR> struct XmChunk {
+  static constexpr int N = NR * (D / 4) / XM_T;
+  static_assert(NR * (D / 4) % XM_T == 0, "chunk must split evenly over the workgroup");
+  f32x4 t[N];
+  __device__ __forceinline__ void load(const float* __restrict__ g, int row_base, int r0, int len, int ld, int col0) {
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      const int i = n * XM_T + threadIdx.x, r = i / (D / 4), c = (i - r * (D / 4)) * 4;
+      t[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (r0 + r < len) t[n] = *reinterpret_cast<const f32x4*>(g + (size_t)(row_base + r0 + r) * ld + col0 + c);
+    }
+  }
+  __device__ __forceinline__ void store(float* __restrict__ lds) const {
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      const int i = n * XM_T + threadIdx.x, r = i / (D / 4), c = (i - r * (D / 4)) * 4;
+      *reinterpret_cast<f32x4*>(lds + r * (D + 4) + c) = t[n];
+    }
+  }
+};
+// [16 staged rows of `tile`] x [the wave's 16 own rows]: the lane gets [staged row 4 g + i][own row lane % 16]
+template <int D>
+__device__ __forceinline__ f32x4 xm_rows_x_own(const float* __restrict__ tile, int r, int grp, const float* reg) {
+  constexpr int LD = D + 4;
+  f32x4 a[D / 16];
+#pragma unroll
+  for (int J = 0; J < D / 16; ++J) a[J] = *reinterpret_cast<const f32x4*>(tile + r * LD + 16 * J + 4 * grp);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int J = 0; J < D / 16; ++J)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) acc = xm_mfma(a[J][jj], reg[4 * J + jj], acc);
+  return acc;
+}
+// Two products at once -- [16 staged rows of tA] x [own rows as regA] and [16 staged rows of tB] x [own rows as regB]: the
+// lane gets [staged row 4 g + i][own row lane % 16] of each.  All fragments are requested before the first MFMA and the
+// two accumulation chains alternate (left to the compiler, every ds_read_b128 was followed by a full lgkmcnt(0) wait and
+// four dependent MFMAs: the LDS round trip was exposed once per 128 matrix cycles).
+template <int D>
+__device__ __forceinline__ void xm_rows_x_own2(const float* __restrict__ tA, const float* __restrict__ tB, int r, int grp,
+                                               const float* regA, const float* regB, f32x4& oA, f32x4& oB) {
+  constexpr int LD = D + 4;
+  f32x4 a[D / 16], b[D / 16];
+#pragma unroll
+  for (int J = 0; J < D / 16; ++J) {
+    a[J] = *reinterpret_cast<const f32x4*>(tA + r * LD + 16 * J + 4 * grp);
+    b[J] = *reinterpret_cast<const f32x4*>(tB + r * LD + 16 * J + 4 * grp);
+  }
+  f32x4 ca = {0.f, 0.f, 0.f, 0.f}, cb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int J = 0; J < D / 16; ++J)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      ca = xm_mfma(a[J][jj], regA[4 * J + jj], ca);
+      cb = xm_mfma(b[J][jj], regB[4 * J + jj], cb);
+    }
+  oA = ca; oB = cb;
+}
+// acc^T[dimension][own row] += staged^T[dimension][staged row 4 g + i] . w[staged row 4 g + i][own row]   (D / 16 independent chains)
+template <int D>
+__device__ __forceinline__ void xm_accum_t(f32x4 (&acc)[D / 16], const float* __restrict__ tile, int r, int grp, const f32x4 w) {
+  constexpr int LD = D + 4;
+  float a[D / 16][4];
+#pragma unroll
+  for (int dt = 0; dt < D / 16; ++dt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[dt][i] = tile[(4 * grp + i) * LD + 16 * dt + r];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int dt = 0; dt < D / 16; ++dt) acc[dt] = xm_mfma(a[dt][i], w[i], acc[dt]);
+}
+template <int D>
+__device__ __forceinline__ void xm_store_t(float* __restrict__ g, int grp, const f32x4 (&acc)[D / 16], float s) {
+#pragma unroll
+  for (int dt = 0; dt < D / 16; ++dt)
+    *reinterpret_cast<f32x4*>(g + 16 * dt + 4 * grp) = f32x4{acc[dt][0] * s, acc[dt][1] * s, acc[dt][2] * s, acc[dt][3] * s};
+}
+__device__ __forceinline__ float xm_groups_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
+__device__ __forceinline__ float xm_groups_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
+
+// Forward.  NT = 16-key tiles a query row can have (4 / 8 / 16): the whole score row of a query lives in registers
+// (exact two-pass softmax), K streams through LDS 64 keys at a time, then V.
+template <int D, int NT>
+__global__ __launch_bounds__(XM_T, UNIMM_X3M_MIN_WAVES) void x3m_attn_fwd_kernel(AttnF32 p) {
+  constexpr bool OWN_Q = true;
+  constexpr int LD = D + 4, KC = 64;
+  __shared__ __attribute__((aligned(16))) float Xs[KC * LD];
+  drop_resolve(p.drop);
+  int blk, head, b;
+  if (!xm_decode(OWN_Q ? (p.Tq + XM_R - 1) / XM_R : (p.Tk + XM_R - 1) / XM_R, p.H, p.B, blk, head, b)) return;
+  const int qlen = p.q_len != nullptr ? p.q_len[b] : p.Tq, qoff = p.q_off != nullptr ? p.q_off[b] : b * p.Tq;
+  const int klen = p.k_len != nullptr ? p.k_len[b] : p.Tk, koff = p.k_off != nullptr ? p.k_off[b] : b * p.Tk;
+  const int r0 = blk * XM_R;
+  if (r0 >= qlen) return;                                  // workgroup-uniform
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, grp = lane >> 4;
+  const bool live = r0 + wave * 16 < qlen;                 // wave-uniform: some of the wave's queries exist
+  const bool valid = r0 + wave * 16 + r < qlen;
+  const int qr = valid ? r0 + wave * 16 + r : qlen - 1;
+  float qreg[D / 4];
+  xm_load_b<D>(p.q + (size_t)(qoff + qr) * p.ldq + head * D, grp, qreg);
+  // the query's mask words, requested with Q (left inside the softmax loops each was a global load with its use right
+  // behind it: one exposed round trip per word)
+  const uint32_t* mrow = p.mask + (size_t)b * p.mbs + (size_t)qr * p.mqs;
+  const int nmw = (p.Tk + 31) >> 5;
+  uint32_t mws[NT / 2];
+#pragma unroll
+  for (int w = 0; w < NT / 2; ++w) mws[w] = mrow[w < nmw ? w : nmw - 1];
+  f32x4 s[NT];
+  XmChunk<D, KC> pre;
+  pre.load(p.k, koff, 0, klen, p.ldk, head * D);
+#pragma unroll
+  for (int ch = 0; ch < NT / 4; ++ch) {
+    if (ch * KC < klen) {
+      __syncthreads();
+      pre.store(Xs);
+      __syncthreads();
+      if ((ch + 1) * KC < klen) pre.load(p.k, koff, (ch + 1) * KC, klen, p.ldk, head * D);   // next K chunk, or V's first
+      else pre.load(p.v, koff, 0, klen, p.ldv, head * D);
+      if (live) {
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+          if (ch * KC + tt * 16 < klen) s[4 * ch + tt] = xm_rows_x_own<D>(Xs + tt * 16 * LD, r, grp, qreg);
+      }
+    }
+  }
+  // mask + softmax: the lane holds keys 16 t + 4 g + i of query qr; the row's other keys are in lanes ^16, ^32, ^48
+  const uint32_t hrow = ((uint32_t)b * p.H + head) * p.Tq + (uint32_t)qr;
+  const float sc2 = p.scale * XM_LOG2E;
+  float m = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (16 * t < klen) {
+      const uint32_t mw = mws[t >> 1] >> (16 * (t & 1) + 4 * grp);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float sv = (16 * t + 4 * grp + i < klen) ? fmaf(s[t][i], sc2, ((mw >> i) & 1u) ? 0.f : XM_NEG2) : -INFINITY;   // log2 domain
+        s[t][i] = sv;
+        m = fmaxf(m, sv);
+      }
+    }
+  }
+  m = xm_groups_max(m);
+  float l = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (16 * t < klen) {
+      const uint32_t kb = p.drop.thr != 0u ? drop_bits4(p.drop, hrow, (uint32_t)p.Tk, (uint32_t)(16 * t + 4 * grp)) : 0xfu;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float e = __builtin_amdgcn_exp2f(s[t][i] - m);
+        l += e;
+        s[t][i] = ((kb >> i) & 1u) ? e : 0.f;
+      }
+    }
+  }
+  l = xm_groups_sum(l);
+  f32x4 acc[D / 16];
+#pragma unroll
+  for (int dt = 0; dt < D / 16; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ch = 0; ch < NT / 4; ++ch) {
+    if (ch * KC < klen) {
+      __syncthreads();
+      pre.store(Xs);
+      __syncthreads();
+      if ((ch + 1) * KC < klen) pre.load(p.v, koff, (ch + 1) * KC, klen, p.ldv, head * D);
+      if (live) {
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+          if (ch * KC + tt * 16 < klen) xm_accum_t<D>(acc, Xs + tt * 16 * LD, r, grp, s[4 * ch + tt]);
+      }
+    }
+  }
+  if (!valid) return;
+  // acc is out^T: lane holds dimensions 16 dt + 4 g + i of query qr
+  const float inv = (p.drop.thr != 0u ? p.drop.scale : 1.0f) / l;
+  xm_store_t<D>(p.out + (size_t)(qoff + qr) * p.ldo + head * D, grp, acc, inv);
+  if (p.lse != nullptr && grp == 0) p.lse[((size_t)b * p.H + head) * p.Tq + qr] = m * 0.6931471805599453f + __logf(l);
+}
+
+// dQ (+ delta = rowsum(dO o O)): the wave's 16 queries in registers (Q and dO as B operands), K and V staged
+template <int D>
+__global__ __launch_bounds__(XM_T, UNIMM_X3M_MIN_WAVES) void x3m_attn_bwd_dq_kernel(AttnF32 p) {
+  constexpr bool OWN_Q = true;
+  constexpr int LD = D + 4, KC = D == 64 ? 64 : 32;
+  __shared__ __attribute__((aligned(16))) float Ks[KC * LD];
+  __shared__ __attribute__((aligned(16))) float Vs[KC * LD];
+  __shared__ uint32_t Mq[XM_R * 9];                        // mask words of the 64 queries (rows of 8 + 1 pad)
+  drop_resolve(p.drop);
+  int blk, head, b;
+  if (!xm_decode(OWN_Q ? (p.Tq + XM_R - 1) / XM_R : (p.Tk + XM_R - 1) / XM_R, p.H, p.B, blk, head, b)) return;
+  const int qlen = p.q_len != nullptr ? p.q_len[b] : p.Tq, qoff = p.q_off != nullptr ? p.q_off[b] : b * p.Tq;
+  const int klen = p.k_len != nullptr ? p.k_len[b] : p.Tk, koff = p.k_off != nullptr ? p.k_off[b] : b * p.Tk;
+  const int r0 = blk * XM_R;
+  if (r0 >= qlen) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, grp = lane >> 4;
+  const bool live = r0 + wave * 16 < qlen;
+  const bool valid = r0 + wave * 16 + r < qlen;
+  const int qr = valid ? r0 + wave * 16 + r : qlen - 1;
+  XmChunk<D, KC> prek, prev;                               // first K / V chunk: requested before anything that waits
+  prek.load(p.k, koff, 0, klen, p.ldk, head * D);
+  prev.load(p.v, koff, 0, klen, p.ldv, head * D);
+  {
+    const int nmw = (p.Tk + 31) >> 5;
+    for (int i = threadIdx.x; i < XM_R * 8; i += XM_T) {
+      const int ql = i >> 3, w = i & 7, qq = r0 + ql < qlen ? r0 + ql : qlen - 1;
+      Mq[ql * 9 + w] = w < nmw ? p.mask[(size_t)b * p.mbs + (size_t)qq * p.mqs + w] : 0u;   // (visible after the loop's first barrier)
+    }
+  }
+  float qreg[D / 4], doreg[D / 4];
+  xm_load_b<D>(p.q + (size_t)(qoff + qr) * p.ldq + head * D, grp, qreg);
+  xm_load_b<D>(p.dout + (size_t)(qoff + qr) * p.lddo + head * D, grp, doreg);
+  float delta = 0.f;
+  {
+    float oreg[D / 4];
+    xm_load_b<D>(p.o + (size_t)(qoff + qr) * p.ldo + head * D, grp, oreg);
+#pragma unroll
+    for (int c = 0; c < D / 4; ++c) delta = fmaf(doreg[c], oreg[c], delta);
+    delta = xm_groups_sum(delta);
+  }
+  const size_t li = ((size_t)b * p.H + head) * p.Tq + qr;
+  const float lse2 = p.lse[li] * XM_LOG2E, sc2 = p.scale * XM_LOG2E;         // exp(x) = exp2(x log2 e): one v_exp_f32 per element
+  if (valid && grp == 0) p.delta[li] = delta;
+  f32x4 dq[D / 16];
+#pragma unroll
+  for (int dt = 0; dt < D / 16; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const uint32_t* mrow = Mq + (wave * 16 + r) * 9;
+  const uint32_t hrow = ((uint32_t)b * p.H + head) * p.Tq + (uint32_t)qr;
+  const float dsc = p.drop.thr != 0u ? p.drop.scale : 1.0f;
+  const uint32_t nodrop = p.drop.thr != 0u ? 0u : 0xfu;
+  for (int k0 = 0; k0 < klen; k0 += KC) {
+    __syncthreads();
+    prek.store(Ks);
+    prev.store(Vs);
+    __syncthreads();
+    if (k0 + KC < klen) {
+      prek.load(p.k, koff, k0 + KC, klen, p.ldk, head * D);
+      prev.load(p.v, koff, k0 + KC, klen, p.ldv, head * D);
+    }
+    if (!live) continue;
+    // Tiles of 16 keys, software-pipelined: the two products of tile t + 1 (32 MFMAs, nothing but LDS reads in front of them) are
+    // issued BEFORE the elementwise work of tile t, whose ~60 vector instructions then run in the shadow of those MFMAs (a
+    // v_mfma_f32_16x16x4_f32 holds the issue port for 8 of its 32 cycles); dS of tile t feeds the third product.
+    const int nt = (klen - k0 + 15) >> 4 < KC / 16 ? (klen - k0 + 15) >> 4 : KC / 16;
+    auto elementwise = [&](const f32x4& st, const f32x4& dpt, int kt) {
+      const uint32_t mw = mrow[kt >> 5] >> ((kt & 16) + 4 * grp);
+      const uint32_t kb = drop_bits4(p.drop, hrow, (uint32_t)p.Tk, (uint32_t)(kt + 4 * grp)) | nodrop;   // (no branch: one basic block)
+      f32x4 ds;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        // keys past klen: their staged K rows are zero, so whatever dS they get adds nothing to dQ
+        const float pr = __builtin_amdgcn_exp2f(fmaf(st[i], sc2, (((mw >> i) & 1u) ? 0.f : XM_NEG2) - lse2));
+        ds[i] = (pr * p.scale) * fmaf(dpt[i], ((kb >> i) & 1u) ? dsc : 0.f, -delta);
+      }
+      return ds;
+    };
+    f32x4 st, dpt;
+    xm_rows_x_own2<D>(Ks, Vs, r, grp, qreg, doreg, st, dpt);
+    for (int tt = 0; tt + 1 < nt; ++tt) {
+      f32x4 stn, dptn;
+      xm_rows_x_own2<D>(Ks + (tt + 1) * 16 * LD, Vs + (tt + 1) * 16 * LD, r, grp, qreg, doreg, stn, dptn);
+      const f32x4 ds = elementwise(st, dpt, k0 + tt * 16);
+      xm_accum_t<D>(dq, Ks + tt * 16 * LD, r, grp, ds);
+      st = stn; dpt = dptn;
+      // issue order asked of the scheduler: the products' fragment reads, then one MFMA with three vector instructions behind
+      // it until the elementwise work is spent, the transposed fragment reads, the third product
+      XM_SGB(0x100, D / 8 + 1);
+#pragma unroll
+      for (int i = 0; i < D / 2; ++i) { XM_SGB(0x008, 1); XM_SGB(0x002, D == 64 ? 3 : 2); }
+      XM_SGB(0x100, D / 8);
+#pragma unroll
+      for (int i = 0; i < D / 4; ++i) { XM_SGB(0x008, 1); XM_SGB(0x002, 1); }
+    }
+    {
+      const f32x4 ds = elementwise(st, dpt, k0 + (nt - 1) * 16);
+      xm_accum_t<D>(dq, Ks + (nt - 1) * 16 * LD, r, grp, ds);
+    }
+  }
+  if (valid) xm_store_t<D>(p.dq + (size_t)(qoff + qr) * p.lddq + head * D, grp, dq, 1.0f);
+}
+
+// dK, dV: the wave's 16 keys in registers (K and V as B operands), Q and dO rows staged with their lse / delta / mask words
+template <int D>
+__global__ __launch_bounds__(XM_T, UNIMM_X3M_MIN_WAVES) void x3m_attn_bwd_dkv_kernel(AttnF32 p) {
+  constexpr bool OWN_Q = false;
+  constexpr int LD = D + 4, QC = D == 64 ? 64 : 32;
+  __shared__ __attribute__((aligned(16))) float Qs[QC * LD];
+  __shared__ __attribute__((aligned(16))) float Os[QC * LD];
+  __shared__ float Ls[QC], Ds[QC];
+  __shared__ uint32_t Ms[QC * 2];                          // per staged query: the two mask words this workgroup's 64 keys lie in
+  drop_resolve(p.drop);
+  int blk, head, b;
+  if (!xm_decode(OWN_Q ? (p.Tq + XM_R - 1) / XM_R : (p.Tk + XM_R - 1) / XM_R, p.H, p.B, blk, head, b)) return;
+  const int qlen = p.q_len != nullptr ? p.q_len[b] : p.Tq, qoff = p.q_off != nullptr ? p.q_off[b] : b * p.Tq;
+  const int klen = p.k_len != nullptr ? p.k_len[b] : p.Tk, koff = p.k_off != nullptr ? p.k_off[b] : b * p.Tk;
+  const int r0 = blk * XM_R;
+  if (r0 >= klen) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, grp = lane >> 4;
+  const bool live = r0 + wave * 16 < klen;
+  const bool valid = r0 + wave * 16 + r < klen;
+  const int key = valid ? r0 + wave * 16 + r : klen - 1;
+  float kreg[D / 4], vreg[D / 4];
+  xm_load_b<D>(p.k + (size_t)(koff + key) * p.ldk + head * D, grp, kreg);
+  xm_load_b<D>(p.v + (size_t)(koff + key) * p.ldv + head * D, grp, vreg);
+  f32x4 dk[D / 16], dv[D / 16];
+#pragma unroll
+  for (int dt = 0; dt < D / 16; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  const uint32_t hbase = ((uint32_t)b * p.H + head) * p.Tq;
+  const float dsc = p.drop.thr != 0u ? p.drop.scale : 1.0f, sc2 = p.scale * XM_LOG2E;
+  const size_t lbase = ((size_t)b * p.H + head) * p.Tq;
+  // every key of this workgroup lies in mask word r0 / 32 or the next one (64 keys from a multiple of 64): the word
+  // of the wave's 16 keys is wave-uniform
+  const int mword = (wave * 16) >> 5;                       // (r0 is a multiple of 64: word r0 / 32 or the next one)
+  XmChunk<D, QC> preq, preo;
+  float prel = 0.f, pred = 0.f;
+  uint32_t prem = 0u;
+  const int nmw = (p.Tk + 31) >> 5;
+  auto request = [&](int q0) {
+    preq.load(p.q, qoff, q0, qlen, p.ldq, head * D);
+    preo.load(p.dout, qoff, q0, qlen, p.lddo, head * D);
+    if (threadIdx.x < QC) {
+      const bool ok = q0 + (int)threadIdx.x < qlen;
+      prel = ok ? p.lse[lbase + q0 + threadIdx.x] * XM_LOG2E : 0.f;        // log2 domain
+      pred = ok ? p.delta[lbase + q0 + threadIdx.x] : 0.f;
+    } else if (threadIdx.x < 3 * QC) {
+      const int ql = (threadIdx.x - QC) >> 1, w = (r0 >> 5) + (threadIdx.x & 1);
+      prem = (q0 + ql < qlen && w < nmw) ? p.mask[(size_t)b * p.mbs + (size_t)(q0 + ql) * p.mqs + w] : 0u;
+    }
+  };
+  request(0);
+  for (int q0 = 0; q0 < qlen; q0 += QC) {
+    __syncthreads();
+    preq.store(Qs);
+    preo.store(Os);
+    if (threadIdx.x < QC) { Ls[threadIdx.x] = prel; Ds[threadIdx.x] = pred; }
+    else if (threadIdx.x < 3 * QC) Ms[threadIdx.x - QC] = prem;
+    __syncthreads();
+    if (q0 + QC < qlen) request(q0 + QC);
+    if (!live) continue;
+#pragma unroll
+    for (int tt = 0; tt < QC / 16; ++tt) {
+      const int qt = q0 + tt * 16;
+      if (qt >= qlen) break;
+      f32x4 sq, dpq;                                                          // [query 4 g + i][key r]
+      xm_rows_x_own2<D>(Qs + tt * 16 * LD, Os + tt * 16 * LD, r, grp, kreg, vreg, sq, dpq);
+      f32x4 pd, ds;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ql = tt * 16 + 4 * grp + i, qq = q0 + ql;
+        const bool qok = qq < qlen;
+        const uint32_t mw = Ms[ql * 2 + mword];
+        const float pr = (qok && valid) ? __builtin_amdgcn_exp2f(fmaf(sq[i], sc2, (((mw >> (key & 31)) & 1u) ? 0.f : XM_NEG2) - Ls[ql])) : 0.f;
+        const bool keep = xa_keep(p.drop, hbase + (uint32_t)qq, (uint32_t)p.Tk, (uint32_t)key);
+        pd[i] = keep ? pr * dsc : 0.f;
+        const float dP = keep ? dpq[i] * dsc : 0.f;
+        ds[i] = pr * (dP - Ds[ql]) * p.scale;
+      }
+      xm_accum_t<D>(dv, Os + tt * 16 * LD, r, grp, pd);
+      xm_accum_t<D>(dk, Qs + tt * 16 * LD, r, grp, ds);
+    }
+  }
+  if (!valid) return;
+  xm_store_t<D>(p.dk + (size_t)(koff + key) * p.lddk + head * D, grp, dk, 1.0f);
+  xm_store_t<D>(p.dv + (size_t)(koff + key) * p.lddv + head * D, grp, dv, 1.0f);
+}
+
+int g_x3_attn_impl = 1;       // 1 = matrix-instruction kernels, 0 = the vector kernels (A/B: unimm_x3_attn_set_impl)
+
 int fill_attn(const unimm_attn_args* a, AttnF32& p) {
   if (a == nullptr || !a->q || !a->k || !a->v || !a->out || !a->mask) return UNIMM_E_ARG;
   if (a->B <= 0 || a->H <= 0 || a->Tq <= 0 || a->Tk <= 0 || a->Tq > 256 || a->Tk > 256) return UNIMM_E_SHAPE;
@@ -668,12 +1089,28 @@ extern "C" int unimm_x3_attn_fwd(const unimm_attn_args* a, void* stream) {
   const int rc = fill_attn(a, p);
   if (rc != UNIMM_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
-  // forward: 64 dimensions per lane (176-184 registers: two waves per SIMD either way, half the cross-lane adds)
+  if (g_x3_attn_impl != 0) {
+    const dim3 grid(xm_grid((a->Tq + XM_R - 1) / XM_R, a->H, a->B));
+    const int nt = (a->Tk + 15) / 16;
+#define UNIMM_X3M_FWD(D_, NT_) hipLaunchKernelGGL((x3m_attn_fwd_kernel<D_, NT_>), grid, dim3(XM_T), 0, s, p)
+    if (a->D == 64) { if (nt <= 4) UNIMM_X3M_FWD(64, 4); else if (nt <= 8) UNIMM_X3M_FWD(64, 8); else UNIMM_X3M_FWD(64, 16); }
+    else { if (nt <= 4) UNIMM_X3M_FWD(128, 4); else if (nt <= 8) UNIMM_X3M_FWD(128, 8); else UNIMM_X3M_FWD(128, 16); }
+#undef UNIMM_X3M_FWD
+    UNIMM_CHECK_LAUNCH();
+    return UNIMM_OK;
+  }
+  // the vector kernels: 64 dimensions per lane (176-184 registers: two waves per SIMD either way, half the cross-lane adds)
   constexpr int DH = UNIMM_X3_ATTN_FWD_DH;
   constexpr int R64 = XA_T / (64 / DH), R128 = XA_T / (128 / DH);
   if (a->D == 64) hipLaunchKernelGGL((x3_attn_fwd_kernel<64, DH>), dim3((a->Tq + R64 - 1) / R64, a->H, a->B), dim3(XA_T), 0, s, p);
   else hipLaunchKernelGGL((x3_attn_fwd_kernel<128, DH>), dim3((a->Tq + R128 - 1) / R128, a->H, a->B), dim3(XA_T), 0, s, p);
   UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
+}
+
+extern "C" int unimm_x3_attn_set_impl(int32_t impl) {
+  if (impl != 0 && impl != 1) return UNIMM_E_ARG;
+  g_x3_attn_impl = impl;
   return UNIMM_OK;
 }
 
@@ -695,7 +1132,19 @@ extern "C" int unimm_x3_attn_bwd(const unimm_attn_bwd_args* a, void* stream) {
   p.dq = (float*)a->dq; p.dk = (float*)a->dk; p.dv = (float*)a->dv;
   p.lddo = a->lddo; p.lddq = a->lddq; p.lddk = a->lddk; p.lddv = a->lddv;
   hipStream_t s = (hipStream_t)stream;
-  // backward: 32 dimensions per lane (the dK / dV kernel holds k, v, dk, dv: 4 x 64 registers at 64 per lane = one wave per SIMD
+  if (g_x3_attn_impl != 0) {
+    const dim3 gq(xm_grid((a->Tq + XM_R - 1) / XM_R, a->H, a->B)), gk(xm_grid((a->Tk + XM_R - 1) / XM_R, a->H, a->B));
+    if (a->D == 64) {
+      hipLaunchKernelGGL((x3m_attn_bwd_dq_kernel<64>), gq, dim3(XM_T), 0, s, p);
+      hipLaunchKernelGGL((x3m_attn_bwd_dkv_kernel<64>), gk, dim3(XM_T), 0, s, p);
+    } else {
+      hipLaunchKernelGGL((x3m_attn_bwd_dq_kernel<128>), gq, dim3(XM_T), 0, s, p);
+      hipLaunchKernelGGL((x3m_attn_bwd_dkv_kernel<128>), gk, dim3(XM_T), 0, s, p);
+    }
+    UNIMM_CHECK_LAUNCH();
+    return UNIMM_OK;
+  }
+  // the vector kernels: 32 dimensions per lane (the dK / dV kernel holds k, v, dk, dv: 4 x 64 registers at 64 per lane = one wave per SIMD
   // with nothing to hide the LDS round trips behind)
   constexpr int DH = UNIMM_X3_ATTN_BWD_DH;
   if (a->D == 64) {

@@ -13,7 +13,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libunimm_hip.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROP_RESID, EPI_BIAS_RELU, EPI_DGELU, EPI_ADD, EPI_MUL, EPI_BIAS_GELU_DG = range(8)
 
@@ -94,7 +94,7 @@ SYMBOLS = ["unimm_version", "unimm_arch", "unimm_gemm_nt", "unimm_gemm_tn", "uni
            "unimm_colpartials_finish_grouped", "unimm_gemm_tn_grouped_ws", "unimm_linear_f32", "unimm_rows_add_f32", "unimm_transpose_bf16", "unimm_sum_slabs_bf16", "unimm_attn_probs",
            # the fp32-accuracy mode (csrc/x3ops.hip)
            "unimm_x3_split", "unimm_x3_split_wt", "unimm_x3_layernorm_bwd_partials", "unimm_embed_bwd_f32", "unimm_x3_lm_loss_bwd",
-           "unimm_x3_kl_loss_bwd", "unimm_x3_rows_add", "unimm_x3_attn_fwd", "unimm_x3_attn_bwd", "unimm_prof_tag", "unimm_prof_tagged",
+           "unimm_x3_kl_loss_bwd", "unimm_x3_rows_add", "unimm_x3_attn_fwd", "unimm_x3_attn_bwd", "unimm_x3_attn_set_impl", "unimm_prof_tag", "unimm_prof_tagged",
            "unimm_sum_dropout", "unimm_sum_dropout_bwd", "unimm_mse_loss_fwd", "unimm_mse_loss_bwd"]
 
 
@@ -887,3 +887,8 @@ def x3_attn_bwd(q, k, v, out, dout, lse, delta, dq, dk, dv, mask, B, H, Tq, Tk, 
     a.drop_key, a.drop_thr, a.drop_scale = drop[:3]
     a.drop_salt = _salt(drop)
     _check(lib().unimm_x3_attn_bwd(C.byref(a), _stream()), "unimm_x3_attn_bwd")
+
+
+def x3_attn_set_impl(impl):
+    """1 = fp32 matrix-instruction attention kernels (default), 0 = the vector-ALU kernels (A/B runs)."""
+    _check(lib().unimm_x3_attn_set_impl(int(impl)), "unimm_x3_attn_set_impl")
