@@ -298,6 +298,7 @@ def main():
     if args.compute != "bf16":
         from unimm_amd import lib as _lib
         _lib.x3_attn_set_impl(1 if args.x3_attn == "mfma" else 0)
+        enc.bert_pretrained.engine.attn_planes = args.x3_attn == "mfma"
     enc.train()
     model = enc.bert_pretrained
     model.set_dropout_seed(1234 + rank)

@@ -505,6 +505,11 @@ int unimm_x3_layernorm_bwd_partials(const float* dy, const float* x, const float
                                     uint32_t drop_thr, float drop_scale, uint32_t odrop_key, uint32_t odrop_thr,
                                     float odrop_scale, int32_t* blocks_out, const int32_t* m_dev, const uint32_t* drop_salt,
                                     void* stream);
+/* unimm_layernorm_fwd that also writes the normalised rows as an x-type split operand y3 [M, 3 H] (H % 64 == 0); y32 (or NULL),
+ * mean / rstd (both or neither), dropout as there. */
+int unimm_x3_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y32, void* y3, float* mean, float* rstd,
+                           int32_t M, int32_t H, float eps, uint32_t drop_key, uint32_t drop_thr, float drop_scale,
+                           const uint32_t* drop_salt, void* stream);
 /* unimm_embed_bwd with an fp32 upstream gradient */
 int unimm_embed_bwd_f32(const unimm_embed_args* args, const float* dy, float* dword, float* dpos, float* dtype, float* dext,
                         float* dgamma, float* dbeta, float* partials, void* stream);
@@ -519,8 +524,17 @@ int unimm_x3_kl_loss_bwd(const float* pred, const float* target, const int32_t* 
 int unimm_x3_rows_add(float* dst, const int32_t* idx, const float* src, int32_t n, int32_t H, int32_t ldd, void* stream);
 /* unimm_attn_fwd / unimm_attn_bwd with fp32 q / k / v / out / dout / dq / dk / dv (same argument structs, row strides in
  * fp32 elements, multiples of 4; every other field -- masks, lse, variable-length offsets, dropout -- as there). */
-int unimm_x3_attn_fwd(const unimm_attn_args* args, void* stream);
-int unimm_x3_attn_bwd(const unimm_attn_bwd_args* args, void* stream);
+typedef struct {
+  void* out3;                      /* forward: the context ALSO as an x-type split operand [rows, 3 cp3] (bf16), or NULL */
+  void* dq3; void* dk3; void* dv3; /* backward: dQ / dK / dV as x-type split operands INSTEAD of fp32 (all three or none; the args'
+                                    * dq / dk / dv may then be NULL); each points at its first column of plane 0 */
+  int32_t ld3;                     /* row stride of the split buffers, bf16 elements (>= 3 cp3) */
+  int32_t cp3;                     /* plane stride = columns per plane (multiple of 8, >= H * D); buffers 16-byte aligned, ld3 % 8 == 0 */
+} unimm_x3_attn_planes;
+/* planes (or NULL): what the next GEMM reads, written by the attention kernel itself instead of a unimm_x3_split pass over its
+ * fp32 result.  Matrix-instruction kernels only (UNIMM_E_ARG under unimm_x3_attn_set_impl(0)). */
+int unimm_x3_attn_fwd(const unimm_attn_args* args, const unimm_x3_attn_planes* planes, void* stream);
+int unimm_x3_attn_bwd(const unimm_attn_bwd_args* args, const unimm_x3_attn_planes* planes, void* stream);
 /* Which kernels the two entry points above launch: 1 (default) = the fp32 matrix-instruction kernels
  * (v_mfma_f32_16x16x4_f32, exact fp32 operands), 0 = the vector-ALU kernels of the first version (kept for A/B runs). */
 int unimm_x3_attn_set_impl(int32_t impl);

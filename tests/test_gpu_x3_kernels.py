@@ -223,6 +223,81 @@ def test_fp32_attention_vector_kernels_still_agree(B, H, Tq, Tk, D, dense):
         lib.x3_attn_set_impl(1)
 
 
+def _unsplit(x3, cols):
+    """x-type split operand [rows, 3 cp] -> (hi + lo as fp32, the three planes)"""
+    cp = x3.shape[1] // 3
+    hi, lo, hi2 = x3[:, :cp].float(), x3[:, cp:2 * cp].float(), x3[:, 2 * cp:].float()
+    return (hi + lo)[:, :cols], hi, lo, hi2
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk,D", [(2, 2, 200, 200, 64), (2, 2, 37, 150, 128)])
+def test_fp32_attention_split_outputs_equal_split_of_fp32_outputs(B, H, Tq, Tk, D):
+    """The planes the attention kernels write themselves (context forward; dQ / dK / dV backward, into column slices of a wider
+    gradient buffer) are bit for bit unimm_x3_split of their fp32 results."""
+    from unimm_amd import dropout as DR
+    from unimm_amd import lib
+    g = torch.Generator(device=DEV).manual_seed(Tq)
+    HD = H * D
+    q = torch.randn((B * Tq, HD), generator=g, device=DEV)
+    k = torch.randn((B * Tk, HD), generator=g, device=DEV)
+    v = torch.randn((B * Tk, HD), generator=g, device=DEV)
+    m = torch.rand((B, Tq, Tk), generator=g, device=DEV) < 0.7
+    m[:, :, 0] = True
+    packed = lib.mask_pack(m)
+    mq, mb = (Tk + 31) // 32, Tq * ((Tk + 31) // 32)
+    drop = DR.drop_arg(0.1, DR.make_key(3, 1, Tq))
+    scale = 1.0 / math.sqrt(D)
+    out, out_b = torch.empty((B * Tq, HD), device=DEV), torch.empty((B * Tq, HD), device=DEV)
+    lse = torch.empty((B, H, Tq), device=DEV)
+    out3 = torch.zeros((B * Tq, 3 * HD), dtype=torch.bfloat16, device=DEV)
+    lib.x3_attn_fwd(q, k, v, out, lse, packed, B, H, Tq, Tk, D, scale, mq, mb, drop, out3=out3)
+    lib.x3_attn_fwd(q, k, v, out_b, lse, packed, B, H, Tq, Tk, D, scale, mq, mb, drop)
+    want3 = torch.empty_like(out3)
+    lib.x3_split(out_b, out3=want3)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out_b) and torch.equal(out3, want3)
+    dout = torch.randn((B * Tq, HD), generator=g, device=DEV)
+    delta = torch.empty_like(lse)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    lib.x3_attn_bwd(q, k, v, out, dout, lse, delta, dq, dk, dv, packed, B, H, Tq, Tk, D, scale, mq, mb, drop)
+    # gradient buffers as the engine lays them out: [rows, 3 N] with N = 3 HD, dq / dk / dv in column slices of plane 0
+    N = 3 * HD
+    gq = torch.zeros((B * Tq, 3 * N), dtype=torch.bfloat16, device=DEV)
+    gk = torch.zeros((B * Tk, 3 * N), dtype=torch.bfloat16, device=DEV)
+    lib.x3_attn_bwd(q, k, v, out, dout, lse, delta, gq[:, :HD], gk[:, HD:2 * HD], gk[:, 2 * HD:3 * HD], packed, B, H, Tq, Tk, D, scale,
+                    mq, mb, drop, planes=(N, gq.stride(0)))
+    torch.cuda.synchronize()
+    for t32, buf, c0 in ((dq, gq, 0), (dk, gk, HD), (dv, gk, 2 * HD)):
+        want = torch.empty((t32.shape[0], 3 * HD), dtype=torch.bfloat16, device=DEV)
+        lib.x3_split(t32, out3=want)
+        torch.cuda.synchronize()
+        for pl in range(3):
+            assert torch.equal(buf[:, pl * N + c0:pl * N + c0 + HD], want[:, pl * HD:(pl + 1) * HD]), (c0, pl)
+    assert float(gq[:, HD:N].abs().max()) == 0.0            # nothing written outside the slices
+
+
+@pytest.mark.parametrize("M,H", [(1000, 768), (77, 1024)])
+def test_fp32_layernorm_forward_split_output(M, H):
+    from unimm_amd import dropout as DR
+    from unimm_amd import lib
+    g = torch.Generator(device=DEV).manual_seed(M)
+    x = torch.randn((M, H), generator=g, device=DEV) * 3 - 0.7
+    gamma = torch.randn(H, generator=g, device=DEV) * 0.2 + 1
+    beta = torch.randn(H, generator=g, device=DEV) * 0.1
+    for drop in (DR.drop_arg(0.1, DR.make_key(2, 5, M)), lib.NO_DROP):
+        y_a, y_b = torch.empty((M, H), device=DEV), torch.empty((M, H), device=DEV)
+        m_a, r_a, m_b, r_b = (torch.empty(M, device=DEV) for _ in range(4))
+        y3 = torch.empty((M, 3 * H), dtype=torch.bfloat16, device=DEV)
+        lib.x3_layernorm_fwd(x, gamma, beta, y_a, y3, m_a, r_a, M, H, drop=drop)
+        lib.layernorm_fwd(x, gamma, beta, y_b, None, m_b, r_b, M, H, drop=drop)
+        want3 = torch.empty_like(y3)
+        lib.x3_split(y_b, out3=want3)
+        torch.cuda.synchronize()
+        assert torch.equal(y_a, y_b) and torch.equal(m_a, m_b) and torch.equal(r_a, r_b) and torch.equal(y3, want3)
+    ref = torch.nn.functional.layer_norm(x.double(), (H,), gamma.double(), beta.double(), 1e-12)
+    assert rel(_unsplit(y3, H)[0], ref) < 3e-5 and rel(y_a, ref) < 2e-6         # (last pass: no dropout)
+
+
 @pytest.mark.parametrize("M,H", [(1000, 768), (333, 1024), (64, 128)])
 def test_fp32_layernorm_backward(M, H):
     from unimm_amd import dropout as DR

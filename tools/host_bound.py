@@ -6,11 +6,12 @@ import torch
 from unimm_amd import VisualDialogEncoder, synth
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+COMPUTE = sys.argv[2] if len(sys.argv) > 2 else "bf16"      # or fp32x3
 K = 20
 dev = torch.device("cuda", 0)
 cfgp = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "unimm_amd", "config", "bert_base_6layer_6conect.json")
 torch.manual_seed(0)
-enc = VisualDialogEncoder(cfgp).to(dev).train()
+enc = VisualDialogEncoder(cfgp, compute_dtype=COMPUTE).to(dev).train()
 model = enc.bert_pretrained
 batch = synth.make_batch(n_seq=B, cfg=model.config, seed=1234, device=dev)
 nsp_w = batch.pop("nsp_weight")
@@ -76,4 +77,4 @@ for _ in range(5):
     step()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(40)
+st.sort_stats("tottime").print_stats(int(os.environ.get("HOST_BOUND_ROWS", "40")))

@@ -133,6 +133,46 @@ __device__ __forceinline__ void store_row_split3(bf16_t* __restrict__ p, int cp,
 }
 
 // ------------------------------------------------------------------------------------------------
+// LayerNorm forward (layernorm_fwd_kernel of rowops.hip, same arithmetic) that also writes the normalised row as an x-type
+// split operand: the next GEMM's input without a pass of its own over the fp32 row.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void x3_layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float* __restrict__ y32,
+                                                               bf16_t* __restrict__ y3, float* __restrict__ mean_o,
+                                                               float* __restrict__ rstd_o, int M, int H, float eps, DropoutArg drop) {
+  drop_resolve(drop);
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * (blockDim.x >> 6);
+  Row8 g, b;
+  load_vec_f32(gamma, H, lane, g);
+  load_vec_f32(beta, H, lane, b);
+  Row8 xv;
+  if (wave < M) load_vec_f32(x + (size_t)wave * H, H, lane, xv);
+  for (int row = wave; row < M; row += nwaves) {
+    Row8 nx;
+    const int nrow = row + nwaves;
+    if (nrow < M) load_vec_f32(x + (size_t)nrow * H, H, lane, nx);      // next row in flight while this one is reduced
+    float mean, rstd;
+    row_stats(xv, H, mean, rstd, eps);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const uint32_t kb = drop.thr != 0u ? drop_bits8(drop, (uint32_t)row, (uint32_t)H, (uint32_t)((lane + 64 * i) * 8)) : 0u;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float v = (xv.v[i][j] - mean) * rstd * g.v[i][j] + b.v[i][j];
+        if (drop.thr != 0u) v = ((kb >> j) & 1u) ? v * drop.scale : 0.f;
+        xv.v[i][j] = v;
+      }
+    }
+    if (y32 != nullptr) store_row_f32(y32 + (size_t)row * H, H, lane, xv);
+    store_row_split3(y3 + (size_t)row * 3 * H, H, H, lane, xv);
+    if (lane == 0 && mean_o != nullptr) { mean_o[row] = mean; rstd_o[row] = rstd; }
+    if (nrow < M) xv = nx;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // LayerNorm backward on fp32 gradients (same arithmetic and partials layout as layernorm_bwd_kernel of rowops.hip):
 // dx32 = gradient w.r.t. the pre-LayerNorm sum (fp32, the residual branch), dxd3 = its dropout-masked copy as an
 // x-type split operand (the dY of the dense branch: dgrad GEMM operand and weight-gradient operand).
@@ -330,6 +370,9 @@ struct AttnF32 {
   int mqs, mbs;
   float scale;
   DropoutArg drop;
+  // optional x-type split outputs (planes of `cp3` columns, row stride ld3): the forward's context, the backward's dQ / dK / dV
+  bf16_t* o3; bf16_t* dq3; bf16_t* dk3; bf16_t* dv3;
+  int ld3, cp3;
 };
 
 #ifndef UNIMM_X3_ATTN_BWD_DH
@@ -692,11 +735,46 @@ __device__ __forceinline__ void xm_accum_t(f32x4 (&acc)[D / 16], const float* __
 #pragma unroll
     for (int dt = 0; dt < D / 16; ++dt) acc[dt] = xm_mfma(a[dt][i], w[i], acc[dt]);
 }
+// Result tiles leave the workgroup row-contiguously.  The accumulators are transposed -- a lane holds dimensions 16 dt + 4 g + i
+// of ONE own row -- so storing them directly is a 16-byte (fp32) or 8-byte (split planes) piece per lane on 16 different rows
+// per instruction; with the split planes written that way the forward kernel of the 37-region sides ran 40 % longer (58.8 ->
+// 82.7 us).  Instead every wave puts its [16 rows][D] tile into its quarter of the (by then dead) staging buffer and walks it
+// with consecutive lanes on consecutive 16 bytes: fp32 rows (out32 or NULL) four floats per lane, the x-type split planes
+// [hi | lo | hi] (out3 or NULL) eight values per lane.  nrows = how many of the wave's 16 rows exist.
 template <int D>
-__device__ __forceinline__ void xm_store_t(float* __restrict__ g, int grp, const f32x4 (&acc)[D / 16], float s) {
+__device__ __forceinline__ void xm_store_rows(float* __restrict__ tile, const f32x4 (&acc)[D / 16], float s, int r, int grp, int lane,
+                                              int nrows, float* __restrict__ out32, int ld32, bf16_t* __restrict__ out3, int ld3, int cp) {
+  constexpr int LD = D + 4;
 #pragma unroll
   for (int dt = 0; dt < D / 16; ++dt)
-    *reinterpret_cast<f32x4*>(g + 16 * dt + 4 * grp) = f32x4{acc[dt][0] * s, acc[dt][1] * s, acc[dt][2] * s, acc[dt][3] * s};
+    *reinterpret_cast<f32x4*>(tile + r * LD + 16 * dt + 4 * grp) = f32x4{acc[dt][0] * s, acc[dt][1] * s, acc[dt][2] * s, acc[dt][3] * s};
+  // (wave-private rows: the wave's own LDS writes are ordered before its reads by the waitcnt the compiler places)
+  if (out32 != nullptr) {
+#pragma unroll
+    for (int it = 0; it < D / 16; ++it) {
+      const int idx = it * 64 + lane, row = idx / (D / 4), c = (idx % (D / 4)) * 4;
+      const f32x4 t = *reinterpret_cast<const f32x4*>(tile + row * LD + c);
+      if (row < nrows) *reinterpret_cast<f32x4*>(out32 + (size_t)row * ld32 + c) = t;
+    }
+  }
+  if (out3 != nullptr) {
+#pragma unroll
+    for (int it = 0; it < D / 32; ++it) {
+      const int idx = it * 64 + lane, row = idx / (D / 8), c = (idx % (D / 8)) * 8;
+      const f32x4 t0 = *reinterpret_cast<const f32x4*>(tile + row * LD + c), t1 = *reinterpret_cast<const f32x4*>(tile + row * LD + c + 4);
+      float hi[8], lo[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { split2(t0[e], hi[e], lo[e]); split2(t1[e], hi[4 + e], lo[4 + e]); }
+      const u32x4 Hh = u32x4{pack2bf(hi[0], hi[1]), pack2bf(hi[2], hi[3]), pack2bf(hi[4], hi[5]), pack2bf(hi[6], hi[7])};
+      const u32x4 Ll = u32x4{pack2bf(lo[0], lo[1]), pack2bf(lo[2], lo[3]), pack2bf(lo[4], lo[5]), pack2bf(lo[6], lo[7])};
+      if (row < nrows) {
+        bf16_t* o = out3 + (size_t)row * ld3 + c;
+        *reinterpret_cast<u32x4*>(o) = Hh;
+        *reinterpret_cast<u32x4*>(o + cp) = Ll;
+        *reinterpret_cast<u32x4*>(o + 2 * cp) = Hh;
+      }
+    }
+  }
 }
 __device__ __forceinline__ float xm_groups_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
 __device__ __forceinline__ float xm_groups_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
@@ -794,11 +872,14 @@ __global__ __launch_bounds__(XM_T, UNIMM_X3M_MIN_WAVES) void x3m_attn_fwd_kernel
       }
     }
   }
-  if (!valid) return;
+  __syncthreads();                                         // every wave is done with the last V chunk: the buffer becomes the store tiles
+  if (!live) return;
   // acc is out^T: lane holds dimensions 16 dt + 4 g + i of query qr
   const float inv = (p.drop.thr != 0u ? p.drop.scale : 1.0f) / l;
-  xm_store_t<D>(p.out + (size_t)(qoff + qr) * p.ldo + head * D, grp, acc, inv);
-  if (p.lse != nullptr && grp == 0) p.lse[((size_t)b * p.H + head) * p.Tq + qr] = m * 0.6931471805599453f + __logf(l);
+  const int row0 = r0 + wave * 16, nrows = qlen - row0 < 16 ? qlen - row0 : 16;
+  xm_store_rows<D>(Xs + wave * 16 * LD, acc, inv, r, grp, lane, nrows, p.out + (size_t)(qoff + row0) * p.ldo + head * D, p.ldo,
+                   p.o3 != nullptr ? p.o3 + (size_t)(qoff + row0) * p.ld3 + head * D : nullptr, p.ld3, p.cp3);
+  if (valid && p.lse != nullptr && grp == 0) p.lse[((size_t)b * p.H + head) * p.Tq + qr] = m * 0.6931471805599453f + __logf(l);
 }
 
 // dQ (+ delta = rowsum(dO o O)): the wave's 16 queries in registers (Q and dO as B operands), K and V staged
@@ -806,8 +887,10 @@ template <int D>
 __global__ __launch_bounds__(XM_T, UNIMM_X3M_MIN_WAVES) void x3m_attn_bwd_dq_kernel(AttnF32 p) {
   constexpr bool OWN_Q = true;
   constexpr int LD = D + 4, KC = D == 64 ? 64 : 32;
-  __shared__ __attribute__((aligned(16))) float Ks[KC * LD];
-  __shared__ __attribute__((aligned(16))) float Vs[KC * LD];
+  __shared__ __attribute__((aligned(16))) float KV[2 * KC * LD];   // K chunk | V chunk; at the end the four waves' store tiles
+  float* const Ks = KV;
+  float* const Vs = KV + KC * LD;
+  static_assert(2 * KC >= XM_R, "store tiles: 16 rows per wave must fit the staging buffer");
   __shared__ uint32_t Mq[XM_R * 9];                        // mask words of the 64 queries (rows of 8 + 1 pad)
   drop_resolve(p.drop);
   int blk, head, b;
@@ -899,7 +982,12 @@ __global__ __launch_bounds__(XM_T, UNIMM_X3M_MIN_WAVES) void x3m_attn_bwd_dq_ker
       xm_accum_t<D>(dq, Ks + (nt - 1) * 16 * LD, r, grp, ds);
     }
   }
-  if (valid) xm_store_t<D>(p.dq + (size_t)(qoff + qr) * p.lddq + head * D, grp, dq, 1.0f);
+  __syncthreads();                                         // the staging buffer becomes the store tiles
+  if (!live) return;
+  const int row0 = r0 + wave * 16, nrows = qlen - row0 < 16 ? qlen - row0 : 16;
+  xm_store_rows<D>(KV + wave * 16 * LD, dq, 1.0f, r, grp, lane, nrows,
+                   p.dq3 == nullptr ? p.dq + (size_t)(qoff + row0) * p.lddq + head * D : nullptr, p.lddq,
+                   p.dq3 != nullptr ? p.dq3 + (size_t)(qoff + row0) * p.ld3 + head * D : nullptr, p.ld3, p.cp3);
 }
 
 // dK, dV: the wave's 16 keys in registers (K and V as B operands), Q and dO rows staged with their lse / delta / mask words
@@ -907,8 +995,10 @@ template <int D>
 __global__ __launch_bounds__(XM_T, UNIMM_X3M_MIN_WAVES) void x3m_attn_bwd_dkv_kernel(AttnF32 p) {
   constexpr bool OWN_Q = false;
   constexpr int LD = D + 4, QC = D == 64 ? 64 : 32;
-  __shared__ __attribute__((aligned(16))) float Qs[QC * LD];
-  __shared__ __attribute__((aligned(16))) float Os[QC * LD];
+  __shared__ __attribute__((aligned(16))) float QO[2 * QC * LD];   // Q chunk | dO chunk; at the end the four waves' store tiles
+  float* const Qs = QO;
+  float* const Os = QO + QC * LD;
+  static_assert(2 * QC >= XM_R, "store tiles: 16 rows per wave must fit the staging buffer");
   __shared__ float Ls[QC], Ds[QC];
   __shared__ uint32_t Ms[QC * 2];                          // per staged query: the two mask words this workgroup's 64 keys lie in
   drop_resolve(p.drop);
@@ -982,9 +1072,15 @@ __global__ __launch_bounds__(XM_T, UNIMM_X3M_MIN_WAVES) void x3m_attn_bwd_dkv_ke
       xm_accum_t<D>(dk, Qs + tt * 16 * LD, r, grp, ds);
     }
   }
-  if (!valid) return;
-  xm_store_t<D>(p.dk + (size_t)(koff + key) * p.lddk + head * D, grp, dk, 1.0f);
-  xm_store_t<D>(p.dv + (size_t)(koff + key) * p.lddv + head * D, grp, dv, 1.0f);
+  __syncthreads();                                         // the staging buffer becomes the store tiles
+  if (!live) return;
+  const int row0 = r0 + wave * 16, nrows = klen - row0 < 16 ? klen - row0 : 16;
+  float* tile = QO + wave * 16 * LD;
+  const bool pl = p.dk3 != nullptr;
+  xm_store_rows<D>(tile, dk, 1.0f, r, grp, lane, nrows, pl ? nullptr : p.dk + (size_t)(koff + row0) * p.lddk + head * D, p.lddk,
+                   pl ? p.dk3 + (size_t)(koff + row0) * p.ld3 + head * D : nullptr, p.ld3, p.cp3);
+  xm_store_rows<D>(tile, dv, 1.0f, r, grp, lane, nrows, pl ? nullptr : p.dv + (size_t)(koff + row0) * p.lddv + head * D, p.lddv,
+                   pl ? p.dv3 + (size_t)(koff + row0) * p.ld3 + head * D : nullptr, p.ld3, p.cp3);
 }
 
 int g_x3_attn_impl = 1;       // 1 = matrix-instruction kernels, 0 = the vector kernels (A/B: unimm_x3_attn_set_impl)
@@ -1053,6 +1149,21 @@ extern "C" int unimm_x3_layernorm_bwd_partials(const float* dy, const float* x, 
   return UNIMM_OK;
 }
 
+extern "C" int unimm_x3_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y32, void* y3, float* mean,
+                                      float* rstd, int32_t M, int32_t H, float eps, uint32_t drop_key, uint32_t drop_thr,
+                                      float drop_scale, const uint32_t* drop_salt, void* stream) {
+  if (!x || !gamma || !beta || !y3 || ((mean == nullptr) != (rstd == nullptr))) return UNIMM_E_ARG;
+  if (M <= 0 || H <= 0 || H > MAXC * 512 || (H % 64) != 0) return UNIMM_E_SHAPE;
+  if (((uintptr_t)y3) & 15) return UNIMM_E_ALIGN;
+  int blocks = (M + 3) / 4;
+  blocks = blocks > 2048 ? 2048 : blocks;
+  DropoutArg d{drop_key, drop_thr, drop_scale, drop_salt, 0u};
+  hipLaunchKernelGGL(x3_layernorm_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y32, (bf16_t*)y3,
+                     mean, rstd, M, H, eps, d);
+  UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
+}
+
 extern "C" int unimm_x3_lm_loss_bwd(const float* logits, const int32_t* labels, const int32_t* weights, const float* lse,
                                     const float* g, float inv_denom, void* out3, int32_t n, int32_t V, int32_t ld, int32_t cp,
                                     const int32_t* n_dev, const float* inv_dev, void* stream) {
@@ -1084,10 +1195,15 @@ extern "C" int unimm_x3_rows_add(float* dst, const int32_t* idx, const float* sr
   return UNIMM_OK;
 }
 
-extern "C" int unimm_x3_attn_fwd(const unimm_attn_args* a, void* stream) {
+extern "C" int unimm_x3_attn_fwd(const unimm_attn_args* a, const unimm_x3_attn_planes* pl, void* stream) {
   AttnF32 p;
   const int rc = fill_attn(a, p);
   if (rc != UNIMM_OK) return rc;
+  if (pl != nullptr && pl->out3 != nullptr) {
+    if (g_x3_attn_impl == 0) return UNIMM_E_ARG;                       // split outputs: the matrix kernels only
+    if ((((uintptr_t)pl->out3) & 15) || (pl->ld3 % 8) || (pl->cp3 % 8) || pl->cp3 < a->H * a->D || pl->ld3 < 3 * pl->cp3) return UNIMM_E_ALIGN;
+    p.o3 = (bf16_t*)pl->out3; p.ld3 = pl->ld3; p.cp3 = pl->cp3;
+  }
   hipStream_t s = (hipStream_t)stream;
   if (g_x3_attn_impl != 0) {
     const dim3 grid(xm_grid((a->Tq + XM_R - 1) / XM_R, a->H, a->B));
@@ -1114,8 +1230,10 @@ extern "C" int unimm_x3_attn_set_impl(int32_t impl) {
   return UNIMM_OK;
 }
 
-extern "C" int unimm_x3_attn_bwd(const unimm_attn_bwd_args* a, void* stream) {
-  if (a == nullptr || !a->out || !a->dout || !a->lse || !a->delta || !a->dq || !a->dk || !a->dv) return UNIMM_E_ARG;
+extern "C" int unimm_x3_attn_bwd(const unimm_attn_bwd_args* a, const unimm_x3_attn_planes* pl, void* stream) {
+  const bool planes = pl != nullptr && (pl->dq3 != nullptr || pl->dk3 != nullptr || pl->dv3 != nullptr);
+  if (a == nullptr || !a->out || !a->dout || !a->lse || !a->delta) return UNIMM_E_ARG;
+  if (planes ? (!pl->dq3 || !pl->dk3 || !pl->dv3 || g_x3_attn_impl == 0) : (!a->dq || !a->dk || !a->dv)) return UNIMM_E_ARG;
   unimm_attn_args f{};
   f.q = a->q; f.k = a->k; f.v = a->v; f.out = (void*)a->out; f.lse = (float*)a->lse; f.mask = a->mask;
   f.q_off = a->q_off; f.q_len = a->q_len; f.k_off = a->k_off; f.k_len = a->k_len;
@@ -1126,11 +1244,18 @@ extern "C" int unimm_x3_attn_bwd(const unimm_attn_bwd_args* a, void* stream) {
   AttnF32 p;
   const int rc = fill_attn(&f, p);
   if (rc != UNIMM_OK) return rc;
-  if ((a->lddo % 4) || (a->lddq % 4) || (a->lddk % 4) || (a->lddv % 4)) return UNIMM_E_ALIGN;
-  if (((uintptr_t)a->dout | (uintptr_t)a->dq | (uintptr_t)a->dk | (uintptr_t)a->dv) & 15) return UNIMM_E_ALIGN;
-  p.o = (const float*)a->out; p.out = nullptr; p.dout = (const float*)a->dout; p.delta = a->delta;
-  p.dq = (float*)a->dq; p.dk = (float*)a->dk; p.dv = (float*)a->dv;
-  p.lddo = a->lddo; p.lddq = a->lddq; p.lddk = a->lddk; p.lddv = a->lddv;
+  if ((a->lddo % 4) || (((uintptr_t)a->dout) & 15)) return UNIMM_E_ALIGN;
+  p.o = (const float*)a->out; p.out = nullptr; p.dout = (const float*)a->dout; p.delta = a->delta; p.lddo = a->lddo;
+  if (planes) {
+    if ((((uintptr_t)pl->dq3 | (uintptr_t)pl->dk3 | (uintptr_t)pl->dv3) & 15) || (pl->ld3 % 8) || (pl->cp3 % 8) || pl->ld3 < 3 * pl->cp3)
+      return UNIMM_E_ALIGN;
+    p.dq3 = (bf16_t*)pl->dq3; p.dk3 = (bf16_t*)pl->dk3; p.dv3 = (bf16_t*)pl->dv3; p.ld3 = pl->ld3; p.cp3 = pl->cp3;
+  } else {
+    if ((a->lddq % 4) || (a->lddk % 4) || (a->lddv % 4)) return UNIMM_E_ALIGN;
+    if (((uintptr_t)a->dq | (uintptr_t)a->dk | (uintptr_t)a->dv) & 15) return UNIMM_E_ALIGN;
+    p.dq = (float*)a->dq; p.dk = (float*)a->dk; p.dv = (float*)a->dv;
+    p.lddq = a->lddq; p.lddk = a->lddk; p.lddv = a->lddv;
+  }
   hipStream_t s = (hipStream_t)stream;
   if (g_x3_attn_impl != 0) {
     const dim3 gq(xm_grid((a->Tq + XM_R - 1) / XM_R, a->H, a->B)), gk(xm_grid((a->Tk + XM_R - 1) / XM_R, a->H, a->B));

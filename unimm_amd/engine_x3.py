@@ -44,6 +44,8 @@ class EngineX3(Engine):
         self.dual_stream = True           # the base engine's two-stream schedule (image side beside the text side)
         self.lazy_ln = False
         self.splitk = False
+        self.attn_planes = True      # attention kernels write the next GEMM's split operand themselves (matrix kernels; False for
+                                     # A/B runs of the vector kernels: fp32 result + a split pass)
 
     # ------------------------------------------------------------------------------------------
     # weights: split copies instead of the bf16 copies
@@ -100,9 +102,6 @@ class EngineX3(Engine):
     def _split(self, a, rows=None, cols=None):
         return self._op3(a, rows=rows, cols=cols)[0]
 
-    def _add32(self, a, b):
-        return self._op3(a, op=L.X3_ADD, b=b, want3=False, want32=True)[1]
-
     def _lin3(self, x3, lin, epi=L.EPI_BIAS, aux=None, drop=None, ldo=None, M=None, bias=True):
         M = x3.shape[0] if M is None else M
         out = torch.empty((M, ldo or lin.N), dtype=F32, device=x3.device)
@@ -116,15 +115,19 @@ class EngineX3(Engine):
         self._wgrad(dy3[:, Np:Np + N], xh, gw, M, N, K, dbias=dbias, m_dev=m_dev)
         self._wgrad(dy3[:, :N], xl, gw, M, N, K, dbias=None, m_dev=m_dev)
 
-    def _lin3_bwd(self, dy3, x3, lin, need_dx=True, bias_grad=True, M=None, m_dev=None):
-        """dW += dy^T x ; db += colsum(dy) ; returns dx = dy @ W (fp32) or None."""
+    def _lin3_bwd(self, dy3, x3, lin, need_dx=True, bias_grad=True, M=None, m_dev=None, add=None):
+        """dW += dy^T x ; db += colsum(dy) ; returns dx = dy @ W [+ add] (fp32) or None.  `add` (fp32 [M, K]): the other
+        gradient that meets dx at a residual fork, added in the GEMM's residual epilogue instead of a pass of its own."""
         M = dy3.shape[0] if M is None else M
         self._wgrad3(dy3, x3, lin.gw, M, lin.N, lin.K, lin.Np, lin.Kp,
                      dbias=lin.gb if (bias_grad and lin.gb is not None) else None, m_dev=m_dev)
         if not need_dx:
             return None
         dx = torch.empty((M, lin.K), dtype=F32, device=dy3.device)
-        L.gemm_nt(dy3, lin.wt3, dx, bias=None, M=M, N=lin.K, K=3 * lin.Np)
+        if add is None:
+            L.gemm_nt(dy3, lin.wt3, dx, bias=None, M=M, N=lin.K, K=3 * lin.Np)
+        else:
+            L.gemm_nt(dy3, lin.wt3, dx, bias=None, epilogue=L.EPI_BIAS_DROP_RESID, aux=add, M=M, N=lin.K, K=3 * lin.Np)
         return dx
 
     def _ln3(self, x, key, save, drop=L.NO_DROP, want3=True):
@@ -134,8 +137,12 @@ class EngineX3(Engine):
         y32 = torch.empty((M, H), dtype=F32, device=x.device)
         mean = torch.empty(M, dtype=F32, device=x.device) if save else None
         rstd = torch.empty(M, dtype=F32, device=x.device) if save else None
-        L.layernorm_fwd(x, gmm, bta, y32, None, mean, rstd, M, H, drop=drop)
-        return y32, (self._split(y32) if want3 else None), mean, rstd
+        if not want3:
+            L.layernorm_fwd(x, gmm, bta, y32, None, mean, rstd, M, H, drop=drop)
+            return y32, None, mean, rstd
+        y3 = torch.empty((M, 3 * H), dtype=BF16, device=x.device)       # the next GEMM's operand, written by the same kernel
+        L.x3_layernorm_fwd(x, gmm, bta, y32, y3, mean, rstd, M, H, drop=drop)
+        return y32, y3, mean, rstd
 
     def _ln3_bwd(self, dy, x, mean, rstd, key, dbias=None, drop=L.NO_DROP, out_drop=L.NO_DROP, m_dev=None, want3=True, want32=True,
                  dbias2=None):
@@ -154,17 +161,38 @@ class EngineX3(Engine):
         return dx32, dxd3
 
     def _attn(self, q, k, v, mask, B, H, Tq, Tk, D, drop, save, qvar=None, kvar=None, tag=None):
+        """-> (context fp32, context as a split operand, log-sum-exp)"""
         out = torch.empty((q.shape[0], H * D), dtype=F32, device=q.device)
         lse = torch.empty((B, H, Tq), dtype=F32, device=q.device) if save else None
         words, mq, mb = mask
-        L.x3_attn_fwd(q, k, v, out, lse, words, B, H, Tq, Tk, D, 1.0 / math.sqrt(D), mq, mb, drop, qvar=qvar, kvar=kvar)
+        out3 = torch.empty((q.shape[0], 3 * _rup(H * D, 64)), dtype=BF16, device=q.device) if self.attn_planes else None
+        L.x3_attn_fwd(q, k, v, out, lse, words, B, H, Tq, Tk, D, 1.0 / math.sqrt(D), mq, mb, drop, qvar=qvar, kvar=kvar, out3=out3)
+        if out3 is None:
+            out3 = self._split(out)
         if self.attn_sink is not None:          # diagnostic output (output_all_attention_masks): bf16-operand probabilities
             if qvar is not None or kvar is not None:
                 raise RuntimeError("attention probabilities are collected on the padded schedule only")
             probs = torch.empty((B, H, Tq, Tk), dtype=F32, device=q.device)
             L.attn_probs(q.to(BF16), k.to(BF16), probs, words, B, H, Tq, Tk, D, 1.0 / math.sqrt(D), mq, mb, drop)
             self.attn_sink[tag] = probs
-        return out, lse
+        return out, out3, lse
+
+    def _qkv_grad(self, qkv):
+        """Gradient buffer of a fused projection output qkv (fp32 [rows, N], N % 64 == 0): with the matrix attention kernels a
+        split operand [rows, 3 N] whose planes the attention backward fills directly, otherwise fp32 (split afterwards)."""
+        if self.attn_planes:
+            return torch.empty((qkv.shape[0], 3 * qkv.shape[1]), dtype=BF16, device=qkv.device)
+        return torch.empty_like(qkv)
+
+    def _qkv_grad3(self, g):
+        return g if self.attn_planes else self._split(g)
+
+    def _attn_bwd(self, q, k, v, ctx, dctx, lse, mask, dq, dk, dv, N, B, H, Tq, Tk, D, drop, qvar=None, kvar=None):
+        """dq / dk / dv: column slices [:, c0:c1] of `_qkv_grad` buffers (N = their projection width = the plane stride)."""
+        delta = torch.empty_like(lse)
+        words, mq, mb = mask
+        L.x3_attn_bwd(q, k, v, ctx, dctx, lse, delta, dq, dk, dv, words, B, H, Tq, Tk, D, 1.0 / math.sqrt(D), mq, mb, drop,
+                      qvar=qvar, kvar=kvar, planes=(N, dq.stride(0)) if self.attn_planes else None)
 
     # ------------------------------------------------------------------------------------------
     # blocks
@@ -180,8 +208,7 @@ class EngineX3(Engine):
         qkv = self._lin3(x3, qkv_l)
         q, k, v = qkv[:, :Hd], qkv[:, Hd:2 * Hd], qkv[:, 2 * Hd:]
         d_attn = self._drop(pname + "attn", p_attn, train)
-        ctx, lse = self._attn(q, k, v, mask, B, heads, T, T, D, d_attn, save, qvar=var, kvar=var, tag=key)
-        ctx3 = self._split(ctx)
+        ctx, ctx3, lse = self._attn(q, k, v, mask, B, heads, T, T, D, d_attn, save, qvar=var, kvar=var, tag=key)
         d_so = self._drop(pname + "so", p_hid, train)
         pre1 = self._lin3(ctx3, so, L.EPI_BIAS_DROP_RESID, aux=x32, drop=d_so)
         x1_32, x1_3, m1, r1 = self._ln3(pre1, key + ".ln1", save)
@@ -196,15 +223,13 @@ class EngineX3(Engine):
                 dpre2, dpre2d3 = self._ln3_bwd(dx2, pre2, m2, r2, key + ".ln2", dbias=ff2.gb, drop=d_out, m_dev=md)
                 du_t = self._lin3_bwd(dpre2d3, h3, ff2, bias_grad=False, m_dev=md)
                 du3 = self._op3(du_t, op=L.X3_MUL_DGELU, b=u)[0]
-                dx1 = self._add32(self._lin3_bwd(du3, x1_3, ff1, m_dev=md), dpre2)
+                dx1 = self._lin3_bwd(du3, x1_3, ff1, m_dev=md, add=dpre2)
                 dpre1, dpre1d3 = self._ln3_bwd(dx1, pre1, m1, r1, key + ".ln1", dbias=so.gb, drop=d_so, m_dev=md)
                 dctx = self._lin3_bwd(dpre1d3, ctx3, so, bias_grad=False, m_dev=md)
-                dqkv = torch.empty_like(qkv)
-                delta = torch.empty_like(lse)
-                words, mq, mb = mask
-                L.x3_attn_bwd(q, k, v, ctx, dctx, lse, delta, dqkv[:, :Hd], dqkv[:, Hd:2 * Hd], dqkv[:, 2 * Hd:], words,
-                              B, heads, T, T, D, 1.0 / math.sqrt(D), mq, mb, d_attn, qvar=var, kvar=var)
-                return self._add32(self._lin3_bwd(self._split(dqkv), x3, qkv_l, m_dev=md), dpre1)
+                dqkv = self._qkv_grad(qkv)
+                self._attn_bwd(q, k, v, ctx, dctx, lse, mask, dqkv[:, :Hd], dqkv[:, Hd:2 * Hd], dqkv[:, 2 * Hd:3 * Hd], 3 * Hd,
+                               B, heads, T, T, D, d_attn, qvar=var, kvar=var)
+                return self._lin3_bwd(self._qkv_grad3(dqkv), x3, qkv_l, m_dev=md, add=dpre1)
             tape.append((key, bwd))
         return x2_32, x2_3
 
@@ -216,7 +241,6 @@ class EngineX3(Engine):
         pn = f"bert.encoder.c_layer.{i}."
         Hb, nh = cfg.bi_hidden_size, cfg.bi_num_attention_heads
         D = Hb // nh
-        sc = 1.0 / math.sqrt(D)
         lq1, lq2, d1, d2 = (self.lin[key + s] for s in (".qkv1", ".qkv2", ".d1", ".d2"))
         vff1, vff2, tff1, tff2 = (self.lin[key + s] for s in (".vff1", ".vff2", ".tff1", ".tff2"))
         # The two halves run on their own streams (`_img()` = image side, otherwise the text side); the only exchanges are the
@@ -236,8 +260,7 @@ class EngineX3(Engine):
         dto = self._drop(pn + "tout", cfg.hidden_dropout_prob, train)
         # image half: regions attend text (:701-721), BertBiOutput (:744-754, call order :775), image FFN
         with self._img():
-            ctx_v, lse_v = self._attn(q1, k2, v2, comask, B, nh, R, T, D, da2, save, kvar=var, tag=key + "/2")
-            ctx_v3 = self._split(ctx_v)
+            ctx_v, ctx_v3, lse_v = self._attn(q1, k2, v2, comask, B, nh, R, T, D, da2, save, kvar=var, tag=key + "/2")
             prev = self._lin3(ctx_v3, d1, L.EPI_BIAS_DROP_RESID, aux=xv32, drop=db1)
             av32, av3, mv1, rv1 = self._ln3(prev, key + ".lnb1", save)
             uv = self._lin3(av3, vff1)
@@ -245,8 +268,7 @@ class EngineX3(Engine):
             prev2 = self._lin3(hv3, vff2, L.EPI_BIAS_DROP_RESID, aux=av32, drop=dvo)
             ov32, ov3, mv2, rv2 = self._ln3(prev2, key + ".lnv", save)
         # text half: text attends regions (:681-698)
-        ctx_t, lse_t = self._attn(q2, k1, v1, vmask, B, nh, T, R, D, da1, save, qvar=var, tag=key + "/1")
-        ctx_t3 = self._split(ctx_t)
+        ctx_t, ctx_t3, lse_t = self._attn(q2, k1, v1, vmask, B, nh, T, R, D, da1, save, qvar=var, tag=key + "/1")
         pret = self._lin3(ctx_t3, d2, L.EPI_BIAS_DROP_RESID, aux=xt32, drop=db2)
         at32, at3, mt1, rt1 = self._ln3(pret, key + ".lnb2", save)
         ut = self._lin3(at3, tff1)
@@ -259,35 +281,31 @@ class EngineX3(Engine):
                 # gradient buffers of the two projections: each is written by BOTH attention backward kernels (every slice exactly
                 # once), i.e. from both streams -> allocate first and let each stream see the other's
                 with self._img():
-                    dqkv1 = torch.empty_like(qkv1)
-                dqkv2 = torch.empty_like(qkv2)
+                    dqkv1 = self._qkv_grad(qkv1)
+                dqkv2 = self._qkv_grad(qkv2)
                 self._to_txt(dqkv1)
                 self._to_img(dqkv2)
                 with self._img():                                   # image half
                     dp, dpd3 = self._ln3_bwd(dov, prev2, mv2, rv2, key + ".lnv", dbias=vff2.gb, drop=dvo)
                     duv3 = self._op3(self._lin3_bwd(dpd3, hv3, vff2, bias_grad=False), op=L.X3_MUL_DGELU, b=uv)[0]
-                    dav = self._add32(self._lin3_bwd(duv3, av3, vff1), dp)
+                    dav = self._lin3_bwd(duv3, av3, vff1, add=dp)
                     dprev, dprevd3 = self._ln3_bwd(dav, prev, mv1, rv1, key + ".lnb1", dbias=d1.gb, drop=db1)
                     dctx_v = self._lin3_bwd(dprevd3, ctx_v3, d1, bias_grad=False)
-                    delta_v = torch.empty_like(lse_v)
-                    w, mq, mb = comask
-                    L.x3_attn_bwd(q1, k2, v2, ctx_v, dctx_v, lse_v, delta_v, dqkv1[:, :Hb], dqkv2[:, Hb:2 * Hb], dqkv2[:, 2 * Hb:],
-                                  w, B, nh, R, T, D, sc, mq, mb, da2, kvar=var)
+                    self._attn_bwd(q1, k2, v2, ctx_v, dctx_v, lse_v, comask, dqkv1[:, :Hb], dqkv2[:, Hb:2 * Hb], dqkv2[:, 2 * Hb:3 * Hb],
+                                   3 * Hb, B, nh, R, T, D, da2, kvar=var)
                 # text half
                 dp, dpd3 = self._ln3_bwd(dot, pret2, mt2, rt2, key + ".lnt", dbias=tff2.gb, drop=dto, m_dev=md)
                 dut3 = self._op3(self._lin3_bwd(dpd3, ht3, tff2, bias_grad=False, m_dev=md), op=L.X3_MUL_DGELU, b=ut)[0]
-                dat = self._add32(self._lin3_bwd(dut3, at3, tff1, m_dev=md), dp)
+                dat = self._lin3_bwd(dut3, at3, tff1, m_dev=md, add=dp)
                 dpret, dpretd3 = self._ln3_bwd(dat, pret, mt1, rt1, key + ".lnb2", dbias=d2.gb, drop=db2, m_dev=md)
                 dctx_t = self._lin3_bwd(dpretd3, ctx_t3, d2, bias_grad=False, m_dev=md)
-                delta_t = torch.empty_like(lse_t)
-                w, mq, mb = vmask
-                L.x3_attn_bwd(q2, k1, v1, ctx_t, dctx_t, lse_t, delta_t, dqkv2[:, :Hb], dqkv1[:, Hb:2 * Hb], dqkv1[:, 2 * Hb:],
-                              w, B, nh, T, R, D, sc, mq, mb, da1, qvar=var)
+                self._attn_bwd(q2, k1, v1, ctx_t, dctx_t, lse_t, vmask, dqkv2[:, :Hb], dqkv1[:, Hb:2 * Hb], dqkv1[:, 2 * Hb:3 * Hb],
+                               3 * Hb, B, nh, T, R, D, da1, qvar=var)
                 self._to_img()                                      # dK1 / dV1 written by the text side
                 self._to_txt()                                      # dK2 / dV2 written by the image side
                 with self._img():
-                    dxv = self._add32(self._lin3_bwd(self._split(dqkv1), xv3, lq1), dprev)
-                dxt = self._add32(self._lin3_bwd(self._split(dqkv2), xt3, lq2, m_dev=md), dpret)
+                    dxv = self._lin3_bwd(self._qkv_grad3(dqkv1), xv3, lq1, add=dprev)
+                dxt = self._lin3_bwd(self._qkv_grad3(dqkv2), xt3, lq2, m_dev=md, add=dpret)
                 return dxv, dxt
             tape.append((key, bwd))
         return ov32, ov3, ot32, ot3

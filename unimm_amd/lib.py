@@ -13,7 +13,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libunimm_hip.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROP_RESID, EPI_BIAS_RELU, EPI_DGELU, EPI_ADD, EPI_MUL, EPI_BIAS_GELU_DG = range(8)
 
@@ -71,13 +71,14 @@ def lib():
     L.unimm_attn_fwd.argtypes = [VP, VP]
     L.unimm_attn_bwd.argtypes = [VP, VP]
     L.unimm_x3_split.argtypes = [VP, VP]
-    L.unimm_x3_attn_fwd.argtypes = [VP, VP]
-    L.unimm_x3_attn_bwd.argtypes = [VP, VP]
+    L.unimm_x3_attn_fwd.argtypes = [VP, VP, VP]
+    L.unimm_x3_attn_bwd.argtypes = [VP, VP, VP]
     L.unimm_attn_probs.argtypes = [VP, VP, VP]
     L.unimm_gemm_tn_grouped.argtypes = [VP, I32, VP]
     L.unimm_gemm_tn_grouped_ws.argtypes = [VP, I32, I32, VP, I64, VP]
     L.unimm_colpartials_finish_grouped.argtypes = [VP, I32, VP]
     L.unimm_layernorm_fwd.argtypes = [VP] * 7 + [I32, I32, F32, U32, U32, F32, VP, VP]
+    L.unimm_x3_layernorm_fwd.argtypes = [VP] * 7 + [I32, I32, F32, U32, U32, F32, VP, VP]
     L.unimm_layernorm_bwd_partials.argtypes = [VP] * 8 + [I32, I32, U32, U32, F32, U32, U32, F32, VP, VP, VP, VP]
     L.unimm_layernorm_bwd.argtypes = [VP] * 11 + [I32, I32, U32, U32, F32, U32, U32, F32, VP, VP]
     _lib = L
@@ -94,7 +95,7 @@ SYMBOLS = ["unimm_version", "unimm_arch", "unimm_gemm_nt", "unimm_gemm_tn", "uni
            "unimm_colpartials_finish_grouped", "unimm_gemm_tn_grouped_ws", "unimm_linear_f32", "unimm_rows_add_f32", "unimm_transpose_bf16", "unimm_sum_slabs_bf16", "unimm_attn_probs",
            # the fp32-accuracy mode (csrc/x3ops.hip)
            "unimm_x3_split", "unimm_x3_split_wt", "unimm_x3_layernorm_bwd_partials", "unimm_embed_bwd_f32", "unimm_x3_lm_loss_bwd",
-           "unimm_x3_kl_loss_bwd", "unimm_x3_rows_add", "unimm_x3_attn_fwd", "unimm_x3_attn_bwd", "unimm_x3_attn_set_impl", "unimm_prof_tag", "unimm_prof_tagged",
+           "unimm_x3_kl_loss_bwd", "unimm_x3_rows_add", "unimm_x3_attn_fwd", "unimm_x3_attn_bwd", "unimm_x3_attn_set_impl", "unimm_x3_layernorm_fwd", "unimm_prof_tag", "unimm_prof_tagged",
            "unimm_sum_dropout", "unimm_sum_dropout_bwd", "unimm_mse_loss_fwd", "unimm_mse_loss_bwd"]
 
 
@@ -856,9 +857,19 @@ def x3_rows_add(dst, idx, src, n, H):
                                    _stream()), "unimm_x3_rows_add")
 
 
-def x3_attn_fwd(q, k, v, out, lse, mask, B, H, Tq, Tk, D, scale, mask_q_stride, mask_b_stride, drop=NO_DROP, qvar=None, kvar=None):
-    """unimm_attn_fwd on fp32 q / k / v / out (2-D views, row stride = stride(0))."""
-    _dev(q, k, v, out, lse, mask)
+class X3AttnPlanes(C.Structure):
+    _fields_ = [("out3", C.c_void_p), ("dq3", C.c_void_p), ("dk3", C.c_void_p), ("dv3", C.c_void_p), ("ld3", C.c_int32), ("cp3", C.c_int32)]
+
+
+def x3_attn_fwd(q, k, v, out, lse, mask, B, H, Tq, Tk, D, scale, mask_q_stride, mask_b_stride, drop=NO_DROP, qvar=None, kvar=None,
+                out3=None):
+    """unimm_attn_fwd on fp32 q / k / v / out (2-D views, row stride = stride(0)).  out3 (bf16 [rows, 3 cp]): the context also
+    as an x-type split operand."""
+    _dev(q, k, v, out, lse, mask, out3)
+    pl = None
+    if out3 is not None:
+        pl = X3AttnPlanes()
+        pl.out3, pl.ld3, pl.cp3 = out3.data_ptr(), out3.stride(0), out3.shape[1] // 3
     a = AttnArgs()
     a.q, a.k, a.v, a.out, a.lse, a.mask = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _P(lse), mask.data_ptr()
     a.q_off, a.q_len = (qvar[0].data_ptr(), qvar[1].data_ptr()) if qvar is not None else (None, None)
@@ -868,27 +879,41 @@ def x3_attn_fwd(q, k, v, out, lse, mask, B, H, Tq, Tk, D, scale, mask_q_stride, 
     a.mask_q_stride, a.mask_b_stride, a.scale = mask_q_stride, mask_b_stride, scale
     a.drop_key, a.drop_thr, a.drop_scale = drop[:3]
     a.drop_salt = _salt(drop)
-    _check(lib().unimm_x3_attn_fwd(C.byref(a), _stream()), "unimm_x3_attn_fwd")
+    _check(lib().unimm_x3_attn_fwd(C.byref(a), C.byref(pl) if pl is not None else None, _stream()), "unimm_x3_attn_fwd")
 
 
 def x3_attn_bwd(q, k, v, out, dout, lse, delta, dq, dk, dv, mask, B, H, Tq, Tk, D, scale, mask_q_stride, mask_b_stride,
-                drop=NO_DROP, qvar=None, kvar=None):
+                drop=NO_DROP, qvar=None, kvar=None, planes=None):
+    """planes = (cp3, ld3): dq / dk / dv are bf16 views of plane 0 of x-type split buffers (plane stride cp3, row stride ld3) and
+    receive the gradients as split operands instead of fp32."""
     _dev(q, k, v, out, dout, lse, delta, dq, dk, dv, mask)
     a = AttnBwdArgs()
+    pl = None
+    if planes is not None:
+        pl = X3AttnPlanes()
+        pl.dq3, pl.dk3, pl.dv3, pl.cp3, pl.ld3 = dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), planes[0], planes[1]
     a.q_off, a.q_len = (qvar[0].data_ptr(), qvar[1].data_ptr()) if qvar is not None else (None, None)
     a.k_off, a.k_len = (kvar[0].data_ptr(), kvar[1].data_ptr()) if kvar is not None else (None, None)
     a.q, a.k, a.v, a.out, a.dout = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr()
-    a.lse, a.delta, a.dq, a.dk, a.dv, a.mask = (lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
-                                                mask.data_ptr())
+    a.lse, a.delta, a.mask = lse.data_ptr(), delta.data_ptr(), mask.data_ptr()
+    if pl is None:
+        a.dq, a.dk, a.dv = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+        a.lddq, a.lddk, a.lddv = dq.stride(0), dk.stride(0), dv.stride(0)
     a.B, a.H, a.Tq, a.Tk, a.D = B, H, Tq, Tk, D
     a.ldq, a.ldk, a.ldv, a.ldo, a.lddo = q.stride(0), k.stride(0), v.stride(0), out.stride(0), dout.stride(0)
-    a.lddq, a.lddk, a.lddv = dq.stride(0), dk.stride(0), dv.stride(0)
     a.mask_q_stride, a.mask_b_stride, a.scale = mask_q_stride, mask_b_stride, scale
     a.drop_key, a.drop_thr, a.drop_scale = drop[:3]
     a.drop_salt = _salt(drop)
-    _check(lib().unimm_x3_attn_bwd(C.byref(a), _stream()), "unimm_x3_attn_bwd")
+    _check(lib().unimm_x3_attn_bwd(C.byref(a), C.byref(pl) if pl is not None else None, _stream()), "unimm_x3_attn_bwd")
 
 
 def x3_attn_set_impl(impl):
     """1 = fp32 matrix-instruction attention kernels (default), 0 = the vector-ALU kernels (A/B runs)."""
     _check(lib().unimm_x3_attn_set_impl(int(impl)), "unimm_x3_attn_set_impl")
+
+
+def x3_layernorm_fwd(x, gamma, beta, y32, y3, mean, rstd, M, H, eps=1e-12, drop=NO_DROP):
+    """LayerNorm forward writing fp32 rows (or None) and the x-type split operand y3 [M, 3 H]."""
+    _dev(x, gamma, beta, y32, y3, mean, rstd)
+    _check(lib().unimm_x3_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _P(y32), y3.data_ptr(), _P(mean), _P(rstd),
+                                        M, H, eps, drop[0], drop[1], drop[2], _salt(drop), _stream()), "unimm_x3_layernorm_fwd")
