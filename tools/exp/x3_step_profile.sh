@@ -6,9 +6,11 @@ python - <<PY
 import csv
 rows=list(csv.DictReader(open("$out/run_kernel_stats.csv")))
 tot=sum(float(r["TotalDurationNs"]) for r in rows)
-print("summed kernel time per step: %.2f ms (10 steps profiled + extra)" % (tot/1e6/10))
+steps=max([int(r["Calls"]) for r in rows if "neural_ndcg" in r["Name"]] or [1])      # one launch per step
+print("%d steps in the trace; summed kernel time (both queues) %.2f ms per step" % (steps, tot/1e6/steps))
+print("%-96s %9s %9s %9s" % ("kernel", "launches", "ms/step", "us avg"))
 for r in rows[:26]:
-    print("%-96s %5s %8.2f ms %8.1f us" % (r["Name"][:96], r["Calls"], float(r["TotalDurationNs"])/1e6, float(r["AverageNs"])/1e3))
+    print("%-96s %9.1f %9.2f %9.1f" % (r["Name"][:96], int(r["Calls"])/steps, float(r["TotalDurationNs"])/1e6/steps, float(r["AverageNs"])/1e3))
 PY
 tail -1 $out/bench.log | cut -c1-200
 python - <<PY

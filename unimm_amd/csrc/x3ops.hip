@@ -13,8 +13,9 @@
 // buffers ((hi, hi), (lo, hi), (hi, lo)), accumulating into the same fp32 gradient.  Everything between two GEMMs is
 // fp32: the GEMMs write fp32, and the kernels of this file turn fp32 results into the next split operand (with the
 // elementwise op that the bf16 path fuses into its epilogues), run LayerNorm / embedding / loss backward on fp32
-// gradients, and compute the attention cores in fp32 on the vector ALUs (K / V rows broadcast out of LDS; ~1.3 % of
-// the model's FLOPs).  Same dropout counters, mask words, row maps and device-side row counts as the bf16 kernels.
+// gradients, and compute the attention cores in exact fp32 on v_mfma_f32_16x16x4_f32 (~1.3 % of the model's FLOPs; the
+// vector-ALU kernels of the first version stay behind unimm_x3_attn_set_impl(0)).  Same dropout counters, mask words, row
+// maps and device-side row counts as the bf16 kernels.
 #include "common.h"
 #include "rows.h"
 
@@ -353,7 +354,8 @@ __global__ void x3_rows_add_kernel(float* __restrict__ dst, const int32_t* __res
 }
 
 // ------------------------------------------------------------------------------------------------
-// Attention cores in fp32 (models/vilbert_dialog.py:390-410, :519-539, :681-721 and their autograd).
+// Attention cores in fp32 (models/vilbert_dialog.py:390-410, :519-539, :681-721 and their autograd), VECTOR-ALU version
+// (the first one; kept for A/B runs, the product path is the matrix-instruction version below).
 // One lane owns 64 of a row's D dimensions (D = 64: a lane per row; D = 128: two neighbouring lanes per row whose
 // partial dot products meet in one cross-lane add); the other side's rows are staged in LDS in chunks of 32 and read
 // as broadcasts.  Online softmax over the keys in the forward; the backward recomputes P from the saved log-sum-exp,
