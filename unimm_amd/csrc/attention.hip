@@ -108,6 +108,28 @@ __device__ __forceinline__ int key_of_reg(int reg, int h) { return (reg & 3) + 8
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
+// Row store of a transposed 32x32 accumulator set (lane = row, registers = D values): the MFMA layout leaves a lane 4
+// consecutive values of every 8 -- its partner lane ^ 32 (same row) holds the other 4 -- so the direct form is one 8-byte piece
+// per lane and group of 8: 2 D / 8 store instructions per row tensor, and the kernels' result stores are store-ISSUE bound
+// (with them compiled out the text backward drops 275 -> 235 us, the 37-region sides 226 -> 186 / 245 -> 185: twice what the
+// bytes need).  Partner lanes trade pieces with v_permlane32_swap: a lane then owns all 8 values of every second group and
+// writes them as ONE 16-byte store -- half the instructions.  Executed by all lanes (the swap), stored where `ok`.
+template <int D>
+__device__ __forceinline__ void store_acc_row(bf16_t* __restrict__ g, const f32x16 (&a)[D / 32], float s, int h, bool ok) {
+#pragma unroll
+  for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+    for (int qp = 0; qp < 2; ++qp) {
+      const uint32_t a0 = pack2bf(a[dt][8 * qp] * s, a[dt][8 * qp + 1] * s), a1 = pack2bf(a[dt][8 * qp + 2] * s, a[dt][8 * qp + 3] * s);
+      const uint32_t b0 = pack2bf(a[dt][8 * qp + 4] * s, a[dt][8 * qp + 5] * s), b1 = pack2bf(a[dt][8 * qp + 6] * s, a[dt][8 * qp + 7] * s);
+      // swap(x, y): x's lanes 32..63 <-> y's lanes 0..31.  h = 0 lanes end with (own group 2 qp | partner's group 2 qp),
+      // h = 1 lanes with (partner's group 2 qp + 1 | own group 2 qp + 1): 8 consecutive values either way
+      const auto w0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+      const auto w1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+      if (ok) *reinterpret_cast<u32x4*>(g + 32 * dt + 16 * qp + 8 * h) = u32x4{w0[0], w1[0], w0[1], w1[1]};
+    }
+}
+
 template <int D, int NKT>
 __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnParams p) {
   drop_resolve(p.drop);
@@ -263,16 +285,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnParams p) {
     }
   }
 
+  store_acc_row<D>(p.o + (qbase + (qvalid ? qrow : 0)) * p.ldo + head * D, o, inv, h, qvalid);
   if (qvalid) {
-    bf16_t* og = p.o + (qbase + qrow) * p.ldo + head * D;
-#pragma unroll
-    for (int dt = 0; dt < D / 32; ++dt)
-#pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        const int d = 32 * dt + 8 * qd + 4 * h;
-        *reinterpret_cast<u32x2*>(og + d) = u32x2{pack2bf(o[dt][4 * qd] * inv, o[dt][4 * qd + 1] * inv),
-                                                  pack2bf(o[dt][4 * qd + 2] * inv, o[dt][4 * qd + 3] * inv)};
-      }
     if (p.lse != nullptr && h == 0) p.lse[((size_t)b * p.H + head) * p.Tq + qrow] = (mx + __log2f(sum)) * LN2;
   }
   }   // query tiles of this wave
@@ -423,15 +437,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) dq[dt][e] *= p.scale;
 
-  if (qvalid) {
-    bf16_t* dqg = p.dq + grow * p.lddq + head * D;
-#pragma unroll
-    for (int dt = 0; dt < D / 32; ++dt)
-#pragma unroll
-      for (int qd = 0; qd < 4; ++qd)
-        *reinterpret_cast<u32x2*>(dqg + 32 * dt + 8 * qd + 4 * h) =
-            u32x2{pack2bf(dq[dt][4 * qd], dq[dt][4 * qd + 1]), pack2bf(dq[dt][4 * qd + 2], dq[dt][4 * qd + 3])};
-  }
+  store_acc_row<D>(p.dq + (qvalid ? grow : 0) * p.lddq + head * D, dq, 1.0f, h, qvalid);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -594,20 +600,8 @@ __global__ __launch_bounds__(MAXT, MAXT == 256 ? 1 : 2) void attn_bwd_dkv_kernel
   for (int dt = 0; dt < D / 32; ++dt)
 #pragma unroll
     for (int e = 0; e < 16; ++e) dk[dt][e] *= p.scale;
-  if (kvalid) {
-    bf16_t* dkg = p.dk + grow * p.lddk + head * D;
-    bf16_t* dvg = p.dv + grow * p.lddv + head * D;
-#pragma unroll
-    for (int dt = 0; dt < D / 32; ++dt)
-#pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        const int d = 32 * dt + 8 * qd + 4 * h;
-        *reinterpret_cast<u32x2*>(dkg + d) =
-            u32x2{pack2bf(dk[dt][4 * qd], dk[dt][4 * qd + 1]), pack2bf(dk[dt][4 * qd + 2], dk[dt][4 * qd + 3])};
-        *reinterpret_cast<u32x2*>(dvg + d) =
-            u32x2{pack2bf(dv[dt][4 * qd], dv[dt][4 * qd + 1]), pack2bf(dv[dt][4 * qd + 2], dv[dt][4 * qd + 3])};
-      }
-  }
+  store_acc_row<D>(p.dk + (kvalid ? grow : 0) * p.lddk + head * D, dk, 1.0f, h, kvalid);
+  store_acc_row<D>(p.dv + (kvalid ? grow : 0) * p.lddv + head * D, dv, 1.0f, h, kvalid);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -851,19 +845,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(AttnBwdParams p)
   }
   }
 
-  if (wave_on && kvalid) {
-    bf16_t* dkg = p.dk + grow * p.lddk + head * D;
-    bf16_t* dvg = p.dv + grow * p.lddv + head * D;
-#pragma unroll
-    for (int dt = 0; dt < D / 32; ++dt)
-#pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        const int d = 32 * dt + 8 * qd + 4 * h;
-        *reinterpret_cast<u32x2*>(dkg + d) =
-            u32x2{pack2bf(dk[dt][4 * qd] * p.scale, dk[dt][4 * qd + 1] * p.scale), pack2bf(dk[dt][4 * qd + 2] * p.scale, dk[dt][4 * qd + 3] * p.scale)};
-        *reinterpret_cast<u32x2*>(dvg + d) =
-            u32x2{pack2bf(dv[dt][4 * qd], dv[dt][4 * qd + 1]), pack2bf(dv[dt][4 * qd + 2], dv[dt][4 * qd + 3])};
-      }
+  if (wave_on) {                                                // (wave-uniform: the lane swap inside needs every lane)
+    const bool ok = kvalid;
+    store_acc_row<D>(p.dk + (ok ? grow : 0) * p.lddk + head * D, dk, p.scale, h, ok);
+    store_acc_row<D>(p.dv + (ok ? grow : 0) * p.lddv + head * D, dv, 1.0f, h, ok);
   }
   __syncthreads();                                              // every wave's dQ partials are in the accumulator
   for (int i = tid; i < qpad_b * 8; i += blockDim.x) {          // 8 lanes = one 128-byte dQ row
