@@ -7,8 +7,9 @@ import torch
 from unimm_amd import VisualDialogEncoder, synth
 
 dev = torch.device("cuda", 0)
+COMPUTE = sys.argv[2] if len(sys.argv) > 2 else "bf16"      # or fp32x3
 enc = VisualDialogEncoder(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "unimm_amd", "config",
-                                       "bert_base_6layer_6conect.json")).to(dev).train()
+                                       "bert_base_6layer_6conect.json"), compute_dtype=COMPUTE).to(dev).train()
 model = enc.bert_pretrained
 eng = model.engine
 eng.ensure(dev)
