@@ -3,12 +3,13 @@ import torch
 from unimm_amd import VisualDialogEncoder, synth
 from unimm_amd.optim import FusedAdamW, WarmupLinearScheduleNonZero, default_language_weights, reference_param_groups
 dev = torch.device("cuda", 0)
-enc = VisualDialogEncoder("unimm_amd/config/bert_base_6layer_6conect.json").to(dev); enc.train()
+COMPUTE = sys.argv[4] if len(sys.argv) > 4 else "bf16"      # or fp32x3
+enc = VisualDialogEncoder("unimm_amd/config/bert_base_6layer_6conect.json", compute_dtype=COMPUTE).to(dev); enc.train()
 opt = FusedAdamW(reference_param_groups(enc, 2e-5, 2e-5, default_language_weights(enc)), enc.bert_pretrained.engine, lr=2e-5)
 sch = WarmupLinearScheduleNonZero(opt, 100, 1000)
 losses = []
 t0 = time.time()
-# python tools/soak.py [steps=40] [sequences=240] [graphs: 0 | 1]
+# python tools/soak.py [steps=40] [sequences=240] [graphs: 0 | 1] [bf16 | fp32x3]
 STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 NSEQ = int(sys.argv[2]) if len(sys.argv) > 2 else 240
 if len(sys.argv) > 3 and sys.argv[3] == "1":
