@@ -3,6 +3,7 @@
 dropout on, all three losses) at batch 240 x 256 tokens x 37 regions on N MI355X.
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus N ...          (no launcher: starts the N ranks itself as child processes, see self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -104,6 +105,8 @@ def parse():
                     "(c * x.mean() + ...) instead of harness.combine_losses (one autograd node)")
     ap.add_argument("--no-splitk", action="store_true", help="A/B: engine.splitk = False (no split-K for the long reductions of small batches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rank-probe", action="store_true",
+                    help="launch check only: every rank joins a gloo group on the CPU, all-reduces a one, rank 0 prints what it saw")
     ap.add_argument("--gemm-tile", type=int, default=0, metavar="CODE",
                     help="tuning: unimm_gemm_nt_args.tile = CODE for every launch of the run (1000 x tile columns per group + 100 x {1 persistent, "
                          "2 one workgroup per tile} + tile configuration; 0 = the library's defaults)")
@@ -260,14 +263,71 @@ def scoring(args, world, rank, dev, enc, lib, synth, dist):
         dist.destroy_process_group()
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` run as a plain process (RANK / WORLD_SIZE unset): spawn the ranks the way the external launcher
+    does -- python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port>
+    bench.py <the same arguments> -- as a child process, relay rank 0's JSON line(s) on stdout (everything else the ranks print
+    goes to stderr) and return the child's exit code.  The parent never initialises the GPU and never exec()s (a process that
+    has touched the device must not be replaced on this pool; this one has not, but a child is the form that is always allowed).
+    Replaces the single-process fan-out of utils/data_parallel.py:120-129 at the command line."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this image
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    env["UNIMM_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, env=env)
+    for line in child.stdout:
+        if line.lstrip().startswith("{"):
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(line)
+    return child.wait()
+
+
+def rank_probe(world, rank, batch):
+    """--rank-probe: the launch path without the engine -- every rank joins a gloo group (no GPU needed), all-reduces a one, and
+    rank 0 prints a JSON line with what it saw.  What tests/test_bench_launch_cpu.py runs on the CPU-only build box."""
+    import torch.distributed as dist
+    if batch < world:                                          # the same refusal as the real path (shard_range below)
+        raise SystemExit(f"--batch {batch} leaves rank {world - 1} of {world} without a sequence")
+    seen = 1
+    if world > 1:
+        dist.init_process_group("gloo")
+        ones = torch.ones(1)
+        dist.all_reduce(ones)
+        seen = int(ones.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"probe": True, "n_gpus": world, "comm": {"backend": "gloo", "rccl_ranks": seen},
+                          "launcher": "self" if os.environ.get("TORCHELASTIC_RUN_ID") is not None and os.environ.get("UNIMM_SELF_LAUNCHED") else "external"}),
+              flush=True)
+    if seen != world:
+        raise SystemExit(f"process group reduced ones to {seen}, expected {world}")
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves as CHILD processes (this process has not
+        # touched the GPU and never will) and exit with their return code
+        raise SystemExit(self_launch(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (torch.distributed.run --nproc-per-node {args.gpus}), "
+                         "or run `python bench.py --gpus N` without a launcher")
+    if args.rank_probe:
+        return rank_probe(world, rank, args.batch)
     # Rehearsal of the N > 1 path on a one-GPU box: UNIMM_BENCH_REHEARSAL=1 puts every rank on device 0 and
     # exchanges gradients over gloo (RCCL refuses two ranks on one device).  Never set by the driver.
     rehearsal = os.environ.get("UNIMM_BENCH_REHEARSAL", "0") == "1"
@@ -346,7 +406,7 @@ def main():
         h2d_bytes = sum(v.numel() * v.element_size() for v in hbs[0].values() if torch.is_tensor(v))
         if args.host_inputs == "prefetch":
             from unimm_amd.inputs import DevicePrefetcher
-            src = DevicePrefetcher(itertools.cycle(hbs), dev)
+            src = DevicePrefetcher(itertools.cycle(hbs), dev, cache_pinned=True)   # a cycled list of immutable batches: pinned once
         else:
             src = itertools.cycle(hbs)
 

@@ -148,6 +148,8 @@ int unimm_gemm_tn_grouped_ws(const unimm_gemm_tn_args* args, int32_t count, int3
  * Tq / Tk remain the PADDED lengths that index mask, lse and the dropout counters.  Padding rows
  * (fully masked queries that no valid row attends, models/vilbert_dialog.py:1418) are then never
  * computed at all.
+ * Alignment: q, k, v, out (and dq, dk, dv, dout of the backward) 16-byte aligned, every row stride a multiple of 8
+ * elements: operand fragments are 16-byte loads and result rows leave as 16-byte stores; UNIMM_E_ALIGN otherwise.
  * ------------------------------------------------------------------------------------------- */
 typedef struct {
   const void* q; const void* k; const void* v; /* bf16 */

@@ -1,5 +1,6 @@
-"""bench.py prints ONE JSON line with the fields the driver reads (a small batch, one step; run as a child process the way
-the driver runs it)."""
+"""bench.py prints ONE JSON line with the fields the contract names (a small batch, one step; run as a child process).  N > 1 is
+run in both launch forms: `python bench.py --gpus 2` (bench.self_launch starts the ranks) and under an external
+torch.distributed.run."""
 import json
 import os
 import subprocess
@@ -38,7 +39,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
 
 
 def test_bench_two_ranks_rehearsal_with_the_graph_executor():
-    """The N > 1 path of bench.py as the driver launches it (torch.distributed.run, one JSON line from rank 0), rehearsed on
+    """The N > 1 path of bench.py under an external torch.distributed.run (one JSON line from rank 0), rehearsed on
     one GPU: UNIMM_BENCH_REHEARSAL=1 puts both ranks on device 0 and exchanges over gloo (RCCL refuses two ranks on one
     device).  A small global batch, the graph executor forced on: the data-parallel hooks between the replayed segments of
     backward, the bucket bookkeeping assert of the timed region, the `comm` block."""
@@ -58,3 +59,24 @@ def test_bench_two_ranks_rehearsal_with_the_graph_executor():
     c = j["comm"]
     assert c["buckets_per_step"] > 0 and 0 < c["collectives_per_step"] <= c["buckets_per_step"]
     assert c["bytes_per_step"] > 0 and c["exchange_alone_ms"] > 0
+
+
+def test_bench_two_ranks_rehearsal_launched_as_plain_python():
+    """`python bench.py --gpus 2` with no launcher around it: bench.self_launch spawns the two ranks as child processes and relays
+    rank 0's line (rehearsal: both ranks on device 0 over gloo).  tools/check_scale.py reads the same line."""
+    env = dict(os.environ, UNIMM_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "24",
+                        "--no-cpu-baseline", "--no-padded"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), lines
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 24 and j["comm"]["rccl_ranks"] == 2
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_scale", os.path.join(ROOT, "tools", "check_scale.py"))
+    cs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cs)
+    msgs = cs.check(j)                       # a rehearsal is gloo on one device at 12 sequences per rank: only the structural checks apply
+    assert not any("is not global_batch / ms_per_step" in m or "no `comm` block" in m or "RCCL saw" in m for m in msgs), msgs

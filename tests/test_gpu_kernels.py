@@ -542,3 +542,34 @@ def test_combine_losses_equals_the_written_out_arithmetic():
         assert a.grad.shape == b.grad.shape and torch.allclose(a.grad, b.grad)
     cpu = [torch.tensor([1.0, 2.0], requires_grad=True) for _ in range(3)]          # several replicas / CPU: the plain arithmetic
     assert abs(float(harness.combine_losses(*cpu, 1.0, 1.0, 1.0)) - 4.5) < 1e-6
+
+
+def test_device_prefetcher_reads_fresh_host_buffers_and_keeps_pinned_memory_bounded():
+    """unimm_amd.inputs.DevicePrefetcher with a loader that REUSES one host buffer and mutates it every step (and hands over
+    fresh tensors besides): every batch must arrive with the values it had when it was drawn, and the staging memory must
+    stay at `ring` pinned sets however many batches pass (round-4 advisor finding: the per-tensor pinned cache grew without
+    bound and re-sent the first sighting of a reused buffer).  cache_pinned=True keeps the one-pin-per-tensor form for cycled,
+    immutable batches."""
+    from unimm_amd.inputs import DevicePrefetcher
+    shared = torch.zeros(1024, dtype=torch.int64)
+
+    def loader(n):
+        for i in range(n):
+            shared.fill_(i)                                    # the loader's reused buffer
+            yield {"reused": shared, "fresh": torch.full((257,), float(i)), "meta": i}
+
+    pf = DevicePrefetcher(loader(12), "cuda", ring=3)
+    seen = 0
+    for i, b in enumerate(pf):
+        assert b["meta"] == i and b["reused"].is_cuda and b["fresh"].is_cuda
+        assert int(b["reused"][0]) == i and int(b["reused"][-1]) == i, (i, b["reused"][:2])
+        assert float(b["fresh"][3]) == float(i)
+        seen += 1
+    assert seen == 12
+    assert len(pf._pinned) == 0 and len(pf._ring) == 3
+    assert sum(len(s["bufs"]) for s in pf._ring) <= 3 * 2      # two pageable tensors per batch, three staging sets
+    hb = [{"x": torch.full((64,), float(k))} for k in range(2)]
+    import itertools
+    pf2 = DevicePrefetcher(itertools.islice(itertools.cycle(hb), 8), "cuda", cache_pinned=True)
+    vals = [float(b["x"][0]) for b in pf2]
+    assert vals == [0.0, 1.0] * 4 and len(pf2._pinned) == 2

@@ -29,12 +29,15 @@ shapes = [  # (name, M, N, K, epilogue)
     ("image ff2 dgrad", Mi, 1024, 1024, E.EPI_MUL), ("image ff1 dgrad", Mi, 1024, 1024, E.EPI_ADD),
     ("image bi-output dgrad", Mi, 1024, 1024, E.EPI_BIAS), ("image qkv1 dgrad", Mi, 1024, 3072, E.EPI_ADD),
 ]
-tiles = [0, 8, 6, 1, 7]
+if os.environ.get("TEXT_LAYER"):          # the text layers' own shapes (models/vilbert_dialog.py:385-483) on top
+    shapes += [("text qkv fwd", Mt, 2304, 768, E.EPI_BIAS), ("text attn-out fwd", Mt, 768, 768, E.EPI_BIAS_DROP_RESID),
+               ("text attn-out dgrad", Mt, 768, 768, E.EPI_BIAS), ("text qkv dgrad", Mt, 768, 2304, E.EPI_ADD)]
+tiles = [int(t) for t in os.environ.get("TILES", "0,8,6,1,7").split(",")]
 _x = torch.randn((Mt, 768), device="cuda").to(torch.bfloat16); _w = torch.randn((3072, 768), device="cuda").to(torch.bfloat16)
 _o = torch.empty((Mt, 3072), device="cuda", dtype=torch.bfloat16)
 timeit(lambda: lib.gemm_nt(_x, _w, _o), iters=300)          # clocks and caches up before the first row is timed
 tot = {t: 0.0 for t in tiles}; best = 0.0; flops = 0.0
-print(f"{'shape':24s} {'M':>6s} {'N':>5s} {'K':>5s}  " + "  ".join(f"{lib._TILE_NAMES.get(t, 'auto'):>10s}" for t in tiles))
+print(f"{'shape':24s} {'M':>6s} {'N':>5s} {'K':>5s}  " + "  ".join(f"{lib._TILE_NAMES.get(t % 100, 'auto') + ('' if t < 100 else ('p' if t // 100 == 1 else 'n')):>10s}" for t in tiles))
 for name, M, N, K, epi in shapes:
     x = torch.randn((M, K), generator=g, device="cuda").to(torch.bfloat16)
     w = (torch.randn((N, K), generator=g, device="cuda") * 0.05).to(torch.bfloat16)
@@ -54,5 +57,5 @@ for name, M, N, K, epi in shapes:
         tot[t] += us
     best += min(row); flops += 2.0 * M * N * K
     print(f"{name:24s} {M:6d} {N:5d} {K:5d}  " + "  ".join(f"{u:7.1f} us" for u in row) + f"   auto {2.0 * M * N * K / row[0] / 1e6:6.0f} TF/s")
-print("sum per layer: " + "  ".join(f"{lib._TILE_NAMES.get(t, 'auto')} {tot[t]:.0f} us ({flops / tot[t] / 1e6:.0f} TF/s)" for t in tiles) +
+print("sum per layer: " + "  ".join(f"{lib._TILE_NAMES.get(t % 100, 'auto') + ('' if t < 100 else ('p' if t // 100 == 1 else 'n'))} {tot[t]:.0f} us ({flops / tot[t] / 1e6:.0f} TF/s)" for t in tiles) +
       f"   best-of per shape {best:.0f} us ({flops / best / 1e6:.0f} TF/s)")

@@ -51,7 +51,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print("compiled", os.path.basename(src), file=sys.stderr)
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=8) as ex:
         list(ex.map(compile_one, jobs))
     objs = [os.path.join(OBJ, os.path.basename(s)[:-4] + ".o") for s in sources()]
     if force or jobs or _stale(LIB, objs):

@@ -1027,8 +1027,8 @@ extern "C" int unimm_attn_fwd(const unimm_attn_args* a, void* stream) {
   if (a == nullptr || !a->q || !a->k || !a->v || !a->out || !a->mask) return UNIMM_E_ARG;
   if (a->B <= 0 || a->H <= 0 || a->Tq <= 0 || a->Tk <= 0 || a->Tq > 256 || a->Tk > 256) return UNIMM_E_SHAPE;
   if (a->D != 64 && a->D != 128) return UNIMM_E_SHAPE;
-  if ((a->ldq % 8) || (a->ldk % 8) || (a->ldv % 8) || (a->ldo % 4)) return UNIMM_E_ALIGN;
-  if (((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v) & 15) return UNIMM_E_ALIGN;
+  if ((a->ldq % 8) || (a->ldk % 8) || (a->ldv % 8) || (a->ldo % 8)) return UNIMM_E_ALIGN;   // result rows leave as 16-byte stores (store_acc_row)
+  if (((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v | (uintptr_t)a->out) & 15) return UNIMM_E_ALIGN;
   AttnParams p;
   p.q = (const bf16_t*)a->q; p.k = (const bf16_t*)a->k; p.v = (const bf16_t*)a->v;
   p.o = (bf16_t*)a->out; p.lse = a->lse; p.mask = a->mask;
@@ -1073,10 +1073,11 @@ extern "C" int unimm_attn_bwd(const unimm_attn_bwd_args* a, void* stream) {
     return UNIMM_E_ARG;
   if (a->B <= 0 || a->H <= 0 || a->Tq <= 0 || a->Tk <= 0 || a->Tq > 256 || a->Tk > 256) return UNIMM_E_SHAPE;
   if (a->D != 64 && a->D != 128) return UNIMM_E_SHAPE;
-  if ((a->ldq % 8) || (a->ldk % 8) || (a->ldv % 8) || (a->ldo % 8) || (a->lddo % 8) || (a->lddq % 4) || (a->lddk % 4) ||
-      (a->lddv % 4))
-    return UNIMM_E_ALIGN;
-  if (((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v | (uintptr_t)a->out | (uintptr_t)a->dout) & 15)
+  if ((a->ldq % 8) || (a->ldk % 8) || (a->ldv % 8) || (a->ldo % 8) || (a->lddo % 8) || (a->lddq % 8) || (a->lddk % 8) ||
+      (a->lddv % 8))
+    return UNIMM_E_ALIGN;                                         // dQ / dK / dV rows leave as 16-byte stores (store_acc_row)
+  if (((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v | (uintptr_t)a->out | (uintptr_t)a->dout | (uintptr_t)a->dq |
+       (uintptr_t)a->dk | (uintptr_t)a->dv) & 15)
     return UNIMM_E_ALIGN;
   AttnBwdParams p;
   p.q = (const bf16_t*)a->q; p.k = (const bf16_t*)a->k; p.v = (const bf16_t*)a->v; p.o = (const bf16_t*)a->out;

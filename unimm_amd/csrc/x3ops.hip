@@ -492,7 +492,7 @@ __global__ __launch_bounds__(XA_T) void x3_attn_fwd_kernel(AttnF32 p) {
     }
   }
   if (!valid) return;
-  const float inv = (p.drop.thr != 0u ? p.drop.scale : 1.0f) / l;
+  const float inv = l > 0.f ? (p.drop.thr != 0u ? p.drop.scale : 1.0f) / l : 0.f;
   xa_store<DH>(p.out + (size_t)(qoff + qr) * p.ldo + head * D + half * DH, acc, inv);
   if (p.lse != nullptr && half == 0) p.lse[((size_t)b * p.H + head) * p.Tq + qr] = m + __logf(l);
 }
@@ -877,7 +877,8 @@ __global__ __launch_bounds__(XM_T, UNIMM_X3M_MIN_WAVES) void x3m_attn_fwd_kernel
   __syncthreads();                                         // every wave is done with the last V chunk: the buffer becomes the store tiles
   if (!live) return;
   // acc is out^T: lane holds dimensions 16 dt + 4 g + i of query qr
-  const float inv = (p.drop.thr != 0u ? p.drop.scale : 1.0f) / l;
+  // (a sequence with no keys at all -- k_len[b] == 0 -- has l = 0: its rows are written as zeros, not 0 * inf)
+  const float inv = l > 0.f ? (p.drop.thr != 0u ? p.drop.scale : 1.0f) / l : 0.f;
   const int row0 = r0 + wave * 16, nrows = qlen - row0 < 16 ? qlen - row0 : 16;
   xm_store_rows<D>(Xs + wave * 16 * LD, acc, inv, r, grp, lane, nrows, p.out + (size_t)(qoff + row0) * p.ldo + head * D, p.ldo,
                    p.o3 != nullptr ? p.o3 + (size_t)(qoff + row0) * p.ld3 + head * D : nullptr, p.ld3, p.cp3);
@@ -1249,7 +1250,8 @@ extern "C" int unimm_x3_attn_bwd(const unimm_attn_bwd_args* a, const unimm_x3_at
   if ((a->lddo % 4) || (((uintptr_t)a->dout) & 15)) return UNIMM_E_ALIGN;
   p.o = (const float*)a->out; p.out = nullptr; p.dout = (const float*)a->dout; p.delta = a->delta; p.lddo = a->lddo;
   if (planes) {
-    if ((((uintptr_t)pl->dq3 | (uintptr_t)pl->dk3 | (uintptr_t)pl->dv3) & 15) || (pl->ld3 % 8) || (pl->cp3 % 8) || pl->ld3 < 3 * pl->cp3)
+    if ((((uintptr_t)pl->dq3 | (uintptr_t)pl->dk3 | (uintptr_t)pl->dv3) & 15) || (pl->ld3 % 8) || (pl->cp3 % 8) || pl->cp3 < a->H * a->D ||
+        pl->ld3 < 3 * pl->cp3)                                            // a plane narrower than H * D would overlap its neighbour
       return UNIMM_E_ALIGN;
     p.dq3 = (bf16_t*)pl->dq3; p.dk3 = (bf16_t*)pl->dk3; p.dv3 = (bf16_t*)pl->dv3; p.ld3 = pl->ld3; p.cp3 = pl->cp3;
   } else {

@@ -375,7 +375,10 @@ class Engine:
         if K < 2048 or N > 1024 or ((M + 127) // 128) * ((N + 127) // 128) > 256:
             return None
         dev = self.arena.flat.device
-        key = "img" if self._on_side else "txt"
+        # The workspace (slabs + zero-between-launches tickets) is private to launches of ONE stream: key it by the stream the
+        # launch goes to (the caller's stream in eager steps, the capturing stream under graph capture), so a text-side GEMM
+        # issued from another stream can never share tickets with one in flight
+        key = int(torch.cuda.current_stream(dev).cuda_stream)
         ws = self._splitk_ws.get(key)
         if ws is None:
             ws = self._splitk_ws[key] = torch.zeros(self.splitk_ws_bytes, dtype=torch.uint8, device=dev)

@@ -81,21 +81,37 @@ class DevicePrefetcher:
             loss = step(batch)
     """
 
-    def __init__(self, batches, device, pin=True):
+    def __init__(self, batches, device, pin=True, cache_pinned=False, ring=3):
+        """pin: stage pageable host tensors through pinned memory (asynchronous copies).  cache_pinned=False (default, what a
+        real DataLoader needs: fresh tensors every step, buffers possibly reused): every batch is copied into one of `ring`
+        reusable pinned staging sets (re-allocated only when a tensor's shape / dtype changes) -- pinned memory stays bounded by
+        ring x one batch, nothing the caller hands over is kept alive, and a loader that mutates or reuses its host buffers is
+        read afresh every time; a staging set is reused only after the host->device copies issued from it have completed
+        (its event).  cache_pinned=True: the caller promises a CYCLED list of IMMUTABLE batches (bench.py --host-inputs
+        prefetch): each distinct host tensor is pinned once and the pinned copy is re-sent."""
         self.it = iter(batches)
         self.device = torch.device(device)
         self.pin = pin
+        self.cache_pinned = cache_pinned
         self.stream = torch.cuda.Stream(device=self.device)
-        self._pinned = {}                        # id(host tensor) -> pinned copy (a cycled list of batches is pinned once)
+        self._pinned = {}                        # cache_pinned: id(host tensor) -> (host tensor, pinned copy)
+        self._ring = [dict(bufs={}, ev=None) for _ in range(max(2, int(ring)))]   # staging sets: key -> pinned buffer; ev = last copy-out
+        self._turn = 0
         self._next = self._issue()
 
-    def _host(self, t):
+    def _host(self, key, t, slot):
         if not self.pin or t.is_pinned():
             return t
-        p = self._pinned.get(id(t))
-        if p is None:
-            p = self._pinned[id(t)] = (t, t.pin_memory())      # keep `t` alive: its id is the key
-        return p[1]
+        if self.cache_pinned:
+            p = self._pinned.get(id(t))
+            if p is None:
+                p = self._pinned[id(t)] = (t, t.pin_memory())      # keep `t` alive: its id is the key
+            return p[1]
+        buf = slot["bufs"].get(key)
+        if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
+            buf = slot["bufs"][key] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        buf.copy_(t)                               # host -> pinned staging (the slot's previous copies have completed: _issue waited)
+        return buf
 
     def _issue(self):
         try:
@@ -103,15 +119,20 @@ class DevicePrefetcher:
         except StopIteration:
             return None
         db = {}
+        slot = self._ring[self._turn % len(self._ring)]
+        self._turn += 1
+        if slot["ev"] is not None:
+            slot["ev"].synchronize()               # the copies that last read this staging set (ring - 1 batches ago) are done
         self.stream.wait_stream(torch.cuda.current_stream(self.device))      # buffers freed by the consumer may be reused here
         with torch.cuda.stream(self.stream):
             for k, v in hb.items():
                 if torch.is_tensor(v) and not v.is_cuda:
-                    db[k] = self._host(v).to(self.device, non_blocking=True)
+                    db[k] = self._host(k, v, slot).to(self.device, non_blocking=True)
                 else:
                     db[k] = v
             ev = torch.cuda.Event()
             ev.record(self.stream)
+        slot["ev"] = ev
         return db, ev
 
     def __iter__(self):
