@@ -104,6 +104,11 @@ def parse():
     ap.add_argument("--plain-loss", action="store_true", help="A/B: combine the three losses with the written-out torch arithmetic "
                     "(c * x.mean() + ...) instead of harness.combine_losses (one autograd node)")
     ap.add_argument("--no-splitk", action="store_true", help="A/B: engine.splitk = False (no split-K for the long reductions of small batches)")
+    ap.add_argument("--shared-context", choices=["on", "off"], default="on",
+                    help="scoring workload: compute the context rows and the image stream once per dialog round (default; bf16 engine) "
+                         "or per candidate as the reference does")
+    ap.add_argument("--scoring-chunk", type=int, default=250, metavar="N",
+                    help="scoring workload: sequences per forward call (250 = the reference's val_lm.log; 1000 = one image per call)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rank-probe", action="store_true",
                     help="launch check only: every rank joins a gloo group on the CPU, all-reduces a one, rank 0 prints what it saw")
@@ -188,29 +193,44 @@ def scoring(args, world, rank, dev, enc, lib, synth, dist):
     """BASELINE configs[4]: val_lm.py generative scoring.  One step = one image: 10 rounds x 100 candidate answers =
     1000 sequences, run as 4 chunks of 250 (val_lm.py:104-136, chunk size from the reference's val_lm.log), each chunk a
     forward + per-sequence log-likelihood on the labelled rows, then ranks per round (utils/visdial_metrics.py:21-39).
-    Ranks process different images (weak scaling, no collective)."""
+    The 100 candidates of a round share image, history and question (dataloader/dataloader_visdial.py builds them so;
+    synth.make_scoring_batch); with --shared-context on (default, bf16 engine) the context rows and the image stream are
+    computed once per round and chunk (unimm_amd/scoring.py) -- the per-candidate schedule, which recomputes them 100 times as
+    the reference does, is timed beside it (`config.per_candidate_value`).  Ranks process different images (weak scaling, no
+    collective)."""
     from unimm_amd import harness
     model = enc.bert_pretrained
     enc.eval()
     cfg = model.config
-    chunks = []
-    for c in range(4):                            # gen-mode sequences, no random masking: labels = the answer copy
-        b = synth.make_batch(n_seq=250, cfg=cfg, seed=4321 + 16 * rank + c, device=dev, modes=["gen"] * 250, mask_prob=0.0,
-                             sequences_per_image=250)
-        chunks.append(b)
-    n_rows = sum(int((b["masked_lm_labels"] != -1).sum()) for b in chunks)
+    img = synth.make_scoring_batch(rounds=10, options=100, cfg=cfg, seed=4321 + 16 * rank, device=dev)
+    spec = img.pop("mask_spec")
+    ck = args.scoring_chunk
+    if 1000 % ck:
+        raise SystemExit("--scoring-chunk must divide 1000")
+    chunks = [{k: v[ck * c:ck * (c + 1)] for k, v in img.items()} for c in range(1000 // ck)]
+    if args.compact_inputs:                       # row F3: mask descriptors instead of dense masks, one image entry + an index
+        from unimm_amd.inputs import DialogMaskSpec
+        for c, b in enumerate(chunks):
+            sl = slice(ck * c, ck * (c + 1))
+            b["attention_mask"] = DialogMaskSpec(spec.mode[sl], spec.length[sl], spec.answer[sl])
+            b["co_attention_mask"] = None
+            b["image_feat"], b["image_loc"] = b["image_feat"][:1].contiguous(), b["image_loc"][:1].contiguous()
+            b["image_index"] = torch.zeros(ck, dtype=torch.int64, device=dev)
+    n_rows = int((img["masked_lm_labels"] != -1).sum())
+    shared = args.shared_context == "on" and args.compute == "bf16"
 
-    def step():
+    def step(shared=shared):
         sc = []
         for b in chunks:
             s, _ = model.sequence_log_likelihood(b["input_ids"], b["image_feat"], b["image_loc"], b["masked_lm_labels"],
                                                  token_type_ids=b["token_type_ids"], position_ids=b["token_position_ids"],
                                                  attention_mask=b["attention_mask"], image_attention_mask=b["image_attention_mask"],
-                                                 co_attention_mask=b["co_attention_mask"])
+                                                 co_attention_mask=b["co_attention_mask"], image_index=b.get("image_index"),
+                                                 shared_context=b["context_group"] if shared else None)
             sc.append(s)
         return harness.scores_to_ranks(torch.cat(sc).view(1, 10, 100))
 
-    log(f"scoring: 4 chunks x 250 sequences ready on {dev}, {n_rows} decoded rows per image")
+    log(f"scoring: {len(chunks)} chunks x {ck} sequences ready on {dev}, {n_rows} decoded rows per image, shared context {'on' if shared else 'off'}")
     for _ in range(args.warmup):
         step()
 
@@ -229,6 +249,16 @@ def scoring(args, world, rank, dev, enc, lib, synth, dist):
     dt = time.perf_counter() - t0
     prof = lib.prof_collect()
     lib.prof_enable(False)
+    per_cand = None
+    if shared:                                    # the reference's schedule (every candidate recomputes context and image), same inputs
+        step(False)
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            ranks_pc = step(False)
+        fence()
+        per_cand = 1000 * 3 / (time.perf_counter() - t1)
+        rank_agree = float((ranks_pc == ranks).float().mean())
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -244,10 +274,16 @@ def scoring(args, world, rank, dev, enc, lib, synth, dist):
                "value": round(value, 2), "unit": "dialog-sequences/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": "val_lm generative scoring (BASELINE configs[4]): 1 image = 10 rounds x 100 candidates per step, "
-                                      "4 chunks of 250 sequences, forward only, row-sparse decoder on the answer-copy rows, "
-                                      "per-sequence log-likelihood, ranks per round",
-                          "global_batch": 1000 * world, "per_gpu_batch": 1000, "chunk": 250, "seq_len": 256, "regions": 37,
+               "config": {"workload": "val_lm generative scoring (BASELINE configs[4]): 1 image = 10 rounds x 100 candidates per step (the "
+                                      "candidates of a round share image and dialog context), 4 chunks of 250 sequences, forward only, "
+                                      "row-sparse decoder on the answer-copy rows, per-sequence log-likelihood, ranks per round",
+                          "schedule": ("shared context: context rows + image stream once per round and chunk, candidate rows per sequence "
+                                       "(unimm_amd/scoring.py)" if shared else "per candidate (the reference's schedule: everything per sequence)"),
+                          "per_candidate_value": round(per_cand, 2) if per_cand is not None else None,
+                          "ranks_equal_to_per_candidate_schedule": round(rank_agree, 4) if per_cand is not None else None,
+                          "global_batch": 1000 * world, "per_gpu_batch": 1000, "chunk": args.scoring_chunk,
+                          "inputs": "mask descriptors + one image entry + image_index (row F3)" if args.compact_inputs else "reference layout (dense masks, per-sequence image copies)",
+                          "seq_len": 256, "regions": 37,
                           "parallelism": f"dp{world}", "lm_rows_decoded_per_seq": round(n_rows / 1000, 2),
                           "gflop_per_seq_fwd_padded_equivalent": round(f_fwd, 3),
                           "gemm_gflop_per_seq_executed": round(gemm_fl / args.steps / 1000 / 1e9, 3),

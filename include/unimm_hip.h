@@ -163,6 +163,14 @@ typedef struct {
   float scale;
   uint32_t drop_key, drop_thr; float drop_scale;
   const uint32_t* drop_salt; /* or NULL (see unimm_gemm_nt_args.drop_salt) */ /* element index = ((b*H+h)*Tq+q)*Tk+k */
+  /* unimm_attn_fwd only (NULL elsewhere), with k_off / k_len given and dropout off: a SHARED key/value segment -- rows
+   * [ks_off[b], ks_off[b] + ks_len[b]) of the same k / v matrices -- spliced into sequence b's keys after its first ks_ins
+   * private rows.  Key position j of sequence b is private row j (j < ks_ins), shared row j - ks_ins (j < ks_ins + ks_len[b]),
+   * else private row j - ks_len[b]; the sequence has k_len[b] + ks_len[b] <= 256 keys and the mask words index key positions.
+   * Generative scoring (val_lm.py:52-121): the 100 candidate answers of a dialog round attend the round's context rows,
+   * which are computed once (utils/data_utils.py:199-210: context rows never see the answer).  ABI 16. */
+  const int32_t* ks_off; const int32_t* ks_len;
+  int32_t ks_ins;
 } unimm_attn_args;
 
 int unimm_attn_fwd(const unimm_attn_args* args, void* stream);

@@ -35,10 +35,10 @@ def rel_to_scale(got, want):
     return float(np.abs(got.astype(np.float64) - want.astype(np.float64)).max() / max(float(np.abs(want).max()), 1e-30))
 
 
-def build_full(seed):
+def build_full(seed, compute="bf16"):
     from oracle import vilbert_ref as R
     from unimm_amd import BertConfig, BertForMultiModalPreTraining
-    model = BertForMultiModalPreTraining(BertConfig.from_json_file(CFG_PATH))
+    model = BertForMultiModalPreTraining(BertConfig.from_json_file(CFG_PATH), compute_dtype=compute)
     ocfg = R.make_config(CFG_PATH)
     sd = R.init_state_dict(ocfg, seed=seed)
     model.load_state_dict(sd, strict=True)
@@ -397,6 +397,8 @@ def test_bs240_full_config_properties(golden_dir):
     d_grad = float((base[2] - padded[2]).abs().max() / padded[2].abs().max())
     print(f"  unpadded vs padded: losses {d_loss:.2e}, nsp {d_nsp:.2e}, gradients {d_grad:.2e} of max|g|")
     assert d_loss <= 2e-3 and d_nsp <= 2e-3 and d_grad <= 1e-2
+    if compute == "fp32x3":                                            # fp32 arithmetic: padding rows change nothing beyond rounding
+        assert d_loss <= 2e-5 and d_nsp <= 2e-5 and d_grad <= 1e-4, (d_loss, d_nsp, d_grad)
     assert torch.equal(base[0], single[0]) and torch.equal(base[1], single[1])      # same kernels, same words
     d2 = float((base[2] - single[2]).abs().max() / single[2].abs().max())
     print(f"  two streams vs one: losses bit-identical, gradients {d2:.2e} of max|g| (atomics order)")
@@ -412,10 +414,11 @@ def test_bs240_full_config_properties(golden_dir):
             want = R.forward(leaves, ocfg, *cargs, **ckw)
         for name, gi in (("lm_loss", 0), ("img_loss", 1), ("nsp_loss", 2)):
             e = abs(float(got[gi]) - float(want[name]))
-            print(f"  chunk {c}: {name} hip {float(got[gi]):.4f} oracle {float(want[name]):.4f}")
-            assert e <= 1e-2 * (1 + abs(float(want[name]))), (c, name, e)
-        e = float((got[5].cpu() - want["nsp"]).abs().max())
-        assert e <= 1e-2 * (1 + float(want["nsp"].abs().max())), (c, "nsp", e)
+            print(f"  chunk {c}: {name} hip {float(got[gi]):.5f} oracle {float(want[name]):.5f}  (|err| {e:.2e}, gate {tol:.0e} allclose)")
+            assert e <= tol * (1 + abs(float(want[name]))), (c, name, e)
+        err = (got[5].cpu() - want["nsp"]).abs()
+        assert bool((err <= tol + tol * want["nsp"].abs()).all()), (c, "nsp", float(err.max()))      # every NSP logit, allclose form
+        print(f"  chunk {c}: NSP logits max |err| {float(err.max()):.2e}")
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -432,14 +435,22 @@ def _call_kwargs(b, sl=slice(None), dev=None, labels=True):
     return (mv(b["input_ids"]), mv(b["image_feat"]), mv(b["image_loc"])), kw
 
 
-def test_dense_finetune_b100_full_config_properties():
+# Oracle gates of the two workloads, per arithmetic class: |err| <= tol + tol * |want| (north_star: 1e-2 bf16 / 1e-3 fp32).
+# configs[3] is the reference's fp32 script (dense_annotation_finetuning.py:253 runs without autocast), so its own class is fp32x3.
+CLASS_TOL = {"bf16": 1e-2, "fp32x3": 1e-3}
+
+
+@pytest.mark.parametrize("compute", ["bf16", "fp32x3"])
+def test_dense_finetune_b100_full_config_properties(compute):
     """BASELINE configs[3] (dense_annotation_finetuning.py:253-296): one micro-step of 100 discriminative sequences,
     2 per image, objective = NeuralNDCG^T over the 100 options + LM loss + 0 x NSP, full config, dropout off:
     finite; unpadded == padded; two streams == one; the ranking term equals the PyTorch (CPU-formulation) path of
-    unimm_amd.ranking on the same scores; losses and NSP logits of two 6-row chunks == the CPU oracle."""
+    unimm_amd.ranking on the same scores; losses and NSP logits of two 6-row chunks == the CPU oracle in allclose form at the
+    class tolerance (bf16 engine 1e-2; fp32x3 engine -- the reference's own arithmetic for this script -- 1e-3)."""
     from oracle import vilbert_ref as R
     from unimm_amd import ranking, synth
-    model, ocfg, sd = build_full(seed=5)
+    tol = CLASS_TOL[compute]
+    model, ocfg, sd = build_full(seed=5, compute=compute)
     eng = model.engine
     n = 100
     b = synth.make_batch(n_seq=n, T=256, R=37, cfg=model.config, seed=4321, sequences_per_image=2, device="cuda", modes=["dis"] * n)
@@ -471,6 +482,8 @@ def test_dense_finetune_b100_full_config_properties():
     d_grad = float((base[2] - padded[2]).abs().max() / padded[2].abs().max())
     print(f"  unpadded vs padded: losses {d_loss:.2e}, nsp {d_nsp:.2e}, gradients {d_grad:.2e} of max|g|")
     assert d_loss <= 2e-3 and d_nsp <= 2e-3 and d_grad <= 1e-2
+    if compute == "fp32x3":                                            # fp32 arithmetic: padding rows change nothing beyond rounding
+        assert d_loss <= 2e-5 and d_nsp <= 2e-5 and d_grad <= 1e-4, (d_loss, d_nsp, d_grad)
     assert torch.equal(base[0], single[0]) and torch.equal(base[1], single[1])
     d2 = float((base[2] - single[2]).abs().max() / single[2].abs().max())
     print(f"  two streams vs one: losses bit-identical, gradients {d2:.2e} of max|g| (atomics order)")
@@ -491,21 +504,24 @@ def test_dense_finetune_b100_full_config_properties():
             want = R.forward(dict(sd), ocfg, *cargs, **ckw)
         for name, gi in (("lm_loss", 0), ("img_loss", 1), ("nsp_loss", 2)):
             e = abs(float(got[gi]) - float(want[name]))
-            print(f"  chunk {c}: {name} hip {float(got[gi]):.4f} oracle {float(want[name]):.4f}")
-            assert e <= 1e-2 * (1 + abs(float(want[name]))), (c, name, e)
-        e = float((got[5].cpu() - want["nsp"]).abs().max())
-        assert e <= 1e-2 * (1 + float(want["nsp"].abs().max())), (c, "nsp", e)
+            print(f"  chunk {c}: {name} hip {float(got[gi]):.5f} oracle {float(want[name]):.5f}  (|err| {e:.2e}, gate {tol:.0e} allclose)")
+            assert e <= tol * (1 + abs(float(want[name]))), (c, name, e)
+        err = (got[5].cpu() - want["nsp"]).abs()
+        assert bool((err <= tol + tol * want["nsp"].abs()).all()), (c, "nsp", float(err.max()))      # every NSP logit, allclose form
+        print(f"  chunk {c}: NSP logits max |err| {float(err.max()):.2e}")
 
 
-def test_generative_scoring_chunk250_full_config_properties():
+@pytest.mark.parametrize("compute", ["bf16", "fp32x3"])
+def test_generative_scoring_chunk250_full_config_properties(compute):
     """BASELINE configs[4] (val_lm.py:121-149): one chunk of 250 generative candidate sequences, full config: the
     sequence log-likelihoods (decoded on the labelled rows only) are finite, the unpadded schedule == the padded one,
     12 sampled sequences == the oracle's dense-logits cross entropy summed per sequence, and the ranks the scores
-    induce agree with the oracle's wherever the oracle's margin between two candidates exceeds the tolerance."""
+    induce agree with the oracle's wherever the oracle's margin between two candidates exceeds the tolerance
+    (bf16 engine: 1e-2 of the largest |log-likelihood|; fp32x3 engine: allclose form at 1e-3 and IDENTICAL ranks)."""
     from oracle import vilbert_ref as R
     from unimm_amd import synth
     from unimm_amd.harness import scores_to_ranks
-    model, ocfg, sd = build_full(seed=5)
+    model, ocfg, sd = build_full(seed=5, compute=compute)
     eng = model.engine
     n = 250
     b = synth.make_batch(n_seq=n, T=256, R=37, cfg=model.config, seed=999, sequences_per_image=250, device="cuda",
@@ -541,6 +557,9 @@ def test_generative_scoring_chunk250_full_config_properties():
     tol = 1e-2 * float(want.abs().max())
     print(f"  12 sequences vs oracle: max |err| {float((sel - want).abs().max()):.3e} (values {float(want.min()):.2f} .. {float(want.max()):.2f}, gate {tol:.3e})")
     assert float((sel - want).abs().max()) <= tol
+    if compute == "fp32x3":
+        assert bool(((sel - want).abs() <= 1e-3 + 1e-3 * want.abs()).all()), (sel - want).abs().max()      # allclose form, every sequence
+        assert scores_to_ranks(sel.view(1, 1, -1)).view(-1).tolist() == scores_to_ranks(want.view(1, 1, -1)).view(-1).tolist()
     # ranks among the 12 sampled candidates: every pair the oracle separates by more than 2 x tol keeps its order
     r_got = scores_to_ranks(sel.view(1, 1, -1)).view(-1)
     r_want = scores_to_ranks(want.view(1, 1, -1)).view(-1)
@@ -549,3 +568,81 @@ def test_generative_scoring_chunk250_full_config_properties():
             if want[a_] - want[c_] > 2 * tol:
                 assert r_got[a_] < r_got[c_], (a_, c_, float(want[a_]), float(want[c_]), float(sel[a_]), float(sel[c_]))
     assert sorted(r_got.tolist()) == list(range(1, 13)) and sorted(r_want.tolist()) == list(range(1, 13))
+
+
+def test_generative_scoring_shared_context_full_config():
+    """val_lm.py:52-121 scores 100 candidates per dialog round that share image, history and question.  With
+    `shared_context=<round index>` the context rows and the image stream are computed once per round
+    (unimm_amd/scoring.py: under the generative mask they never see the candidate, utils/data_utils.py:199-210).  One
+    chunk of 250 = 2.5 rounds at the full config: scores == the per-sequence path within 2e-3 of the largest |score|, NSP
+    logits likewise, ranks inside every round identical wherever two candidates are further apart than that tolerance
+    (and >= 97 % identical outright: candidates closer than the bf16 noise of the two schedules, ~0.03 on scores of
+    -30 .. -140, may trade places); 12 sampled sequences == the oracle at 1e-2; mask descriptors == dense masks bit for
+    bit; a sequence whose context does NOT match its group comes back as NaN and nothing else changes."""
+    from oracle import vilbert_ref as R
+    from unimm_amd import synth
+    from unimm_amd.harness import scores_to_ranks
+    model, ocfg, sd = build_full(seed=5)
+    full = synth.make_scoring_batch(rounds=3, options=100, cfg=model.config, seed=2024, device="cuda")
+    n = 250
+    spec_full = full.pop("mask_spec")
+    b = {k: v[:n] for k, v in full.items()}
+    grp = b["context_group"]
+    args = (b["input_ids"], b["image_feat"], b["image_loc"], b["masked_lm_labels"])
+    kw = dict(token_type_ids=b["token_type_ids"], position_ids=b["token_position_ids"], attention_mask=b["attention_mask"],
+              co_attention_mask=b["co_attention_mask"], image_attention_mask=b["image_attention_mask"])
+    base, nsp0 = model.sequence_log_likelihood(*args, **kw)
+    got, nsp1 = model.sequence_log_likelihood(*args, shared_context=grp, **kw)
+    torch.cuda.synchronize()
+    assert torch.isfinite(got).all() and (got < 0).all()
+    scale = float(base.abs().max())
+    d = float((got - base).abs().max())
+    dn = float((nsp1 - nsp0).abs().max())
+    print(f"\nshared-context scoring, 250 sequences = 2.5 rounds: scores {float(got.min()):.2f} .. {float(got.max()):.2f}; "
+          f"vs the per-sequence path {d:.3e} ({d / scale:.2e} of scale), NSP logits {dn:.3e}")
+    assert d <= 2e-3 * scale and dn <= 2e-2 * (1 + float(nsp0.abs().max()))
+    tol = 2e-3 * scale
+    same_rank = total = 0
+    for r0, r1 in ((0, 100), (100, 200), (200, 250)):
+        ra = scores_to_ranks(base[r0:r1].view(1, 1, -1)).view(-1)
+        rb = scores_to_ranks(got[r0:r1].view(1, 1, -1)).view(-1)
+        same_rank += int((ra == rb).sum())
+        total += r1 - r0
+        s0 = base[r0:r1]
+        far = (s0[:, None] - s0[None, :]) > tol                       # pairs the per-sequence path separates clearly
+        assert bool((rb[:, None] < rb[None, :])[far].all())
+    print(f"  ranks identical for {same_rank} of {total} candidates")
+    assert same_rank >= 0.97 * total
+    # mask descriptors instead of dense masks: the same packed words, the same result
+    from unimm_amd.inputs import DialogMaskSpec
+    spec = DialogMaskSpec(spec_full.mode[:n], spec_full.length[:n], spec_full.answer[:n])
+    kw2 = dict(kw, attention_mask=spec, co_attention_mask=None)
+    got2, _ = model.sequence_log_likelihood(*args, shared_context=grp, **kw2)
+    assert torch.equal(got, got2)
+    # the oracle, one sequence at a time
+    pick = list(range(3, n, 21))[:12]
+    want = []
+    for i in pick:
+        with torch.no_grad():
+            o = R.forward(dict(sd), ocfg, b["input_ids"][i:i + 1].cpu(), b["image_feat"][i:i + 1].cpu(), b["image_loc"][i:i + 1].cpu(),
+                          token_type_ids=b["token_type_ids"][i:i + 1].cpu(), position_ids=b["token_position_ids"][i:i + 1].cpu(),
+                          attention_mask=b["attention_mask"][i:i + 1].cpu(), co_attention_mask=b["co_attention_mask"][i:i + 1].cpu(),
+                          image_attention_mask=b["image_attention_mask"][i:i + 1].cpu())
+            lab = b["masked_lm_labels"][i:i + 1].cpu()
+            nll = torch.nn.functional.cross_entropy(o["pred_t"].view(-1, o["pred_t"].shape[-1]), lab.view(-1), ignore_index=-1,
+                                                    reduction="none")
+        want.append(float(-nll.sum()))
+    want = torch.tensor(want)
+    e = float((got[pick].cpu() - want).abs().max())
+    print(f"  12 sequences vs oracle: max |err| {e:.3e} (values {float(want.min()):.2f} .. {float(want.max()):.2f})")
+    assert e <= 1e-2 * float(want.abs().max())
+    # a context that is not shared is reported, not silently scored against the wrong rows
+    ids_bad = b["input_ids"].clone()
+    ids_bad[137, 5] = ids_bad[137, 5] + 1
+    bad, _ = model.sequence_log_likelihood(ids_bad, *args[1:], shared_context=grp, **kw)
+    assert torch.isnan(bad[137]) and int(torch.isnan(bad).sum()) == 1
+    keep = torch.ones(n, dtype=torch.bool, device=bad.device)
+    keep[137] = False
+    assert torch.equal(bad[keep], got[keep])
+    with pytest.raises(ValueError):                                   # groups of different context lengths are refused up front
+        model.sequence_log_likelihood(*args, shared_context=torch.zeros(n, dtype=torch.int64), **kw)

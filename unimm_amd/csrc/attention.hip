@@ -29,6 +29,11 @@ struct AttnParams {
   // matrices; NULL = fixed layout (rows b*T .. b*T+T-1).  Tq/Tk stay the PADDED lengths: they index the
   // mask, lse and dropout counters, so a packed run reproduces the padded run bit for bit on valid rows.
   const int* q_off; const int* q_len; const int* k_off; const int* k_len;
+  // forward only: a SHARED key/value segment (rows [ks_off[b], ks_off[b] + ks_len[b]) of the same k / v matrices) spliced into
+  // sequence b's keys after its first ks_ins private rows: key position j is private row j (j < ks_ins), shared row j - ks_ins,
+  // or private row j - ks_len[b].  The sequence then has k_len[b] + ks_len[b] keys; mask words index key POSITIONS.  What the
+  // candidates of one dialog round use to attend the round's context rows, computed once (unimm_amd/scoring.py).
+  const int* ks_off; const int* ks_len; int ks_ins;
   int B, H, Tq, Tk, ldq, ldk, ldv, ldo;
   int mask_q_stride, mask_b_stride;  // in words; q stride 0 = one row per sequence (key padding)
   int parts;                          // workgroups per (sequence, head): each owns a contiguous run of 32-row tiles
@@ -66,6 +71,24 @@ __device__ __forceinline__ void stage_head(const bf16_t* __restrict__ g, int ld,
     const int row = grp * RPI + rl;
     if (row < nrows) {
       const bf16_t* src = g + (size_t)row * ld + ((pc ^ swz<D>(row)) << 3);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(img + grp * 1024), 16, 0, 0);
+    } else {
+      *reinterpret_cast<u32x4*>(img + grp * 1024 + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+    }
+  }
+}
+// The same with the rows of a spliced key sequence (AttnParams.ks_*): base = first element of the head in row 0 of the matrix.
+template <int D>
+__device__ __forceinline__ void stage_head_seg(const bf16_t* __restrict__ base, int ld, size_t kbase, size_t sbase, int ins, int slen,
+                                               int nrows, int nrows_pad, char* img, int tid, int nthreads) {
+  constexpr int CPR = D / 8, RPI = 64 / CPR;
+  const int wave = tid >> 6, lane = tid & 63, nwaves = nthreads >> 6;
+  const int rl = lane / CPR, pc = lane % CPR;
+  for (int grp = wave; grp < nrows_pad / RPI; grp += nwaves) {
+    const int row = grp * RPI + rl;
+    if (row < nrows) {
+      const size_t grow = row < ins ? kbase + row : (row < ins + slen ? sbase + (row - ins) : kbase + (row - slen));
+      const bf16_t* src = base + grow * ld + ((pc ^ swz<D>(row)) << 3);
       __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(img + grp * 1024), 16, 0, 0);
     } else {
       *reinterpret_cast<u32x4*>(img + grp * 1024 + lane * 16) = u32x4{0u, 0u, 0u, 0u};
@@ -143,15 +166,17 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnParams p) {
   const int nwv = blockDim.x >> 6;                     // waves of this workgroup: wave w owns query tiles w, w + nwv, ...
   const int r = lane & 31, h = lane >> 5;
 
-  const int Tq_b = p.q_len ? p.q_len[b] : p.Tq, Tk_b = p.k_len ? p.k_len[b] : p.Tk;
+  const int Ts_b = p.ks_len ? p.ks_len[b] : 0;                                  // spliced shared keys (AttnParams.ks_*)
+  int Tk_b = (p.k_len ? p.k_len[b] : p.Tk) + Ts_b;
+  Tk_b = Tk_b < KPAD ? Tk_b : KPAD;                                             // (the images hold KPAD rows; the host checks the sum)
+  const int Tq_b = p.q_len ? p.q_len[b] : p.Tq;
   if (part * (int)(blockDim.x >> 6) * 32 >= Tq_b) return;   // whole workgroup is padding: nothing staged
   const size_t qbase = p.q_off ? (size_t)p.q_off[b] : (size_t)b * p.Tq;
   const size_t kbase = p.k_off ? (size_t)p.k_off[b] : (size_t)b * p.Tk;
+  const size_t sbase = p.ks_off ? (size_t)p.ks_off[b] : 0;
   const int kpad_b = ((Tk_b + 31) & ~31) < KPAD ? ((Tk_b + 31) & ~31) : KPAD;   // key tiles past it are skipped
-  const bf16_t* kg = p.k + kbase * p.ldk + head * D;
-  const bf16_t* vg = p.v + kbase * p.ldv + head * D;
-  stage_head<D>(kg, p.ldk, Tk_b, kpad_b, kimg, tid, blockDim.x);
-  stage_head<D>(vg, p.ldv, Tk_b, kpad_b, vimg, tid, blockDim.x);
+  stage_head_seg<D>(p.k + head * D, p.ldk, kbase, sbase, p.ks_ins, Ts_b, Tk_b, kpad_b, kimg, tid, blockDim.x);
+  stage_head_seg<D>(p.v + head * D, p.ldv, kbase, sbase, p.ks_ins, Ts_b, Tk_b, kpad_b, vimg, tid, blockDim.x);
 
   // Q fragments straight from HBM (each element is used once per key tile, by this wave only) and the mask words
   // of the query row; the first tile's are requested before the staging barrier
@@ -1034,6 +1059,10 @@ extern "C" int unimm_attn_fwd(const unimm_attn_args* a, void* stream) {
   p.o = (bf16_t*)a->out; p.lse = a->lse; p.mask = a->mask;
   p.q_off = a->q_off; p.q_len = a->q_len; p.k_off = a->k_off; p.k_len = a->k_len;
   if ((p.q_off == nullptr) != (p.q_len == nullptr) || (p.k_off == nullptr) != (p.k_len == nullptr)) return UNIMM_E_ARG;
+  p.ks_off = a->ks_off; p.ks_len = a->ks_len; p.ks_ins = a->ks_ins;
+  if ((p.ks_off == nullptr) != (p.ks_len == nullptr)) return UNIMM_E_ARG;
+  if (p.ks_off != nullptr && (p.k_off == nullptr || a->ks_ins < 0 || a->drop_thr != 0u)) return UNIMM_E_ARG;   // variable-length keys, inference
+  if (p.ks_off == nullptr) p.ks_ins = 0;
   p.B = a->B; p.H = a->H; p.Tq = a->Tq; p.Tk = a->Tk;
   p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo;
   p.mask_q_stride = a->mask_q_stride; p.mask_b_stride = a->mask_b_stride;
@@ -1047,13 +1076,14 @@ extern "C" int unimm_attn_fwd(const unimm_attn_args* a, void* stream) {
 
 extern "C" int unimm_attn_probs(const unimm_attn_args* a, float* probs, void* stream) {
   if (a == nullptr || !a->q || !a->k || !a->mask || !probs) return UNIMM_E_ARG;
-  if (a->q_off || a->q_len || a->k_off || a->k_len) return UNIMM_E_ARG;          // fixed layout only
+  if (a->q_off || a->q_len || a->k_off || a->k_len || a->ks_off || a->ks_len) return UNIMM_E_ARG;   // fixed layout only
   if (a->B <= 0 || a->H <= 0 || a->Tq <= 0 || a->Tk <= 0 || a->Tq > 256 || a->Tk > 256) return UNIMM_E_SHAPE;
   if (a->D != 64 && a->D != 128) return UNIMM_E_SHAPE;
   if ((a->ldq % 8) || (a->ldk % 8) || (((uintptr_t)a->q | (uintptr_t)a->k) & 15)) return UNIMM_E_ALIGN;
   AttnParams p;
   p.q = (const bf16_t*)a->q; p.k = (const bf16_t*)a->k; p.v = nullptr; p.o = nullptr; p.lse = nullptr; p.mask = a->mask;
   p.q_off = p.q_len = p.k_off = p.k_len = nullptr;
+  p.ks_off = p.ks_len = nullptr; p.ks_ins = 0;
   p.B = a->B; p.H = a->H; p.Tq = a->Tq; p.Tk = a->Tk;
   p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = 0; p.ldo = 0;
   p.mask_q_stride = a->mask_q_stride; p.mask_b_stride = a->mask_b_stride; p.parts = 1;

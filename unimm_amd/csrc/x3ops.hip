@@ -1095,6 +1095,7 @@ int fill_attn(const unimm_attn_args* a, AttnF32& p) {
   if ((a->ldq % 4) || (a->ldk % 4) || (a->ldv % 4) || (a->ldo % 4)) return UNIMM_E_ALIGN;
   if (((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v | (uintptr_t)a->out) & 15) return UNIMM_E_ALIGN;
   if ((a->q_off == nullptr) != (a->q_len == nullptr) || (a->k_off == nullptr) != (a->k_len == nullptr)) return UNIMM_E_ARG;
+  if (a->ks_off != nullptr || a->ks_len != nullptr) return UNIMM_E_ARG;      // the spliced shared key segment is a bf16-kernel feature
   p = AttnF32{};
   p.q = (const float*)a->q; p.k = (const float*)a->k; p.v = (const float*)a->v; p.out = (float*)a->out; p.lse = a->lse;
   p.mask = a->mask; p.q_off = a->q_off; p.q_len = a->q_len; p.k_off = a->k_off; p.k_len = a->k_len;

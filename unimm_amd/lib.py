@@ -13,7 +13,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libunimm_hip.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROP_RESID, EPI_BIAS_RELU, EPI_DGELU, EPI_ADD, EPI_MUL, EPI_BIAS_GELU_DG = range(8)
 
@@ -252,7 +252,8 @@ class AttnArgs(C.Structure):
                 ("B", C.c_int32), ("H", C.c_int32), ("Tq", C.c_int32), ("Tk", C.c_int32), ("D", C.c_int32),
                 ("ldq", C.c_int32), ("ldk", C.c_int32), ("ldv", C.c_int32), ("ldo", C.c_int32),
                 ("mask_q_stride", C.c_int32), ("mask_b_stride", C.c_int32), ("scale", C.c_float),
-                ("drop_key", C.c_uint32), ("drop_thr", C.c_uint32), ("drop_scale", C.c_float), ("drop_salt", C.c_void_p)]
+                ("drop_key", C.c_uint32), ("drop_thr", C.c_uint32), ("drop_scale", C.c_float), ("drop_salt", C.c_void_p),
+                ("ks_off", C.c_void_p), ("ks_len", C.c_void_p), ("ks_ins", C.c_int32)]
 
 
 class AttnBwdArgs(C.Structure):
@@ -271,9 +272,11 @@ NO_DROP = (0, 0, 1.0)
 
 
 def attn_fwd(q, k, v, out, lse, mask, B, H, Tq, Tk, D, scale, mask_q_stride, mask_b_stride, drop=NO_DROP,
-             qvar=None, kvar=None):
+             qvar=None, kvar=None, kshared=None):
     """q/k/v/out: 2-D bf16 views [rows, >=H*D] (row stride = stride(0)); mask: packed uint32 words.
-    qvar / kvar: (offsets, lengths) int32 [B] tensors for the variable-length layout, or None."""
+    qvar / kvar: (offsets, lengths) int32 [B] tensors for the variable-length layout, or None.
+    kshared: (offsets, lengths, ins) -- a shared key/value segment spliced into every sequence's keys after its first `ins`
+    private rows (unimm_attn_args.ks_*; needs kvar, inference only)."""
     _dev(q, k, v, out, lse, mask)
     st = getattr(_tls, "af", None)
     if st is None:
@@ -283,6 +286,10 @@ def attn_fwd(q, k, v, out, lse, mask, B, H, Tq, Tk, D, scale, mask_q_stride, mas
     a.q, a.k, a.v, a.out, a.lse, a.mask = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _P(lse), mask.data_ptr()
     a.q_off, a.q_len = (qvar[0].data_ptr(), qvar[1].data_ptr()) if qvar is not None else (None, None)
     a.k_off, a.k_len = (kvar[0].data_ptr(), kvar[1].data_ptr()) if kvar is not None else (None, None)
+    if kshared is not None:
+        a.ks_off, a.ks_len, a.ks_ins = kshared[0].data_ptr(), kshared[1].data_ptr(), int(kshared[2])
+    else:
+        a.ks_off, a.ks_len, a.ks_ins = None, None, 0
     a.B, a.H, a.Tq, a.Tk, a.D = B, H, Tq, Tk, D
     a.ldq, a.ldk, a.ldv, a.ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
     a.mask_q_stride, a.mask_b_stride, a.scale = mask_q_stride, mask_b_stride, scale
@@ -299,6 +306,8 @@ def attn_probs(q, k, probs, mask, B, H, Tq, Tk, D, scale, mask_q_stride, mask_b_
     a = AttnArgs()
     a.q, a.k, a.v, a.out, a.lse, a.mask = q.data_ptr(), k.data_ptr(), None, None, None, mask.data_ptr()
     a.q_off = a.q_len = a.k_off = a.k_len = None
+    a.ks_off = a.ks_len = None
+    a.ks_ins = 0
     a.B, a.H, a.Tq, a.Tk, a.D = B, H, Tq, Tk, D
     a.ldq, a.ldk, a.ldv, a.ldo = q.stride(0), k.stride(0), 0, 0
     a.mask_q_stride, a.mask_b_stride, a.scale = mask_q_stride, mask_b_stride, scale

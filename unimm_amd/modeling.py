@@ -239,9 +239,17 @@ class BertForMultiModalPreTraining(nn.Module):
 
     # generative scoring without the [B,T,vocab] tensor (val_lm.py:121-136 / val_avg_lm.py:135)
     @torch.no_grad()
-    def sequence_log_likelihood(self, input_ids, image_feat, image_loc, masked_lm_labels, average=False, **kw):
+    def sequence_log_likelihood(self, input_ids, image_feat, image_loc, masked_lm_labels, average=False, shared_context=None, **kw):
         """-sum_t CE(pred_t, labels, ignore_index=-1) per sequence, computed on the labelled rows only by
-        the fused decoder + log-softmax kernels.  Returns (scores[B] fp32, nsp[B,2])."""
+        the fused decoder + log-softmax kernels.  Returns (scores[B] fp32, nsp[B,2]).
+        shared_context (an extension): one group id per sequence -- sequences of a group share image and dialog context and
+        differ only in the candidate answer, as the 100 options of a round in val_lm.py:52-121 do (pass the round index).  The
+        context rows and the image stream are then computed once per group (unimm_amd/scoring.py); a sequence whose context does
+        not match its group comes back as NaN.  bf16 engine; the fp32x3 engine takes the per-sequence path."""
+        if shared_context is not None and self.compute_dtype == "bf16":
+            from .scoring import sequence_log_likelihood_shared
+            return sequence_log_likelihood_shared(self, input_ids, image_feat, image_loc, masked_lm_labels, shared_context,
+                                                  average=average, **kw)
         eng = self._engine
         eng.ensure(self._device())
         inp = dict(input_ids=input_ids, image_feat=image_feat, image_loc=image_loc, masked_lm_labels=masked_lm_labels,

@@ -163,6 +163,47 @@ def make_batch(n_seq=240, T=256, R=37, cfg=None, seed=1234, dis_rate=0.5, num_ne
     return batch
 
 
+def make_scoring_batch(rounds=10, options=100, T=256, R=37, cfg=None, seed=1234, device="cpu", mask_dtype=torch.bool,
+                       c_range=(40, 200), a_range=(2, 12)):
+    """One image as val_lm.py:52-121 sees it: `rounds` dialog rounds x `options` candidate answers, generative mode, no random
+    masking (labels = the answer copy).  The `options` sequences of a round share the image and the whole context
+    [CLS] caption [SEP] q1 [SEP] a1 ... q_r [SEP] (tokens, segments, positions) and differ in the candidate answer only --
+    dataloader/dataloader_visdial.py builds them that way.  Returns the same keys as make_batch (sequence b = round b // options,
+    option b % options) plus `context_group` [rounds * options] = the round index, and `mask_spec`."""
+    vocab = cfg.vocab_size if cfg is not None else 30522
+    F = cfg.v_feature_size if cfg is not None else 2048
+    rng = np.random.default_rng(seed)
+    rows, group = [], []
+    for r in range(rounds):
+        ctx = random_utterances(rng, T, c_range=c_range, a_range=(a_range[1], a_range[1]))[:-1]     # context sized for the longest answer
+        ctx_tok = [rng.integers(min(1000, vocab // 2), vocab, size=l) for l in ctx]
+        seg0 = int(rng.integers(0, 2))
+        for _ in range(options):
+            a = int(rng.integers(a_range[0], a_range[1] + 1))
+            ans = rng.integers(min(1000, vocab // 2), vocab, size=a)
+            rows.append(build_sequence(ctx + [a], "gen", False, T=T, vocab=vocab, mask_prob=0.0, rng=rng, tokens=ctx_tok + [ans],
+                                       start_segment=seg0))
+            group.append(r)
+    n_seq = len(rows)
+    stack = lambda k: torch.from_numpy(np.stack([r[k] for r in rows]))
+    feat = np.maximum(rng.standard_normal((1, R, F), dtype=np.float32), 0)
+    feat[:, 0] = feat[:, 1:].mean(1)
+    loc = rng.random((1, R, 5), dtype=np.float32)
+    loc[:, 0] = [0, 0, 1, 1, 1]
+    co = stack("co_attention_mask")[:, None, :].expand(n_seq, R, T)
+    from .inputs import DialogMaskSpec
+    batch = dict(
+        input_ids=stack("tokens"), token_type_ids=stack("segments"), token_position_ids=stack("positions"),
+        masked_lm_labels=stack("labels"), attention_mask=stack("txt_attention_mask").to(mask_dtype),
+        co_attention_mask=co.to(mask_dtype).contiguous(),
+        image_feat=torch.from_numpy(feat).expand(n_seq, R, F).contiguous(), image_loc=torch.from_numpy(loc).expand(n_seq, R, 5).contiguous(),
+        image_attention_mask=torch.ones(n_seq, R), context_group=torch.tensor(group, dtype=torch.int64))
+    if device != "cpu":
+        batch = {k: v.to(device) for k, v in batch.items()}
+    batch["mask_spec"] = DialogMaskSpec([1] * n_seq, [r["L"] for r in rows], [r["n"] for r in rows])
+    return batch
+
+
 def make_loader_batch(n_img=2, rounds=2, samples=3, T=256, R=37, cfg=None, seed=1234, **kw):
     """The same content in the DATALOADER's layout (what train.py's `forward` receives, train.py:30-112):
     text fields [n_img, rounds, samples, ...], image fields per image [n_img, R, ...] (train.py:413-432
