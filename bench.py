@@ -567,8 +567,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    use_graphs = (args.graphs == "on" or (args.graphs == "auto" and per_gpu <= GRAPHS_AUTO_MAX_SEQ)) and args.workload == "train" \
-        and not args.compact_inputs and not args.host_profile and args.compute == "bf16" and args.host_inputs == "off"
+    use_graphs = (args.graphs == "on" or (args.graphs == "auto" and per_gpu <= GRAPHS_AUTO_MAX_SEQ)) and args.workload in ("train", "dense") \
+        and not args.compact_inputs and not args.host_profile and args.host_inputs == "off"
     gx = None
     if use_graphs:
         gx = model.engine.enable_graphs(True)

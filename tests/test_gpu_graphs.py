@@ -13,11 +13,11 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _build(golden_dir):
+def _build(golden_dir, compute="bf16"):
     from oracle import vilbert_ref as R
     from unimm_amd import BertConfig, BertForMultiModalPreTraining
     cfgd = json.load(open(os.path.join(golden_dir, "small_config.json")))
-    model = BertForMultiModalPreTraining(BertConfig.from_dict(cfgd))
+    model = BertForMultiModalPreTraining(BertConfig.from_dict(cfgd), compute_dtype=compute)
     model.load_state_dict(R.init_state_dict(R.make_config(cfgd), seed=11), strict=True)
     return model.cuda()
 
@@ -34,10 +34,11 @@ def _step(model, b):
     return (torch.stack([lm, img, nsp_l]).flatten().detach().clone(), nsp.detach().clone(), model.engine.arena.grad_flat.clone())
 
 
+@pytest.mark.parametrize("compute", ["bf16", "fp32x3"])
 @pytest.mark.parametrize("train", [True, False])
-def test_graph_replay_equals_eager_steps(golden_dir, train):
+def test_graph_replay_equals_eager_steps(golden_dir, train, compute):
     from unimm_amd import synth
-    ref, gm = _build(golden_dir), _build(golden_dir)
+    ref, gm = _build(golden_dir, compute), _build(golden_dir, compute)
     for m in (ref, gm):
         m.train(train)
         m.set_dropout_seed(321)

@@ -10,7 +10,7 @@ residual-join that the bf16 path fuses into GEMM epilogues), run LayerNorm / emb
 and compute the attention cores in fp32 on the vector ALUs.  Masks, the unpadded schedule, dropout counters, the row-sparse
 decoder, the fp32 pooler / NSP heads, the loss kernels and the flat gradient arena are the base engine's.
 
-The base engine's two-stream schedule (image side beside the text side), eager launches (no graph executor), no lazy
+The base engine's two-stream schedule (image side beside the text side), eager launches or the graph executor, no lazy
 LayerNorm: this is the accuracy mode, ~0.3 of the bf16 engine's throughput.  There is no CPU / eager-PyTorch fallback here either."""
 from __future__ import annotations
 
@@ -43,7 +43,7 @@ class EngineX3(Engine):
         super().__init__(model, cfg)
         self.dual_stream = True           # the base engine's two-stream schedule (image side beside the text side)
         self.lazy_ln = False
-        self.splitk = False
+        self.splitk = True                # small batches: the long reductions (K = 3 x 768 ... 3 x 3072) as two workgroups per tile
         self.attn_planes = True      # attention kernels write the next GEMM's split operand themselves (matrix kernels; False for
                                      # A/B runs of the vector kernels: fp32 result + a split pass)
 
@@ -80,10 +80,32 @@ class EngineX3(Engine):
         torch.add(A.view(v + "image_embeddings.bias"), A.view(v + "image_location_embeddings.bias"), out=self.vemb_b)
         self._w_version = ver
 
-    def enable_graphs(self, on=True, **kw):
-        if on:
-            raise L.UnimmHipError("the graph executor replays the bf16 engine's launch sequence; the fp32x3 mode runs eagerly")
-        self.graphs = None
+    # (enable_graphs is the base engine's: the fp32x3 launch sequence carries the same device-side row counts, loss
+    #  denominators and dropout salt word through its kernels, so unimm_amd/graphs.py captures and replays it unchanged --
+    #  round 5; configs[3] on 8 GPUs is 12-13 sequences per rank in this arithmetic class, where ~17 ms of host calls per
+    #  eager step would otherwise bound the step)
+
+    def _splitk(self, M, N, K):
+        """(tile code, splitk, workspace) for a GEMM of the small-batch regime, or None.  Every reduction of this mode is three
+        planes long (K = 2304 ... 9216) while a per-rank share of configs[3] has ~1.7k text rows: 162 tiles of 64x128, each a
+        36-144 step chain.  Measured at 1,700 rows (profiles/r5*_x3_small_batch_gemm_microbench.txt): N = 768, K = 9216 78.7 us ->
+        41.5 us as 128x128 tiles with four workgroups per tile; K = 2304 / 3072 22.3 / 30.2 -> 18.1 / 24.1 us on the 3-slot ring
+        of the 64x128 tile (two K steps in flight), no split.  (Four splits: the sum's last bits depend on which split arrives
+        last, like the atomically accumulated weight gradients.)"""
+        if not self.splitk or self._on_side or self.gemm_tile != 0 or self._step_rows is None or self._step_rows >= self.small_rows:
+            return None
+        if M != self._step_rows or N > 1024 or K < 2048:
+            return None
+        t128 = ((M + 127) // 128) * ((N + 127) // 128)
+        if K >= 6144 and 2 * t128 <= 512:
+            dev = self.arena.flat.device
+            key = int(torch.cuda.current_stream(dev).cuda_stream)
+            ws = self._splitk_ws.get(key)
+            if ws is None:
+                ws = self._splitk_ws[key] = torch.zeros(self.splitk_ws_bytes, dtype=torch.uint8, device=dev)
+            return 1, (4 if 4 * t128 <= 512 else 2), ws
+        if ((M + 63) // 64) * ((N + 127) // 128) <= 512:
+            return 9, 0, None
         return None
 
     # ------------------------------------------------------------------------------------------
@@ -105,7 +127,9 @@ class EngineX3(Engine):
     def _lin3(self, x3, lin, epi=L.EPI_BIAS, aux=None, drop=None, ldo=None, M=None, bias=True):
         M = x3.shape[0] if M is None else M
         out = torch.empty((M, ldo or lin.N), dtype=F32, device=x3.device)
-        L.gemm_nt(x3, lin.w3, out, bias=lin.bias if bias else None, epilogue=epi, aux=aux, drop=drop, M=M, N=lin.N, K=3 * lin.Kp)
+        sk = self._splitk(M, lin.N, 3 * lin.Kp)
+        skw = dict(tile=sk[0], splitk=sk[1], splitk_ws=sk[2]) if sk is not None else {}
+        L.gemm_nt(x3, lin.w3, out, bias=lin.bias if bias else None, epilogue=epi, aux=aux, drop=drop, M=M, N=lin.N, K=3 * lin.Kp, **skw)
         return out
 
     def _wgrad3(self, dy3, x3, gw, M, N, K, Np, Kp, dbias=None, m_dev=None, xcol0=0):
@@ -124,10 +148,12 @@ class EngineX3(Engine):
         if not need_dx:
             return None
         dx = torch.empty((M, lin.K), dtype=F32, device=dy3.device)
+        sk = self._splitk(M, lin.K, 3 * lin.Np)
+        skw = dict(tile=sk[0], splitk=sk[1], splitk_ws=sk[2]) if sk is not None else {}
         if add is None:
-            L.gemm_nt(dy3, lin.wt3, dx, bias=None, M=M, N=lin.K, K=3 * lin.Np)
+            L.gemm_nt(dy3, lin.wt3, dx, bias=None, M=M, N=lin.K, K=3 * lin.Np, **skw)
         else:
-            L.gemm_nt(dy3, lin.wt3, dx, bias=None, epilogue=L.EPI_BIAS_DROP_RESID, aux=add, M=M, N=lin.K, K=3 * lin.Np)
+            L.gemm_nt(dy3, lin.wt3, dx, bias=None, epilogue=L.EPI_BIAS_DROP_RESID, aux=add, M=M, N=lin.K, K=3 * lin.Np, **skw)
         return dx
 
     def _ln3(self, x, key, save, drop=L.NO_DROP, want3=True):
