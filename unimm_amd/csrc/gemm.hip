@@ -10,7 +10,6 @@ int unimm_nt_launch_cfg7(const GemmNtParams& p, int epi, bool out_f32, int want_
 int unimm_nt_launch_cfg8(const GemmNtParams& p, int epi, bool out_f32, int want_persist, hipStream_t s, const NtSplit& sk);
 int unimm_nt_launch_cfg9(const GemmNtParams& p, int epi, bool out_f32, int want_persist, hipStream_t s, const NtSplit& sk);
 int unimm_nt_launch_cfg10(const GemmNtParams& p, int epi, bool out_f32, int want_persist, hipStream_t s, const NtSplit& sk);
-int unimm_nt_launch_cfg11(const GemmNtParams& p, int epi, bool out_f32, int want_persist, hipStream_t s, const NtSplit& sk);
 
 int unimm_cu_count() {
   static int n = 0;
@@ -622,10 +621,10 @@ struct NtTune { int cfg, persist, gn; };
 inline bool nt_tune_decode(int code, NtTune& t) {
   if (code < 0 || code > 999 * 1000 + 999) return false;
   const int pc = (code % 1000) / 100;
-  t.persist = pc == 0 ? -1 : (pc == 1 ? 1 : (pc == 2 ? 0 : pc));   // x1xx persistent, x2xx one workgroup per tile, x3xx / x4xx the same with a staggered start, else automatic
+  t.persist = pc == 0 ? -1 : (pc == 1 ? 1 : 0);           // x1xx persistent, x2xx one workgroup per tile, else automatic
   t.cfg = code % 100;
   t.gn = code / 1000;
-  return pc <= 4 && (t.cfg == 0 || t.cfg == 1 || t.cfg == 3 || t.cfg == 6 || t.cfg == 7 || t.cfg == 8 || t.cfg == 9 || t.cfg == 10 || t.cfg == 11);
+  return pc <= 2 && (t.cfg == 0 || t.cfg == 1 || t.cfg == 3 || t.cfg == 6 || t.cfg == 7 || t.cfg == 8 || t.cfg == 9 || t.cfg == 10);
 }
 
 
@@ -674,9 +673,6 @@ int launch_nt(const GemmNtParams& p, int epi, bool out_f32, const NtTune& tune, 
   if (cfg == 9) return unimm_nt_launch_cfg9(p, epi, out_f32, wp, s, sk);
   if (cfg == 10) return unimm_nt_launch_cfg10(p, epi, out_f32, wp, s, sk);
   if (cfg == 3) return unimm_nt_launch_cfg3(p, epi, out_f32, wp, s, nosplit);
-  // 11 = 128x256 as 4 waves of 128x64 on a 3-slot ring of BK = 32 (72 KiB): TWO workgroups per CU, each with the wave tile of
-  // the 256x256 kernels, so that one workgroup's epilogue runs under the other's main loop (round 5)
-  if (cfg == 11) return unimm_nt_launch_cfg11(p, epi, out_f32, wp, s, nosplit);
   return unimm_nt_launch_cfg1(p, epi, out_f32, wp, s, sk);
 }
 

@@ -36,7 +36,6 @@ struct GemmNtParams {
   // split-K (ring-loop tiles only; see nt_split_join): ksplit workgroups share one output tile, each reduces a slice of K,
   // partial tiles meet in `slabs` and the last arriver (ticket in `counters`) runs the epilogue.  ksplit <= 1: off.
   int ksplit; float* slabs; int* counters;
-  int stagger;       // > 0: workgroups 256..511 of the grid (the second resident workgroup of every CU) start this many 10-ns ticks late
 };
 struct NtSplit { int want; void* ws; long ws_bytes; };     // want: 0 / 1 = off, >= 2 = that many splits, -1 = the library's choice
 
@@ -889,21 +888,10 @@ __device__ __forceinline__ void nt_tile(const GemmNtParams& p, char* smem, int l
   nt_epilogue<C, EPI, OUT_F32>(p, acc, smem, m0, n0, wm, wn, wave, lane);
 }
 
-// Two workgroups per CU that start together run in phase: both in their main loops (sharing the CU's staging path), then both in
-// their epilogues (no MFMA issued at all).  Holding back the second resident workgroup of every CU by about half a tile puts
-// one workgroup's epilogue under the other's main loop.  Which workgroups share a CU is the dispatcher's business (speed only).
-__device__ __forceinline__ void nt_stagger(const GemmNtParams& p) {
-  if (p.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
-    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-    while (__builtin_amdgcn_s_memrealtime() - t0 < (uint64_t)p.stagger) __builtin_amdgcn_s_sleep(16);
-  }
-}
-
 template <class C, int EPI, bool OUT_F32>
 __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES) void gemm_nt_kernel(GemmNtParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if constexpr (EPI == UNIMM_EPI_BIAS_DROP_RESID) drop_resolve(p.drop);
-  if constexpr (C::WG_PER_CU == 2 && C::MT == 8) nt_stagger(p);
   nt_tile<C, EPI, OUT_F32>(p, smem, xcd_remap(blockIdx.x, gridDim.x));
 }
 
@@ -915,7 +903,6 @@ template <class C, int EPI, bool OUT_F32>
 __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES) void gemm_ntp_kernel(GemmNtParams p, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if constexpr (EPI == UNIMM_EPI_BIAS_DROP_RESID) drop_resolve(p.drop);
-  if constexpr (C::WG_PER_CU == 2 && C::MT == 8) nt_stagger(p);
   for (int lt = blockIdx.x; lt < ntiles; lt += gridDim.x) {
     if (lt != (int)blockIdx.x) __builtin_amdgcn_s_barrier();   // every wave has left its epilogue slab (it aliases the ring)
     nt_tile<C, EPI, OUT_F32>(p, smem, xcd_remap(lt, ntiles));
@@ -923,7 +910,7 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES) void gemm_ntp_kernel(Gemm
 }
 
 template <class C> constexpr int nt_tile_code() {
-  return C::PP ? 8 : (C::MT == 8 ? (C::NW == 4 ? 11 : 3) : (C::MT == 6 ? 6 : (C::MT == 2 ? (C::STAGES == 3 ? 9 : 7) : (C::STAGES == 3 ? 10 : 1))));
+  return C::PP ? 8 : (C::MT == 8 ? 3 : (C::MT == 6 ? 6 : (C::MT == 2 ? (C::STAGES == 3 ? 9 : 7) : (C::STAGES == 3 ? 10 : 1))));
 }
 
 template <class C, int EPI, bool F32> constexpr auto pick_nt_kernel() { return &gemm_nt_kernel<C, EPI, F32>; }
@@ -931,13 +918,6 @@ template <class C, int EPI, bool F32> constexpr auto pick_nt_kernel() { return &
 template <class C, int EPI>
 int launch_nt_cfg(const GemmNtParams& p_in, bool out_f32, int want_persist, hipStream_t s, const NtSplit& sk = NtSplit{0, nullptr, 0}) {
   GemmNtParams p = p_in;
-  p.stagger = 0;
-  if (want_persist >= 3) {                       // x3xx persistent + staggered start, x4xx one workgroup per tile + staggered start
-    static int ticks_per_step = -1;
-    if (ticks_per_step < 0) { const char* e = getenv("UNIMM_EXP_STAGGER"); ticks_per_step = e ? atoi(e) : 40; }
-    p.stagger = (p.K / 64) * ticks_per_step;
-    want_persist = want_persist == 3 ? 1 : 0;
-  }
   int nwg = ((p.M + C::BM - 1) / C::BM) * ((p.N + C::BN - 1) / C::BN);
   p.ksplit = 1; p.slabs = nullptr; p.counters = nullptr;
   if (!C::PP && sk.want != 0 && sk.want != 1 && sk.ws != nullptr) {
