@@ -115,6 +115,8 @@ def parse():
     ap.add_argument("--gemm-tile", type=int, default=0, metavar="CODE",
                     help="tuning: unimm_gemm_nt_args.tile = CODE for every launch of the run (1000 x tile columns per group + 100 x {1 persistent, "
                          "2 one workgroup per tile} + tile configuration; 0 = the library's defaults)")
+    ap.add_argument("--tile-table", default="", metavar="SPEC",
+                    help="tuning: per-shape tile codes of the small-batch regime, e.g. t:3072:768=8,i:1024:1024=6 (side:N:K=code)")
     ap.add_argument("--host-profile", default=None, metavar="FILE",
                     help="after warm-up, cProfile 5 untimed steps of host-side enqueue work into FILE (text, by own time)")
     ap.add_argument("--no-padded", action="store_true", help="skip the 3 extra steps that time the padded schedule beside the default")
@@ -526,6 +528,11 @@ def main():
         return fwd_bwd()
 
     model.engine.gemm_tile = args.gemm_tile      # per-call tuning code of every unimm_gemm_nt launch (0 = automatic)
+    if args.tile_table:
+        for ent in args.tile_table.split(","):
+            k, code = ent.split("=")
+            side, n_, k_ = k.split(":")
+            model.engine.tile_table[(side, int(n_), int(k_))] = int(code)
     if args.no_splitk:
         model.engine.splitk = False
     if args.single_stream:

@@ -112,6 +112,10 @@ typedef struct {
   int32_t lddy, ldx, lddw;
   const int32_t* m_dev; /* or NULL: device word holding the number of reduction rows actually present; M is then the
                          * CAPACITY the launch is sized for (replayed launch sequences: see unimm_plan_build) */
+  int32_t overwrite;    /* != 0: DW = DY^T X instead of +=.  The caller asserts that dw is all zero and that no other problem,
+                         * launch or stream adds to it concurrently; a tile reduced by one workgroup is then written with plain
+                         * stores (no memory-side atomics).  Ignored (+= as usual) where the reduction is split.  dbias always +=.
+                         * ABI 16. */
 } unimm_gemm_tn_args;
 
 int unimm_gemm_tn(const unimm_gemm_tn_args* args, void* stream);

@@ -451,3 +451,43 @@ def test_gemm_nt_split_k_hand_off_under_uneven_load():
         b2 = torch.empty_like(a)
         lib.gemm_nt(xs[0], w, b2, epilogue=lib.EPI_ADD, aux=aux, tile=1, splitk=2, splitk_ws=ws)
         assert torch.equal(a, b2)
+
+
+def test_gemm_tn_overwrite_writes_what_the_atomic_path_adds_to_zeros():
+    """unimm_gemm_tn_args.overwrite: a problem whose gradient is known to be zero and has no other contributor is WRITTEN (plain
+    stores) -- bit-identical to the atomic path on a zeroed buffer where one workgroup reduces a tile, whatever the buffer held
+    before (NaN-filled here); pad columns of a strided gradient stay untouched; the bias gradient still accumulates; and where
+    the launch splits the reduction over several workgroups (short M against few tiles) the flag is ignored and += survives."""
+    from unimm_amd import lib
+    g = torch.Generator(device="cuda").manual_seed(77)
+    M = 1500                                # < 2,048 reduction rows: the launch never splits the reduction (one workgroup per tile)
+    shapes = [(768, 768), (2304, 768), (768, 3072), (1000, 520), (200, 72)]
+    pa, pb = [], []
+    for (N, K) in shapes:
+        ldy, ldx, ldw = (N + 7) // 8 * 8, (K + 7) // 8 * 8, K + 4
+        dy = torch.zeros((M, ldy), device="cuda", dtype=torch.bfloat16)
+        x = torch.zeros((M, ldx), device="cuda", dtype=torch.bfloat16)
+        dy[:, :N] = _rand((M, N), g)
+        x[:, :K] = _rand((M, K), g)
+        dwa = torch.zeros((N, ldw), device="cuda")
+        dwb = torch.full((N, ldw), float("nan"), device="cuda")
+        dwb[:, K:] = 7.0
+        dba, dbb = torch.ones(N, device="cuda"), torch.ones(N, device="cuda")
+        pa.append((dy, x, dwa[:, :K], M, N, K, dba, None, False))
+        pb.append((dy, x, dwb[:, :K], M, N, K, dbb, None, True))
+    lib.gemm_tn_grouped(pa, shared=True)
+    lib.gemm_tn_grouped(pb, shared=True)
+    torch.cuda.synchronize()
+    for (_, _, dwa, _, N, K, dba, *_), (_, _, dwb, _, _, _, dbb, *_) in zip(pa, pb):
+        assert torch.equal(dwa, dwb), (N, K, float((dwa - dwb).abs().max()))
+        assert (dwb.as_strided((N, 4), (K + 4, 1), dwb.storage_offset() + K) == 7.0).all()
+        assert (dba - dbb).abs().max().item() <= 1e-4 * max(1.0, dba.abs().max().item())     # (atomics from several tiles: order)
+    # a launch that splits the reduction: 3 tiles of 256 x 256 against 40,000 rows -> several workgroups per tile, += kept
+    M2, N2, K2 = 40000, 256, 768
+    dy, x = _rand((M2, N2), g), _rand((M2, K2), g)
+    base = torch.randn((N2, K2), generator=g, device="cuda")
+    dw = base.clone()
+    lib.gemm_tn_grouped([(dy, x, dw, M2, N2, K2, None, None, True)], shared=False)
+    torch.cuda.synchronize()
+    ref = base + dy.float().t() @ x.float()
+    assert (dw - ref).abs().max().item() <= 3e-3 * ref.abs().max().item()

@@ -597,3 +597,51 @@ def test_mask_rank_errors_and_default_masks(golden_dir, small):
     with torch.no_grad():
         want = R_.forward(leaves, ocfg, ids, feat, loc, position_ids=kw["position_ids"])
     close(none[2], want["nsp"].numpy(), what="nsp with default masks")
+
+
+def test_weight_gradients_written_into_a_fresh_arena_equal_the_atomic_path(golden_dir):
+    """Engine.wgrad_overwrite: after arena.zero_grads() the weight gradients with a single contributor are WRITTEN by their
+    grouped launches (unimm_gemm_tn_args.overwrite) instead of added with atomics.  Same gradients as the atomic path (the
+    tied word-embedding / decoder matrix and the biases still accumulate); a second backward WITHOUT zeroing in between
+    (batch_multiply accumulation) must add, not overwrite; gradients dropped with set_to_none come back zeroed and fresh."""
+    from unimm_amd import synth
+    model, _, _ = build_small(golden_dir)
+    model.train()
+    eng = model.engine
+    b = synth.make_batch(n_seq=12, T=64, R=37, cfg=model.config, seed=41, sequences_per_image=6, device="cuda")
+    nsp_w = b.pop("nsp_weight")
+    kw = dict(token_type_ids=b["token_type_ids"], position_ids=b["token_position_ids"], attention_mask=b["attention_mask"],
+              co_attention_mask=b["co_attention_mask"], image_attention_mask=b["image_attention_mask"],
+              masked_lm_labels=b["masked_lm_labels"], image_label=b["image_label"], image_target=b["image_target"],
+              next_sentence_label=b["next_sentence_label"], nsp_weight=nsp_w, lm_weight=b["lm_weight"], _want_lm_scores=False)
+
+    def two_steps(overwrite, zero):
+        eng.wgrad_overwrite = overwrite
+        model.set_dropout_seed(9, step=0)
+        out = []
+        zero()
+        for k in range(2):                                   # second backward accumulates on top of the first
+            r = model(b["input_ids"], b["image_feat"], b["image_loc"], **kw)
+            if k == 0:
+                assert eng.arena.fresh
+            (r[0] + r[1] + r[2]).sum().backward()
+            torch.cuda.synchronize()
+            assert not eng.arena.fresh
+            out.append(eng.arena.grad_flat.clone())
+        return out
+
+    was = eng.wgrad_overwrite
+    try:
+        eng.ensure(torch.device("cuda", 0))
+        r0 = model(b["input_ids"], b["image_feat"], b["image_loc"], **kw)      # builds the arena
+        (r0[0] + r0[1] + r0[2]).sum().backward()
+        ref = two_steps(False, eng.arena.zero_grads)
+        got = two_steps(True, eng.arena.zero_grads)
+        got2 = two_steps(True, lambda: model.zero_grad(set_to_none=True))
+    finally:
+        eng.wgrad_overwrite = was
+    for a, c, d in zip(ref, got, got2):
+        assert torch.isfinite(c).all()
+        scale = float(a.abs().max())
+        assert float((a - c).abs().max()) <= 1e-5 * scale and float((a - d).abs().max()) <= 1e-5 * scale
+    assert float((got[1] - got[0]).abs().max()) > 0.1 * float(got[0].abs().max())      # the second pass really accumulated

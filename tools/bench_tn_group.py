@@ -14,7 +14,7 @@ for (N, K) in [(2304, 768), (768, 768), (3072, 768), (768, 3072)] * nblocks:
     dy = torch.randn((M, N), generator=g, device="cuda").to(torch.bfloat16)
     x = torch.randn((M, K), generator=g, device="cuda").to(torch.bfloat16)
     dw = torch.zeros((N, K), device="cuda"); db = torch.zeros(N, device="cuda")
-    probs.append((dy, x, dw, None, None, None, None if "nobias" in sys.argv else db))
+    probs.append((dy, x, dw, None, None, None, None if "nobias" in sys.argv else db, None, "overwrite" in sys.argv))
     fl += 2.0 * M * N * K
 def timed(code):
     def run(): lib.gemm_tn_grouped(probs, shared=code)

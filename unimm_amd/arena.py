@@ -46,6 +46,7 @@ class FlatArena:
                 view.copy_(p.data.to(self.device))
                 p.data = view
         self._grads_attached = False
+        self.fresh = False                        # see zero_grads
         probe = []
         for _, items in groups:
             for name, _ in items:
@@ -96,12 +97,18 @@ class FlatArena:
         if ok:
             return
         self.grad_flat.zero_()
+        self.fresh = True
         for name, p in self.params.items():
             p.grad = None if P.is_unused(name) else self.grad(name)
         self._grads_attached = True
 
     def zero_grads(self):
+        """One memset; marks the arena `fresh`: every gradient is known to be zero until the next backward has run (the engine
+        then WRITES the weight gradients that have a single contributor instead of adding to them with atomics, Engine._wgrad).
+        Anything else that changes gradients in place behind the arena's back (a caller adding to p.grad by hand before
+        backward) must clear the flag: `arena.fresh = False`."""
         self.grad_flat.zero_()
+        self.fresh = True
 
     def used_ranges(self) -> List[Tuple[str, int, int]]:
         return list(self.buckets)

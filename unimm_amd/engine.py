@@ -118,6 +118,9 @@ class Engine:
         self._inject_header = None       # header values of the step, read ahead of a graph capture (see _forward, graphs.py)
         self.graphs = None               # unimm_amd.graphs.StepGraphs once enable_graphs() was called
         self.image_tile = 8              # tile code of the image side's GEMMs in the large-batch regime (0 = the library's choice; see _tile)
+        self.wgrad_overwrite = True      # weight gradients with a single contributor are WRITTEN into a freshly zeroed arena (no atomics)
+        self._bwd_fresh = False
+        self.tile_table = {}             # {("t" | "i", N, K): tile code}: per-shape choices of the small-batch regime (see _tile)
         self.small_rows = 12000          # text rows per step below which the encoder GEMMs take the small-batch tile rule (_tile)
         self._step_rows = None           # text rows of the running step (set by _forward)
         self.image_head_side = True      # image prediction head (forward and backward) on the image stream, beside the MLM head
@@ -336,10 +339,10 @@ class Engine:
                       tile=sk[0], splitk=sk[1], splitk_ws=sk[2])
         else:
             L.gemm_nt(x, lin.w, out, bias=lin.bias, epilogue=epi, aux=aux, out2=u, drop=drop, M=M, N=lin.N, K=lin.K, aux_ln=aux_ln,
-                      tile=self._tile(M, lin.N))
+                      tile=self._tile(M, lin.N, lin.K))
         return (out, u) if want_u else out
 
-    def _tile(self, M, N):
+    def _tile(self, M, N, K=None):
         """Tile code of one encoder GEMM (unimm_gemm_nt_args.tile).  0 = the kernel library's own choice, which is tuned for
         launches that have the chip to themselves.  In the small-batch regime (fewer than `small_rows` text rows in the step: the
         per-GPU share of a batch split over 4-8 ranks) neither stream's launches fill the chip and the two streams' kernels run
@@ -355,6 +358,10 @@ class Engine:
             return self.gemm_tile
         if self._step_rows is None:               # outside a step: the library's own choice
             return 0
+        if self.tile_table and K is not None:     # per-shape codes (side, N, K) of the small-batch regime (bench.py --tile-table)
+            code = self.tile_table.get(("i" if self._on_side else "t", N, K))
+            if code is not None and self._step_rows < self.small_rows:
+                return code
         if self._step_rows >= self.small_rows:
             return self.image_tile if (self._on_side and self.image_tile) else 0
         if self._on_side:
@@ -402,11 +409,16 @@ class Engine:
         dx = torch.empty((M, K), dtype=F32, device=dy.device)
         return L.linear_f32(dy, w32, dx, M, K, N, (dy.stride(0), 1), (w32.stride(0), 1))
 
-    def _wgrad(self, dy, x, gw, M, N, K, dbias=None, m_dev=None):
+    def _wgrad(self, dy, x, gw, M, N, K, dbias=None, m_dev=None, sole=False):
         """dW += dy^T x (+ bias gradient).  Nothing downstream in the backward chain reads a weight gradient,
         so the call is only queued; `_flush_wgrad` hands the list of SEVERAL encoder blocks to one grouped launch
-        (`_flush_due` says when).  dy / x stay referenced by the queue until then."""
-        (self._wq_img if self._on_side else self._wq).append((dy, x, gw, M, N, K, dbias, m_dev))
+        (`_flush_due` says when).  dy / x stay referenced by the queue until then.
+        sole: this call is the ONLY contribution to gw in a backward pass (every encoder nn.Linear; not the tied decoder /
+        word-embedding matrix, not the three split-operand products of the fp32x3 mode).  When the gradient arena is also known
+        to be zero (`arena.fresh`: zeroed since the last backward) the kernel then writes the tile with plain stores instead of
+        256 KiB of memory-side atomics per workgroup (unimm_gemm_tn_args.overwrite)."""
+        ow = bool(sole and self._bwd_fresh and self.wgrad_overwrite)
+        (self._wq_img if self._on_side else self._wq).append((dy, x, gw, M, N, K, dbias, m_dev, ow))
         self._nq[1 if self._on_side else 0] += 1
         if self.prof_conn is not None:            # FLOPs of the weight gradients queued from inside / outside a connection layer
             MM = dy.shape[0] if M is None else M
@@ -514,7 +526,7 @@ class Engine:
         M = dy.shape[0] if M is None else M
         N = lin.N if N is None else N
         self._wgrad(dy, x, lin.gw, M, N, lin.K if xk is None else xk,
-                    dbias=lin.gb if (bias_grad and lin.gb is not None) else None, m_dev=m_dev)
+                    dbias=lin.gb if (bias_grad and lin.gb is not None) else None, m_dev=m_dev, sole=lin is not self.lin.get("dec"))
         if not need_dx:
             return None
         dx = torch.empty((M, lin.K), dtype=BF16, device=dy.device)
@@ -523,7 +535,7 @@ class Engine:
         if sk is not None:
             L.gemm_nt(dy, lin.wt, dx, bias=None, epilogue=epi, aux=aux, M=M, N=lin.K, K=kdim, tile=sk[0], splitk=sk[1], splitk_ws=sk[2])
         else:
-            L.gemm_nt(dy, lin.wt, dx, bias=None, epilogue=epi, aux=aux, M=M, N=lin.K, K=kdim, tile=self._tile(M, lin.K))
+            L.gemm_nt(dy, lin.wt, dx, bias=None, epilogue=epi, aux=aux, M=M, N=lin.K, K=kdim, tile=self._tile(M, lin.K, kdim))
         return dx
 
     def _decoder_dx(self, dlog, dec, n, V):
@@ -1090,8 +1102,8 @@ class Engine:
                     before = dbias.clone()
                     dpre, _ = self._layernorm_bwd(dxv, prev, mv, rv, "emb_v", dbias=dbias, out_drop=d_embv, defer=False)
                     A.grad(v + "image_location_embeddings.bias").add_(dbias - before)
-                    self._wgrad(dpre, packed, A.grad(v + "image_embeddings.weight"), B * R, Hv, F)
-                    self._wgrad(dpre, packed[:, F:], A.grad(v + "image_location_embeddings.weight"), B * R, Hv, 5)
+                    self._wgrad(dpre, packed, A.grad(v + "image_embeddings.weight"), B * R, Hv, F, sole=True)
+                    self._wgrad(dpre, packed[:, F:], A.grad(v + "image_location_embeddings.weight"), B * R, Hv, 5, sole=True)
 
         pl = self._prep_plan(inp, B, T, R, tmask, comask, lm_rows, dev)
         ids32, typ32, pos32, labels = pl["ids32"], pl["typ32"], pl["pos32"], pl["labels"]
@@ -1312,6 +1324,7 @@ class Engine:
         H, Hv = cfg.hidden_size, cfg.v_hidden_size
         seq_t, seq_v = out["seq_out_t"], out["seq_out_v"]
         self.arena.attach_grads()
+        self._bwd_fresh = bool(self.arena.fresh)   # gradients known to be zero: sole contributors may write instead of add (_wgrad)
         self._step_rows = out["Mt"]              # the tile rule follows THIS step's rows (another forward may have run since)
 
         def gvec(g):
@@ -1409,6 +1422,8 @@ class Engine:
         bw["embt"](gt)
         self._to_txt()                                       # everything joined before the caller continues
         self._bucket_done("text_embeddings")
+        self.arena.fresh = False                             # the arena holds this pass's gradients now
+        self._bwd_fresh = False
 
     def _bucket_done(self, group):
         """A block's backward is enqueued.  Its weight gradients may stay queued for a later grouped launch (`_flush_due`);

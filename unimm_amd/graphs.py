@@ -238,16 +238,20 @@ class StepGraphs:
         eng = self.eng
         dev = eng.arena.device
         grads = (g_lm, g_img, g_nsp, g_scores)
-        gkey = tuple(None if g is None else tuple(g.shape) for g in grads)
         eng.arena.attach_grads()        # BEFORE a capture: it zeroes the arena when .grad was dropped, which must not be replayed
+        shapes = tuple(None if g is None else tuple(g.shape) for g in grads)
+        fresh = bool(eng.arena.fresh)   # write-vs-add of the weight gradients is frozen into the launches: one program per state
         self._set_salt(ent.salt_val)    # the masks of THIS step's forward (another replay may have re-salted since)
-        if ent.gB is None or ent.gkey != gkey:
-            ent.gkey = gkey
+        if ent.gB is None or ent.gkey != shapes:
+            ent.gkey = shapes
             ent.gin = [None if g is None else torch.zeros(g.shape, dtype=torch.float32, device=dev) for g in grads]
+            ent.gB = {}
+        prog = ent.gB.get(fresh)
+        if prog is None:
             for s, g in zip(ent.gin, grads):
                 if s is not None:
                     s.copy_(g.detach().to(torch.float32))
-            ent.gB = self._capture_backward(ent)
+            prog = ent.gB[fresh] = self._capture_backward(ent)
             self.stats["captures"] += 1
         else:
             pairs = [(s, g.detach()) for s, g in zip(ent.gin, grads) if s is not None]
@@ -257,9 +261,10 @@ class StepGraphs:
                 for s, g in pairs:
                     s.copy_(g, non_blocking=True)
         hook = eng.grad_bucket_hook
-        for item in ent.gB:                                    # graph segments and, between them, the bucket hand-overs
+        for item in prog:                                      # graph segments and, between them, the bucket hand-overs
             if isinstance(item, tuple):
                 if hook is not None:
                     hook(*item)
             else:
                 item.replay()
+        eng.arena.fresh = False                                # (a replay does not run Engine._backward, which clears it eagerly)

@@ -39,7 +39,7 @@ class GemmNtArgs(C.Structure):
 class GemmTnArgs(C.Structure):
     _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("dbias", C.c_void_p),
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
-                ("lddy", C.c_int32), ("ldx", C.c_int32), ("lddw", C.c_int32), ("m_dev", C.c_void_p)]
+                ("lddy", C.c_int32), ("ldx", C.c_int32), ("lddw", C.c_int32), ("m_dev", C.c_void_p), ("overwrite", C.c_int32)]
 
 
 _lib = None
@@ -218,8 +218,9 @@ def gemm_tn(dy, x, dw, M=None, N=None, K=None, dbias=None, m_dev=None):
 
 
 def gemm_tn_grouped(problems, shared=None, ws=None):
-    """problems: list of (dy, x, dw, M, N, K, dbias[, m_dev]) -- every dw[N,K] += dy[:M,:N]^T @ x[:M,:K] in as few
-    launches as possible (one per <= 12 problems of the same tile class).
+    """problems: list of (dy, x, dw, M, N, K, dbias[, m_dev[, overwrite]]) -- every dw[N,K] += dy[:M,:N]^T @ x[:M,:K] in as few
+    launches as possible (one per <= 12 problems of the same tile class).  overwrite: dw is known to be zero and has no other
+    contributor -> plain stores instead of atomics (unimm_gemm_tn_args.overwrite).
     shared: the launches run beside another stream's kernels (split heuristic hint; None = the process-wide default).
     ws: zero-initialised uint8 device tensor private to the launch stream (partial-tile slabs + arrival counters);
     None = every split adds its partial tile with fp32 atomics."""
@@ -231,6 +232,7 @@ def gemm_tn_grouped(problems, shared=None, ws=None):
         _dev(dy, x, dw, dbias)
         a.dy, a.x, a.dw, a.dbias = dy.data_ptr(), x.data_ptr(), dw.data_ptr(), (dbias.data_ptr() if dbias is not None else None)
         a.m_dev = rest[0].data_ptr() if rest and rest[0] is not None else None
+        a.overwrite = 1 if (len(rest) > 1 and rest[1]) else 0
         a.M = dy.shape[0] if M is None else M
         a.N = dy.shape[1] if N is None else N
         a.K = x.shape[1] if K is None else K
