@@ -36,6 +36,14 @@ python tools/exp/splitk_time.py 1110 >> $out/small_batch_gemm_microbench.txt 2>&
 python tools/exp/splitk_time.py 7800 >> $out/small_batch_gemm_microbench.txt 2>&1
 python tools/exp/tn_sharing.py > $out/tn_panel_sharing_experiment.txt 2>&1
 python bench.py --workload scoring --no-cpu-baseline > $out/bench_scoring.json 2> $out/bench_scoring.err
+python bench.py --workload scoring --no-cpu-baseline --compact-inputs > $out/bench_scoring_compact.json 2> $out/bench_scoring_compact.err
+python bench.py --workload scoring --no-cpu-baseline --scoring-chunk 1000 > $out/bench_scoring_chunk1000.json 2> $out/bench_scoring_chunk1000.err
+python bench.py --workload scoring --no-cpu-baseline --shared-context off > $out/bench_scoring_per_candidate.json 2> $out/bench_scoring_per_candidate.err
+python bench.py --workload scoring --no-cpu-baseline --compute fp32x3 > $out/bench_scoring_fp32x3.json 2> $out/bench_scoring_fp32x3.err
+python bench.py --workload dense --compute fp32x3 --batch 13 --graphs on --steps 30 --warmup 4 --no-cpu-baseline > $out/bench_dense_b13_fp32x3_graphs.json 2> $out/bench_dense_b13_fp32x3_graphs.err
+python bench.py --workload dense --compute fp32x3 --batch 13 --graphs off --steps 30 --warmup 4 --no-cpu-baseline > $out/bench_dense_b13_fp32x3_eager.json 2> $out/bench_dense_b13_fp32x3_eager.err
+python bench.py --workload dense --batch 13 --graphs on --steps 30 --warmup 4 --no-cpu-baseline > $out/bench_dense_b13_bf16_graphs.json 2> $out/bench_dense_b13_bf16_graphs.err
+python bench.py --compute fp32x3 --steps 6 --no-cpu-baseline --no-padded > $out/bench_b240_fp32x3.json 2> $out/bench_b240_fp32x3.err
 rm -rf $out/pmc_fetch $out/pmc_write $out/pmc_sq $out/stats_x3
 find $out -name "*kernel_trace.csv" -size +20M -delete
 ls -la $out | head -30
