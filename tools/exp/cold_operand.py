@@ -29,7 +29,11 @@ for (N, K, epi, tile) in [(768, 3072, E.EPI_ADD, 0), (768, 2304, E.EPI_ADD, 0), 
         j = i % nbuf if rot else 0
         lib.gemm_nt(xs[j], w, os_[j], bias=b if epi not in (E.EPI_MUL, E.EPI_ADD) else None, epilogue=epi,
                     aux=axs[j] if epi in (E.EPI_MUL, E.EPI_ADD, E.EPI_BIAS_DROP_RESID) else None, out2=o2 if epi == E.EPI_BIAS_GELU_DG else None, tile=tile)
-    warm = timeit(lambda i: run(i, False))
-    cold = timeit(lambda i: run(i, True))
-    warm2 = timeit(lambda i: run(i, False))
-    print(f"N={N:5d} K={K:5d} epi={epi}: same buffers {warm:6.1f} us   rotating {nbuf} buffers {cold:6.1f} us (+{(cold / warm - 1) * 100:4.1f} %)   same again {warm2:6.1f} us")
+    out = []
+    for tl in [int(t) for t in os.environ.get("TILES", "0").split(",")]:
+        tile = tl
+        timeit(lambda i: run(i, False), iters=20)
+        warm = timeit(lambda i: run(i, False))
+        cold = timeit(lambda i: run(i, True))
+        out.append(f"tile {tl}: resident {warm:6.1f} us, rotating {nbuf} buffers {cold:6.1f} us (+{(cold / warm - 1) * 100:4.1f} %)")
+    print(f"N={N:5d} K={K:5d} epi={epi}: " + "   ".join(out))

@@ -10,6 +10,7 @@ int unimm_nt_launch_cfg7(const GemmNtParams& p, int epi, bool out_f32, int want_
 int unimm_nt_launch_cfg8(const GemmNtParams& p, int epi, bool out_f32, int want_persist, hipStream_t s, const NtSplit& sk);
 int unimm_nt_launch_cfg9(const GemmNtParams& p, int epi, bool out_f32, int want_persist, hipStream_t s, const NtSplit& sk);
 int unimm_nt_launch_cfg10(const GemmNtParams& p, int epi, bool out_f32, int want_persist, hipStream_t s, const NtSplit& sk);
+int unimm_nt_launch_cfg12(const GemmNtParams& p, int epi, bool out_f32, int want_persist, hipStream_t s, const NtSplit& sk);
 
 int unimm_cu_count() {
   static int n = 0;
@@ -652,7 +653,7 @@ inline bool nt_tune_decode(int code, NtTune& t) {
   t.persist = pc == 0 ? -1 : (pc == 1 ? 1 : 0);           // x1xx persistent, x2xx one workgroup per tile, else automatic
   t.cfg = code % 100;
   t.gn = code / 1000;
-  return pc <= 2 && (t.cfg == 0 || t.cfg == 1 || t.cfg == 3 || t.cfg == 6 || t.cfg == 7 || t.cfg == 8 || t.cfg == 9 || t.cfg == 10);
+  return pc <= 2 && (t.cfg == 0 || t.cfg == 1 || t.cfg == 3 || t.cfg == 6 || t.cfg == 7 || t.cfg == 8 || t.cfg == 9 || t.cfg == 10 || t.cfg == 12);
 }
 
 
@@ -675,7 +676,10 @@ int launch_nt(const GemmNtParams& p, int epi, bool out_f32, const NtTune& tune, 
     } else {
       struct Cand { int cfg, bm, bn, w; double eff; };
       // 256x256 = the ping-pong loop (configuration 8; 3 = the lock-step ring, reachable through unimm_gemm_set_tile for A/B runs)
-      const Cand cand[3] = {{8, 256, 256, 1, 1.0}, {6, 192, 256, 1, 0.95}, {1, 128, 128, 2, 0.85}};
+#ifndef UNIMM_CFG192
+#define UNIMM_CFG192 12       // 192x256 with the X operand on a three-slot ring (6 = both operands on two slots: A/B builds)
+#endif
+      const Cand cand[3] = {{8, 256, 256, 1, 1.0}, {UNIMM_CFG192, 192, 256, 1, 0.95}, {1, 128, 128, 2, 0.85}};
       double best = 1e30;
       for (const Cand& c : cand) {
         const long tiles = (long)((p.M + c.bm - 1) / c.bm) * ((p.N + c.bn - 1) / c.bn);
@@ -701,6 +705,7 @@ int launch_nt(const GemmNtParams& p, int epi, bool out_f32, const NtTune& tune, 
   if (cfg == 9) return unimm_nt_launch_cfg9(p, epi, out_f32, wp, s, sk);
   if (cfg == 10) return unimm_nt_launch_cfg10(p, epi, out_f32, wp, s, sk);
   if (cfg == 3) return unimm_nt_launch_cfg3(p, epi, out_f32, wp, s, nosplit);
+  if (cfg == 12) return unimm_nt_launch_cfg12(p, epi, out_f32, wp, s, nosplit);
   return unimm_nt_launch_cfg1(p, epi, out_f32, wp, s, sk);
 }
 

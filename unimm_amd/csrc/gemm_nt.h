@@ -70,9 +70,14 @@ __device__ __forceinline__ void tile_of(int lid, int nbm, int nbn, int gn, int& 
 //                     rounds of 256 CUs, where 256x256 gives 366 tiles = 1.43 rounds and 128x128 is staging-bound)
 //   Cfg<2,2,2,64,2>:  64x128, 4 waves of 32x64 (48 KiB, 3 workgroups per CU): twice the waves of the 128x128 tile
 //                     for grids that do not fill the chip (per-GPU batches of 30-60 sequences under strong scaling)
-template <int WM_, int WN_, int MT_, int BK_, int STAGES_, int PP_ = 0>
+//   Cfg<2,4,6,64,2,0,3>: 192x256 with the X operand on a ring of THREE slots (W on two): X(t+2) is requested while step t
+//                     computes.  In the step the X operand of a K >= 2304 GEMM was just written by the previous kernel and
+//                     streams from HBM (W, a few MB, stays in L2): one K step of prefetch does not cover that latency
+//                     (profiles/r5h_cold_operand_microbench.txt: +15-22 %), and 2 x 32 + 3 x 24 = 136 KiB is what the LDS has
+template <int WM_, int WN_, int MT_, int BK_, int STAGES_, int PP_ = 0, int XS_ = 0>
 struct Cfg {
   static constexpr int WM = WM_, WN = WN_, MT = MT_, BK = BK_, STAGES = STAGES_;
+  static constexpr int XS = XS_ ? XS_ : STAGES_;              // ring slots of the X operand (W: STAGES)
   static constexpr bool PP = PP_ != 0;                        // ping-pong main loop (nt_mainloop_pp)
   static constexpr int BM = 16 * MT * WM, BN = 64 * WN, NW = WM * WN, THREADS = 64 * NW;
   static constexpr int ROWB = BK * 2;                         // bytes per staged row
@@ -82,7 +87,10 @@ struct Cfg {
   static constexpr int JP = MT == 6 ? 3 : (MT < 4 ? MT : 4);  // 16-row sub-tiles of a wave's tile per epilogue pass
   static constexpr int SLAB_ROWS = 16 * JP;                   // rows per pass
   static constexpr int SLAB_BYTES = NW * SLAB_ROWS * 68 * 4;  // epilogue transpose slabs
-  static constexpr int LDS = STAGES * STAGE_BYTES > SLAB_BYTES ? STAGES * STAGE_BYTES : SLAB_BYTES;
+  static constexpr int WB = BN * ROWB, XB = BM * ROWB;         // bytes of a staged W / X tile
+  static constexpr int GW = BN / RPI / NW, GX = BM / RPI / NW; // LDS-DMA wave-instructions per wave per K-step, by operand
+  static constexpr int RING_BYTES = STAGES * WB + XS * XB;
+  static constexpr int LDS = RING_BYTES > SLAB_BYTES ? RING_BYTES : SLAB_BYTES;
   static constexpr int WG_PER_CU = LDS <= 53 * 1024 ? 3 : (LDS <= 80 * 1024 ? 2 : 1);
   static constexpr int MIN_WAVES = (WG_PER_CU * NW + 3) / 4;
   static_assert((BM + BN) % (RPI * NW) == 0, "tile rows must split evenly over the waves");
@@ -127,6 +135,22 @@ template <class C>
 __device__ __forceinline__ void ring_stage_one(const RingStage<C>& st, int k0, int slot, int wave, int r) {
   const bool is_w = r < C::BN / (C::RPI * C::NW);
   const uint32_t dst = st.lds + (uint32_t)(slot * C::STAGE_BYTES + (r * C::NW + wave) * 1024);
+  const uint32_t soff = (uint32_t)k0 * 2u;
+  uint32_t keep;
+  if (is_w)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(st.so[r]), "s"(dst), "s"(st.srd_w), "s"(soff) : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(st.so[r]), "s"(dst), "s"(st.srd_x), "s"(soff) : "memory");
+}
+// The same with the operands on rings of their own ([W slot 0 | W slot 1 | X slot 0 | X slot 1 | X slot 2], Cfg::XS): instruction
+// r of the wave's G belongs to W (r < GW: K step kw, slot kw_slot) or to X (K step kx, slot kx_slot); `on` = that step exists.
+template <class C>
+__device__ __forceinline__ void ring_stage_one_x(const RingStage<C>& st, int r, int k0, int slot, int wave) {
+  const bool is_w = r < C::GW;
+  const uint32_t dst = st.lds + (uint32_t)(is_w ? slot * C::WB + (r * C::NW + wave) * 1024
+                                                : C::STAGES * C::WB + slot * C::XB + ((r - C::GW) * C::NW + wave) * 1024);
   const uint32_t soff = (uint32_t)k0 * 2u;
   uint32_t keep;
   if (is_w)
@@ -811,15 +835,28 @@ __device__ __forceinline__ void nt_tile(const GemmNtParams& p, char* smem, int l
   // issue only shortens the time the loads have to land (measured 15-20 % slower), so those refill at
   // the top of the step.
   constexpr bool SPREAD = (S == 2 && C::NW == 8);
+  constexpr bool X3 = C::XS == 3 && S == 2;  // the X operand runs one K step further ahead than W (Cfg<...,3>)
+  static_assert(C::XS == S || (X3 && SPREAD), "separate operand rings: two W slots + three X slots on the 8-wave tiles");
+  if constexpr (X3) {
+    // prologue, in this order (vmcnt is in-order): W(0), X(0), then X(1) -- which the first wait leaves in flight
+#pragma unroll
+    for (int r = 0; r < G; ++r) ring_stage_one_x<C>(rst, r, kb * BK, 0, wave_u);
+    if (nk > 1) {
+#pragma unroll
+      for (int r = C::GW; r < G; ++r) ring_stage_one_x<C>(rst, r, (kb + 1) * BK, 1, wave_u);
+    }
+  } else {
   // prologue: fill S-1 ring slots
 #pragma unroll
   for (int s = 0; s < S - 1; ++s)
     if (s < nk) ring_stage_step<C>(rst, (kb + s) * BK, s, wave_u);
+  }
 
   for (int t = 0; t < nk; ++t) {
     // K-step t has landed once at most min(S-2, nk-1-t) younger steps are still in flight
     const int rem = nk - 1 - t;
-    if constexpr (S == 2) wait_vmcnt<0>();
+    if constexpr (X3) { if (rem >= 1) wait_vmcnt<C::GX>(); else wait_vmcnt<0>(); }   // W(t), X(t) landed; X(t+1) may be in flight
+    else if constexpr (S == 2) wait_vmcnt<0>();
     else if constexpr (S == 3) { if (rem >= 1) wait_vmcnt<G>(); else wait_vmcnt<0>(); }
     else { if (rem >= 2) wait_vmcnt<2 * G>(); else if (rem == 1) wait_vmcnt<G>(); else wait_vmcnt<0>(); }
     __builtin_amdgcn_s_barrier();            // every wave's loads of step t landed; step t-1 fully read
@@ -844,10 +881,12 @@ __device__ __forceinline__ void nt_tile(const GemmNtParams& p, char* smem, int l
       constexpr int KS = BK / 32, U = KS * MT, RB = C::ROWB;
       constexpr int WP0 = FragPipe<MT, KS>::WP0, WPN = FragPipe<MT, KS>::WPN;
       bf16x8 fw[2][4], fx[3];
-      const uint32_t so = (uint32_t)((t % S) * C::STAGE_BYTES);
+      const uint32_t so = (uint32_t)((t % S) * (X3 ? C::WB : C::STAGE_BYTES));
+      // (X3: ax0 points at the X tile of the lock-step layout, BN rows behind the W tile of slot 0; X slot x starts at S * WB + x * XB)
+      const uint32_t sx = X3 ? (uint32_t)((S - 1) * C::WB + (t % 3) * C::XB) : so;
       uint32_t aw[KS], ax[KS];
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) { aw[ks] = aw0[ks] + so; ax[ks] = ax0[ks] + so; }
+      for (int ks = 0; ks < KS; ++ks) { aw[ks] = aw0[ks] + so; ax[ks] = ax0[ks] + sx; }
       fw[0][0] = lds_read_b128<0 * 16 * RB>(aw[0]);
       fw[0][1] = lds_read_b128<1 * 16 * RB>(aw[0]);
       fw[0][2] = lds_read_b128<2 * 16 * RB>(aw[0]);
@@ -871,7 +910,12 @@ __device__ __forceinline__ void nt_tile(const GemmNtParams& p, char* smem, int l
           acc[i][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ks_ & 1][i], fx[(u) % 3], acc[i][j_], 0, 0, 0); \
         if constexpr (FragPipe<MT, KS>::AFTER) { UNIMM_PREFETCH(u) }                                         \
         if constexpr (SPREAD && (u) < G) {                                         /* refill, one LDS-DMA per unit */ \
-          if (t + 1 < nk) ring_stage_one<C>(rst, (kb + t + 1) * BK, (t + 1) & 1, wave_u, u);               \
+          if constexpr (X3) {                                                      /* W(t+1) first, then X(t+2) */    \
+            if ((u) < C::GW ? (t + 1 < nk) : (t + 2 < nk))                                                           \
+              ring_stage_one_x<C>(rst, u, (kb + t + ((u) < C::GW ? 1 : 2)) * BK, (u) < C::GW ? ((t + 1) & 1) : ((t + 2) % 3), wave_u); \
+          } else {                                                                                                   \
+            if (t + 1 < nk) ring_stage_one<C>(rst, (kb + t + 1) * BK, (t + 1) & 1, wave_u, u);             \
+          }                                                                                                          \
         }                                                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
       }
@@ -910,7 +954,7 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES) void gemm_ntp_kernel(Gemm
 }
 
 template <class C> constexpr int nt_tile_code() {
-  return C::PP ? 8 : (C::MT == 8 ? 3 : (C::MT == 6 ? 6 : (C::MT == 2 ? (C::STAGES == 3 ? 9 : 7) : (C::STAGES == 3 ? 10 : 1))));
+  return C::PP ? 8 : (C::MT == 8 ? 3 : (C::MT == 6 ? (C::XS == 3 ? 12 : 6) : (C::MT == 2 ? (C::STAGES == 3 ? 9 : 7) : (C::STAGES == 3 ? 10 : 1))));
 }
 
 template <class C, int EPI, bool F32> constexpr auto pick_nt_kernel() { return &gemm_nt_kernel<C, EPI, F32>; }
