@@ -117,7 +117,7 @@ class Engine:
         self.salt_word = None            # int32 [1] device tensor holding dropout.step_salt(seed, step), or None (see _drop)
         self._inject_header = None       # header values of the step, read ahead of a graph capture (see _forward, graphs.py)
         self.graphs = None               # unimm_amd.graphs.StepGraphs once enable_graphs() was called
-        self.image_tile = 8              # tile code of the image side's GEMMs in the large-batch regime (0 = the library's choice; see _tile)
+        self.image_tile = 0              # tile code of the image side's GEMMs in the large-batch regime (0 = the library's choice; see _tile)
         self.wgrad_overwrite = True      # weight gradients with a single contributor are WRITTEN into a freshly zeroed arena (no atomics)
         self._bwd_fresh = False
         self.tile_table = {}             # {("t" | "i", N, K): tile code}: per-shape choices of the small-batch regime (see _tile)
@@ -351,9 +351,10 @@ class Engine:
         the 64x128 tile (twice the workgroups, 23 KiB per MFLOP): +3 % at 60 sequences; the text side's N = 768 GEMMs at ~4k rows
         (fewer than 256 tiles of 128x128) stay on 64x128 (-1.7 % otherwise at 30 sequences).
         In the large-batch regime the text side's launches fill the chip with one-per-CU workgroups, and what the image side's
-        launches (M = 37 rows per sequence: a fraction of a round) cost the step is the CUs they keep from the text side: the
-        256x256 ping-pong tile puts an image GEMM on 140 CUs instead of the 188 of the library's own choice (192x256, faster
-        alone): +0.8 % at 240 sequences, neutral at 120."""
+        launches (M = 37 rows per sequence: a fraction of a round) cost the step is the CUs they keep from the text side: in
+        rounds 3-4 the 256x256 ping-pong tile (140 CUs per image GEMM instead of 188) was +0.8 % at 240 sequences; with the
+        three-slot X ring of round 5 the library's own 192x256 choice is back in front (+0.3 %, two alternating pairs), so
+        `image_tile` is 0 again."""
         if self.gemm_tile != 0:                   # an explicit tuning code reaches both sides (A/B runs: bench.py --gemm-tile)
             return self.gemm_tile
         if self._step_rows is None:               # outside a step: the library's own choice
