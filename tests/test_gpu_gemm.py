@@ -193,6 +193,33 @@ def test_gemm_nt_ping_pong_loop_is_race_free_and_bit_equal_to_the_ring_loop(K):
         assert bad == 0, (rep, bad)
 
 
+@pytest.mark.parametrize("K", [64, 128, 192, 768, 3072])
+def test_gemm_nt_three_slot_x_ring_is_race_free_and_bit_equal_to_the_two_slot_ring(K):
+    """Tile configuration 12 (192x256, the X operand on a ring of three slots: X(t+2) in flight while step t computes, one
+    counted vmcnt per step) accumulates every output element in the same K order as configuration 6 (both operands on two
+    slots): bit-identical results, on a grid of several persistent rounds with a ragged M edge, every one of 8 repetitions, from
+    1 to 48 K steps (a staging race -- a slot refilled before its last reader, a fragment read before its DMA landed -- shows
+    up as a sporadic mismatch), with the heaviest epilogue in between to vary the timing."""
+    from unimm_amd import lib
+    M, N = 31162, 768
+    g = torch.Generator(device="cuda").manual_seed(K)
+    x, w = _rand((M, K), g), _rand((N, K), g, 0.05)
+    bias = torch.randn(N, generator=g, device="cuda")
+    ref = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+    lib.gemm_nt(x, w, ref, bias=bias, epilogue=lib.EPI_BIAS, tile=6)
+    resid = torch.randn((M, N), generator=g, device="cuda")
+    ref32, out32 = torch.empty((M, N), device="cuda"), torch.empty((M, N), device="cuda")
+    lib.gemm_nt(x, w, ref32, bias=bias, epilogue=lib.EPI_BIAS_DROP_RESID, aux=resid, tile=6)
+    for rep in range(8):
+        out = torch.zeros_like(ref)
+        lib.gemm_nt(x, w, out, bias=bias, epilogue=lib.EPI_BIAS, tile=12)
+        lib.gemm_nt(x, w, out32, bias=bias, epilogue=lib.EPI_BIAS_DROP_RESID, aux=resid, tile=112 if rep % 2 else 212)
+        torch.cuda.synchronize()
+        bad = (out.view(torch.int16) != ref.view(torch.int16)).sum().item()
+        assert bad == 0, (rep, bad)
+        assert torch.equal(out32, ref32), rep
+
+
 @pytest.mark.parametrize("M,N,K", [(515, 768, 128), (4096, 1024, 1024), (300, 200, 64)])
 def test_gemm_nt_residual_from_lazy_layernorm(M, N, K):
     """aux_mean/rstd/gamma/beta: the residual operand is LayerNorm(aux) evaluated in the epilogue; must equal

@@ -622,8 +622,8 @@ def test_weight_gradients_written_into_a_fresh_arena_equal_the_atomic_path(golde
         zero()
         for k in range(2):                                   # second backward accumulates on top of the first
             r = model(b["input_ids"], b["image_feat"], b["image_loc"], **kw)
-            if k == 0:
-                assert eng.arena.fresh
+            if k == 0 and zero == eng.arena.zero_grads:
+                assert eng.arena.fresh               # (set_to_none: the arena is zeroed, and marked fresh, when backward re-attaches the gradients)
             (r[0] + r[1] + r[2]).sum().backward()
             torch.cuda.synchronize()
             assert not eng.arena.fresh
