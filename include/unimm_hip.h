@@ -75,8 +75,10 @@ typedef struct {
    *   cfg: 0 automatic (a cost model over {256x256, 192x256, 128x128}; 64x128 for grids that do not fill the chip),
    *        1 = 128x128 / 4 waves / 2-slot ring of BK 64 / 2 workgroups per CU,   3 = 256x256 / 8 waves / lock-step ring,
    *        6 = 192x256 / 8 waves,   7 = 64x128 / 4 waves of 32x64 / 3 workgroups per CU,   8 = 256x256 / ping-pong loop,
-   *        9 = 64x128 with a 3-slot ring (two K steps in flight, 2 workgroups per CU),   10 = 128x128 with a 3-slot ring (1 per CU);
-   *        anything else is rejected with UNIMM_E_ARG
+   *        9 = 64x128 with a 3-slot ring (two K steps in flight, 2 workgroups per CU),   10 = 128x128 with a 3-slot ring (1 per CU),
+   *        12 / 14 / 15 = 192x256 / 128x128 / 64x128 with the X operand alone on a three-slot ring (W stays on two: X(t+2) is in
+   *        flight while step t computes -- in a training step X was just written by the previous kernel and streams from HBM;
+   *        12 is what the automatic choice uses for its 192x256 class);  anything else is rejected with UNIMM_E_ARG
    *   p:   0 automatic, 1 persistent workgroups (one per CU slot walks several tiles), 2 one workgroup per tile
    *   gn:  n-tiles per column group of the tile order (0 = default 4) */
   int32_t tile;

@@ -130,7 +130,7 @@ def test_gemm_tn(M, N, K):
     assert (db - ref_b).abs().max().item() <= 2e-3 * max(1.0, ref_b.abs().max().item())
 
 
-@pytest.mark.parametrize("cfg", [1, 3, 6, 7, 8, 12])
+@pytest.mark.parametrize("cfg", [1, 3, 6, 7, 8, 12, 14, 15])
 @pytest.mark.parametrize("M,N,K", [(300, 200, 64), (1000, 1000, 768), (515, 2304, 128), (4096, 768, 3072), (257, 257 * 3, 320)])
 def test_gemm_nt_every_tile_configuration(cfg, M, N, K):
     """All block-tile / ring configurations of unimm_gemm_nt give the same result (the automatic choice only
@@ -151,7 +151,7 @@ def test_gemm_nt_every_tile_configuration(cfg, M, N, K):
         assert torch.isnan(out[:, N:]).all()
 
 
-@pytest.mark.parametrize("cfg", [101, 103, 108, 112, 201, 203, 208, 212])
+@pytest.mark.parametrize("cfg", [101, 103, 108, 112, 114, 201, 203, 208, 212, 215])
 def test_gemm_nt_persistent_workgroups(cfg):
     """x1xx = persistent workgroups (one per CU slot walking several tiles), x2xx = one workgroup per tile: same
     result on a grid of several rounds, ragged M edge, GELU epilogue with its second output."""
@@ -297,7 +297,7 @@ def test_gemm_rejects_bad_arguments():
         lib.gemm_nt(x.cpu(), w, out)
 
 
-@pytest.mark.parametrize("cfg", [1, 3, 6, 7, 8, 12])
+@pytest.mark.parametrize("cfg", [1, 3, 6, 7, 8, 12, 14, 15])
 @pytest.mark.parametrize("epi", ["add", "mul", "bias16", "resid_drop", "resid_ln"])
 def test_gemm_nt_epilogue_layout_against_torch(cfg, epi):
     """Every epilogue family on every instantiated tile (the automatic rule picks 6 for N = 768 / 2304 and 8 for
@@ -349,7 +349,7 @@ def test_gemm_nt_rejects_uninstantiated_tiles():
     x = torch.zeros((256, 64), device="cuda", dtype=torch.bfloat16)
     w = torch.zeros((256, 64), device="cuda", dtype=torch.bfloat16)
     out = torch.zeros((256, 256), device="cuda", dtype=torch.bfloat16)
-    for bad in (2, 4, 5, 11, 13, 308, -1):
+    for bad in (2, 4, 5, 11, 13, 16, 308, -1):
         with pytest.raises(lib.UnimmHipError):
             lib.gemm_nt(x, w, out, tile=bad)
 

@@ -2,12 +2,15 @@
 mkdir -p gpurun_out/r5e
 run() { b=$1; name=$2; shift 2; python bench.py --batch $b --steps 30 --no-cpu-baseline --no-padded --graphs on "$@" > gpurun_out/r5e/b${b}_$name.json 2>/dev/null; python -c "
 import json;d=json.load(open('gpurun_out/r5e/b${b}_$name.json'));print('b$b $name', d['value'], d['ms_per_step'])"; }
-A=t:3072:1024=0,t:3072:768=0,t:2304:768=0
-run 30 base
-run 30 wide_auto --tile-table $A
-run 30 wide_192 --tile-table t:3072:1024=6,t:3072:768=6,t:2304:768=6
-run 60 wide_auto --tile-table $A
-run 60 wide_auto_img --tile-table $A,i:3072:1024=0,i:1024:3072=0
-run 60 wide_auto_768 --tile-table $A,t:768:768=0,t:1024:768=0,t:768:1024=0
-run 30 wide_auto_768 --tile-table $A,t:768:768=0,t:1024:768=0,t:768:1024=0
-run 60 base
+I14=i:3072:1024=14,i:1024:1024=14,i:1024:3072=14
+I15=i:3072:1024=15,i:1024:1024=15,i:1024:3072=15
+TL15=t:768:3072=15,t:768:2304=15
+for r in 1 2; do
+for b in 30 60; do
+run $b base
+run $b img14 --tile-table $I14
+run $b img15 --tile-table $I15
+run $b img14_tl15 --tile-table $I14,$TL15 --no-splitk
+run $b img14_nosplit --tile-table $I14 --no-splitk
+done
+done

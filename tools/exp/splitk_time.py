@@ -23,7 +23,7 @@ for (N, K, epi) in [(768, 3072, lib.EPI_ADD), (768, 2304, lib.EPI_ADD), (768, 30
     o = torch.empty((M, N), device="cuda") if resid else torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
     ax = torch.randn((M, N), device="cuda") if resid else torch.randn((M, N), device="cuda").to(torch.bfloat16)
     res = []
-    for tile, sks in ((7, (0, 2)), (1, (0, 2)), (9, (0, 2)), (10, (0, 2))):
+    for tile, sks in ((7, (0, 2)), (1, (0, 2)), (9, (0, 2)), (10, (0, 2)), (14, (0, 2)), (15, (0, 2))):
         for sk in sks:
             t = timeit(lambda: lib.gemm_nt(x, w, o, bias=b, epilogue=epi, aux=ax, tile=tile, splitk=sk, splitk_ws=ws))
             res.append(f"t{tile}/s{sk} {t:5.1f}")

@@ -11,6 +11,8 @@ int unimm_nt_launch_cfg8(const GemmNtParams& p, int epi, bool out_f32, int want_
 int unimm_nt_launch_cfg9(const GemmNtParams& p, int epi, bool out_f32, int want_persist, hipStream_t s, const NtSplit& sk);
 int unimm_nt_launch_cfg10(const GemmNtParams& p, int epi, bool out_f32, int want_persist, hipStream_t s, const NtSplit& sk);
 int unimm_nt_launch_cfg12(const GemmNtParams& p, int epi, bool out_f32, int want_persist, hipStream_t s, const NtSplit& sk);
+int unimm_nt_launch_cfg14(const GemmNtParams& p, int epi, bool out_f32, int want_persist, hipStream_t s, const NtSplit& sk);
+int unimm_nt_launch_cfg15(const GemmNtParams& p, int epi, bool out_f32, int want_persist, hipStream_t s, const NtSplit& sk);
 
 int unimm_cu_count() {
   static int n = 0;
@@ -653,7 +655,7 @@ inline bool nt_tune_decode(int code, NtTune& t) {
   t.persist = pc == 0 ? -1 : (pc == 1 ? 1 : 0);           // x1xx persistent, x2xx one workgroup per tile, else automatic
   t.cfg = code % 100;
   t.gn = code / 1000;
-  return pc <= 2 && (t.cfg == 0 || t.cfg == 1 || t.cfg == 3 || t.cfg == 6 || t.cfg == 7 || t.cfg == 8 || t.cfg == 9 || t.cfg == 10 || t.cfg == 12);
+  return pc <= 2 && (t.cfg == 0 || t.cfg == 1 || t.cfg == 3 || t.cfg == 6 || t.cfg == 7 || t.cfg == 8 || t.cfg == 9 || t.cfg == 10 || t.cfg == 12 || t.cfg == 14 || t.cfg == 15);
 }
 
 
@@ -706,6 +708,8 @@ int launch_nt(const GemmNtParams& p, int epi, bool out_f32, const NtTune& tune, 
   if (cfg == 10) return unimm_nt_launch_cfg10(p, epi, out_f32, wp, s, sk);
   if (cfg == 3) return unimm_nt_launch_cfg3(p, epi, out_f32, wp, s, nosplit);
   if (cfg == 12) return unimm_nt_launch_cfg12(p, epi, out_f32, wp, s, nosplit);
+  if (cfg == 14) return unimm_nt_launch_cfg14(p, epi, out_f32, wp, s, sk);
+  if (cfg == 15) return unimm_nt_launch_cfg15(p, epi, out_f32, wp, s, sk);
   return unimm_nt_launch_cfg1(p, epi, out_f32, wp, s, sk);
 }
 

@@ -836,7 +836,7 @@ __device__ __forceinline__ void nt_tile(const GemmNtParams& p, char* smem, int l
   // the top of the step.
   constexpr bool SPREAD = (S == 2 && C::NW == 8);
   constexpr bool X3 = C::XS == 3 && S == 2;  // the X operand runs one K step further ahead than W (Cfg<...,3>)
-  static_assert(C::XS == S || (X3 && SPREAD), "separate operand rings: two W slots + three X slots on the 8-wave tiles");
+  static_assert(C::XS == S || X3, "separate operand rings: two W slots + three X slots");
   if constexpr (X3) {
     // prologue, in this order (vmcnt is in-order): W(0), X(0), then X(1) -- which the first wait leaves in flight
 #pragma unroll
@@ -861,7 +861,16 @@ __device__ __forceinline__ void nt_tile(const GemmNtParams& p, char* smem, int l
     else { if (rem >= 2) wait_vmcnt<2 * G>(); else if (rem == 1) wait_vmcnt<G>(); else wait_vmcnt<0>(); }
     __builtin_amdgcn_s_barrier();            // every wave's loads of step t landed; step t-1 fully read
     __builtin_amdgcn_sched_barrier(0);
-    if (t + S - 1 < nk)                      // refill the slot step t-1 used
+    if constexpr (X3 && !SPREAD) {           // 4-wave tiles refill at the top of the step: W(t+1) first, then X(t+2)
+      if (t + 1 < nk) {
+#pragma unroll
+        for (int r = 0; r < C::GW; ++r) ring_stage_one_x<C>(rst, r, (kb + t + 1) * BK, (t + 1) & 1, wave_u);
+      }
+      if (t + 2 < nk) {
+#pragma unroll
+        for (int r = C::GW; r < G; ++r) ring_stage_one_x<C>(rst, r, (kb + t + 2) * BK, (t + 2) % 3, wave_u);
+      }
+    } else if (t + S - 1 < nk)               // refill the slot step t-1 used
       if constexpr (!SPREAD) ring_stage_step<C>(rst, (kb + t + S - 1) * BK, (t + S - 1) % S, wave_u);
     const char* tw = smem + (t % S) * C::STAGE_BYTES;
     const char* tx = tw + BN * C::ROWB;
@@ -954,7 +963,7 @@ __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES) void gemm_ntp_kernel(Gemm
 }
 
 template <class C> constexpr int nt_tile_code() {
-  return C::PP ? 8 : (C::MT == 8 ? 3 : (C::MT == 6 ? (C::XS == 3 ? 12 : 6) : (C::MT == 2 ? (C::STAGES == 3 ? 9 : 7) : (C::STAGES == 3 ? 10 : 1))));
+  return C::PP ? 8 : (C::MT == 8 ? 3 : (C::MT == 6 ? (C::XS == 3 ? 12 : 6) : (C::MT == 2 ? (C::STAGES == 3 ? 9 : (C::XS == 3 ? 15 : 7)) : (C::STAGES == 3 ? 10 : (C::XS == 3 ? 14 : 1)))));
 }
 
 template <class C, int EPI, bool F32> constexpr auto pick_nt_kernel() { return &gemm_nt_kernel<C, EPI, F32>; }

@@ -366,7 +366,7 @@ class Engine:
         if self._step_rows >= self.small_rows:
             return self.image_tile if (self._on_side and self.image_tile) else 0
         if self._on_side:
-            return 1
+            return 14                             # 128x128 with the X operand on a three-slot ring (round 5: +0.5 % at 30, +1 % at 60 over tile 1)
         t128 = ((M + 127) // 128) * ((N + 127) // 128)
         return 7 if t128 < 256 else 1
 

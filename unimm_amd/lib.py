@@ -690,7 +690,7 @@ def gather_rows(src, idx, dst, n, H, scatter=False, n_dev=None):
 
 
 _EPI_NAMES = ["BIAS", "BIAS_GELU", "BIAS_DROP_RESID", "BIAS_RELU", "DGELU", "ADD", "MUL", "BIAS_GELU_DG"]
-_TILE_NAMES = {1: "128x128", 3: "256x256", 6: "192x256", 7: "64x128", 8: "256x256pp", 9: "64x128s3", 10: "128x128s3", 12: "192x256x3"}
+_TILE_NAMES = {1: "128x128", 3: "256x256", 6: "192x256", 7: "64x128", 8: "256x256pp", 9: "64x128s3", 10: "128x128s3", 12: "192x256x3", 14: "128x128x3", 15: "64x128x3"}
 PROF_VARIANTS = 516
 
 
