@@ -98,6 +98,22 @@ def test_graph_entries_are_evicted_and_recaptured(golden_dir):
         assert d <= 2e-5, (i, d)
 
 
+def test_replays_survive_a_single_hardware_queue(golden_dir):
+    """With one hardware queue per priority class every internal stream of a graph exec shares the queue of a
+    normal-priority launch stream, which the HIP runtime of this image answers with a read past the end of its stream list
+    (SIGSEGV in hip::Graph::UpdateStreams; with the default four queues it takes unevenly loaded queues: 1 run in ~8 of this
+    suite).  The executor launches from a high-priority stream (StepGraphs._replay), whose queue comes from another pool: the
+    eviction scenario above must run through in a child process restricted to one queue."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys; sys.path[:0] = [%r, %r]; import test_gpu_graphs as T; "
+            "T.test_graph_entries_are_evicted_and_recaptured(%r); print('ran through')" % (os.path.dirname(here), here, golden_dir))
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ran through" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+
+
 def test_graph_replays_follow_optimizer_steps(golden_dir):
     """Weights change between replays (FusedAdamW updates the arena in place, the engine re-casts its bf16 copies before the
     next replay): six optimizer steps over two alternating batches under the graph executor reproduce the eager run's losses

@@ -5,7 +5,10 @@
 namespace {
 
 constexpr int MAXC = 2;          // 8-element chunks per lane: hidden sizes up to 1024
-constexpr int RED_BLOCKS = 512;  // row-kernel grid for kernels that emit per-block column partials
+#ifndef UNIMM_RED_BLOCKS
+#define UNIMM_RED_BLOCKS 512
+#endif
+constexpr int RED_BLOCKS = UNIMM_RED_BLOCKS;  // row-kernel grid for kernels that emit per-block column partials
 
 // ------------------------------------------------------------------------------------------------
 // row helpers: a wave owns one row of H elements as 8-element (16-byte) chunks, chunk c = lane + 64*i

@@ -29,6 +29,8 @@ Not covered (falls back to the eager path): inputs on the host, mask descriptors
 (`output_lm_scores=True`)."""
 from __future__ import annotations
 
+import contextlib
+import gc
 from collections import OrderedDict
 
 import torch
@@ -43,6 +45,22 @@ _TENSOR_KEYS = ("input_ids", "image_feat", "image_loc", "token_type_ids", "posit
 
 def _rup(x, m):
     return (x + m - 1) // m * m
+
+
+@contextlib.contextmanager
+def _quiet_collector():
+    """No cyclic garbage collection while a stream is capturing.  The collector runs wherever an allocation count trips it;
+    if that is in the middle of a capture and the garbage holds another executor's graphs (a dropped model: engine <->
+    executor <-> entries is a cycle), their destructors synchronise the device and return pool memory -- inside the capture.
+    Collect first (outside), then hold the collector off until the capture has ended."""
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 
 class _Entry:
@@ -65,6 +83,27 @@ class StepGraphs:
         self.salt = None
         self._salt_val = None
         self.stats = dict(replays=0, captures=0, eager=0, busy=0)
+        self._launch = None
+
+    def _replay(self, g):
+        """hipGraphLaunch from a HIGH-PRIORITY stream, fenced against the caller's stream on both sides.
+
+        Why not the caller's stream: the first launch of an exec with parallel branches (ours: text / image side) assigns its
+        internal streams to the branches, skipping those that share the launch stream's hardware queue -- and the runtime
+        shipped with torch 2.10 (hip::Graph::UpdateStreams) walks that list without a bound: with two internal streams on the
+        launch stream's queue it reads past the end and the process dies with SIGSEGV.  Queues are dealt least-used-first out
+        of 4 per priority class, so this needs unevenly loaded queues, i.e. graph execs destroyed earlier (evicted entries,
+        dropped models): 1 run in ~8 of the GPU suite.  The internal streams are normal-priority; a high-priority launch
+        stream takes its queue from another pool and can never collide (tools/exp/hip_graph_stream_alias.py reproduces the
+        fault and shows this)."""
+        dev = self.eng.arena.device
+        if self._launch is None:
+            self._launch = torch.cuda.Stream(device=dev, priority=-1)
+        cur = torch.cuda.current_stream(dev)
+        self._launch.wait_stream(cur)
+        with torch.cuda.stream(self._launch):
+            g.replay()
+        cur.wait_stream(self._launch)
 
     # ------------------------------------------------------------------------------------------
     def eligible(self, inp, opts):
@@ -138,7 +177,7 @@ class StepGraphs:
                 if torch.is_tensor(t):
                     t.copy_(inp[k], non_blocking=True)
         ent.salt_val = self._set_salt()
-        ent.gF.replay()
+        self._replay(ent.gF)
         self.stats["replays"] += 1
         import weakref
         tok = _Token()
@@ -173,7 +212,7 @@ class StepGraphs:
             torch.cuda.current_stream().wait_stream(ent.stream)
             torch.cuda.synchronize()
             ent.gF = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ent.gF, pool=ent.pool, stream=ent.stream, capture_error_mode="thread_local"):
+            with _quiet_collector(), torch.cuda.graph(ent.gF, pool=ent.pool, stream=ent.stream, capture_error_mode="thread_local"):
                 ent.out = eng.forward(ent.sin, train=opts["train"], save=True, lm_rows="labelled", want_pred_v=True)
                 ent.losses = eng.losses(ent.out, ent.sin)
                 ent.nsp = ent.out["nsp"]
@@ -219,7 +258,7 @@ class StepGraphs:
         try:
             torch.cuda.synchronize()
             ent.stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(ent.stream):
+            with _quiet_collector(), torch.cuda.stream(ent.stream):
                 begin()
                 try:
                     eng.backward(ent.out, *ent.gin)
@@ -266,5 +305,5 @@ class StepGraphs:
                 if hook is not None:
                     hook(*item)
             else:
-                item.replay()
+                self._replay(item)
         eng.arena.fresh = False                                # (a replay does not run Engine._backward, which clears it eagerly)
