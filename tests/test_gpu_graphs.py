@@ -98,20 +98,64 @@ def test_graph_entries_are_evicted_and_recaptured(golden_dir):
         assert d <= 2e-5, (i, d)
 
 
-def test_replays_survive_a_single_hardware_queue(golden_dir):
-    """With one hardware queue per priority class every internal stream of a graph exec shares the queue of a
-    normal-priority launch stream, which the HIP runtime of this image answers with a read past the end of its stream list
-    (SIGSEGV in hip::Graph::UpdateStreams; with the default four queues it takes unevenly loaded queues: 1 run in ~8 of this
-    suite).  The executor launches from a high-priority stream (StepGraphs._replay), whose queue comes from another pool: the
-    eviction scenario above must run through in a child process restricted to one queue."""
+def test_isolated_launch_survives_a_single_hardware_queue(golden_dir):
+    """The HIP runtime of this image reads past the end of an exec's internal stream list (SIGSEGV in
+    hip::Graph::UpdateStreams) when all of them share the launch stream's hardware queue -- certain with one queue per
+    priority class (GPU_MAX_HW_QUEUES=1), and possible with the default four once destroyed execs have left the queues
+    unevenly loaded (unimm_amd/graphs.py never destroys one for that reason).  enable_graphs(launch="isolated") launches from
+    a high-priority stream, whose queue comes from another pool: a child process restricted to one queue must run
+    captured steps through (and reproduce the eager losses)."""
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    code = ("import sys; sys.path[:0] = [%r, %r]; import test_gpu_graphs as T; "
-            "T.test_graph_entries_are_evicted_and_recaptured(%r); print('ran through')" % (os.path.dirname(here), here, golden_dir))
+    code = """
+import sys
+sys.path[:0] = [%r, %r]
+import torch
+import test_gpu_graphs as T
+from unimm_amd import synth
+ref, gm = T._build(%r), T._build(%r)
+for m in (ref, gm):
+    m.train(True); m.set_dropout_seed(3)
+b = synth.make_batch(n_seq=12, T=64, R=37, cfg=ref.config, seed=5, device="cuda")
+want = [T._step(ref, b) for _ in range(3)]
+gm.engine.ensure(torch.device("cuda", 0))
+gx = gm.engine.enable_graphs(row_bucket=64, lm_bucket=16, capture_after=0, launch="isolated")
+got = [T._step(gm, b) for _ in range(3)]
+assert gx.stats["replays"] == 3, gx.stats
+for w, h in zip(want, got):
+    assert (w[0] - h[0]).abs().max() <= 2e-6 * max(1.0, float(w[0].abs().max()))
+    assert float((w[2] - h[2]).abs().max() / w[2].abs().max()) <= 2e-5
+print("ran through")
+""" % (os.path.dirname(here), here, golden_dir, golden_dir)
     env = dict(os.environ, GPU_MAX_HW_QUEUES="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ran through" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+
+
+def test_graph_execs_outlive_their_entries_and_pools_are_recycled(golden_dir):
+    """No graph exec is ever destroyed (see unimm_amd/graphs.py); an evicted entry's memory pool is captured into again."""
+    import gc
+    from unimm_amd import graphs as G, synth
+    gm = _build(golden_dir)
+    gm.train(True)
+    cfg = gm.config
+    b1 = synth.make_batch(n_seq=12, T=64, R=37, cfg=cfg, seed=5, device="cuda")
+    b2 = synth.make_batch(n_seq=6, T=64, R=37, cfg=cfg, seed=6, device="cuda")
+    gm.engine.ensure(torch.device("cuda", 0))
+    gx = gm.engine.enable_graphs(row_bucket=64, lm_bucket=16, capture_after=0, max_entries=1)
+    kept0 = len(G._KEPT)
+    pools = []
+    for b in (b1, b2, b1, b2):
+        _step(gm, b)
+        pools.append(next(iter(gx.entries.values())).pool)
+    assert len(G._KEPT) - kept0 == gx.stats["captures"] == 8           # forward + backward of four entries, all alive
+    assert len(set(pools)) <= 2, pools                                   # the third entry took over the first one's pool
+    del gx
+    gm.engine.graphs = None
+    gc.collect()
+    assert len(G._KEPT) - kept0 == 8
+    assert pools[-1] in G._FREE_POOLS[0]
 
 
 def test_graph_replays_follow_optimizer_steps(golden_dir):

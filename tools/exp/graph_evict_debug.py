@@ -1,4 +1,10 @@
-"""Where does tests/test_gpu_graphs.py::test_graph_entries_are_evicted_and_recaptured die?  argv: evict | all | all-nogc"""
+"""Where did tests/test_gpu_graphs.py::test_graph_entries_are_evicted_and_recaptured die?  argv: evict | all | all-nogc
+
+The investigation tool behind the note at the top of unimm_amd/graphs.py: runs the graph tests in the suite's order with a
+line per capture / replay, under switches that move the fault around (HIST = which earlier tests run, COLLECT = where
+gc.collect() runs, DUAL=0 = single-stream graphs, BURN = pool streams taken first, SHARED=1 = one capture stream).  With
+graph execs destroyed (the state before that note) `all` died at the third step's backward replay -- under rocgdb in
+hip::Graph::UpdateStreams; since execs are kept alive every mode runs through."""
 import contextlib, faulthandler, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

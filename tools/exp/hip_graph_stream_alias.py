@@ -23,7 +23,22 @@ iters = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 dev = torch.device("cuda", 0)
 cap = torch.cuda.Stream(dev)
 sides = [torch.cuda.Stream(dev) for _ in range(2)]
-launch = torch.cuda.Stream(dev, priority=-1) if mode == "prio" else None
+def cumask_stream():
+    """A normal-priority stream with a (full) CU mask: such streams get a hardware queue of their own, outside the pool."""
+    import ctypes, os
+    hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    n = torch.cuda.get_device_properties(dev).multi_processor_count
+    words = (n + 31) // 32
+    mask = (ctypes.c_uint32 * words)(*([0xFFFFFFFF] * words))
+    if n % 32:
+        mask[words - 1] = (1 << (n % 32)) - 1
+    h = ctypes.c_void_p()
+    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(words), mask)
+    assert rc == 0, rc
+    return torch.cuda.ExternalStream(h.value, device=dev)
+
+
+launch = torch.cuda.Stream(dev, priority=-1) if mode == "prio" else cumask_stream() if mode == "cumask" else None
 xs = [torch.zeros(1024, device=dev) for _ in range(3)]
 
 

@@ -31,6 +31,7 @@ from __future__ import annotations
 
 import contextlib
 import gc
+import weakref
 from collections import OrderedDict
 
 import torch
@@ -45,6 +46,49 @@ _TENSOR_KEYS = ("input_ids", "image_feat", "image_loc", "token_type_ids", "posit
 
 def _rup(x, m):
     return (x + m - 1) // m * m
+
+
+# ------------------------------------------------------------------------------------------------
+# Graph execs are never destroyed; their memory pools are recycled.
+#
+# A hipGraph exec with parallel branches (ours: text side / image side) owns internal streams, created at instantiation and
+# dealt to the least-used of the 4 hardware queues of their priority class.  On EVERY hipGraphLaunch the runtime shipped
+# with torch 2.10 (hip::Graph::UpdateStreams) picks those whose queue differs from the launch stream's -- walking the list
+# without a bound: when ALL of an exec's internal streams share the launch stream's queue it reads past the end (SIGSEGV;
+# native backtrace and a reproducer: tools/exp/hip_graph_stream_alias.py).  While streams are only ever created, the deal
+# is round-robin and two streams created back to back never share a queue; once streams have been DESTROYED (= execs
+# destroyed: evicted entries, dropped models) the queues are unevenly loaded and they can -- which is how the GPU suite
+# died once in ~8 runs.  Launching from a stream of another priority class (or with a CU mask) is immune but costs 5 ms of
+# a 9 ms step (StepGraphs(launch="isolated")).  So: every CUDAGraph this module creates stays referenced here for the life
+# of the process (an exec is ~1 MB of host memory), and what would otherwise be lost with it -- the private memory pool
+# holding an entry's activations -- goes back to a free list when the entry dies and is captured into again by the next
+# entry (the dead entry's graphs are never launched again, so sharing their pool is harmless).
+# ------------------------------------------------------------------------------------------------
+_KEPT = []                      # every graph exec ever instantiated here
+_FREE_POOLS = {}                # device index -> pool handles whose entry is gone
+
+
+def _new_graph():
+    g = torch.cuda.CUDAGraph()
+    _KEPT.append(g)
+    if len(_KEPT) in (1024, 8192, 65536):
+        import warnings
+        warnings.warn(f"unimm_amd.graphs: {len(_KEPT)} graph execs captured so far (none is ever destroyed, ~1 MB of host memory "
+                      "each): signatures keep being evicted and captured again -- raise max_entries or widen the row buckets")
+    return g
+
+
+def _dev_index(dev):
+    return dev.index if dev.index is not None else torch.cuda.current_device()
+
+
+def _take_pool(dev):
+    free = _FREE_POOLS.get(_dev_index(dev))
+    return free.pop() if free else torch.cuda.graph_pool_handle()
+
+
+def _give_pool(index, pool):
+    _FREE_POOLS.setdefault(index, []).append(pool)
 
 
 @contextlib.contextmanager
@@ -64,7 +108,8 @@ def _quiet_collector():
 
 
 class _Entry:
-    __slots__ = ("pool", "sin", "gF", "out", "losses", "nsp", "gB", "gin", "gkey", "stream", "lvec", "lshape", "inflight", "salt_val")
+    __slots__ = ("pool", "sin", "gF", "out", "losses", "nsp", "gB", "gin", "gkey", "stream", "lvec", "lshape", "inflight", "salt_val",
+                 "__weakref__")
 
 
 class _Token:
@@ -74,7 +119,7 @@ class _Token:
 
 
 class StepGraphs:
-    def __init__(self, engine, row_bucket=128, lm_bucket=64, max_entries=4, capture_after=1):
+    def __init__(self, engine, row_bucket=128, lm_bucket=64, max_entries=4, capture_after=1, launch="caller"):
         self.eng = engine
         self.row_bucket, self.lm_bucket = row_bucket, lm_bucket
         self.max_entries, self.capture_after = max_entries, capture_after
@@ -83,27 +128,27 @@ class StepGraphs:
         self.salt = None
         self._salt_val = None
         self.stats = dict(replays=0, captures=0, eager=0, busy=0)
-        self._launch = None
+        if launch not in ("caller", "isolated"):
+            raise ValueError("launch: 'caller' or 'isolated'")
+        self.launch = launch
+        self._launch_stream = None
 
     def _replay(self, g):
-        """hipGraphLaunch from a HIGH-PRIORITY stream, fenced against the caller's stream on both sides.
-
-        Why not the caller's stream: the first launch of an exec with parallel branches (ours: text / image side) assigns its
-        internal streams to the branches, skipping those that share the launch stream's hardware queue -- and the runtime
-        shipped with torch 2.10 (hip::Graph::UpdateStreams) walks that list without a bound: with two internal streams on the
-        launch stream's queue it reads past the end and the process dies with SIGSEGV.  Queues are dealt least-used-first out
-        of 4 per priority class, so this needs unevenly loaded queues, i.e. graph execs destroyed earlier (evicted entries,
-        dropped models): 1 run in ~8 of the GPU suite.  The internal streams are normal-priority; a high-priority launch
-        stream takes its queue from another pool and can never collide (tools/exp/hip_graph_stream_alias.py reproduces the
-        fault and shows this)."""
-        dev = self.eng.arena.device
-        if self._launch is None:
-            self._launch = torch.cuda.Stream(device=dev, priority=-1)
-        cur = torch.cuda.current_stream(dev)
-        self._launch.wait_stream(cur)
-        with torch.cuda.stream(self._launch):
+        """hipGraphLaunch on the caller's stream, or (launch="isolated") on a high-priority stream fenced against it on both
+        sides: its hardware queue comes from another pool than the execs' internal streams, which makes the runtime fault
+        described at the top of this file impossible whatever else the process creates and destroys -- at 14.0 instead of
+        9.1 ms per 30-sequence step (a CU-masked or a low-priority launch stream measured the same or worse)."""
+        if self.launch == "caller":
             g.replay()
-        cur.wait_stream(self._launch)
+            return
+        dev = self.eng.arena.device
+        if self._launch_stream is None:
+            self._launch_stream = torch.cuda.Stream(device=dev, priority=-1)
+        cur = torch.cuda.current_stream(dev)
+        self._launch_stream.wait_stream(cur)
+        with torch.cuda.stream(self._launch_stream):
+            g.replay()
+        cur.wait_stream(self._launch_stream)
 
     # ------------------------------------------------------------------------------------------
     def eligible(self, inp, opts):
@@ -179,7 +224,6 @@ class StepGraphs:
         ent.salt_val = self._set_salt()
         self._replay(ent.gF)
         self.stats["replays"] += 1
-        import weakref
         tok = _Token()
         ent.inflight = weakref.ref(tok)
         ent.out["_token"] = tok                                # handed to the autograd context by _HotPath.forward
@@ -192,7 +236,8 @@ class StepGraphs:
         while len(self.entries) >= self.max_entries:           # each signature owns its activations
             self.entries.popitem(last=False)
         ent = _Entry()
-        ent.pool = torch.cuda.graph_pool_handle()
+        ent.pool = _take_pool(dev)
+        weakref.finalize(ent, _give_pool, _dev_index(dev), ent.pool)      # with its tensors gone the pool is free for the next entry
         ent.sin = {k: (v.clone() if torch.is_tensor(v) and v.is_cuda else v) for k, v in inp.items()}
         ent.gB, ent.gin, ent.gkey = None, None, None
         ent.inflight, ent.salt_val = None, None
@@ -211,7 +256,7 @@ class StepGraphs:
                 del out
             torch.cuda.current_stream().wait_stream(ent.stream)
             torch.cuda.synchronize()
-            ent.gF = torch.cuda.CUDAGraph()
+            ent.gF = _new_graph()
             with _quiet_collector(), torch.cuda.graph(ent.gF, pool=ent.pool, stream=ent.stream, capture_error_mode="thread_local"):
                 ent.out = eng.forward(ent.sin, train=opts["train"], save=True, lm_rows="labelled", want_pred_v=True)
                 ent.losses = eng.losses(ent.out, ent.sin)
@@ -233,7 +278,7 @@ class StepGraphs:
         hook = eng.grad_bucket_hook
 
         def begin():
-            g = torch.cuda.CUDAGraph()
+            g = _new_graph()
             g.capture_begin(pool=ent.pool, capture_error_mode="thread_local")   # other threads (a process group's watchdog) may touch the device
             cur[0] = g
 
