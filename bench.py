@@ -64,6 +64,12 @@ def parse():
     ap.add_argument("--with-optimizer", action="store_true",
                     help="also run the fused AdamW step (train.py:322-348 grouping and schedule) inside the timed step; "
                          "NOT the headline metric, which is fwd+bwd (the config block says which was run)")
+    ap.add_argument("--attn-order", choices=["on", "off"], default="on",
+                    help="A/B: off = the attention launches take their (sequence, head) items in batch order (engine.attn_longest_first "
+                         "= False) instead of longest sequence first")
+    ap.add_argument("--order-by-length", choices=["off", "desc", "asc"], default="off",
+                    help="experiment: permute the synthetic batch's sequences by valid length before the run (the same work; the "
+                         "attention kernels take their (sequence, head) items in batch order)")
     ap.add_argument("--compact-inputs", action="store_true",
                     help="feed mask descriptors + per-image tensors + image_index (SURVEY 8 row F3) instead of the "
                          "reference-shaped dense masks and per-sequence image copies")
@@ -424,6 +430,13 @@ def main():
     else:
         batch = synth.make_batch(n_seq=per_gpu, cfg=cfg, seed=1234 + rank, device=dev, compact=args.compact_inputs)
         coeff = dict(lm=1.0, nsp=1.0, img=1.0)    # options.py:68-70 defaults
+    if args.order_by_length != "off" and torch.is_tensor(batch.get("attention_mask")):
+        am = batch["attention_mask"]
+        lens = am.ne(0).any(-1).sum(1) if am.dim() == 3 else am.ne(0).sum(1)
+        perm = torch.argsort(lens, descending=args.order_by_length == "desc", stable=True)
+        nb = am.shape[0]
+        batch = {k: (v.index_select(0, perm.to(v.device)).contiguous() if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == nb else v)
+                 for k, v in batch.items()}
     nsp_w = batch.pop("nsp_weight")
     n_lm_rows = int((batch["lm_weight"] != 0).sum())
     feed = None
@@ -539,6 +552,8 @@ def main():
         model.engine.dual_stream = False
     if args.wgrad_stream:
         model.engine.wgrad_stream = True
+    if args.attn_order == "off":
+        model.engine.attn_longest_first = False
     if args.wgrad_rounds > 0:
         model.engine.wgrad_group_rounds = args.wgrad_rounds
     if args.image_head_main:

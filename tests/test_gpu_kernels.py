@@ -405,6 +405,53 @@ def test_attention_variable_length_matches_padded():
     assert relerr(dqkv_v, dqkv_p[rows]) < 1e-2
 
 
+@pytest.mark.parametrize("D,Tq,Tk", [(64, 256, 256), (128, 37, 256), (128, 256, 37)])
+def test_attention_item_order_changes_nothing_but_the_schedule(D, Tq, Tk):
+    """unimm_attn_args.order (the sequences longest first, from unimm_plan_build): forward outputs, log-sum-exps and all three
+    gradients are the same bits whatever order the workgroups take the (sequence, head) items in -- every kernel form (the
+    one-kernel text backward, the dQ + dK/dV pair of the 37-region directions), with dropout."""
+    from unimm_amd import dropout as DR
+    from unimm_amd import lib
+    B, H = 7, 3
+    HD = H * D
+    g = torch.Generator(device=DEV).manual_seed(D + Tq)
+    lens = [200, 37, 129, 256, 64, 1, 255]
+    var_q, var_k = Tq == 256, Tk == 256
+    ql = lens if var_q else [Tq] * B
+    kl = lens if var_k else [Tk] * B
+    nq, nk = sum(ql), sum(kl)
+    q = bf(torch.randn((nq, HD), generator=g, device=DEV))
+    kv = bf(torch.randn((nk, 2 * HD), generator=g, device=DEV))
+    m = torch.zeros((B, Tq, Tk), dtype=torch.bool, device=DEV)
+    for b in range(B):
+        m[b, :ql[b], :kl[b]] = torch.rand((ql[b], kl[b]), generator=g, device=DEV) < 0.7
+        m[b, :ql[b], 0] = True
+    packed = lib.mask_pack(m)
+    nw = packed.shape[-1]
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=DEV)
+    cum = lambda v: i32([sum(v[:i]) for i in range(B)])
+    drop = DR.drop_arg(0.1, DR.make_key(2, 7, 1))
+    dout = bf(torch.randn((nq, HD), generator=g, device=DEV))
+    res = []
+    for order in (None, i32(sorted(range(B), key=lambda b: (-lens[b], b))), i32([3, 0, 6, 5, 1, 2, 4])):
+        qv = (cum(ql), i32(ql), None, order) if var_q else None
+        kvv = (cum(kl), i32(kl), None, order) if var_k else None
+        out = torch.zeros((nq, HD), device=DEV, dtype=torch.bfloat16)
+        lse = torch.zeros((B, H, Tq), device=DEV)
+        lib.attn_fwd(q, kv[:, :HD], kv[:, HD:], out, lse, packed, B, H, Tq, Tk, D, D ** -0.5, Tk // 32 * 0 + nw, Tq * nw, drop,
+                     qvar=qv, kvar=kvv)
+        dq, dkv = torch.zeros_like(q), torch.zeros_like(kv)
+        delta = torch.zeros((B, H, Tq), device=DEV)
+        lib.attn_bwd(q, kv[:, :HD], kv[:, HD:], out, dout, lse, delta, dq, dkv[:, :HD], dkv[:, HD:], packed, B, H, Tq, Tk, D,
+                     D ** -0.5, nw, Tq * nw, drop, qvar=qv, kvar=kvv)
+        torch.cuda.synchronize()
+        res.append((out, lse, dq, dkv))
+    for r in res[1:]:
+        for a, b in zip(res[0], r):
+            assert torch.equal(a.view(torch.int16) if a.dtype == torch.bfloat16 else a, b.view(torch.int16) if b.dtype == torch.bfloat16 else b)
+    assert float(res[0][2].float().abs().max()) > 0
+
+
 def test_mask_synth_matches_the_oracle_encoders_bit_for_bit():
     """unimm_mask_synth against oracle/masks.py (itself pinned to the reference's encode_input_gen / _dis by golden
     G5): packed text and co-attention words for generative and discriminative sequences, incl. one-token answers,
@@ -506,6 +553,8 @@ def test_plan_kernels_match_the_dense_formulation():
         assert built["lm_idx"].cpu().tolist() == inv[pos].tolist()
         assert built["lm_label"].cpu().tolist() == labels.reshape(-1)[pos].tolist()
         assert built["lm_weight"].cpu().tolist() == (weights.reshape(-1)[pos].tolist() if use_w else [1] * n)
+        # the item order of the attention launches: by length, longest first, ties in batch order
+        assert built["order"].cpu().tolist() == sorted(range(B), key=lambda b: (-int(want_len[b]), b))
     # nothing labelled, no masks beyond labels=None: counts are zero and the lm group may be omitted
     header = L.plan_lengths((tw, nw, T * nw), None, 0, None, None, None, B, T)
     assert sum(header.tolist()[B:2 * B]) == 0

@@ -34,6 +34,10 @@ struct AttnParams {
   // or private row j - ks_len[b].  The sequence then has k_len[b] + ks_len[b] keys; mask words index key POSITIONS.  What the
   // candidates of one dialog round use to attend the round's context rows, computed once (unimm_amd/scoring.py).
   const int* ks_off; const int* ks_len; int ks_ins;
+  // or NULL: a permutation of the sequences; workgroups take their (sequence, head) items in THIS order.  With variable lengths
+  // the longest sequences first: the dispatcher hands items to free CU slots in grid order, so the launch's tail is then made of
+  // the shortest items instead of whatever the batch order put last (the step's plan writes it: unimm_plan_build).
+  const int* order;
   int B, H, Tq, Tk, ldq, ldk, ldv, ldo;
   int mask_q_stride, mask_b_stride;  // in words; q stride 0 = one row per sequence (key padding)
   int parts;                          // workgroups per (sequence, head): each owns a contiguous run of 32-row tiles
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnParams p) {
   char* vimg = smem + KPAD * 2 * D;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int item = blockIdx.x / p.parts, part = blockIdx.x % p.parts;
-  const int b = item / p.H, head = item % p.H;
+  const int b = p.order != nullptr ? p.order[item / p.H] : item / p.H, head = item % p.H;
   const int nwv = blockDim.x >> 6;                     // waves of this workgroup: wave w owns query tiles w, w + nwv, ...
   const int r = lane & 31, h = lane >> 5;
 
@@ -330,6 +334,7 @@ struct AttnBwdParams {
   bf16_t* dq; bf16_t* dk; bf16_t* dv;
   const uint32_t* mask;
   const int* q_off; const int* q_len; const int* k_off; const int* k_len;
+  const int* order;      // as AttnParams.order
   int B, H, Tq, Tk, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
   int mask_q_stride, mask_b_stride;
   int parts;
@@ -346,7 +351,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
   char* vimg = smem + KPAD * 2 * D;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int item = blockIdx.x / p.parts, part = blockIdx.x % p.parts;
-  const int b = item / p.H, head = item % p.H;
+  const int b = p.order != nullptr ? p.order[item / p.H] : item / p.H, head = item % p.H;
   const int wt = part * (blockDim.x >> 6) + wave;
   const int r = lane & 31, h = lane >> 5;
 
@@ -485,7 +490,7 @@ __global__ __launch_bounds__(MAXT, MAXT == 256 ? 1 : 2) void attn_bwd_dkv_kernel
   uint32_t* mw_s = reinterpret_cast<uint32_t*>(del_s + QPAD);   // [key tile (wave)][query] mask words
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int item = blockIdx.x / p.parts, part = blockIdx.x % p.parts;
-  const int b = item / p.H, head = item % p.H;
+  const int b = p.order != nullptr ? p.order[item / p.H] : item / p.H, head = item % p.H;
   const int wt = part * (blockDim.x >> 6) + wave;      // this wave's 32-key tile
   const int r = lane & 31, h = lane >> 5;
 
@@ -681,7 +686,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(AttnBwdParams p)
   int* turn = reinterpret_cast<int*>(acc + QPAD * AS);          // [NQT]: the wave whose turn it is to add its partial of that query tile
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int item = blockIdx.x;
-  const int b = item / p.H, head = item % p.H;
+  const int b = p.order != nullptr ? p.order[item / p.H] : item / p.H, head = item % p.H;
   const int wt = wave;                                          // this wave's 32-key tile
   const int r = lane & 31, h = lane >> 5;
 
@@ -1063,6 +1068,7 @@ extern "C" int unimm_attn_fwd(const unimm_attn_args* a, void* stream) {
   if ((p.ks_off == nullptr) != (p.ks_len == nullptr)) return UNIMM_E_ARG;
   if (p.ks_off != nullptr && (p.k_off == nullptr || a->ks_ins < 0 || a->drop_thr != 0u)) return UNIMM_E_ARG;   // variable-length keys, inference
   if (p.ks_off == nullptr) p.ks_ins = 0;
+  p.order = a->order;
   p.B = a->B; p.H = a->H; p.Tq = a->Tq; p.Tk = a->Tk;
   p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo;
   p.mask_q_stride = a->mask_q_stride; p.mask_b_stride = a->mask_b_stride;
@@ -1084,6 +1090,7 @@ extern "C" int unimm_attn_probs(const unimm_attn_args* a, float* probs, void* st
   p.q = (const bf16_t*)a->q; p.k = (const bf16_t*)a->k; p.v = nullptr; p.o = nullptr; p.lse = nullptr; p.mask = a->mask;
   p.q_off = p.q_len = p.k_off = p.k_len = nullptr;
   p.ks_off = p.ks_len = nullptr; p.ks_ins = 0;
+  p.order = nullptr;
   p.B = a->B; p.H = a->H; p.Tq = a->Tq; p.Tk = a->Tk;
   p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = 0; p.ldo = 0;
   p.mask_q_stride = a->mask_q_stride; p.mask_b_stride = a->mask_b_stride; p.parts = 1;
@@ -1115,6 +1122,7 @@ extern "C" int unimm_attn_bwd(const unimm_attn_bwd_args* a, void* stream) {
   p.dq = (bf16_t*)a->dq; p.dk = (bf16_t*)a->dk; p.dv = (bf16_t*)a->dv; p.mask = a->mask;
   p.q_off = a->q_off; p.q_len = a->q_len; p.k_off = a->k_off; p.k_len = a->k_len;
   if ((p.q_off == nullptr) != (p.q_len == nullptr) || (p.k_off == nullptr) != (p.k_len == nullptr)) return UNIMM_E_ARG;
+  p.order = a->order;
   p.B = a->B; p.H = a->H; p.Tq = a->Tq; p.Tk = a->Tk;
   p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo; p.lddo = a->lddo;
   p.lddq = a->lddq; p.lddk = a->lddk; p.lddv = a->lddv;

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void plan_build_kernel(const int32_t* __restri
                                                          int32_t* __restrict__ lm_pos, int32_t* __restrict__ lm_idx,
                                                          int32_t* __restrict__ lm_lab, int32_t* __restrict__ lm_w,
                                                          int rows_cap, int lm_cap, int32_t* __restrict__ dims_i,
-                                                         float* __restrict__ dims_f) {
+                                                         float* __restrict__ dims_f, int32_t* __restrict__ order) {
   __shared__ int s_off, s_lmoff, wave_cnt[4];
   const int b = blockIdx.x, t = threadIdx.x;
   if (b == (int)gridDim.x - 1) {
@@ -206,6 +206,14 @@ __global__ __launch_bounds__(256) void plan_build_kernel(const int32_t* __restri
     if (rows != nullptr) for (int i = mv + t; i < rows_cap; i += 256) rows[i] = 0;
     if (lm_pos != nullptr)
       for (int i = nlm + t; i < lm_cap; i += 256) { lm_pos[i] = 0; lm_idx[i] = 0; lm_lab[i] = -1; lm_w[i] = 0; }
+    // the sequences by length, longest first (rank sort; B is a few hundred): the item order of the attention launches
+    if (order != nullptr)
+      for (int i = t; i < B; i += 256) {
+        const int li = header[i];
+        int rank = 0;
+        for (int j = 0; j < B; ++j) { const int lj = header[j]; rank += (lj > li || (lj == li && j < i)) ? 1 : 0; }
+        order[rank] = i;
+      }
     return;
   }
   // exclusive prefix sums over the sequences before this one (B is a few hundred: one strided pass)
@@ -1027,13 +1035,13 @@ extern "C" int unimm_plan_lengths(const uint32_t* text_words, int32_t t_q_stride
 extern "C" int unimm_plan_build(const int32_t* header, const int32_t* labels, const int32_t* weights, int32_t B, int32_t T,
                                 int32_t* off, int32_t* lens, int64_t* rows, int64_t* inv, int32_t* lm_pos, int32_t* lm_idx,
                                 int32_t* lm_label, int32_t* lm_weight, int32_t rows_cap, int32_t lm_cap, int32_t* dims_i,
-                                float* dims_f, void* stream) {
+                                float* dims_f, int32_t* order, void* stream) {
   if ((dims_i == nullptr) != (dims_f == nullptr)) return UNIMM_E_ARG;
   if (header == nullptr || off == nullptr || lens == nullptr) return UNIMM_E_ARG;
   if (lm_pos != nullptr && (lm_idx == nullptr || lm_label == nullptr || lm_weight == nullptr || labels == nullptr)) return UNIMM_E_ARG;
   if (B <= 0 || T <= 0 || T > 256) return UNIMM_E_SHAPE;
   hipLaunchKernelGGL(plan_build_kernel, dim3(B + 1), dim3(256), 0, (hipStream_t)stream, header, labels, weights, B, T, off, lens,
-                     rows, inv, lm_pos, lm_idx, lm_label, lm_weight, rows_cap, lm_cap, dims_i, dims_f);
+                     rows, inv, lm_pos, lm_idx, lm_label, lm_weight, rows_cap, lm_cap, dims_i, dims_f, order);
   UNIMM_CHECK_LAUNCH();
   return UNIMM_OK;
 }

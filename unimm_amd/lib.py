@@ -13,7 +13,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libunimm_hip.so")
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROP_RESID, EPI_BIAS_RELU, EPI_DGELU, EPI_ADD, EPI_MUL, EPI_BIAS_GELU_DG = range(8)
 
@@ -255,7 +255,7 @@ class AttnArgs(C.Structure):
                 ("ldq", C.c_int32), ("ldk", C.c_int32), ("ldv", C.c_int32), ("ldo", C.c_int32),
                 ("mask_q_stride", C.c_int32), ("mask_b_stride", C.c_int32), ("scale", C.c_float),
                 ("drop_key", C.c_uint32), ("drop_thr", C.c_uint32), ("drop_scale", C.c_float), ("drop_salt", C.c_void_p),
-                ("ks_off", C.c_void_p), ("ks_len", C.c_void_p), ("ks_ins", C.c_int32)]
+                ("ks_off", C.c_void_p), ("ks_len", C.c_void_p), ("ks_ins", C.c_int32), ("order", C.c_void_p)]
 
 
 class AttnBwdArgs(C.Structure):
@@ -267,7 +267,16 @@ class AttnBwdArgs(C.Structure):
                 ("ldq", C.c_int32), ("ldk", C.c_int32), ("ldv", C.c_int32), ("ldo", C.c_int32), ("lddo", C.c_int32),
                 ("lddq", C.c_int32), ("lddk", C.c_int32), ("lddv", C.c_int32),
                 ("mask_q_stride", C.c_int32), ("mask_b_stride", C.c_int32), ("scale", C.c_float),
-                ("drop_key", C.c_uint32), ("drop_thr", C.c_uint32), ("drop_scale", C.c_float), ("drop_salt", C.c_void_p)]
+                ("drop_key", C.c_uint32), ("drop_thr", C.c_uint32), ("drop_scale", C.c_float), ("drop_salt", C.c_void_p),
+                ("order", C.c_void_p)]
+
+
+def _item_order(qvar, kvar):
+    """The item order of an attention launch (unimm_attn_args.order): element 3 of a variable-length descriptor, if it has one."""
+    for v in (qvar, kvar):
+        if v is not None and len(v) > 3 and v[3] is not None:
+            return v[3].data_ptr()
+    return None
 
 
 NO_DROP = (0, 0, 1.0)
@@ -292,6 +301,7 @@ def attn_fwd(q, k, v, out, lse, mask, B, H, Tq, Tk, D, scale, mask_q_stride, mas
         a.ks_off, a.ks_len, a.ks_ins = kshared[0].data_ptr(), kshared[1].data_ptr(), int(kshared[2])
     else:
         a.ks_off, a.ks_len, a.ks_ins = None, None, 0
+    a.order = _item_order(qvar, kvar)
     a.B, a.H, a.Tq, a.Tk, a.D = B, H, Tq, Tk, D
     a.ldq, a.ldk, a.ldv, a.ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
     a.mask_q_stride, a.mask_b_stride, a.scale = mask_q_stride, mask_b_stride, scale
@@ -310,6 +320,7 @@ def attn_probs(q, k, probs, mask, B, H, Tq, Tk, D, scale, mask_q_stride, mask_b_
     a.q_off = a.q_len = a.k_off = a.k_len = None
     a.ks_off = a.ks_len = None
     a.ks_ins = 0
+    a.order = None
     a.B, a.H, a.Tq, a.Tk, a.D = B, H, Tq, Tk, D
     a.ldq, a.ldk, a.ldv, a.ldo = q.stride(0), k.stride(0), 0, 0
     a.mask_q_stride, a.mask_b_stride, a.scale = mask_q_stride, mask_b_stride, scale
@@ -337,6 +348,7 @@ def attn_bwd(q, k, v, out, dout, lse, delta, dq, dk, dv, mask, B, H, Tq, Tk, D, 
     a.mask_q_stride, a.mask_b_stride, a.scale = mask_q_stride, mask_b_stride, scale
     a.drop_key, a.drop_thr, a.drop_scale = drop[:3]
     a.drop_salt = _salt(drop)
+    a.order = _item_order(qvar, kvar)
     rc = fn(addr, _stream())
     if rc != 0:
         _check(rc, "unimm_attn_bwd")
@@ -505,10 +517,12 @@ def plan_build(header, labels, weights, B, T, Mv, n_lm, want_rows=True, dims=Non
     lm = [i32(n_lm) for _ in range(4)] if (n_lm > 0 and labels is not None) else [None] * 4
     di, df = dims if dims is not None else (None, None)
     _dev(di, df)
+    order = i32(B)                     # the sequences by length, longest first: the item order of the attention launches
     _check(lib().unimm_plan_build(_ptr(header), _ptr(labels), _ptr(weights), C.c_int32(B), C.c_int32(T), _ptr(off), _ptr(lens),
                                   _ptr(rows), _ptr(inv), *[_ptr(t) for t in lm], C.c_int32(Mv if want_rows else 0),
-                                  C.c_int32(n_lm if lm[0] is not None else 0), _ptr(di), _ptr(df), _stream()), "unimm_plan_build")
-    return dict(off=off, lens=lens, rows=rows, inv=inv, lm_pos=lm[0], lm_idx=lm[1], lm_label=lm[2], lm_weight=lm[3])
+                                  C.c_int32(n_lm if lm[0] is not None else 0), _ptr(di), _ptr(df), _ptr(order), _stream()),
+           "unimm_plan_build")
+    return dict(off=off, lens=lens, rows=rows, inv=inv, lm_pos=lm[0], lm_idx=lm[1], lm_label=lm[2], lm_weight=lm[3], order=order)
 
 
 def transpose_cast(src, dst, R, C_, ldd):
