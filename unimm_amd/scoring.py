@@ -165,6 +165,8 @@ def _forward_shared(eng, inp, groups, want_nsp):
     gid = _i64(plan.gid, dev)
     rep = _i64(plan.rep, dev)
     ks_off, ks_len = s_off[gid], s_len[gid]                        # [B]: the group's rows, per sequence
+    # item order of the candidates' launches: most keys first (unimm_attn_args.order: the tail of a launch is its shortest items)
+    p_ord = _i32(np.argsort(-(plan.s_len[plan.gid] + plan.p_len), kind="stable"), dev)
     # P-row masks: rows {0, c .. length) of each sequence's packed mask, key positions unchanged
     prow = _i64(plan.prow, dev)                                    # [B, 32]
     pwords = twords.view(B, T, nw)[torch.arange(B, device=dev)[:, None], prow].contiguous()        # [B, 32, nw]
@@ -252,8 +254,8 @@ def _forward_shared(eng, inp, groups, want_nsp):
         ctx = torch.empty((M, H), dtype=BF16, device=dev)
         sc = 1.0 / math.sqrt(D)
         L.attn_fwd(q, k, v, ctx, None, ones_t, G, heads, T, T, D, sc, 0, nw, NO, qvar=(s_off, s_len), kvar=(s_off, s_len))
-        L.attn_fwd(q, k, v, ctx, None, pwords, B, heads, 32, T, D, sc, nw, 32 * nw, NO, qvar=(p_off, p_len), kvar=(p_off, p_len),
-                   kshared=(ks_off, ks_len, 1))
+        L.attn_fwd(q, k, v, ctx, None, pwords, B, heads, 32, T, D, sc, nw, 32 * nw, NO, qvar=(p_off, p_len, None, p_ord),
+                   kvar=(p_off, p_len), kshared=(ks_off, ks_len, 1))
         pre1 = eng._linear(ctx, so, L.EPI_BIAS_DROP_RESID, aux=x32, drop=NO, out_f32=True)
         x1_32, x1, _, _ = eng._layernorm(pre1, key + ".ln1", False, lazy=True)
         h = eng._linear(x1, ff1, L.EPI_BIAS_GELU)
