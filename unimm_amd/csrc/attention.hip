@@ -892,6 +892,247 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(AttnBwdParams p)
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// backward in ONE kernel for the co-attention direction whose QUERIES are the 37 regions (and for the image self-attention):
+// D = 128, at most 64 queries x 256 keys.  The structure of attn_bwd_fused_kernel (key on the lane, a wave = one 32-key tile,
+// dQ partials meet in an LDS accumulator in wave order), in two phases so that it fits 256 registers: the score phase forms S,
+// dP, P, dS of both query tiles ONCE (the two-kernel path formed them twice, in kernels of 235 and 256 + 27 spilled registers),
+// adds the dQ partials, and keeps P^T / dS^T as bf16 MFMA operands (32 registers); dV and dK of the wave's keys then come out one
+// 32-wide slice of D at a time.  The K tile sits in a wave-private LDS image for the transposed reads of dQ.
+// LDS: Q / dO images 32 KiB + K images 64 KiB + accumulator 33 KiB + dS tiles 16 KiB + words 3 KiB = 148 KiB: one per CU.
+// ------------------------------------------------------------------------------------------------
+template <int NQT>
+__global__ __launch_bounds__(512, 2) void attn_bwd_fewq128_kernel(AttnBwdParams p) {
+  constexpr int D = 128;
+  static_assert(NQT == 2, "the (sequence, head) item's queries are two 32-row tiles: P / dS of both stay in registers for phase 2");
+  drop_resolve(p.drop);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int QPAD = NQT * 32;
+  constexpr int AS = D + 4;                                     // accumulator row stride in floats (16-byte accesses of 16 rows cover all banks)
+  char* qimg = smem;
+  char* doimg = smem + QPAD * 2 * D;
+  float* lse_s = reinterpret_cast<float*>(smem + 2 * QPAD * 2 * D);
+  float* del_s = lse_s + QPAD;
+  uint32_t* mw_s = reinterpret_cast<uint32_t*>(del_s + QPAD);   // [key tile (wave)][query] mask words
+  char* scr = reinterpret_cast<char*>(mw_s + 8 * QPAD);         // [wave][32 keys][32 queries] bf16
+  char* kimgs = scr + 8 * 2048;                                 // [wave][32 keys][D] bf16: the wave's K tile, read back transposed for dQ
+  float* acc = reinterpret_cast<float*>(kimgs + 8 * 32 * 2 * D); // [QPAD q][AS] fp32
+  int* turn = reinterpret_cast<int*>(acc + QPAD * AS);          // [NQT]: the wave whose turn it is to add its partial of that query tile
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int item = blockIdx.x;
+  const int b = p.order != nullptr ? p.order[item / p.H] : item / p.H, head = item % p.H;
+  const int wt = wave;                                          // this wave's 32-key tile
+  const int r = lane & 31, h = lane >> 5;
+
+  const int Tq_b = p.q_len ? p.q_len[b] : p.Tq, Tk_b = p.k_len ? p.k_len[b] : p.Tk;
+  const size_t qbase = p.q_off ? (size_t)p.q_off[b] : (size_t)b * p.Tq;
+  const size_t kbase = p.k_off ? (size_t)p.k_off[b] : (size_t)b * p.Tk;
+  const int qpad_b = ((Tq_b + 31) & ~31) < QPAD ? ((Tq_b + 31) & ~31) : QPAD;
+  stage_head<D>(p.q + qbase * p.ldq + head * D, p.ldq, Tq_b, qpad_b, qimg, tid, blockDim.x);
+  stage_head<D>(p.dout + qbase * p.lddo + head * D, p.lddo, Tq_b, qpad_b, doimg, tid, blockDim.x);
+  for (int i = tid; i < qpad_b; i += blockDim.x) {
+    const size_t stat = ((size_t)b * p.H + head) * p.Tq + i;
+    lse_s[i] = i < Tq_b ? -p.lse[stat] * LOG2E : -INFINITY;     // NEGATED; -inf => P = 0 for padded queries
+  }
+  // delta[q] = sum_d dO[q, d] O[q, d]: 16 consecutive lanes share a row (16-byte chunks), reduced by four exchanges
+  for (int i = tid; i < qpad_b * 16; i += blockDim.x) {
+    const int row = i >> 4, c = i & 15;
+    float part = 0.f;
+    if (row < Tq_b) {
+      const u32x4 a = *reinterpret_cast<const u32x4*>(p.dout + (qbase + row) * p.lddo + head * D + 8 * c);
+      const u32x4 o = *reinterpret_cast<const u32x4*>(p.o + (qbase + row) * p.ldo + head * D + 8 * c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        part = fmaf(__uint_as_float(a[e] << 16), __uint_as_float(o[e] << 16), part);
+        part = fmaf(__uint_as_float(a[e] & 0xffff0000u), __uint_as_float(o[e] & 0xffff0000u), part);
+      }
+    }
+    part += __shfl_xor(part, 1, 64);
+    part += __shfl_xor(part, 2, 64);
+    part += __shfl_xor(part, 4, 64);
+    part += __shfl_xor(part, 8, 64);
+    if (c == 0) del_s[row] = part;
+  }
+  {
+    const int nkt_b = (Tk_b + 31) >> 5;
+    const uint32_t* mb = p.mask + (size_t)b * p.mask_b_stride;
+    for (int i = tid; i < nkt_b * qpad_b; i += blockDim.x) {
+      const int kt = i / qpad_b, qi = i - kt * qpad_b;
+      const int qc = qi < Tq_b ? qi : Tq_b - 1;
+      mw_s[kt * QPAD + qi] = ~mb[(size_t)qc * p.mask_q_stride + kt];   // INVERTED: bit set = masked
+    }
+  }
+  if (tid < NQT) turn[tid] = 0;
+
+  int krow = wt * 32 + r;
+  const bool kvalid = krow < Tk_b;
+  const bool wave_on = wt * 32 < Tk_b;
+  if (!kvalid) krow = Tk_b - 1;
+  const size_t grow = kbase + krow;
+  const bf16_t* kg = p.k + grow * p.ldk + head * D;
+  const bf16_t* vg = p.v + grow * p.ldv + head * D;
+  bf16x8 kf[D / 16], vf[D / 16];
+#pragma unroll
+  for (int ks = 0; ks < D / 16; ++ks) {
+    kf[ks] = *reinterpret_cast<const bf16x8*>(kg + 16 * ks + 8 * h);
+    vf[ks] = *reinterpret_cast<const bf16x8*>(vg + 16 * ks + 8 * h);
+  }
+  // The wave's K tile also goes to a wave-private LDS image (keys past the end as zeros, so whatever those lanes compute as dS
+  // never reaches dQ): dQ reads it back as transposed fragments.  No barrier: a wave's LDS accesses execute in order.
+  char* kimg = kimgs + wave * (32 * 2 * D);
+#pragma unroll
+  for (int ks = 0; ks < D / 16; ++ks) {
+    const u32x4 v = kvalid ? __builtin_bit_cast(u32x4, kf[ks]) : u32x4{0u, 0u, 0u, 0u};
+    *reinterpret_cast<u32x4*>(kimg + r * (2 * D) + (((2 * ks + h) ^ swz<D>(r)) << 4)) = v;
+  }
+  stage_wait();
+  __syncthreads();
+
+  bf16x8 pfr[NQT][2], dsfr[NQT][2];                             // P^T / dS^T of (query tile, 16-query half) as MFMA operands: phase 2
+#pragma unroll
+  for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) { pfr[qt][ss] = bf16x8{}; dsfr[qt][ss] = bf16x8{}; }
+  const uint32_t* mrow = mw_s + wt * QPAD;
+  char* ws = scr + wave * 2048;
+  const uint32_t hbase = ((uint32_t)b * p.H + head) * (uint32_t)p.Tq;
+  const uint32_t halfw = ((uint32_t)p.Tk + 1u) >> 1, halfm = halfw * DROP_M1;
+  const uint32_t dlane = drop_lin(p.drop, (4u * (uint32_t)h + ((uint32_t)r & 1u)) * halfw + ((uint32_t)(wt * 32 + r) >> 1));
+  const float c1 = p.scale * LOG2E;
+  constexpr float MOFF = -10000.0f * LOG2E;
+  const bool dropping = p.drop.thr != 0u;
+  const uint32_t thr16 = dropping ? (p.drop.thr >> 16) : 0u;
+  const float dsc = dropping ? p.drop.scale : 1.0f;
+
+  if (wave_on) {
+#pragma unroll
+  for (int qt = 0; qt < NQT; ++qt) {
+    if (32 * qt < Tq_b) {
+    f32x16 sacc = {}, dpacc = {};
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks) {
+      const bf16x8 qf = read_row_frag<D>(qimg, 32 * qt + r, 2 * ks + h);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[ks], sacc, 0, 0, 0);
+      const bf16x8 df = read_row_frag<D>(doimg, 32 * qt + r, 2 * ks + h);
+      dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, vf[ks], dpacc, 0, 0, 0);
+    }
+    float pd[16], ds[16];
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int qb = 32 * qt + 8 * g4 + 4 * h;   // 4 consecutive queries for registers 4*g4 .. 4*g4+3
+      const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qb);
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + qb);
+      const u32x4 w4 = *reinterpret_cast<const u32x4*>(mrow + qb);
+      uint32_t dwv[4] = {0u, 0u, 0u, 0u};
+      const uint32_t odd = (uint32_t)r & 1u;
+      if (dropping) {       // keys k and k^1 share a hash word: each lane of the pair hashes two of the four queries (see attn_bwd_dkv_kernel)
+        const uint32_t ua = (hbase + (uint32_t)(32 * qt + 8 * g4)) * halfm;
+        const uint32_t wa = drop_fin(p.drop, dlane + ua);
+        const uint32_t wb = drop_fin(p.drop, dlane + ua + 2u * halfm);
+        const uint32_t oa = (uint32_t)__builtin_amdgcn_mov_dpp((int)wa, 0xB1, 0xF, 0xF, true);
+        const uint32_t ob = (uint32_t)__builtin_amdgcn_mov_dpp((int)wb, 0xB1, 0xF, 0xF, true);
+        dwv[0] = odd ? oa : wa; dwv[1] = odd ? wa : oa; dwv[2] = odd ? ob : wb; dwv[3] = odd ? wb : ob;
+      }
+      const uint32_t fsh = odd << 4;
+#pragma unroll
+      for (int i = 0; i < 4; i += 2) {
+        const int e = 4 * g4 + i;
+        f32x2v madd, tk;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const uint32_t mb = (uint32_t)__builtin_amdgcn_sbfe((int)w4[i + u], (uint32_t)r, 1) & __builtin_bit_cast(uint32_t, MOFF);
+          madd[u] = __uint_as_float(mb);
+          tk[u] = __builtin_amdgcn_ubfe(dwv[i + u], fsh, 16) >= thr16 ? dsc : 0.0f;
+        }
+        const f32x2v arg = f32x2v{sacc[e], sacc[e + 1]} * c1 + (f32x2v{l4[i], l4[i + 1]} + madd);
+        f32x2v pe;
+        pe.x = __builtin_amdgcn_exp2f(arg.x); pe.y = __builtin_amdgcn_exp2f(arg.y);
+        const f32x2v pdv = pe * tk;
+        const f32x2v dsv = pe * (f32x2v{dpacc[e], dpacc[e + 1]} * tk - f32x2v{d4[i], d4[i + 1]});
+        pd[e] = pdv.x; pd[e + 1] = pdv.y;
+        ds[e] = dsv.x; ds[e + 1] = dsv.y;
+      }
+    }
+    // dS^T of this (query tile, key tile) -> the wave's LDS tile: row = key (lane), 4 consecutive queries per store
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4)
+      *reinterpret_cast<u32x2*>(ws + r * 64 + 16 * g4 + 8 * h) =
+          u32x2{pack2bf(ds[4 * g4], ds[4 * g4 + 1]), pack2bf(ds[4 * g4 + 2], ds[4 * g4 + 3])};
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) { pfr[qt][ss] = pack8(pd + 8 * ss); dsfr[qt][ss] = pack8(ds + 8 * ss); }
+    // dQ^T partial of the tile over this wave's keys, added into the workgroup's accumulator
+    f32x16 dqp[D / 32];
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt) dqp[dt] = f32x16{};
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) {
+      const bf16x8 dstf = read_tr_tile64(ws, 16 * ss, lane);
+#pragma unroll
+      for (int dt = 0; dt < D / 32; ++dt)
+        dqp[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_tr_frag<D>(kimg, 16 * ss, 32 * dt, lane), dstf, dqp[dt], 0, 0, 0);
+    }
+    // lane (q = r, h) holds d = 32 dt + 8 g + 4 h + {0..3} in registers 4 g .. 4 g + 3 of dqp[dt]
+    float* ap = acc + (32 * qt + r) * AS + 4 * h;
+    if (wt == 0) {
+#pragma unroll
+      for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<f32x4*>(ap + 32 * dt + 8 * g) = f32x4{dqp[dt][4 * g], dqp[dt][4 * g + 1], dqp[dt][4 * g + 2], dqp[dt][4 * g + 3]};
+    } else {
+      while (__hip_atomic_load(turn + qt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != wt) __builtin_amdgcn_s_sleep(2);
+#pragma unroll
+      for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4* a4 = reinterpret_cast<f32x4*>(ap + 32 * dt + 8 * g);
+          const f32x4 o = *a4;
+          *a4 = f32x4{o[0] + dqp[dt][4 * g], o[1] + dqp[dt][4 * g + 1], o[2] + dqp[dt][4 * g + 2], o[3] + dqp[dt][4 * g + 3]};
+        }
+    }
+    if (lane == 0) __hip_atomic_store(turn + qt, wt + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+  }
+
+  // Phase 2: dV = P^T dO and dK = dS^T Q of the wave's 32 keys, one 32-wide slice of D at a time -- 32 accumulator registers
+  // alive instead of 2 x 64 through the whole score phase (which is what made this one kernel fit: 2 x 128 + the K / V
+  // fragments + a query tile's S, dP, P, dS is 350 registers)
+  if (wave_on) {                                                // (wave-uniform: the lane swap inside needs every lane)
+    const bool ok = kvalid;
+    bf16_t* dkp = p.dk + (ok ? grow : 0) * p.lddk + head * D;
+    bf16_t* dvp = p.dv + (ok ? grow : 0) * p.lddv + head * D;
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt) {
+      f32x16 dkc[1] = {f32x16{}}, dvc[1] = {f32x16{}};
+#pragma unroll
+      for (int qt = 0; qt < NQT; ++qt) {
+        if (32 * qt < Tq_b) {
+#pragma unroll
+          for (int ss = 0; ss < 2; ++ss) {
+            const bf16x8 dotf = read_tr_frag<D>(doimg, 32 * qt + 16 * ss, 32 * dt, lane);
+            dvc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf, pfr[qt][ss], dvc[0], 0, 0, 0);
+            const bf16x8 qtf = read_tr_frag<D>(qimg, 32 * qt + 16 * ss, 32 * dt, lane);
+            dkc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, dsfr[qt][ss], dkc[0], 0, 0, 0);
+          }
+        }
+      }
+      store_acc_row<32>(dkp + 32 * dt, dkc, p.scale, h, ok);
+      store_acc_row<32>(dvp + 32 * dt, dvc, 1.0f, h, ok);
+    }
+  }
+  __syncthreads();                                              // every wave's dQ partials are in the accumulator
+  for (int i = tid; i < qpad_b * 16; i += blockDim.x) {         // 16 lanes = one 256-byte dQ row
+    const int q = i >> 4, c = i & 15;
+    if (q >= Tq_b) continue;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = acc[q * AS + 8 * c + j] * p.scale;
+    *reinterpret_cast<u32x4*>(p.dq + (qbase + q) * p.lddq + head * D + 8 * c) =
+        u32x4{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+  }
+}
+
 // Workgroups per (sequence, head).  Default: one workgroup (up to 8 waves) per item.  Two 4-wave
 // workgroups per item fit two to a CU and overlap each other's staging, but both stage the full K/V
 // (or Q/dO) images: measured 589 vs 545 us for the text fwd+bwd trio, so it stays a tuning knob.
@@ -960,6 +1201,19 @@ int launch_bwd_fused(const AttnBwdParams& p, hipStream_t s) {
   const size_t lds = (size_t)2 * QPAD * 2 * D + 2 * QPAD * sizeof(float) + (size_t)8 * QPAD * sizeof(uint32_t) + 8 * 2048 +
                      (size_t)QPAD * (D + 4) * sizeof(float) + NQT * sizeof(int);
   auto kern = attn_bwd_fused_kernel<NQT>;
+  if (set_lds(kern, lds) != UNIMM_OK) return UNIMM_E_HIP;
+  AttnBwdParams q = p;
+  q.parts = 1;
+  hipLaunchKernelGGL(kern, dim3(p.B * p.H), dim3(512), lds, s, q);
+  UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
+}
+
+inline int launch_bwd_fewq128(const AttnBwdParams& p, hipStream_t s) {
+  constexpr int D = 128, NQT = 2, QPAD = NQT * 32;
+  const size_t lds = (size_t)2 * QPAD * 2 * D + 2 * QPAD * sizeof(float) + (size_t)8 * QPAD * sizeof(uint32_t) + 8 * 2048 +
+                     (size_t)8 * 32 * 2 * D + (size_t)QPAD * (D + 4) * sizeof(float) + NQT * sizeof(int);
+  auto kern = attn_bwd_fewq128_kernel<NQT>;
   if (set_lds(kern, lds) != UNIMM_OK) return UNIMM_E_HIP;
   AttnBwdParams q = p;
   q.parts = 1;
@@ -1132,6 +1386,12 @@ extern "C" int unimm_attn_bwd(const unimm_attn_bwd_args* a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const bool small_k = a->Tk <= 64, small_q = a->Tq <= 64;
   if (a->D == 64 && !small_k && !small_q) return launch_bwd_fused<8>(p, s);   // text self-attention: one kernel
+#ifndef UNIMM_ATTN_FEWQ128
+#define UNIMM_ATTN_FEWQ128 1     // (A/B builds: 0 = the dQ + dK/dV kernel pair for the 37-query directions too)
+#endif
+  // regions attend text (37 queries x up to 256 keys): one kernel, 133 against 94 + 134 us per layer at 240 sequences.  (The 37 x 37
+  // image self-attention stays on the pair of small workgroups: two active key-tile waves in a one-per-CU workgroup were 95 against 81 us.)
+  if (UNIMM_ATTN_FEWQ128 && a->D == 128 && small_q && !small_k) return launch_bwd_fewq128(p, s);
   int rc;
   if (a->D == 64) rc = small_k ? launch_bwd_dq<64, 2>(p, s) : launch_bwd_dq<64, 8>(p, s);
   else rc = small_k ? launch_bwd_dq<128, 2>(p, s) : launch_bwd_dq<128, 8>(p, s);
