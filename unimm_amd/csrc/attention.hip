@@ -1133,6 +1133,240 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fewq128_kernel(AttnBwdParams 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// ... and for the mirror direction, text queries attending the 37 regions (D = 128, at most 256 queries x 64 keys): the same
+// orientation (key on the lane), but a wave is a 32-QUERY tile here and walks the two key tiles.  Its Q / dO rows stay in
+// registers as row fragments, K / V are two 16 KiB images shared by the workgroup; dQ of the wave's queries is complete after the
+// two key tiles (registers -> global); dK / dV are sums over ALL queries and meet in two LDS accumulators in wave order (a turn
+// word per output, key tile and 32-wide slice of D).  Their MFMAs want Q^T / dO^T fragments of the wave's tile: phase 2 writes one
+// 32-wide slice of the row fragments at a time into a wave-private 2 KiB tile and reads it back transposed -- which is what
+// keeps the LDS at 150 KiB (a full image per wave would be 128 KiB more).  Replaces a dQ kernel (98 us per layer at 240
+// sequences) and a dK/dV kernel (110 us, 312 registers) that formed S, dP, P, dS twice.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void attn_bwd_fewk128_kernel(AttnBwdParams p) {
+  constexpr int D = 128, NKT = 2, KPAD = NKT * 32, QMAX = 256, AS = D + 4, NSLOT = 2 * NKT * (D / 32);
+  drop_resolve(p.drop);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* kimg = smem;
+  char* vimg = smem + KPAD * 2 * D;
+  float* lse_s = reinterpret_cast<float*>(smem + 2 * KPAD * 2 * D);
+  float* del_s = lse_s + QMAX;
+  uint32_t* mw_s = reinterpret_cast<uint32_t*>(del_s + QMAX);   // [key tile][query] mask words
+  char* scr = reinterpret_cast<char*>(mw_s + NKT * QMAX);       // [wave][dS^T tile of key tile 0 | of key tile 1 | slice tile]: 3 x ([32][32] bf16)
+  float* accK = reinterpret_cast<float*>(scr + 8 * 6144);       // [KPAD keys][AS] fp32
+  float* accV = accK + KPAD * AS;
+  int* turn = reinterpret_cast<int*>(accV + KPAD * AS);         // [dK | dV][key tile][slice]: the wave whose turn it is to add
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int item = blockIdx.x;
+  const int b = p.order != nullptr ? p.order[item / p.H] : item / p.H, head = item % p.H;
+  const int wq = wave;                                          // this wave's 32-query tile
+  const int r = lane & 31, h = lane >> 5;
+
+  const int Tq_b = p.q_len ? p.q_len[b] : p.Tq, Tk_b = p.k_len ? p.k_len[b] : p.Tk;
+  const size_t qbase = p.q_off ? (size_t)p.q_off[b] : (size_t)b * p.Tq;
+  const size_t kbase = p.k_off ? (size_t)p.k_off[b] : (size_t)b * p.Tk;
+  const int qpad_b = ((Tq_b + 31) & ~31) < QMAX ? ((Tq_b + 31) & ~31) : QMAX;
+  const int kpad_b = ((Tk_b + 31) & ~31) < KPAD ? ((Tk_b + 31) & ~31) : KPAD;
+  stage_head<D>(p.k + kbase * p.ldk + head * D, p.ldk, Tk_b, kpad_b, kimg, tid, blockDim.x);
+  stage_head<D>(p.v + kbase * p.ldv + head * D, p.ldv, Tk_b, kpad_b, vimg, tid, blockDim.x);
+  for (int i = tid; i < qpad_b; i += blockDim.x) {
+    const size_t stat = ((size_t)b * p.H + head) * p.Tq + i;
+    lse_s[i] = i < Tq_b ? -p.lse[stat] * LOG2E : -INFINITY;     // NEGATED; -inf => P = 0 for padded queries
+  }
+  // delta[q] = sum_d dO[q, d] O[q, d]: 16 consecutive lanes share a row (16-byte chunks), reduced by four exchanges
+  for (int i = tid; i < qpad_b * 16; i += blockDim.x) {
+    const int row = i >> 4, c = i & 15;
+    float part = 0.f;
+    if (row < Tq_b) {
+      const u32x4 a = *reinterpret_cast<const u32x4*>(p.dout + (qbase + row) * p.lddo + head * D + 8 * c);
+      const u32x4 o = *reinterpret_cast<const u32x4*>(p.o + (qbase + row) * p.ldo + head * D + 8 * c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        part = fmaf(__uint_as_float(a[e] << 16), __uint_as_float(o[e] << 16), part);
+        part = fmaf(__uint_as_float(a[e] & 0xffff0000u), __uint_as_float(o[e] & 0xffff0000u), part);
+      }
+    }
+    part += __shfl_xor(part, 1, 64);
+    part += __shfl_xor(part, 2, 64);
+    part += __shfl_xor(part, 4, 64);
+    part += __shfl_xor(part, 8, 64);
+    if (c == 0) del_s[row] = part;
+  }
+  {
+    const int nkt_b = (Tk_b + 31) >> 5;
+    const uint32_t* mb = p.mask + (size_t)b * p.mask_b_stride;
+    for (int i = tid; i < nkt_b * qpad_b; i += blockDim.x) {
+      const int kt = i / qpad_b, qi = i - kt * qpad_b;
+      const int qc = qi < Tq_b ? qi : Tq_b - 1;
+      mw_s[kt * QMAX + qi] = ~mb[(size_t)qc * p.mask_q_stride + kt];   // INVERTED: bit set = masked
+    }
+  }
+  if (tid < NSLOT) turn[tid] = 0;
+
+  int qrow = wq * 32 + r;
+  const bool qvalid = qrow < Tq_b;
+  const bool wave_on = wq * 32 < Tq_b;
+  if (!qvalid) qrow = Tq_b - 1;
+  const size_t grow = qbase + qrow;
+  const bf16_t* qg = p.q + grow * p.ldq + head * D;
+  const bf16_t* dg = p.dout + grow * p.lddo + head * D;
+  bf16x8 qf[D / 16], dof[D / 16];                               // row fragments of the wave's queries: lane (r, h) = row r, columns 16 ks + 8 h ..
+#pragma unroll
+  for (int ks = 0; ks < D / 16; ++ks) {
+    qf[ks] = *reinterpret_cast<const bf16x8*>(qg + 16 * ks + 8 * h);
+    dof[ks] = *reinterpret_cast<const bf16x8*>(dg + 16 * ks + 8 * h);
+  }
+  stage_wait();
+  __syncthreads();
+
+  bf16x8 pfr[NKT][2], dsfr[NKT][2];                             // P^T / dS^T of (key tile, 16-query half) as MFMA operands: phase 2
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) { pfr[kt][ss] = bf16x8{}; dsfr[kt][ss] = bf16x8{}; }
+  char* wsb = scr + wave * 6144;
+  char* ws2 = wsb + 4096;
+  const uint32_t hbase = ((uint32_t)b * p.H + head) * (uint32_t)p.Tq;
+  const uint32_t halfw = ((uint32_t)p.Tk + 1u) >> 1, halfm = halfw * DROP_M1;
+  const float c1 = p.scale * LOG2E;
+  constexpr float MOFF = -10000.0f * LOG2E;
+  const bool dropping = p.drop.thr != 0u;
+  const uint32_t thr16 = dropping ? (p.drop.thr >> 16) : 0u;
+  const float dsc = dropping ? p.drop.scale : 1.0f;
+
+  if (wave_on) {
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+    if (32 * kt < Tk_b) {
+    const uint32_t* mrow = mw_s + kt * QMAX;
+    char* ws = wsb + kt * 2048;
+    const uint32_t dlane = drop_lin(p.drop, (4u * (uint32_t)h + ((uint32_t)r & 1u)) * halfw + ((uint32_t)(kt * 32 + r) >> 1));
+    f32x16 sacc = {}, dpacc = {};
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks) {
+      const bf16x8 kfr = read_row_frag<D>(kimg, 32 * kt + r, 2 * ks + h);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks], kfr, sacc, 0, 0, 0);
+      const bf16x8 vfr = read_row_frag<D>(vimg, 32 * kt + r, 2 * ks + h);
+      dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof[ks], vfr, dpacc, 0, 0, 0);
+    }
+    float pd[16], ds[16];
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int qb = 32 * wq + 8 * g4 + 4 * h;   // 4 consecutive queries for registers 4*g4 .. 4*g4+3
+      const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qb);
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + qb);
+      const u32x4 w4 = *reinterpret_cast<const u32x4*>(mrow + qb);
+      uint32_t dwv[4] = {0u, 0u, 0u, 0u};
+      const uint32_t odd = (uint32_t)r & 1u;
+      if (dropping) {       // keys k and k^1 share a hash word: each lane of the pair hashes two of the four queries (see attn_bwd_dkv_kernel)
+        const uint32_t ua = (hbase + (uint32_t)(32 * wq + 8 * g4)) * halfm;
+        const uint32_t wa = drop_fin(p.drop, dlane + ua);
+        const uint32_t wb = drop_fin(p.drop, dlane + ua + 2u * halfm);
+        const uint32_t oa = (uint32_t)__builtin_amdgcn_mov_dpp((int)wa, 0xB1, 0xF, 0xF, true);
+        const uint32_t ob = (uint32_t)__builtin_amdgcn_mov_dpp((int)wb, 0xB1, 0xF, 0xF, true);
+        dwv[0] = odd ? oa : wa; dwv[1] = odd ? wa : oa; dwv[2] = odd ? ob : wb; dwv[3] = odd ? wb : ob;
+      }
+      const uint32_t fsh = odd << 4;
+#pragma unroll
+      for (int i = 0; i < 4; i += 2) {
+        const int e = 4 * g4 + i;
+        f32x2v madd, tk;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const uint32_t mb = (uint32_t)__builtin_amdgcn_sbfe((int)w4[i + u], (uint32_t)r, 1) & __builtin_bit_cast(uint32_t, MOFF);
+          madd[u] = __uint_as_float(mb);
+          tk[u] = __builtin_amdgcn_ubfe(dwv[i + u], fsh, 16) >= thr16 ? dsc : 0.0f;
+        }
+        const f32x2v arg = f32x2v{sacc[e], sacc[e + 1]} * c1 + (f32x2v{l4[i], l4[i + 1]} + madd);
+        f32x2v pe;
+        pe.x = __builtin_amdgcn_exp2f(arg.x); pe.y = __builtin_amdgcn_exp2f(arg.y);
+        const f32x2v pdv = pe * tk;
+        const f32x2v dsv = pe * (f32x2v{dpacc[e], dpacc[e + 1]} * tk - f32x2v{d4[i], d4[i + 1]});
+        pd[e] = pdv.x; pd[e + 1] = pdv.y;
+        ds[e] = dsv.x; ds[e + 1] = dsv.y;
+      }
+    }
+    // dS^T of this (query tile, key tile) -> the wave's LDS tile: row = key (lane), 4 consecutive queries per store
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4)
+      *reinterpret_cast<u32x2*>(ws + r * 64 + 16 * g4 + 8 * h) =
+          u32x2{pack2bf(ds[4 * g4], ds[4 * g4 + 1]), pack2bf(ds[4 * g4 + 2], ds[4 * g4 + 3])};
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) { pfr[kt][ss] = pack8(pd + 8 * ss); dsfr[kt][ss] = pack8(ds + 8 * ss); }
+    }
+  }
+  // dQ^T of the wave's queries = K^T dS^T over both key tiles (lane = query, registers = D values): after the score phase, whose
+  // S / dP / P / dS registers are dead by now
+  f32x16 dqp[D / 32];
+#pragma unroll
+  for (int dt = 0; dt < D / 32; ++dt) dqp[dt] = f32x16{};
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+    if (32 * kt < Tk_b) {
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        const bf16x8 dstf = read_tr_tile64(wsb + kt * 2048, 16 * ss, lane);
+#pragma unroll
+        for (int dt = 0; dt < D / 32; ++dt)
+          dqp[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_tr_frag<D>(kimg, 32 * kt + 16 * ss, 32 * dt, lane), dstf, dqp[dt], 0, 0, 0);
+      }
+    }
+  }
+  store_acc_row<D>(p.dq + (qvalid ? grow : 0) * p.lddq + head * D, dqp, p.scale, h, qvalid);
+
+  // Phase 2: dK^T += Q^T dS and dV^T += dO^T P over the wave's 32 queries, per 32-wide slice of D and key tile, into the
+  // workgroup's accumulators in wave order (wave 0 stores, wave w adds once the slot's turn word reads w)
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt) {
+      // the slice [32 queries][32 d] of the row fragments -> the wave's tile (row = query: 2 x 16 bytes per lane)
+      const bf16x8 lo = which == 0 ? qf[2 * dt] : dof[2 * dt], hi = which == 0 ? qf[2 * dt + 1] : dof[2 * dt + 1];
+      *reinterpret_cast<u32x4*>(ws2 + r * 64 + 16 * h) = __builtin_bit_cast(u32x4, lo);
+      *reinterpret_cast<u32x4*>(ws2 + r * 64 + 32 + 16 * h) = __builtin_bit_cast(u32x4, hi);
+      const bf16x8 tf0 = read_tr_tile64(ws2, 0, lane), tf1 = read_tr_tile64(ws2, 16, lane);
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+        if (32 * kt < Tk_b) {
+          f32x16 part = {};
+          part = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf0, which == 0 ? dsfr[kt][0] : pfr[kt][0], part, 0, 0, 0);
+          part = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf1, which == 0 ? dsfr[kt][1] : pfr[kt][1], part, 0, 0, 0);
+          // lane (key = r, h) holds d = 32 dt + 8 g + 4 h + {0..3} in registers 4 g .. 4 g + 3
+          float* ap = (which == 0 ? accK : accV) + (32 * kt + r) * AS + 32 * dt + 4 * h;
+          int* tw = turn + (which * NKT + kt) * (D / 32) + dt;
+          if (wq == 0) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              *reinterpret_cast<f32x4*>(ap + 8 * g) = f32x4{part[4 * g], part[4 * g + 1], part[4 * g + 2], part[4 * g + 3]};
+          } else {
+            while (__hip_atomic_load(tw, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != wq) __builtin_amdgcn_s_sleep(2);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              f32x4* a4 = reinterpret_cast<f32x4*>(ap + 8 * g);
+              const f32x4 o = *a4;
+              *a4 = f32x4{o[0] + part[4 * g], o[1] + part[4 * g + 1], o[2] + part[4 * g + 2], o[3] + part[4 * g + 3]};
+            }
+          }
+          if (lane == 0) __hip_atomic_store(tw, wq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+    }
+  }
+  }
+  __syncthreads();                                              // every wave's partials are in the accumulators
+  for (int i = tid; i < kpad_b * 16; i += blockDim.x) {         // 16 lanes = one 256-byte dK / dV row
+    const int key = i >> 4, c = i & 15;
+    if (key >= Tk_b) continue;
+    float v[8], w[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { v[j] = accK[key * AS + 8 * c + j] * p.scale; w[j] = accV[key * AS + 8 * c + j]; }
+    *reinterpret_cast<u32x4*>(p.dk + (kbase + key) * p.lddk + head * D + 8 * c) =
+        u32x4{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+    *reinterpret_cast<u32x4*>(p.dv + (kbase + key) * p.lddv + head * D + 8 * c) =
+        u32x4{pack2bf(w[0], w[1]), pack2bf(w[2], w[3]), pack2bf(w[4], w[5]), pack2bf(w[6], w[7])};
+  }
+}
+
 // Workgroups per (sequence, head).  Default: one workgroup (up to 8 waves) per item.  Two 4-wave
 // workgroups per item fit two to a CU and overlap each other's staging, but both stage the full K/V
 // (or Q/dO) images: measured 589 vs 545 us for the text fwd+bwd trio, so it stays a tuning knob.
@@ -1214,6 +1448,19 @@ inline int launch_bwd_fewq128(const AttnBwdParams& p, hipStream_t s) {
   const size_t lds = (size_t)2 * QPAD * 2 * D + 2 * QPAD * sizeof(float) + (size_t)8 * QPAD * sizeof(uint32_t) + 8 * 2048 +
                      (size_t)8 * 32 * 2 * D + (size_t)QPAD * (D + 4) * sizeof(float) + NQT * sizeof(int);
   auto kern = attn_bwd_fewq128_kernel<NQT>;
+  if (set_lds(kern, lds) != UNIMM_OK) return UNIMM_E_HIP;
+  AttnBwdParams q = p;
+  q.parts = 1;
+  hipLaunchKernelGGL(kern, dim3(p.B * p.H), dim3(512), lds, s, q);
+  UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
+}
+
+inline int launch_bwd_fewk128(const AttnBwdParams& p, hipStream_t s) {
+  constexpr int D = 128, KPAD = 64, QMAX = 256;
+  const size_t lds = (size_t)2 * KPAD * 2 * D + 2 * QMAX * sizeof(float) + (size_t)2 * QMAX * sizeof(uint32_t) + 8 * 6144 +
+                     (size_t)2 * KPAD * (D + 4) * sizeof(float) + 16 * sizeof(int);
+  auto kern = attn_bwd_fewk128_kernel;
   if (set_lds(kern, lds) != UNIMM_OK) return UNIMM_E_HIP;
   AttnBwdParams q = p;
   q.parts = 1;
@@ -1392,6 +1639,10 @@ extern "C" int unimm_attn_bwd(const unimm_attn_bwd_args* a, void* stream) {
   // regions attend text (37 queries x up to 256 keys): one kernel, 133 against 94 + 134 us per layer at 240 sequences.  (The 37 x 37
   // image self-attention stays on the pair of small workgroups: two active key-tile waves in a one-per-CU workgroup were 95 against 81 us.)
   if (UNIMM_ATTN_FEWQ128 && a->D == 128 && small_q && !small_k) return launch_bwd_fewq128(p, s);
+#ifndef UNIMM_ATTN_FEWK128
+#define UNIMM_ATTN_FEWK128 1     // (A/B builds: 0 = the kernel pair for the text-attends-regions direction)
+#endif
+  if (UNIMM_ATTN_FEWK128 && a->D == 128 && small_k && !small_q) return launch_bwd_fewk128(p, s);   // text attends regions: one kernel
   int rc;
   if (a->D == 64) rc = small_k ? launch_bwd_dq<64, 2>(p, s) : launch_bwd_dq<64, 8>(p, s);
   else rc = small_k ? launch_bwd_dq<128, 2>(p, s) : launch_bwd_dq<128, 8>(p, s);
