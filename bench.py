@@ -64,6 +64,10 @@ def parse():
     ap.add_argument("--with-optimizer", action="store_true",
                     help="also run the fused AdamW step (train.py:322-348 grouping and schedule) inside the timed step; "
                          "NOT the headline metric, which is fwd+bwd (the config block says which was run)")
+    ap.add_argument("--fused-step", choices=["auto", "on", "off"], default="auto",
+                    help="the step through `forward_backward(..., loss_weights)` (forward and backward enqueued back to back, no autograd "
+                         "round trip between them) instead of `loss = combine(...); loss.backward()`.  auto = on under the graph executor "
+                         "(small per-GPU batches, where the round trip is 2-4 %% of the step), off otherwise")
     ap.add_argument("--attn-order", choices=["on", "off"], default="on",
                     help="A/B: off = the attention launches take their (sequence, head) items in batch order (engine.attn_longest_first "
                          "= False) instead of longest sequence first")
@@ -464,6 +468,9 @@ def main():
         def feed():
             batch.update(next(src))
 
+    _hdr_cache = {}
+    fused_step = [False]                        # set below, once it is known whether the graph executor runs the step
+
     def combine(lm, nsp, img):                  # train.py:164-168, as unimm_amd.harness.forward combines them
         if args.plain_loss:
             return coeff["lm"] * lm.mean() + coeff["nsp"] * nsp.mean() + coeff["img"] * img.mean()
@@ -494,6 +501,26 @@ def main():
             loss = combine(lm, nsp, img)
             loss.backward()
             return loss
+        if fused_step[0]:
+            if os.environ.get("UNIMM_EXP_CACHED_HEADER") == "1":      # experiment: upper bound of a prefetched plan header
+                if "hdr" not in _hdr_cache:
+                    _hdr_cache["hdr"] = model.engine.count_rows(dict(batch, nsp_weight=nsp_w))
+                return net.forward_backward(
+                    batch["input_ids"], batch["image_feat"], batch["image_loc"], (coeff["lm"], coeff["nsp"], coeff["img"]),
+                    sep_indices=batch["sep_indices"], sep_len=batch["sep_len"], token_type_ids=batch["token_type_ids"],
+                    token_position_ids=batch["token_position_ids"], attention_mask=batch["attention_mask"],
+                    masked_lm_labels=batch["masked_lm_labels"], next_sentence_label=batch["next_sentence_label"],
+                    image_attention_mask=batch["image_attention_mask"], co_attention_mask=batch["co_attention_mask"],
+                    image_label=batch["image_label"], image_target=batch["image_target"], nsp_weight=nsp_w,
+                    lm_weight=batch["lm_weight"], plan_header=_hdr_cache["hdr"])[0]
+            return net.forward_backward(
+                batch["input_ids"], batch["image_feat"], batch["image_loc"], (coeff["lm"], coeff["nsp"], coeff["img"]),
+                sep_indices=batch["sep_indices"], sep_len=batch["sep_len"], token_type_ids=batch["token_type_ids"],
+                token_position_ids=batch["token_position_ids"], attention_mask=batch["attention_mask"],
+                masked_lm_labels=batch["masked_lm_labels"], next_sentence_label=batch["next_sentence_label"],
+                image_attention_mask=batch["image_attention_mask"], co_attention_mask=batch["co_attention_mask"],
+                image_label=batch["image_label"], image_target=batch["image_target"], nsp_weight=nsp_w,
+                lm_weight=batch["lm_weight"])[0]
         lm, img, nsp = net(batch["input_ids"], batch["image_feat"], batch["image_loc"], sep_indices=batch["sep_indices"],
                            sep_len=batch["sep_len"], token_type_ids=batch["token_type_ids"],
                            token_position_ids=batch["token_position_ids"], attention_mask=batch["attention_mask"],
@@ -592,6 +619,8 @@ def main():
     use_graphs = (args.graphs == "on" or (args.graphs == "auto" and per_gpu <= GRAPHS_AUTO_MAX_SEQ)) and args.workload in ("train", "dense") \
         and not args.compact_inputs and not args.host_profile and args.host_inputs == "off"
     gx = None
+    fused_step[0] = args.workload == "train" and not args.compact_inputs and \
+        (args.fused_step == "on" or (args.fused_step == "auto" and use_graphs))
     if use_graphs:
         gx = model.engine.enable_graphs(True)
         done = 0
@@ -820,6 +849,8 @@ def main():
                        "global_batch": global_batch, "per_gpu_batch": per_gpu, "seq_len": 256, "regions": 37,
                        "parallelism": f"dp{world}", "lm_rows_decoded_per_seq": round(n_lm_rows / per_gpu, 2),
                        "executor": ("hipGraph replay (unimm_amd/graphs.py): " + json.dumps(graph_stats)) if graph_stats else "eager launches",
+                       "step_api": ("forward_backward(batch, loss_weights): forward and backward enqueued back to back (--fused-step)"
+                                    if fused_step[0] else "loss = combine(losses); loss.backward() (autograd, as train.py:164-168, :315)"),
                        "valid_token_rows": valid_rows, "token_rows_padded": per_gpu * 256,
                        "gflop_per_seq_fwd_padded_equivalent": round(f_fwd, 3),
                        "gemm_gflop_per_seq_executed_fwd_bwd": round(exec_gf_seq, 3),

@@ -191,11 +191,15 @@ class StepGraphs:
         return v
 
     # ------------------------------------------------------------------------------------------
-    def forward(self, inp, opts):
-        """-> (lm_loss, img_loss, nsp_loss, nsp, entry) from a replay, or None (the caller runs the eager path)."""
+    def forward(self, inp, opts, defer_outputs=False):
+        """-> (lm_loss, img_loss, nsp_loss, nsp, entry) from a replay, or None (the caller runs the eager path).
+        defer_outputs: -> (None, None, None, None, entry); the caller copies the losses out of the entry's static buffers
+        (`outputs(entry)`) after it has enqueued the backward (BertForMultiModalPreTraining.forward_backward)."""
         eng = self.eng
         eng.refresh_weights()
-        hh = eng.count_rows(inp)                               # the step's one host sync
+        hh = inp.get("_plan_header")                           # a prefetcher may have read the step's header already (count_rows_async)
+        if hh is None:
+            hh = eng.count_rows(inp)                           # the step's one host sync
         B, T = inp["input_ids"].shape
         Mv, n_lm = sum(hh[:B]), sum(hh[B:2 * B])
         Mcap = min(_rup(Mv, self.row_bucket), B * T)
@@ -219,7 +223,7 @@ class StepGraphs:
         else:
             self.entries.move_to_end(sig)
             for k, t in ent.sin.items():
-                if torch.is_tensor(t):
+                if torch.is_tensor(t) and t is not inp[k]:     # (a caller that feeds the entry's own static inputs back skips the copy)
                     t.copy_(inp[k], non_blocking=True)
         ent.salt_val = self._set_salt()
         self._replay(ent.gF)
@@ -227,8 +231,15 @@ class StepGraphs:
         tok = _Token()
         ent.inflight = weakref.ref(tok)
         ent.out["_token"] = tok                                # handed to the autograd context by _HotPath.forward
-        ls = ent.lvec.clone()                                  # one copy out of the static buffers (the next replay overwrites them)
-        return ls[0].reshape(ent.lshape), ls[1].reshape(ent.lshape), ls[2].reshape(ent.lshape), ent.nsp.clone(), ent
+        if defer_outputs:
+            return None, None, None, None, ent
+        return self.outputs(ent) + (ent,)
+
+    @staticmethod
+    def outputs(ent):
+        """(lm_loss, img_loss, nsp_loss, nsp) copied out of the entry's static buffers (the next replay overwrites them)."""
+        ls = ent.lvec.clone()
+        return ls[0].reshape(ent.lshape), ls[1].reshape(ent.lshape), ls[2].reshape(ent.lshape), ent.nsp.clone()
 
     def _capture_forward(self, sig, inp, opts, hh):
         eng = self.eng

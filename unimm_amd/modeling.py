@@ -234,6 +234,62 @@ class BertForMultiModalPreTraining(nn.Module):
         seq_t = eng.padded(out, out["seq32_t"]).view(B, T, H)
         return out.get("pred_t"), out.get("pred_v"), out["nsp"], seq_t, att
 
+    def forward_backward(self, input_ids, image_feat, image_loc, loss_weights, sep_indices=None, sep_len=None, token_type_ids=None,
+                         position_ids=None, attention_mask=None, image_attention_mask=None, co_attention_mask=None,
+                         masked_lm_labels=None, image_label=None, image_target=None, next_sentence_label=None, nsp_weight=None,
+                         lm_weight=None, image_index=None, plan_header=None):
+        """The training step's forward AND backward in one call (an extension; the reference writes
+        `loss = c_lm * lm.mean() + c_nsp * nsp.mean() + c_img * img.mean(); loss.backward()`, train.py:164-168, :315).
+        loss_weights = (c_lm, c_nsp, c_img).  With the weights known up front the backward does not wait for the host to see
+        the losses: both halves are enqueued back to back (two graph replays under the step executor) -- no autograd round trip
+        (a hand-over to the autograd thread and ~8 one-element launches between the halves: 0.2-0.4 ms during which a
+        30-sequence step's GPU idles).  Parameter gradients accumulate into `.grad` exactly as with `loss.backward()`.
+        -> (loss, lm_loss, img_loss, nsp_loss, nsp_logits).  plan_header: `engine.count_rows(...)` of this batch if the caller
+        has it already (a prefetcher: the step then starts without its host sync)."""
+        if masked_lm_labels is None or next_sentence_label is None or image_target is None:
+            raise ValueError("forward_backward needs the training inputs (masked_lm_labels, next_sentence_label, image_target)")
+        eng = self._engine
+        dev = self._device()
+        eng.ensure(dev)
+        inp = dict(input_ids=input_ids, image_feat=image_feat, image_loc=image_loc, token_type_ids=token_type_ids,
+                   position_ids=position_ids, attention_mask=attention_mask, image_attention_mask=image_attention_mask,
+                   co_attention_mask=co_attention_mask, masked_lm_labels=masked_lm_labels, image_label=image_label,
+                   image_target=image_target, next_sentence_label=next_sentence_label, nsp_weight=nsp_weight,
+                   lm_weight=lm_weight, image_index=image_index)
+        if plan_header is not None:
+            inp["_plan_header"] = plan_header
+        if self.training:
+            eng.step += 1
+        c_lm, c_nsp, c_img = (float(c) for c in loss_weights)
+        key = (c_lm, c_nsp, c_img, dev)
+        seeds = self._fb_seeds.get(key) if hasattr(self, "_fb_seeds") else None
+        if seeds is None:
+            if not hasattr(self, "_fb_seeds"):
+                self._fb_seeds = {}
+            w = torch.tensor([c_lm, c_img, c_nsp], dtype=torch.float32, device=dev)
+            seeds = self._fb_seeds[key] = (w[0:1], w[1:2], w[2:3], w)
+        g_lm, g_img, g_nsp, w = seeds
+        opts = dict(train=self.training, want_seq=False)
+        with torch.no_grad():
+            res = None
+            if eng.graphs is not None and eng.graphs.eligible(inp, opts):
+                res = eng.graphs.forward(inp, opts, defer_outputs=True)
+            if res is not None:
+                ent = res[4]
+                tok = ent.out.pop("_token", None)
+                eng.graphs.backward(ent, g_lm, g_img, g_nsp, None)
+                del tok
+                lm_loss, img_loss, nsp_loss, nsp = eng.graphs.outputs(ent)
+            else:
+                inp.pop("_plan_header", None)
+                out = eng.forward(inp, train=self.training, save=True, lm_rows="labelled", want_pred_v=True)
+                ls = eng.losses(out, inp)
+                lm_loss, img_loss, nsp_loss, nsp = ls["lm_loss"], ls["img_loss"], ls["nsp_loss"], out["nsp"].clone()
+                eng.backward(out, g_lm.reshape(lm_loss.shape), g_img.reshape(img_loss.shape), g_nsp.reshape(nsp_loss.shape), None)
+            eng.last_seq_t = None
+            loss = torch.cat((lm_loss.reshape(1), img_loss.reshape(1), nsp_loss.reshape(1))).dot(w).reshape(())
+        return loss, lm_loss, img_loss, nsp_loss, nsp
+
     def _device(self):
         return self.bert.embeddings.word_embeddings.weight.device
 
@@ -302,3 +358,16 @@ class VisualDialogEncoder(nn.Module):
         if output_lm_scores:
             out = out + (prediction_scores_t,)
         return out
+
+    def forward_backward(self, input_ids, image_feat, image_loc, loss_weights, sep_indices=None, sep_len=None, token_type_ids=None,
+                         token_position_ids=None, attention_mask=None, masked_lm_labels=None, next_sentence_label=None,
+                         image_attention_mask=None, co_attention_mask=None, image_label=None, image_target=None,
+                         nsp_weight=None, lm_weight=None, image_index=None, plan_header=None):
+        """forward + `(c_lm * lm + c_nsp * nsp + c_img * img).backward()` in one call, loss_weights = (c_lm, c_nsp, c_img)
+        (BertForMultiModalPreTraining.forward_backward).  -> (loss, lm_loss, img_loss, nsp_loss, nsp_logits)."""
+        return self.bert_pretrained.forward_backward(
+            input_ids, image_feat, image_loc, loss_weights, sep_indices=sep_indices, sep_len=sep_len, token_type_ids=token_type_ids,
+            position_ids=token_position_ids, attention_mask=attention_mask, image_attention_mask=image_attention_mask,
+            co_attention_mask=co_attention_mask, masked_lm_labels=masked_lm_labels, image_label=image_label, image_target=image_target,
+            next_sentence_label=next_sentence_label, nsp_weight=nsp_weight, lm_weight=lm_weight, image_index=image_index,
+            plan_header=plan_header)

@@ -94,6 +94,13 @@ class DataParallelRCCL(nn.Module):
         self._run = None
         return self.module(*inputs, **kwargs)
 
+    def forward_backward(self, *inputs, **kwargs):
+        """The wrapped module's one-call training step (BertForMultiModalPreTraining.forward_backward): the gradient buckets are
+        handed over from inside its backward exactly as under `loss.backward()`."""
+        self._done.clear()
+        self._run = None
+        return self.module.forward_backward(*inputs, **kwargs)
+
     # -- gradient exchange ---------------------------------------------------------------------
     @contextmanager
     def no_sync(self):
