@@ -64,10 +64,10 @@ def parse():
     ap.add_argument("--with-optimizer", action="store_true",
                     help="also run the fused AdamW step (train.py:322-348 grouping and schedule) inside the timed step; "
                          "NOT the headline metric, which is fwd+bwd (the config block says which was run)")
-    ap.add_argument("--fused-step", choices=["auto", "on", "off"], default="auto",
-                    help="the step through `forward_backward(..., loss_weights)` (forward and backward enqueued back to back, no autograd "
-                         "round trip between them) instead of `loss = combine(...); loss.backward()`.  auto = on under the graph executor "
-                         "(small per-GPU batches, where the round trip is 2-4 %% of the step), off otherwise")
+    ap.add_argument("--fused-step", choices=["on", "off"], default="off",
+                    help="A/B: the step through `forward_backward(..., loss_weights)` (forward and backward enqueued back to back, no "
+                         "autograd round trip between them) instead of `loss = combine(...); loss.backward()`: +0.2-1.2 %% at 30 "
+                         "sequences per GPU, nothing at 60 (the host is ahead of the GPU either way)")
     ap.add_argument("--attn-order", choices=["on", "off"], default="on",
                     help="A/B: off = the attention launches take their (sequence, head) items in batch order (engine.attn_longest_first "
                          "= False) instead of longest sequence first")
@@ -468,7 +468,6 @@ def main():
         def feed():
             batch.update(next(src))
 
-    _hdr_cache = {}
     fused_step = [False]                        # set below, once it is known whether the graph executor runs the step
 
     def combine(lm, nsp, img):                  # train.py:164-168, as unimm_amd.harness.forward combines them
@@ -502,17 +501,6 @@ def main():
             loss.backward()
             return loss
         if fused_step[0]:
-            if os.environ.get("UNIMM_EXP_CACHED_HEADER") == "1":      # experiment: upper bound of a prefetched plan header
-                if "hdr" not in _hdr_cache:
-                    _hdr_cache["hdr"] = model.engine.count_rows(dict(batch, nsp_weight=nsp_w))
-                return net.forward_backward(
-                    batch["input_ids"], batch["image_feat"], batch["image_loc"], (coeff["lm"], coeff["nsp"], coeff["img"]),
-                    sep_indices=batch["sep_indices"], sep_len=batch["sep_len"], token_type_ids=batch["token_type_ids"],
-                    token_position_ids=batch["token_position_ids"], attention_mask=batch["attention_mask"],
-                    masked_lm_labels=batch["masked_lm_labels"], next_sentence_label=batch["next_sentence_label"],
-                    image_attention_mask=batch["image_attention_mask"], co_attention_mask=batch["co_attention_mask"],
-                    image_label=batch["image_label"], image_target=batch["image_target"], nsp_weight=nsp_w,
-                    lm_weight=batch["lm_weight"], plan_header=_hdr_cache["hdr"])[0]
             return net.forward_backward(
                 batch["input_ids"], batch["image_feat"], batch["image_loc"], (coeff["lm"], coeff["nsp"], coeff["img"]),
                 sep_indices=batch["sep_indices"], sep_len=batch["sep_len"], token_type_ids=batch["token_type_ids"],
@@ -620,7 +608,7 @@ def main():
         and not args.compact_inputs and not args.host_profile and args.host_inputs == "off"
     gx = None
     fused_step[0] = args.workload == "train" and not args.compact_inputs and \
-        (args.fused_step == "on" or (args.fused_step == "auto" and use_graphs))
+        args.fused_step == "on"
     if use_graphs:
         gx = model.engine.enable_graphs(True)
         done = 0
