@@ -179,7 +179,7 @@ typedef struct {
   int32_t ks_ins;
   /* or NULL: int32 [B], a permutation of 0..B-1 -- the order in which the launch's workgroups take the sequences (every head of
    * order[0] first).  Results do not depend on it; with variable lengths, longest first (unimm_plan_build writes that) keeps the
-   * launch's tail short: +1.6 % on the 240-sequence step.  ABI 17. */
+   * launch's tail short: +1 % on the 240-sequence step.  ABI 17.  (The fp32-class entry points honour it in their matrix-instruction kernels.) */
   const int32_t* order;
 } unimm_attn_args;
 

@@ -367,6 +367,7 @@ struct AttnF32 {
   float* out; float* lse; float* delta; float* dq; float* dk; float* dv;
   const uint32_t* mask;
   const int* q_off; const int* q_len; const int* k_off; const int* k_len;
+  const int* order;      // or NULL: the sequences in the order the workgroups take them (unimm_attn_args.order; the matrix kernels)
   int B, H, Tq, Tk;
   int ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
   int mqs, mbs;
@@ -639,13 +640,15 @@ constexpr float XM_LOG2E = 1.4426950408889634f, XM_NEG2 = -10000.0f * 1.44269504
 // its own L2: with the plain (row block, head, sequence) grid the row blocks of one (sequence, head) -- which stage the SAME
 // other-side rows -- land on different XCDs and each fetches them from HBM.  Here the 1-D id d is decoded as xcd = d % 8,
 // j = d / 8, row block = j % nblk, pair = (j / nblk) * 8 + xcd: all row blocks of a pair run on one XCD, back to back.
-__device__ __forceinline__ bool xm_decode(int nblk, int H, int B, int& blk, int& head, int& b) {
+__device__ __forceinline__ bool xm_decode(int nblk, int H, int B, const int* order, int& blk, int& head, int& b) {
   const int d = blockIdx.x, xcd = d & 7, j = d >> 3;
   blk = j % nblk;
   const int pair = (j / nblk) * 8 + xcd;
-  b = pair / H;
-  head = pair - b * H;
-  return pair < H * B;
+  if (pair >= H * B) return false;
+  const int seq = pair / H;
+  head = pair - seq * H;
+  b = order != nullptr ? order[seq] : seq;       // longest sequences first: the launch's tail is its shortest items
+  return true;
 }
 __host__ inline unsigned xm_grid(int nblk, int H, int B) { return (unsigned)(((H * B + 7) / 8) * nblk * 8); }
 
@@ -790,7 +793,7 @@ __global__ __launch_bounds__(XM_T, UNIMM_X3M_MIN_WAVES) void x3m_attn_fwd_kernel
   __shared__ __attribute__((aligned(16))) float Xs[KC * LD];
   drop_resolve(p.drop);
   int blk, head, b;
-  if (!xm_decode(OWN_Q ? (p.Tq + XM_R - 1) / XM_R : (p.Tk + XM_R - 1) / XM_R, p.H, p.B, blk, head, b)) return;
+  if (!xm_decode(OWN_Q ? (p.Tq + XM_R - 1) / XM_R : (p.Tk + XM_R - 1) / XM_R, p.H, p.B, p.order, blk, head, b)) return;
   const int qlen = p.q_len != nullptr ? p.q_len[b] : p.Tq, qoff = p.q_off != nullptr ? p.q_off[b] : b * p.Tq;
   const int klen = p.k_len != nullptr ? p.k_len[b] : p.Tk, koff = p.k_off != nullptr ? p.k_off[b] : b * p.Tk;
   const int r0 = blk * XM_R;
@@ -897,7 +900,7 @@ __global__ __launch_bounds__(XM_T, UNIMM_X3M_MIN_WAVES) void x3m_attn_bwd_dq_ker
   __shared__ uint32_t Mq[XM_R * 9];                        // mask words of the 64 queries (rows of 8 + 1 pad)
   drop_resolve(p.drop);
   int blk, head, b;
-  if (!xm_decode(OWN_Q ? (p.Tq + XM_R - 1) / XM_R : (p.Tk + XM_R - 1) / XM_R, p.H, p.B, blk, head, b)) return;
+  if (!xm_decode(OWN_Q ? (p.Tq + XM_R - 1) / XM_R : (p.Tk + XM_R - 1) / XM_R, p.H, p.B, p.order, blk, head, b)) return;
   const int qlen = p.q_len != nullptr ? p.q_len[b] : p.Tq, qoff = p.q_off != nullptr ? p.q_off[b] : b * p.Tq;
   const int klen = p.k_len != nullptr ? p.k_len[b] : p.Tk, koff = p.k_off != nullptr ? p.k_off[b] : b * p.Tk;
   const int r0 = blk * XM_R;
@@ -1006,7 +1009,7 @@ __global__ __launch_bounds__(XM_T, UNIMM_X3M_MIN_WAVES) void x3m_attn_bwd_dkv_ke
   __shared__ uint32_t Ms[QC * 2];                          // per staged query: the two mask words this workgroup's 64 keys lie in
   drop_resolve(p.drop);
   int blk, head, b;
-  if (!xm_decode(OWN_Q ? (p.Tq + XM_R - 1) / XM_R : (p.Tk + XM_R - 1) / XM_R, p.H, p.B, blk, head, b)) return;
+  if (!xm_decode(OWN_Q ? (p.Tq + XM_R - 1) / XM_R : (p.Tk + XM_R - 1) / XM_R, p.H, p.B, p.order, blk, head, b)) return;
   const int qlen = p.q_len != nullptr ? p.q_len[b] : p.Tq, qoff = p.q_off != nullptr ? p.q_off[b] : b * p.Tq;
   const int klen = p.k_len != nullptr ? p.k_len[b] : p.Tk, koff = p.k_off != nullptr ? p.k_off[b] : b * p.Tk;
   const int r0 = blk * XM_R;
@@ -1099,6 +1102,7 @@ int fill_attn(const unimm_attn_args* a, AttnF32& p) {
   p = AttnF32{};
   p.q = (const float*)a->q; p.k = (const float*)a->k; p.v = (const float*)a->v; p.out = (float*)a->out; p.lse = a->lse;
   p.mask = a->mask; p.q_off = a->q_off; p.q_len = a->q_len; p.k_off = a->k_off; p.k_len = a->k_len;
+  p.order = a->order;
   p.B = a->B; p.H = a->H; p.Tq = a->Tq; p.Tk = a->Tk;
   p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo;
   p.mqs = a->mask_q_stride; p.mbs = a->mask_b_stride; p.scale = a->scale;
@@ -1241,6 +1245,7 @@ extern "C" int unimm_x3_attn_bwd(const unimm_attn_bwd_args* a, const unimm_x3_at
   unimm_attn_args f{};
   f.q = a->q; f.k = a->k; f.v = a->v; f.out = (void*)a->out; f.lse = (float*)a->lse; f.mask = a->mask;
   f.q_off = a->q_off; f.q_len = a->q_len; f.k_off = a->k_off; f.k_len = a->k_len;
+  f.order = a->order;
   f.B = a->B; f.H = a->H; f.Tq = a->Tq; f.Tk = a->Tk; f.D = a->D;
   f.ldq = a->ldq; f.ldk = a->ldk; f.ldv = a->ldv; f.ldo = a->ldo;
   f.mask_q_stride = a->mask_q_stride; f.mask_b_stride = a->mask_b_stride; f.scale = a->scale;
