@@ -61,11 +61,13 @@ def _rup(x, m):
 # died once in ~8 runs.  Launching from a stream of another priority class (or with a CU mask) is immune but costs 5 ms of
 # a 9 ms step (StepGraphs(launch="isolated")).  So: every CUDAGraph this module creates stays referenced here for the life
 # of the process (an exec is ~1 MB of host memory), and what would otherwise be lost with it -- the private memory pool
-# holding an entry's activations -- goes back to a free list when the entry dies and is captured into again by the next
-# entry (the dead entry's graphs are never launched again, so sharing their pool is harmless).
+# holding an entry's activations -- goes back to a free list when the entry dies, together with the stream the entry was captured
+# on, and is captured into again by the next entry (the dead entry's graphs are never launched again, so sharing their pool is
+# harmless).  tools/soak_graph_churn.py: 300 steps of five signatures evicting each other + a second model coming and going =
+# 204 captures, 236 execs alive at the end, reserved memory level at 14-19 GB (profiles/r5w_graph_churn_soak.txt).
 # ------------------------------------------------------------------------------------------------
 _KEPT = []                      # every graph exec ever instantiated here
-_FREE_POOLS = {}                # device index -> pool handles whose entry is gone
+_FREE_POOLS = {}                # device index -> [(signature, side stream, pool handle, capture stream)] of dead entries, oldest first
 
 
 def _new_graph():
@@ -82,13 +84,31 @@ def _dev_index(dev):
     return dev.index if dev.index is not None else torch.cuda.current_device()
 
 
-def _take_pool(dev):
+def _take_pool(dev, sig, side):
+    """(pool, capture stream) for a new entry.  The caching allocator hands a freed block only to allocations on the stream it was
+    allocated on, so a pool is recycled TOGETHER WITH the stream its entry was captured on (a fresh stream per entry made every
+    capture reserve its memory anew: 17 GB per pool after 100 captures of 2 GB entries, tools/soak_graph_churn.py); the image
+    side's blocks belong to the engine's side stream, so pools of the same engine are preferred -- and among those the one a dead
+    entry of the same signature left behind (that capture allocates what the old one did, in the same order)."""
     free = _FREE_POOLS.get(_dev_index(dev))
-    return free.pop() if free else torch.cuda.graph_pool_handle()
+    best = -1
+    if free:
+        for i in range(len(free) - 1, -1, -1):
+            if free[i][1] == side:
+                if free[i][0] == sig:
+                    best = i
+                    break
+                if best < 0:
+                    best = i
+        if best < 0:
+            best = len(free) - 1
+        _, _, pool, stream = free.pop(best)
+        return pool, stream
+    return torch.cuda.graph_pool_handle(), torch.cuda.Stream(device=dev)
 
 
-def _give_pool(index, pool):
-    _FREE_POOLS.setdefault(index, []).append(pool)
+def _give_pool(index, sig, side, pool, stream):
+    _FREE_POOLS.setdefault(index, []).append((sig, side, pool, stream))
 
 
 @contextlib.contextmanager
@@ -247,12 +267,12 @@ class StepGraphs:
         while len(self.entries) >= self.max_entries:           # each signature owns its activations
             self.entries.popitem(last=False)
         ent = _Entry()
-        ent.pool = _take_pool(dev)
-        weakref.finalize(ent, _give_pool, _dev_index(dev), ent.pool)      # with its tensors gone the pool is free for the next entry
+        side = int(eng._side_stream().cuda_stream) if eng._dual() else 0
+        ent.pool, ent.stream = _take_pool(dev, sig, side)
+        weakref.finalize(ent, _give_pool, _dev_index(dev), sig, side, ent.pool, ent.stream)   # with its tensors gone the pool is free for the next entry
         ent.sin = {k: (v.clone() if torch.is_tensor(v) and v.is_cuda else v) for k, v in inp.items()}
         ent.gB, ent.gin, ent.gkey = None, None, None
         ent.inflight, ent.salt_val = None, None
-        ent.stream = torch.cuda.Stream(device=dev)
         was = (eng.row_bucket, eng.lm_bucket, eng.salt_word, eng._inject_header)
         if self.salt is None:
             self._set_salt()
