@@ -669,6 +669,29 @@ __device__ __forceinline__ bf16x8 read_tr_tile64(const char* tile, int rowbase, 
   return __builtin_bit_cast(bf16x8, v);
 }
 
+// The same tile with its 8-byte chunks XOR-swizzled by the row (chunk c of row r sits at c ^ ((r >> 2) & 7)): rows r and r + 4 are
+// 256 bytes = one pass over the banks apart, so the 8-byte dS^T stores of 16 lanes (rows r .. r + 15, one chunk) hit four bank
+// pairs four times each; swizzled they spread over all of them (SQ_LDS_BANK_CONFLICT was 31 % of the LDS-array cycles of the text
+// backward, profiles/r5x_attention_text_kernels_pmc.txt).
+#ifndef UNIMM_ATTN_TILE_SWZ
+#define UNIMM_ATTN_TILE_SWZ 1      // (A/B builds: 0 = the unswizzled tile)
+#endif
+__device__ __forceinline__ int tile64_swz(int row) { return UNIMM_ATTN_TILE_SWZ ? (row >> 2) & 7 : 0; }
+__device__ __forceinline__ bf16x8 read_tr_tile64s(const char* tile, int rowbase, int lane) {
+  const int h = lane >> 5, i = lane & 15, qq = i >> 2, pp = i & 3;
+  const int chunk = 4 * ((lane >> 4) & 1) + pp;                 // 8-byte chunk = 4 columns
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x4 part[2];
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) {
+    const int row = rowbase + 8 * jj + 4 * h + qq;
+    part[jj] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)LDS_PTR(tile + row * 64 + ((chunk ^ tile64_swz(row)) << 3)));
+  }
+  s16x8 v = {part[0][0], part[0][1], part[0][2], part[0][3], part[1][0], part[1][1], part[1][2], part[1][3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
 template <int NQT>
 __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(AttnBwdParams p) {
   constexpr int D = 64;
@@ -830,7 +853,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(AttnBwdParams p)
     // dS^T of this (query tile, key tile) -> the wave's LDS tile: row = key (lane), 4 consecutive queries per store
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4)
-      *reinterpret_cast<u32x2*>(ws + r * 64 + 16 * g4 + 8 * h) =
+      *reinterpret_cast<u32x2*>(ws + r * 64 + (((2 * g4 + h) ^ tile64_swz(r)) << 3)) =
           u32x2{pack2bf(ds[4 * g4], ds[4 * g4 + 1]), pack2bf(ds[4 * g4 + 2], ds[4 * g4 + 3])};
 #pragma unroll
     for (int ss = 0; ss < 2; ++ss) {
@@ -848,7 +871,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(AttnBwdParams p)
     f32x16 dqp[2] = {f32x16{}, f32x16{}};
 #pragma unroll
     for (int ss = 0; ss < 2; ++ss) {
-      const bf16x8 dstf = read_tr_tile64(ws, 16 * ss, lane);
+      const bf16x8 dstf = read_tr_tile64s(ws, 16 * ss, lane);
       dqp[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[0][ss], dstf, dqp[0], 0, 0, 0);
       dqp[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[1][ss], dstf, dqp[1], 0, 0, 0);
     }
@@ -1056,7 +1079,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fewq128_kernel(AttnBwdParams 
     // dS^T of this (query tile, key tile) -> the wave's LDS tile: row = key (lane), 4 consecutive queries per store
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4)
-      *reinterpret_cast<u32x2*>(ws + r * 64 + 16 * g4 + 8 * h) =
+      *reinterpret_cast<u32x2*>(ws + r * 64 + (((2 * g4 + h) ^ tile64_swz(r)) << 3)) =
           u32x2{pack2bf(ds[4 * g4], ds[4 * g4 + 1]), pack2bf(ds[4 * g4 + 2], ds[4 * g4 + 3])};
 #pragma unroll
     for (int ss = 0; ss < 2; ++ss) { pfr[qt][ss] = pack8(pd + 8 * ss); dsfr[qt][ss] = pack8(ds + 8 * ss); }
@@ -1066,7 +1089,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fewq128_kernel(AttnBwdParams 
     for (int dt = 0; dt < D / 32; ++dt) dqp[dt] = f32x16{};
 #pragma unroll
     for (int ss = 0; ss < 2; ++ss) {
-      const bf16x8 dstf = read_tr_tile64(ws, 16 * ss, lane);
+      const bf16x8 dstf = read_tr_tile64s(ws, 16 * ss, lane);
 #pragma unroll
       for (int dt = 0; dt < D / 32; ++dt)
         dqp[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_tr_frag<D>(kimg, 16 * ss, 32 * dt, lane), dstf, dqp[dt], 0, 0, 0);
@@ -1289,7 +1312,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fewk128_kernel(AttnBwdParams 
     // dS^T of this (query tile, key tile) -> the wave's LDS tile: row = key (lane), 4 consecutive queries per store
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4)
-      *reinterpret_cast<u32x2*>(ws + r * 64 + 16 * g4 + 8 * h) =
+      *reinterpret_cast<u32x2*>(ws + r * 64 + (((2 * g4 + h) ^ tile64_swz(r)) << 3)) =
           u32x2{pack2bf(ds[4 * g4], ds[4 * g4 + 1]), pack2bf(ds[4 * g4 + 2], ds[4 * g4 + 3])};
 #pragma unroll
     for (int ss = 0; ss < 2; ++ss) { pfr[kt][ss] = pack8(pd + 8 * ss); dsfr[kt][ss] = pack8(ds + 8 * ss); }
@@ -1305,7 +1328,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fewk128_kernel(AttnBwdParams 
     if (32 * kt < Tk_b) {
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) {
-        const bf16x8 dstf = read_tr_tile64(wsb + kt * 2048, 16 * ss, lane);
+        const bf16x8 dstf = read_tr_tile64s(wsb + kt * 2048, 16 * ss, lane);
 #pragma unroll
         for (int dt = 0; dt < D / 32; ++dt)
           dqp[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_tr_frag<D>(kimg, 32 * kt + 16 * ss, 32 * dt, lane), dstf, dqp[dt], 0, 0, 0);
