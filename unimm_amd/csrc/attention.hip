@@ -653,6 +653,60 @@ __global__ __launch_bounds__(MAXT, MAXT == 256 ? 1 : 2) void attn_bwd_dkv_kernel
 // LDS: Q / dO images 64 KiB + accumulator 68 KiB + dS tiles 16 KiB + lse / delta / mask words 10 KiB = 158 KiB: one
 // workgroup per CU -- which the 228-register dK / dV kernel was already (two waves per SIMD).
 // ------------------------------------------------------------------------------------------------
+// S and dP of one (32-query tile, 32-key tile) pair in the key-on-the-lane layout (lane (r, h) = key r, register e = query
+// key_of_reg-style: 4 consecutive queries per register quad) -> P^T (dropped and scaled: what multiplies dO) and dS^T (before the
+// softmax scale), as floats.  q0 = first query of the tile; lse_s (NEGATED, log2 domain) / del_s / mrow (INVERTED mask words of this
+// key tile) are LDS arrays indexed by query.  Shared by the three one-kernel backward forms.
+struct BwdScoreCtx {
+  uint32_t dlane, hbase, halfm, thr16;   // dropout: the lane's part of the counter, (b * H + head) * Tq, words per query row * M1, threshold
+  float dsc, c1;                         // keep scale, softmax scale * log2 e
+  bool dropping;
+};
+__device__ __forceinline__ void bwd_score_tile(const AttnBwdParams& p, const BwdScoreCtx& c, const f32x16& sacc, const f32x16& dpacc,
+                                               const float* lse_s, const float* del_s, const uint32_t* mrow, int q0, int r, int h,
+                                               float (&pd)[16], float (&ds)[16]) {
+  constexpr float MOFF = -10000.0f * LOG2E;
+  const uint32_t hbase = c.hbase, halfm = c.halfm, dlane = c.dlane, thr16 = c.thr16;
+  const float dsc = c.dsc, c1 = c.c1;
+  const bool dropping = c.dropping;
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) {
+    const int qb = q0 + 8 * g4 + 4 * h;   // 4 consecutive queries for registers 4*g4 .. 4*g4+3
+    const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qb);
+    const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + qb);
+    const u32x4 w4 = *reinterpret_cast<const u32x4*>(mrow + qb);
+    uint32_t dwv[4] = {0u, 0u, 0u, 0u};
+    const uint32_t odd = (uint32_t)r & 1u;
+    if (dropping) {       // keys k and k^1 share a hash word: each lane of the pair hashes two of the four queries (see attn_bwd_dkv_kernel)
+      const uint32_t ua = (hbase + (uint32_t)(q0 + 8 * g4)) * halfm;
+      const uint32_t wa = drop_fin(p.drop, dlane + ua);
+      const uint32_t wb = drop_fin(p.drop, dlane + ua + 2u * halfm);
+      const uint32_t oa = (uint32_t)__builtin_amdgcn_mov_dpp((int)wa, 0xB1, 0xF, 0xF, true);
+      const uint32_t ob = (uint32_t)__builtin_amdgcn_mov_dpp((int)wb, 0xB1, 0xF, 0xF, true);
+      dwv[0] = odd ? oa : wa; dwv[1] = odd ? wa : oa; dwv[2] = odd ? ob : wb; dwv[3] = odd ? wb : ob;
+    }
+    const uint32_t fsh = odd << 4;
+#pragma unroll
+    for (int i = 0; i < 4; i += 2) {
+      const int e = 4 * g4 + i;
+      f32x2v madd, tk;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const uint32_t mb = (uint32_t)__builtin_amdgcn_sbfe((int)w4[i + u], (uint32_t)r, 1) & __builtin_bit_cast(uint32_t, MOFF);
+        madd[u] = __uint_as_float(mb);
+        tk[u] = __builtin_amdgcn_ubfe(dwv[i + u], fsh, 16) >= thr16 ? dsc : 0.0f;
+      }
+      const f32x2v arg = f32x2v{sacc[e], sacc[e + 1]} * c1 + (f32x2v{l4[i], l4[i + 1]} + madd);
+      f32x2v pe;
+      pe.x = __builtin_amdgcn_exp2f(arg.x); pe.y = __builtin_amdgcn_exp2f(arg.y);
+      const f32x2v pdv = pe * tk;
+      const f32x2v dsv = pe * (f32x2v{dpacc[e], dpacc[e + 1]} * tk - f32x2v{d4[i], d4[i + 1]});
+      pd[e] = pdv.x; pd[e + 1] = pdv.y;
+      ds[e] = dsv.x; ds[e + 1] = dsv.y;
+    }
+  }
+}
+
 __device__ __forceinline__ bf16x8 read_tr_tile64(const char* tile, int rowbase, int lane) {
   // [32 rows][32 cols] bf16, 64-byte rows: element j of lane (r, h) = tile[rowbase + 8 (j >> 2) + 4 h + (j & 3)][r]
   const int h = lane >> 5, i = lane & 15, qq = i >> 2, pp = i & 3;
@@ -796,10 +850,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(AttnBwdParams p)
   const uint32_t halfw = ((uint32_t)p.Tk + 1u) >> 1, halfm = halfw * DROP_M1;
   const uint32_t dlane = drop_lin(p.drop, (4u * (uint32_t)h + ((uint32_t)r & 1u)) * halfw + ((uint32_t)(wt * 32 + r) >> 1));
   const float c1 = p.scale * LOG2E;
-  constexpr float MOFF = -10000.0f * LOG2E;
   const bool dropping = p.drop.thr != 0u;
   const uint32_t thr16 = dropping ? (p.drop.thr >> 16) : 0u;
   const float dsc = dropping ? p.drop.scale : 1.0f;
+  const BwdScoreCtx sctx{dlane, hbase, halfm, thr16, dsc, c1, dropping};
 
   if (wave_on) {
 #pragma unroll 1
@@ -814,42 +868,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(AttnBwdParams p)
       dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, vf[ks], dpacc, 0, 0, 0);
     }
     float pd[16], ds[16];
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      const int qb = 32 * qt + 8 * g4 + 4 * h;   // 4 consecutive queries for registers 4*g4 .. 4*g4+3
-      const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qb);
-      const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + qb);
-      const u32x4 w4 = *reinterpret_cast<const u32x4*>(mrow + qb);
-      uint32_t dwv[4] = {0u, 0u, 0u, 0u};
-      const uint32_t odd = (uint32_t)r & 1u;
-      if (dropping) {       // keys k and k^1 share a hash word: each lane of the pair hashes two of the four queries (see attn_bwd_dkv_kernel)
-        const uint32_t ua = (hbase + (uint32_t)(32 * qt + 8 * g4)) * halfm;
-        const uint32_t wa = drop_fin(p.drop, dlane + ua);
-        const uint32_t wb = drop_fin(p.drop, dlane + ua + 2u * halfm);
-        const uint32_t oa = (uint32_t)__builtin_amdgcn_mov_dpp((int)wa, 0xB1, 0xF, 0xF, true);
-        const uint32_t ob = (uint32_t)__builtin_amdgcn_mov_dpp((int)wb, 0xB1, 0xF, 0xF, true);
-        dwv[0] = odd ? oa : wa; dwv[1] = odd ? wa : oa; dwv[2] = odd ? ob : wb; dwv[3] = odd ? wb : ob;
-      }
-      const uint32_t fsh = odd << 4;
-#pragma unroll
-      for (int i = 0; i < 4; i += 2) {
-        const int e = 4 * g4 + i;
-        f32x2v madd, tk;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const uint32_t mb = (uint32_t)__builtin_amdgcn_sbfe((int)w4[i + u], (uint32_t)r, 1) & __builtin_bit_cast(uint32_t, MOFF);
-          madd[u] = __uint_as_float(mb);
-          tk[u] = __builtin_amdgcn_ubfe(dwv[i + u], fsh, 16) >= thr16 ? dsc : 0.0f;
-        }
-        const f32x2v arg = f32x2v{sacc[e], sacc[e + 1]} * c1 + (f32x2v{l4[i], l4[i + 1]} + madd);
-        f32x2v pe;
-        pe.x = __builtin_amdgcn_exp2f(arg.x); pe.y = __builtin_amdgcn_exp2f(arg.y);
-        const f32x2v pdv = pe * tk;
-        const f32x2v dsv = pe * (f32x2v{dpacc[e], dpacc[e + 1]} * tk - f32x2v{d4[i], d4[i + 1]});
-        pd[e] = pdv.x; pd[e + 1] = pdv.y;
-        ds[e] = dsv.x; ds[e + 1] = dsv.y;
-      }
-    }
+    bwd_score_tile(p, sctx, sacc, dpacc, lse_s, del_s, mrow, 32 * qt, r, h, pd, ds);
     // dS^T of this (query tile, key tile) -> the wave's LDS tile: row = key (lane), 4 consecutive queries per store
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4)
@@ -1022,10 +1041,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fewq128_kernel(AttnBwdParams 
   const uint32_t halfw = ((uint32_t)p.Tk + 1u) >> 1, halfm = halfw * DROP_M1;
   const uint32_t dlane = drop_lin(p.drop, (4u * (uint32_t)h + ((uint32_t)r & 1u)) * halfw + ((uint32_t)(wt * 32 + r) >> 1));
   const float c1 = p.scale * LOG2E;
-  constexpr float MOFF = -10000.0f * LOG2E;
   const bool dropping = p.drop.thr != 0u;
   const uint32_t thr16 = dropping ? (p.drop.thr >> 16) : 0u;
   const float dsc = dropping ? p.drop.scale : 1.0f;
+  const BwdScoreCtx sctx{dlane, hbase, halfm, thr16, dsc, c1, dropping};
 
   if (wave_on) {
 #pragma unroll
@@ -1040,42 +1059,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fewq128_kernel(AttnBwdParams 
       dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, vf[ks], dpacc, 0, 0, 0);
     }
     float pd[16], ds[16];
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      const int qb = 32 * qt + 8 * g4 + 4 * h;   // 4 consecutive queries for registers 4*g4 .. 4*g4+3
-      const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qb);
-      const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + qb);
-      const u32x4 w4 = *reinterpret_cast<const u32x4*>(mrow + qb);
-      uint32_t dwv[4] = {0u, 0u, 0u, 0u};
-      const uint32_t odd = (uint32_t)r & 1u;
-      if (dropping) {       // keys k and k^1 share a hash word: each lane of the pair hashes two of the four queries (see attn_bwd_dkv_kernel)
-        const uint32_t ua = (hbase + (uint32_t)(32 * qt + 8 * g4)) * halfm;
-        const uint32_t wa = drop_fin(p.drop, dlane + ua);
-        const uint32_t wb = drop_fin(p.drop, dlane + ua + 2u * halfm);
-        const uint32_t oa = (uint32_t)__builtin_amdgcn_mov_dpp((int)wa, 0xB1, 0xF, 0xF, true);
-        const uint32_t ob = (uint32_t)__builtin_amdgcn_mov_dpp((int)wb, 0xB1, 0xF, 0xF, true);
-        dwv[0] = odd ? oa : wa; dwv[1] = odd ? wa : oa; dwv[2] = odd ? ob : wb; dwv[3] = odd ? wb : ob;
-      }
-      const uint32_t fsh = odd << 4;
-#pragma unroll
-      for (int i = 0; i < 4; i += 2) {
-        const int e = 4 * g4 + i;
-        f32x2v madd, tk;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const uint32_t mb = (uint32_t)__builtin_amdgcn_sbfe((int)w4[i + u], (uint32_t)r, 1) & __builtin_bit_cast(uint32_t, MOFF);
-          madd[u] = __uint_as_float(mb);
-          tk[u] = __builtin_amdgcn_ubfe(dwv[i + u], fsh, 16) >= thr16 ? dsc : 0.0f;
-        }
-        const f32x2v arg = f32x2v{sacc[e], sacc[e + 1]} * c1 + (f32x2v{l4[i], l4[i + 1]} + madd);
-        f32x2v pe;
-        pe.x = __builtin_amdgcn_exp2f(arg.x); pe.y = __builtin_amdgcn_exp2f(arg.y);
-        const f32x2v pdv = pe * tk;
-        const f32x2v dsv = pe * (f32x2v{dpacc[e], dpacc[e + 1]} * tk - f32x2v{d4[i], d4[i + 1]});
-        pd[e] = pdv.x; pd[e + 1] = pdv.y;
-        ds[e] = dsv.x; ds[e + 1] = dsv.y;
-      }
-    }
+    bwd_score_tile(p, sctx, sacc, dpacc, lse_s, del_s, mrow, 32 * qt, r, h, pd, ds);
     // dS^T of this (query tile, key tile) -> the wave's LDS tile: row = key (lane), 4 consecutive queries per store
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4)
@@ -1252,7 +1236,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fewk128_kernel(AttnBwdParams 
   const uint32_t hbase = ((uint32_t)b * p.H + head) * (uint32_t)p.Tq;
   const uint32_t halfw = ((uint32_t)p.Tk + 1u) >> 1, halfm = halfw * DROP_M1;
   const float c1 = p.scale * LOG2E;
-  constexpr float MOFF = -10000.0f * LOG2E;
   const bool dropping = p.drop.thr != 0u;
   const uint32_t thr16 = dropping ? (p.drop.thr >> 16) : 0u;
   const float dsc = dropping ? p.drop.scale : 1.0f;
@@ -1264,6 +1247,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fewk128_kernel(AttnBwdParams 
     const uint32_t* mrow = mw_s + kt * QMAX;
     char* ws = wsb + kt * 2048;
     const uint32_t dlane = drop_lin(p.drop, (4u * (uint32_t)h + ((uint32_t)r & 1u)) * halfw + ((uint32_t)(kt * 32 + r) >> 1));
+    const BwdScoreCtx sctx{dlane, hbase, halfm, thr16, dsc, c1, dropping};
     f32x16 sacc = {}, dpacc = {};
 #pragma unroll
     for (int ks = 0; ks < D / 16; ++ks) {
@@ -1273,42 +1257,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fewk128_kernel(AttnBwdParams 
       dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof[ks], vfr, dpacc, 0, 0, 0);
     }
     float pd[16], ds[16];
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      const int qb = 32 * wq + 8 * g4 + 4 * h;   // 4 consecutive queries for registers 4*g4 .. 4*g4+3
-      const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qb);
-      const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + qb);
-      const u32x4 w4 = *reinterpret_cast<const u32x4*>(mrow + qb);
-      uint32_t dwv[4] = {0u, 0u, 0u, 0u};
-      const uint32_t odd = (uint32_t)r & 1u;
-      if (dropping) {       // keys k and k^1 share a hash word: each lane of the pair hashes two of the four queries (see attn_bwd_dkv_kernel)
-        const uint32_t ua = (hbase + (uint32_t)(32 * wq + 8 * g4)) * halfm;
-        const uint32_t wa = drop_fin(p.drop, dlane + ua);
-        const uint32_t wb = drop_fin(p.drop, dlane + ua + 2u * halfm);
-        const uint32_t oa = (uint32_t)__builtin_amdgcn_mov_dpp((int)wa, 0xB1, 0xF, 0xF, true);
-        const uint32_t ob = (uint32_t)__builtin_amdgcn_mov_dpp((int)wb, 0xB1, 0xF, 0xF, true);
-        dwv[0] = odd ? oa : wa; dwv[1] = odd ? wa : oa; dwv[2] = odd ? ob : wb; dwv[3] = odd ? wb : ob;
-      }
-      const uint32_t fsh = odd << 4;
-#pragma unroll
-      for (int i = 0; i < 4; i += 2) {
-        const int e = 4 * g4 + i;
-        f32x2v madd, tk;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const uint32_t mb = (uint32_t)__builtin_amdgcn_sbfe((int)w4[i + u], (uint32_t)r, 1) & __builtin_bit_cast(uint32_t, MOFF);
-          madd[u] = __uint_as_float(mb);
-          tk[u] = __builtin_amdgcn_ubfe(dwv[i + u], fsh, 16) >= thr16 ? dsc : 0.0f;
-        }
-        const f32x2v arg = f32x2v{sacc[e], sacc[e + 1]} * c1 + (f32x2v{l4[i], l4[i + 1]} + madd);
-        f32x2v pe;
-        pe.x = __builtin_amdgcn_exp2f(arg.x); pe.y = __builtin_amdgcn_exp2f(arg.y);
-        const f32x2v pdv = pe * tk;
-        const f32x2v dsv = pe * (f32x2v{dpacc[e], dpacc[e + 1]} * tk - f32x2v{d4[i], d4[i + 1]});
-        pd[e] = pdv.x; pd[e + 1] = pdv.y;
-        ds[e] = dsv.x; ds[e + 1] = dsv.y;
-      }
-    }
+    bwd_score_tile(p, sctx, sacc, dpacc, lse_s, del_s, mrow, 32 * wq, r, h, pd, ds);
     // dS^T of this (query tile, key tile) -> the wave's LDS tile: row = key (lane), 4 consecutive queries per store
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4)
