@@ -653,6 +653,42 @@ __global__ __launch_bounds__(MAXT, MAXT == 256 ? 1 : 2) void attn_bwd_dkv_kernel
 // LDS: Q / dO images 64 KiB + accumulator 68 KiB + dS tiles 16 KiB + lse / delta / mask words 10 KiB = 158 KiB: one
 // workgroup per CU -- which the 228-register dK / dV kernel was already (two waves per SIMD).
 // ------------------------------------------------------------------------------------------------
+// What the three one-kernel backward forms put into LDS before their first barrier, per query of the item: -lse log2 e (-inf for
+// padded queries: P = 0 there), delta = sum_d dO[q, d] O[q, d] (D / 8 consecutive lanes share a row, 16-byte chunks, reduced by
+// log2(D / 8) exchanges), and the INVERTED mask words of every (key tile, query) (bit set = masked), row stride `mstride`.
+template <int D>
+__device__ __forceinline__ void bwd_stage_row_stats(const AttnBwdParams& p, int b, int head, size_t qbase, int Tq_b, int Tk_b, int qpad_b,
+                                                    float* lse_s, float* del_s, uint32_t* mw_s, int mstride, int tid, int nthreads) {
+  constexpr int LPR = D / 8;                                    // lanes per row
+  for (int i = tid; i < qpad_b; i += nthreads) {
+    const size_t stat = ((size_t)b * p.H + head) * p.Tq + i;
+    lse_s[i] = i < Tq_b ? -p.lse[stat] * LOG2E : -INFINITY;
+  }
+  for (int i = tid; i < qpad_b * LPR; i += nthreads) {
+    const int row = i / LPR, c = i % LPR;
+    float part = 0.f;
+    if (row < Tq_b) {
+      const u32x4 a = *reinterpret_cast<const u32x4*>(p.dout + (qbase + row) * p.lddo + head * D + 8 * c);
+      const u32x4 o = *reinterpret_cast<const u32x4*>(p.o + (qbase + row) * p.ldo + head * D + 8 * c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        part = fmaf(__uint_as_float(a[e] << 16), __uint_as_float(o[e] << 16), part);
+        part = fmaf(__uint_as_float(a[e] & 0xffff0000u), __uint_as_float(o[e] & 0xffff0000u), part);
+      }
+    }
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) part += __shfl_xor(part, o, 64);
+    if (c == 0) del_s[row] = part;
+  }
+  const int nkt_b = (Tk_b + 31) >> 5;
+  const uint32_t* mb = p.mask + (size_t)b * p.mask_b_stride;
+  for (int i = tid; i < nkt_b * qpad_b; i += nthreads) {
+    const int kt = i / qpad_b, qi = i - kt * qpad_b;
+    const int qc = qi < Tq_b ? qi : Tq_b - 1;
+    mw_s[kt * mstride + qi] = ~mb[(size_t)qc * p.mask_q_stride + kt];
+  }
+}
+
 // S and dP of one (32-query tile, 32-key tile) pair in the key-on-the-lane layout (lane (r, h) = key r, register e = query
 // key_of_reg-style: 4 consecutive queries per register quad) -> P^T (dropped and scaled: what multiplies dO) and dS^T (before the
 // softmax scale), as floats.  q0 = first query of the tile; lse_s (NEGATED, log2 domain) / del_s / mrow (INVERTED mask words of this
@@ -773,37 +809,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(AttnBwdParams p)
   const int qpad_b = ((Tq_b + 31) & ~31) < QPAD ? ((Tq_b + 31) & ~31) : QPAD;
   stage_head<D>(p.q + qbase * p.ldq + head * D, p.ldq, Tq_b, qpad_b, qimg, tid, blockDim.x);
   stage_head<D>(p.dout + qbase * p.lddo + head * D, p.lddo, Tq_b, qpad_b, doimg, tid, blockDim.x);
-  for (int i = tid; i < qpad_b; i += blockDim.x) {
-    const size_t stat = ((size_t)b * p.H + head) * p.Tq + i;
-    lse_s[i] = i < Tq_b ? -p.lse[stat] * LOG2E : -INFINITY;     // NEGATED; -inf => P = 0 for padded queries
-  }
-  // delta[q] = sum_d dO[q, d] O[q, d]: 8 consecutive lanes share a row (16-byte chunks), reduced by three exchanges
-  for (int i = tid; i < qpad_b * 8; i += blockDim.x) {
-    const int row = i >> 3, c = i & 7;
-    float part = 0.f;
-    if (row < Tq_b) {
-      const u32x4 a = *reinterpret_cast<const u32x4*>(p.dout + (qbase + row) * p.lddo + head * D + 8 * c);
-      const u32x4 o = *reinterpret_cast<const u32x4*>(p.o + (qbase + row) * p.ldo + head * D + 8 * c);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        part = fmaf(__uint_as_float(a[e] << 16), __uint_as_float(o[e] << 16), part);
-        part = fmaf(__uint_as_float(a[e] & 0xffff0000u), __uint_as_float(o[e] & 0xffff0000u), part);
-      }
-    }
-    part += __shfl_xor(part, 1, 64);
-    part += __shfl_xor(part, 2, 64);
-    part += __shfl_xor(part, 4, 64);
-    if (c == 0) del_s[row] = part;
-  }
-  {
-    const int nkt_b = (Tk_b + 31) >> 5;
-    const uint32_t* mb = p.mask + (size_t)b * p.mask_b_stride;
-    for (int i = tid; i < nkt_b * qpad_b; i += blockDim.x) {
-      const int kt = i / qpad_b, qi = i - kt * qpad_b;
-      const int qc = qi < Tq_b ? qi : Tq_b - 1;
-      mw_s[kt * QPAD + qi] = ~mb[(size_t)qc * p.mask_q_stride + kt];   // INVERTED: bit set = masked
-    }
-  }
+  bwd_stage_row_stats<D>(p, b, head, qbase, Tq_b, Tk_b, qpad_b, lse_s, del_s, mw_s, QPAD, tid, blockDim.x);
   if (tid < NQT) turn[tid] = 0;
 
   int krow = wt * 32 + r;
@@ -972,38 +978,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fewq128_kernel(AttnBwdParams 
   const int qpad_b = ((Tq_b + 31) & ~31) < QPAD ? ((Tq_b + 31) & ~31) : QPAD;
   stage_head<D>(p.q + qbase * p.ldq + head * D, p.ldq, Tq_b, qpad_b, qimg, tid, blockDim.x);
   stage_head<D>(p.dout + qbase * p.lddo + head * D, p.lddo, Tq_b, qpad_b, doimg, tid, blockDim.x);
-  for (int i = tid; i < qpad_b; i += blockDim.x) {
-    const size_t stat = ((size_t)b * p.H + head) * p.Tq + i;
-    lse_s[i] = i < Tq_b ? -p.lse[stat] * LOG2E : -INFINITY;     // NEGATED; -inf => P = 0 for padded queries
-  }
-  // delta[q] = sum_d dO[q, d] O[q, d]: 16 consecutive lanes share a row (16-byte chunks), reduced by four exchanges
-  for (int i = tid; i < qpad_b * 16; i += blockDim.x) {
-    const int row = i >> 4, c = i & 15;
-    float part = 0.f;
-    if (row < Tq_b) {
-      const u32x4 a = *reinterpret_cast<const u32x4*>(p.dout + (qbase + row) * p.lddo + head * D + 8 * c);
-      const u32x4 o = *reinterpret_cast<const u32x4*>(p.o + (qbase + row) * p.ldo + head * D + 8 * c);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        part = fmaf(__uint_as_float(a[e] << 16), __uint_as_float(o[e] << 16), part);
-        part = fmaf(__uint_as_float(a[e] & 0xffff0000u), __uint_as_float(o[e] & 0xffff0000u), part);
-      }
-    }
-    part += __shfl_xor(part, 1, 64);
-    part += __shfl_xor(part, 2, 64);
-    part += __shfl_xor(part, 4, 64);
-    part += __shfl_xor(part, 8, 64);
-    if (c == 0) del_s[row] = part;
-  }
-  {
-    const int nkt_b = (Tk_b + 31) >> 5;
-    const uint32_t* mb = p.mask + (size_t)b * p.mask_b_stride;
-    for (int i = tid; i < nkt_b * qpad_b; i += blockDim.x) {
-      const int kt = i / qpad_b, qi = i - kt * qpad_b;
-      const int qc = qi < Tq_b ? qi : Tq_b - 1;
-      mw_s[kt * QPAD + qi] = ~mb[(size_t)qc * p.mask_q_stride + kt];   // INVERTED: bit set = masked
-    }
-  }
+  bwd_stage_row_stats<D>(p, b, head, qbase, Tq_b, Tk_b, qpad_b, lse_s, del_s, mw_s, QPAD, tid, blockDim.x);
   if (tid < NQT) turn[tid] = 0;
 
   int krow = wt * 32 + r;
@@ -1176,38 +1151,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fewk128_kernel(AttnBwdParams 
   const int kpad_b = ((Tk_b + 31) & ~31) < KPAD ? ((Tk_b + 31) & ~31) : KPAD;
   stage_head<D>(p.k + kbase * p.ldk + head * D, p.ldk, Tk_b, kpad_b, kimg, tid, blockDim.x);
   stage_head<D>(p.v + kbase * p.ldv + head * D, p.ldv, Tk_b, kpad_b, vimg, tid, blockDim.x);
-  for (int i = tid; i < qpad_b; i += blockDim.x) {
-    const size_t stat = ((size_t)b * p.H + head) * p.Tq + i;
-    lse_s[i] = i < Tq_b ? -p.lse[stat] * LOG2E : -INFINITY;     // NEGATED; -inf => P = 0 for padded queries
-  }
-  // delta[q] = sum_d dO[q, d] O[q, d]: 16 consecutive lanes share a row (16-byte chunks), reduced by four exchanges
-  for (int i = tid; i < qpad_b * 16; i += blockDim.x) {
-    const int row = i >> 4, c = i & 15;
-    float part = 0.f;
-    if (row < Tq_b) {
-      const u32x4 a = *reinterpret_cast<const u32x4*>(p.dout + (qbase + row) * p.lddo + head * D + 8 * c);
-      const u32x4 o = *reinterpret_cast<const u32x4*>(p.o + (qbase + row) * p.ldo + head * D + 8 * c);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        part = fmaf(__uint_as_float(a[e] << 16), __uint_as_float(o[e] << 16), part);
-        part = fmaf(__uint_as_float(a[e] & 0xffff0000u), __uint_as_float(o[e] & 0xffff0000u), part);
-      }
-    }
-    part += __shfl_xor(part, 1, 64);
-    part += __shfl_xor(part, 2, 64);
-    part += __shfl_xor(part, 4, 64);
-    part += __shfl_xor(part, 8, 64);
-    if (c == 0) del_s[row] = part;
-  }
-  {
-    const int nkt_b = (Tk_b + 31) >> 5;
-    const uint32_t* mb = p.mask + (size_t)b * p.mask_b_stride;
-    for (int i = tid; i < nkt_b * qpad_b; i += blockDim.x) {
-      const int kt = i / qpad_b, qi = i - kt * qpad_b;
-      const int qc = qi < Tq_b ? qi : Tq_b - 1;
-      mw_s[kt * QMAX + qi] = ~mb[(size_t)qc * p.mask_q_stride + kt];   // INVERTED: bit set = masked
-    }
-  }
+  bwd_stage_row_stats<D>(p, b, head, qbase, Tq_b, Tk_b, qpad_b, lse_s, del_s, mw_s, QMAX, tid, blockDim.x);
   if (tid < NSLOT) turn[tid] = 0;
 
   int qrow = wq * 32 + r;
