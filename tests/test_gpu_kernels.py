@@ -452,6 +452,57 @@ def test_attention_item_order_changes_nothing_but_the_schedule(D, Tq, Tk):
     assert float(res[0][2].float().abs().max()) > 0
 
 
+@pytest.mark.parametrize("Tq,Tk", [(37, 256), (256, 37)])
+def test_coattention_variable_length_matches_padded(Tq, Tk):
+    """The two co-attention directions (D = 128; 37 regions on one side, packed text rows of per-sequence length on the other --
+    the one-kernel backward forms attn_bwd_fewq128 / attn_bwd_fewk128) against the same problem in the padded layout: forward
+    bit-equal on the valid rows, gradients to bf16 accuracy, with dropout (the counters index padded positions)."""
+    from unimm_amd import dropout as DR
+    from unimm_amd import lib
+    B, H, D = 5, 2, 128
+    HD = H * D
+    g = torch.Generator(device=DEV).manual_seed(Tq)
+    lens = [200, 33, 129, 256, 64]
+    text_q = Tq == 256
+    ql, kl = (lens if text_q else [Tq] * B), ([Tk] * B if text_q else lens)
+    qp = bf(torch.randn((B * Tq, HD), generator=g, device=DEV))
+    kvp = bf(torch.randn((B * Tk, 2 * HD), generator=g, device=DEV))
+    m = torch.zeros((B, Tq, Tk), dtype=torch.bool, device=DEV)
+    for b in range(B):
+        m[b, :ql[b], :kl[b]] = torch.rand((ql[b], kl[b]), generator=g, device=DEV) < 0.7
+        m[b, :ql[b], 0] = True
+    packed = lib.mask_pack(m)
+    nw = packed.shape[-1]
+    drop = DR.drop_arg(0.1, DR.make_key(4, 1, 9))
+    sc = D ** -0.5
+    qrows = torch.cat([torch.arange(b * Tq, b * Tq + l, device=DEV) for b, l in enumerate(ql)])
+    krows = torch.cat([torch.arange(b * Tk, b * Tk + l, device=DEV) for b, l in enumerate(kl)])
+    dout_p = bf(torch.randn((B * Tq, HD), generator=g, device=DEV))
+    keepq = torch.zeros(B * Tq, dtype=torch.bool, device=DEV)
+    keepq[qrows] = True
+    dout_p[~keepq] = 0
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=DEV)
+    cum = lambda v: i32([sum(v[:i]) for i in range(B)])
+
+    def run(q, kv, dout, qv, kvv):
+        out = torch.zeros((q.shape[0], HD), device=DEV, dtype=torch.bfloat16)
+        lse = torch.zeros((B, H, Tq), device=DEV)
+        lib.attn_fwd(q, kv[:, :HD], kv[:, HD:], out, lse, packed, B, H, Tq, Tk, D, sc, nw, Tq * nw, drop, qvar=qv, kvar=kvv)
+        dq, dkv = torch.zeros_like(q), torch.zeros_like(kv)
+        delta = torch.zeros((B, H, Tq), device=DEV)
+        lib.attn_bwd(q, kv[:, :HD], kv[:, HD:], out, dout, lse, delta, dq, dkv[:, :HD], dkv[:, HD:], packed, B, H, Tq, Tk, D, sc,
+                     nw, Tq * nw, drop, qvar=qv, kvar=kvv)
+        torch.cuda.synchronize()
+        return out, dq, dkv
+
+    out_p, dq_p, dkv_p = run(qp, kvp, dout_p, None, None)
+    qv = (cum(ql), i32(ql)) if text_q else None
+    kvv = None if text_q else (cum(kl), i32(kl))
+    out_v, dq_v, dkv_v = run(qp[qrows].contiguous(), kvp[krows].contiguous(), dout_p[qrows].contiguous(), qv, kvv)
+    assert torch.equal(out_v, out_p[qrows])
+    assert relerr(dq_v, dq_p[qrows]) < 1e-2 and relerr(dkv_v, dkv_p[krows]) < 1e-2
+
+
 def test_mask_synth_matches_the_oracle_encoders_bit_for_bit():
     """unimm_mask_synth against oracle/masks.py (itself pinned to the reference's encode_input_gen / _dis by golden
     G5): packed text and co-attention words for generative and discriminative sequences, incl. one-token answers,
