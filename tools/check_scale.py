@@ -13,9 +13,9 @@ one line per finding -- a deviation is a finding about the model of section 6, n
 Expected values ("Expected at N x (240 / N) sequences"; 1-GPU figures measured in round 5, strong scaling of
 the global batch of 240):
   N  per-GPU  step without exchange   collectives/step   exposed exchange (fp32 wire)
-  1    240        40.9 ms                   0                  0
-  2    120        23.0 ms (eager)           11                 <= 1.0 ms  (the last grouped launch's buckets)
-  4     60        13.9 ms (graph replay)    11                 <= 1.2 ms
+  1    240        40.8 ms                   0                  0
+  2    120        22.6 ms (eager)           11                 <= 1.0 ms  (the last grouped launch's buckets)
+  4     60        13.7 ms (graph replay)    11                 <= 1.2 ms
   8     30         9.1 ms (graph replay)    11                 ~0.9 ms (1.6 ms with 4-round grouping)
 (1-GPU figures of profiles/r5p_*: 42.88 / 23.48 / 14.17 / 9.14 ms, + 2 % for the 2-round weight-gradient grouping under N > 1)
 """
@@ -23,9 +23,9 @@ import json
 import sys
 
 EXPECT = {   # n_gpus: (step_ms_without_exchange, collectives_per_step, exposed_exchange_ms)
-    1: (40.9, 0, 0.0),
-    2: (23.0, 11, 1.0),
-    4: (13.9, 11, 1.2),
+    1: (40.8, 0, 0.0),
+    2: (22.6, 11, 1.0),
+    4: (13.7, 11, 1.2),
     8: (9.1, 11, 0.9),
 }
 REL = 0.25
