@@ -1119,14 +1119,14 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fewq128_kernel(AttnBwdParams 
 // ... and for the mirror direction, text queries attending the 37 regions (D = 128, at most 256 queries x 64 keys): the same
 // orientation (key on the lane), but a wave is a 32-QUERY tile here and walks the two key tiles.  Its Q / dO rows stay in
 // registers as row fragments, K / V are two 16 KiB images shared by the workgroup; dQ of the wave's queries is complete after the
-// two key tiles (registers -> global); dK / dV are sums over ALL queries and meet in two LDS accumulators in wave order (a turn
-// word per output, key tile and 32-wide slice of D).  Their MFMAs want Q^T / dO^T fragments of the wave's tile: phase 2 writes one
-// 32-wide slice of the row fragments at a time into a wave-private 2 KiB tile and reads it back transposed -- which is what
-// keeps the LDS at 150 KiB (a full image per wave would be 128 KiB more).  Replaces a dQ kernel (98 us per layer at 240
-// sequences) and a dK/dV kernel (110 us, 312 registers) that formed S, dP, P, dS twice.
+// two key tiles (registers -> global); dK / dV are sums over ALL queries: every wave leaves its P^T / dS^T as MFMA operands in LDS,
+// and after one barrier wave w computes ONE output -- a 32-wide slice of dK or dV for both key tiles -- over all query tiles,
+// its Q^T / dO^T operand coming straight from global memory through a wave-private 2 KiB tile that is read back transposed
+// (phase 2 in the kernel).  148 KiB of LDS.  Replaces a dQ kernel (98 us per layer at 240 sequences) and a dK/dV kernel
+// (110 us, 312 registers) that formed S, dP, P, dS twice: 148 us.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512, 2) void attn_bwd_fewk128_kernel(AttnBwdParams p) {
-  constexpr int D = 128, NKT = 2, KPAD = NKT * 32, QMAX = 256, AS = D + 4, NSLOT = 2 * NKT * (D / 32);
+  constexpr int D = 128, NKT = 2, KPAD = NKT * 32, QMAX = 256, NQT = QMAX / 32;
   drop_resolve(p.drop);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* kimg = smem;
@@ -1135,9 +1135,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fewk128_kernel(AttnBwdParams 
   float* del_s = lse_s + QMAX;
   uint32_t* mw_s = reinterpret_cast<uint32_t*>(del_s + QMAX);   // [key tile][query] mask words
   char* scr = reinterpret_cast<char*>(mw_s + NKT * QMAX);       // [wave][dS^T tile of key tile 0 | of key tile 1 | slice tile]: 3 x ([32][32] bf16)
-  float* accK = reinterpret_cast<float*>(scr + 8 * 6144);       // [KPAD keys][AS] fp32
-  float* accV = accK + KPAD * AS;
-  int* turn = reinterpret_cast<int*>(accV + KPAD * AS);         // [dK | dV][key tile][slice]: the wave whose turn it is to add
+  char* bfrag = scr + 8 * 6144;                                 // [key tile][query tile][dS | P][16-query half]: 1 KiB MFMA operands in register layout
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int item = blockIdx.x;
   const int b = p.order != nullptr ? p.order[item / p.H] : item / p.H, head = item % p.H;
@@ -1152,7 +1150,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fewk128_kernel(AttnBwdParams 
   stage_head<D>(p.k + kbase * p.ldk + head * D, p.ldk, Tk_b, kpad_b, kimg, tid, blockDim.x);
   stage_head<D>(p.v + kbase * p.ldv + head * D, p.ldv, Tk_b, kpad_b, vimg, tid, blockDim.x);
   bwd_stage_row_stats<D>(p, b, head, qbase, Tq_b, Tk_b, qpad_b, lse_s, del_s, mw_s, QMAX, tid, blockDim.x);
-  if (tid < NSLOT) turn[tid] = 0;
 
   int qrow = wq * 32 + r;
   const bool qvalid = qrow < Tq_b;
@@ -1170,13 +1167,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fewk128_kernel(AttnBwdParams 
   stage_wait();
   __syncthreads();
 
-  bf16x8 pfr[NKT][2], dsfr[NKT][2];                             // P^T / dS^T of (key tile, 16-query half) as MFMA operands: phase 2
-#pragma unroll
-  for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-    for (int ss = 0; ss < 2; ++ss) { pfr[kt][ss] = bf16x8{}; dsfr[kt][ss] = bf16x8{}; }
   char* wsb = scr + wave * 6144;
-  char* ws2 = wsb + 4096;
   const uint32_t hbase = ((uint32_t)b * p.H + head) * (uint32_t)p.Tq;
   const uint32_t halfw = ((uint32_t)p.Tk + 1u) >> 1, halfm = halfw * DROP_M1;
   const float c1 = p.scale * LOG2E;
@@ -1208,7 +1199,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fewk128_kernel(AttnBwdParams 
       *reinterpret_cast<u32x2*>(ws + r * 64 + (((2 * g4 + h) ^ tile64_swz(r)) << 3)) =
           u32x2{pack2bf(ds[4 * g4], ds[4 * g4 + 1]), pack2bf(ds[4 * g4 + 2], ds[4 * g4 + 3])};
 #pragma unroll
-    for (int ss = 0; ss < 2; ++ss) { pfr[kt][ss] = pack8(pd + 8 * ss); dsfr[kt][ss] = pack8(ds + 8 * ss); }
+    for (int ss = 0; ss < 2; ++ss) {
+      // P^T / dS^T of this (key tile, query tile) as MFMA operands, in register layout (16 bytes per lane): phase 2 reads them back
+      char* f = bfrag + ((((kt * NQT + wq) * 2) * 2 + ss) << 10) + lane * 16;
+      *reinterpret_cast<u32x4*>(f) = __builtin_bit_cast(u32x4, pack8(ds + 8 * ss));
+      *reinterpret_cast<u32x4*>(f + 2048) = __builtin_bit_cast(u32x4, pack8(pd + 8 * ss));
+    }
     }
   }
   // dQ^T of the wave's queries = K^T dS^T over both key tiles (lane = query, registers = D values): after the score phase, whose
@@ -1230,56 +1226,63 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fewk128_kernel(AttnBwdParams 
   }
   store_acc_row<D>(p.dq + (qvalid ? grow : 0) * p.lddq + head * D, dqp, p.scale, h, qvalid);
 
-  // Phase 2: dK^T += Q^T dS and dV^T += dO^T P over the wave's 32 queries, per 32-wide slice of D and key tile, into the
-  // workgroup's accumulators in wave order (wave 0 stores, wave w adds once the slot's turn word reads w)
+  }
+  __syncthreads();                                              // every query tile's P^T / dS^T operands are in LDS
+
+  // Phase 2, output-stationary: wave w owns ONE output, the 32-wide slice dt = w & 3 of dK (w < 4) or dV (w >= 4) for both key
+  // tiles, and walks ALL query tiles: A = the slice of Q^T (dO^T) -- 32 rows x 64 bytes straight from global memory (L2: phase 1
+  // just read those rows) through the wave's 2 KiB tile, read back transposed -- B = the tile's dS^T (P^T) operand from LDS.  No
+  // accumulator is shared between waves (the first version added every wave's partials into two LDS accumulators in wave order:
+  // 16 hand-overs per wave with nothing to compute between them, ~1/3 of the item's time), and the waves whose query tile does
+  // not exist work here too.  (The phase-1 blocks above are inside `if (wave_on)`; this one is not.)
+  {
+    const int which = wave >> 2, dt = wave & 3;
+    const int nqt = (Tq_b + 31) >> 5;
+    const bf16_t* src = (which == 0 ? p.q : p.dout) + head * D + 32 * dt + 16 * (lane & 1);
+    const size_t ld = which == 0 ? (size_t)p.ldq : (size_t)p.lddo;
+    u32x4 rg[NQT][2];                                           // the slice rows of every query tile: lane = (row = lane >> 1, 32-byte half = lane & 1)
 #pragma unroll
-  for (int which = 0; which < 2; ++which) {
+    for (int qt = 0; qt < NQT; ++qt) {
+      int row = 32 * qt + (lane >> 1);
+      row = row < Tq_b ? row : Tq_b - 1;                        // (rows past the end: their P / dS are zero, any finite values do)
+      const bf16_t* g = src + (qbase + row) * ld;
+      if (qt < nqt) {
+        rg[qt][0] = *reinterpret_cast<const u32x4*>(g);
+        rg[qt][1] = *reinterpret_cast<const u32x4*>(g + 8);
+      } else {
+        rg[qt][0] = u32x4{0u, 0u, 0u, 0u}; rg[qt][1] = u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+    f32x16 oacc[NKT] = {f32x16{}, f32x16{}};
+    char* ws2 = scr + wave * 6144 + 4096;
 #pragma unroll
-    for (int dt = 0; dt < D / 32; ++dt) {
-      // the slice [32 queries][32 d] of the row fragments -> the wave's tile (row = query: 2 x 16 bytes per lane)
-      const bf16x8 lo = which == 0 ? qf[2 * dt] : dof[2 * dt], hi = which == 0 ? qf[2 * dt + 1] : dof[2 * dt + 1];
-      *reinterpret_cast<u32x4*>(ws2 + r * 64 + 16 * h) = __builtin_bit_cast(u32x4, lo);
-      *reinterpret_cast<u32x4*>(ws2 + r * 64 + 32 + 16 * h) = __builtin_bit_cast(u32x4, hi);
-      const bf16x8 tf0 = read_tr_tile64(ws2, 0, lane), tf1 = read_tr_tile64(ws2, 16, lane);
+    for (int qt = 0; qt < NQT; ++qt) {
+      if (qt < nqt) {
+        char* t = ws2 + (lane >> 1) * 64 + (lane & 1) * 32;
+        *reinterpret_cast<u32x4*>(t) = rg[qt][0];
+        *reinterpret_cast<u32x4*>(t + 16) = rg[qt][1];
+        const bf16x8 tf0 = read_tr_tile64(ws2, 0, lane), tf1 = read_tr_tile64(ws2, 16, lane);
 #pragma unroll
-      for (int kt = 0; kt < NKT; ++kt) {
-        if (32 * kt < Tk_b) {
-          f32x16 part = {};
-          part = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf0, which == 0 ? dsfr[kt][0] : pfr[kt][0], part, 0, 0, 0);
-          part = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf1, which == 0 ? dsfr[kt][1] : pfr[kt][1], part, 0, 0, 0);
-          // lane (key = r, h) holds d = 32 dt + 8 g + 4 h + {0..3} in registers 4 g .. 4 g + 3
-          float* ap = (which == 0 ? accK : accV) + (32 * kt + r) * AS + 32 * dt + 4 * h;
-          int* tw = turn + (which * NKT + kt) * (D / 32) + dt;
-          if (wq == 0) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-              *reinterpret_cast<f32x4*>(ap + 8 * g) = f32x4{part[4 * g], part[4 * g + 1], part[4 * g + 2], part[4 * g + 3]};
-          } else {
-            while (__hip_atomic_load(tw, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != wq) __builtin_amdgcn_s_sleep(2);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              f32x4* a4 = reinterpret_cast<f32x4*>(ap + 8 * g);
-              const f32x4 o = *a4;
-              *a4 = f32x4{o[0] + part[4 * g], o[1] + part[4 * g + 1], o[2] + part[4 * g + 2], o[3] + part[4 * g + 3]};
-            }
+        for (int kt = 0; kt < NKT; ++kt) {
+          if (32 * kt < Tk_b) {
+            const char* f = bfrag + ((((kt * NQT + qt) * 2 + which) * 2) << 10) + lane * 16;
+            oacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf0, *reinterpret_cast<const bf16x8*>(f), oacc[kt], 0, 0, 0);
+            oacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf1, *reinterpret_cast<const bf16x8*>(f + 1024), oacc[kt], 0, 0, 0);
           }
-          if (lane == 0) __hip_atomic_store(tw, wq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       }
     }
-  }
-  }
-  __syncthreads();                                              // every wave's partials are in the accumulators
-  for (int i = tid; i < kpad_b * 16; i += blockDim.x) {         // 16 lanes = one 256-byte dK / dV row
-    const int key = i >> 4, c = i & 15;
-    if (key >= Tk_b) continue;
-    float v[8], w[8];
+    // lane (key = r, h) holds d = 32 dt + 8 g + 4 h + {0..3} in registers 4 g .. 4 g + 3: the 64-byte slice of the key's row
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { v[j] = accK[key * AS + 8 * c + j] * p.scale; w[j] = accV[key * AS + 8 * c + j]; }
-    *reinterpret_cast<u32x4*>(p.dk + (kbase + key) * p.lddk + head * D + 8 * c) =
-        u32x4{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
-    *reinterpret_cast<u32x4*>(p.dv + (kbase + key) * p.lddv + head * D + 8 * c) =
-        u32x4{pack2bf(w[0], w[1]), pack2bf(w[2], w[3]), pack2bf(w[4], w[5]), pack2bf(w[6], w[7])};
+    for (int kt = 0; kt < NKT; ++kt) {
+      if (32 * kt < Tk_b) {                                       // (workgroup-uniform: the lane swap inside needs every lane)
+        const int key = 32 * kt + r;
+        const bool ok = key < Tk_b;
+        bf16_t* dst = (which == 0 ? p.dk + (kbase + (ok ? key : 0)) * p.lddk : p.dv + (kbase + (ok ? key : 0)) * p.lddv) + head * D + 32 * dt;
+        const f32x16 one[1] = {oacc[kt]};
+        store_acc_row<32>(dst, one, which == 0 ? p.scale : 1.0f, h, ok);
+      }
+    }
   }
 }
 
@@ -1375,7 +1378,7 @@ inline int launch_bwd_fewq128(const AttnBwdParams& p, hipStream_t s) {
 inline int launch_bwd_fewk128(const AttnBwdParams& p, hipStream_t s) {
   constexpr int D = 128, KPAD = 64, QMAX = 256;
   const size_t lds = (size_t)2 * KPAD * 2 * D + 2 * QMAX * sizeof(float) + (size_t)2 * QMAX * sizeof(uint32_t) + 8 * 6144 +
-                     (size_t)2 * KPAD * (D + 4) * sizeof(float) + 16 * sizeof(int);
+                     (size_t)2 * (QMAX / 32) * 2 * 2 * 1024;
   auto kern = attn_bwd_fewk128_kernel;
   if (set_lds(kern, lds) != UNIMM_OK) return UNIMM_E_HIP;
   AttnBwdParams q = p;
