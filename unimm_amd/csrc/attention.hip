@@ -942,12 +942,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(AttnBwdParams p)
 
 // ------------------------------------------------------------------------------------------------
 // backward in ONE kernel for the co-attention direction whose QUERIES are the 37 regions (and for the image self-attention):
-// D = 128, at most 64 queries x 256 keys.  The structure of attn_bwd_fused_kernel (key on the lane, a wave = one 32-key tile,
-// dQ partials meet in an LDS accumulator in wave order), in two phases so that it fits 256 registers: the score phase forms S,
-// dP, P, dS of both query tiles ONCE (the two-kernel path formed them twice, in kernels of 235 and 256 + 27 spilled registers),
-// adds the dQ partials, and keeps P^T / dS^T as bf16 MFMA operands (32 registers); dV and dK of the wave's keys then come out one
-// 32-wide slice of D at a time.  The K tile sits in a wave-private LDS image for the transposed reads of dQ.
-// LDS: Q / dO images 32 KiB + K images 64 KiB + accumulator 33 KiB + dS tiles 16 KiB + words 3 KiB = 148 KiB: one per CU.
+// D = 128, at most 64 queries x 256 keys.  The orientation of attn_bwd_fused_kernel (key on the lane, a wave = one 32-key tile), in
+// phases so that it fits 256 registers: the score phase forms S, dP, P, dS of both query tiles ONCE (the two-kernel path formed
+// them twice, in kernels of 235 and 256 + 27 spilled registers), leaves dS^T in the wave's LDS tiles and keeps P^T / dS^T as bf16
+// MFMA operands (32 registers); dV and dK of the wave's keys then come out one 32-wide slice of D at a time; after a barrier dQ is
+// computed output-stationary (a wave = one 32-wide slice of one query tile, over all key tiles: K^T from the tiles' LDS images).
+// LDS: Q / dO images 32 KiB + K images 64 KiB + dS tiles 32 KiB + words 3 KiB = 131 KiB: one per CU.
 // ------------------------------------------------------------------------------------------------
 template <int NQT>
 __global__ __launch_bounds__(512, 2) void attn_bwd_fewq128_kernel(AttnBwdParams p) {
@@ -956,16 +956,13 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fewq128_kernel(AttnBwdParams 
   drop_resolve(p.drop);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int QPAD = NQT * 32;
-  constexpr int AS = D + 4;                                     // accumulator row stride in floats (16-byte accesses of 16 rows cover all banks)
   char* qimg = smem;
   char* doimg = smem + QPAD * 2 * D;
   float* lse_s = reinterpret_cast<float*>(smem + 2 * QPAD * 2 * D);
   float* del_s = lse_s + QPAD;
   uint32_t* mw_s = reinterpret_cast<uint32_t*>(del_s + QPAD);   // [key tile (wave)][query] mask words
-  char* scr = reinterpret_cast<char*>(mw_s + 8 * QPAD);         // [wave][32 keys][32 queries] bf16
-  char* kimgs = scr + 8 * 2048;                                 // [wave][32 keys][D] bf16: the wave's K tile, read back transposed for dQ
-  float* acc = reinterpret_cast<float*>(kimgs + 8 * 32 * 2 * D); // [QPAD q][AS] fp32
-  int* turn = reinterpret_cast<int*>(acc + QPAD * AS);          // [NQT]: the wave whose turn it is to add its partial of that query tile
+  char* scr = reinterpret_cast<char*>(mw_s + 8 * QPAD);         // [wave][query tile][32 keys][32 queries] bf16: the wave's dS^T tiles
+  char* kimgs = scr + 8 * NQT * 2048;                           // [wave][32 keys][D] bf16: the wave's K tile, read back transposed for dQ
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int item = blockIdx.x;
   const int b = p.order != nullptr ? p.order[item / p.H] : item / p.H, head = item % p.H;
@@ -979,7 +976,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fewq128_kernel(AttnBwdParams 
   stage_head<D>(p.q + qbase * p.ldq + head * D, p.ldq, Tq_b, qpad_b, qimg, tid, blockDim.x);
   stage_head<D>(p.dout + qbase * p.lddo + head * D, p.lddo, Tq_b, qpad_b, doimg, tid, blockDim.x);
   bwd_stage_row_stats<D>(p, b, head, qbase, Tq_b, Tk_b, qpad_b, lse_s, del_s, mw_s, QPAD, tid, blockDim.x);
-  if (tid < NQT) turn[tid] = 0;
 
   int krow = wt * 32 + r;
   const bool kvalid = krow < Tk_b;
@@ -1011,7 +1007,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fewq128_kernel(AttnBwdParams 
 #pragma unroll
     for (int ss = 0; ss < 2; ++ss) { pfr[qt][ss] = bf16x8{}; dsfr[qt][ss] = bf16x8{}; }
   const uint32_t* mrow = mw_s + wt * QPAD;
-  char* ws = scr + wave * 2048;
   const uint32_t hbase = ((uint32_t)b * p.H + head) * (uint32_t)p.Tq;
   const uint32_t halfw = ((uint32_t)p.Tk + 1u) >> 1, halfm = halfw * DROP_M1;
   const uint32_t dlane = drop_lin(p.drop, (4u * (uint32_t)h + ((uint32_t)r & 1u)) * halfw + ((uint32_t)(wt * 32 + r) >> 1));
@@ -1035,6 +1030,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fewq128_kernel(AttnBwdParams 
     }
     float pd[16], ds[16];
     bwd_score_tile(p, sctx, sacc, dpacc, lse_s, del_s, mrow, 32 * qt, r, h, pd, ds);
+    char* ws = scr + (wave * NQT + qt) * 2048;
     // dS^T of this (query tile, key tile) -> the wave's LDS tile: row = key (lane), 4 consecutive queries per store
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4)
@@ -1042,37 +1038,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fewq128_kernel(AttnBwdParams 
           u32x2{pack2bf(ds[4 * g4], ds[4 * g4 + 1]), pack2bf(ds[4 * g4 + 2], ds[4 * g4 + 3])};
 #pragma unroll
     for (int ss = 0; ss < 2; ++ss) { pfr[qt][ss] = pack8(pd + 8 * ss); dsfr[qt][ss] = pack8(ds + 8 * ss); }
-    // dQ^T partial of the tile over this wave's keys, added into the workgroup's accumulator
-    f32x16 dqp[D / 32];
-#pragma unroll
-    for (int dt = 0; dt < D / 32; ++dt) dqp[dt] = f32x16{};
-#pragma unroll
-    for (int ss = 0; ss < 2; ++ss) {
-      const bf16x8 dstf = read_tr_tile64s(ws, 16 * ss, lane);
-#pragma unroll
-      for (int dt = 0; dt < D / 32; ++dt)
-        dqp[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_tr_frag<D>(kimg, 16 * ss, 32 * dt, lane), dstf, dqp[dt], 0, 0, 0);
-    }
-    // lane (q = r, h) holds d = 32 dt + 8 g + 4 h + {0..3} in registers 4 g .. 4 g + 3 of dqp[dt]
-    float* ap = acc + (32 * qt + r) * AS + 4 * h;
-    if (wt == 0) {
-#pragma unroll
-      for (int dt = 0; dt < D / 32; ++dt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          *reinterpret_cast<f32x4*>(ap + 32 * dt + 8 * g) = f32x4{dqp[dt][4 * g], dqp[dt][4 * g + 1], dqp[dt][4 * g + 2], dqp[dt][4 * g + 3]};
-    } else {
-      while (__hip_atomic_load(turn + qt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != wt) __builtin_amdgcn_s_sleep(2);
-#pragma unroll
-      for (int dt = 0; dt < D / 32; ++dt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          f32x4* a4 = reinterpret_cast<f32x4*>(ap + 32 * dt + 8 * g);
-          const f32x4 o = *a4;
-          *a4 = f32x4{o[0] + dqp[dt][4 * g], o[1] + dqp[dt][4 * g + 1], o[2] + dqp[dt][4 * g + 2], o[3] + dqp[dt][4 * g + 3]};
-        }
-    }
-    if (lane == 0) __hip_atomic_store(turn + qt, wt + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
   }
@@ -1103,15 +1068,31 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fewq128_kernel(AttnBwdParams 
       store_acc_row<32>(dvp + 32 * dt, dvc, 1.0f, h, ok);
     }
   }
-  __syncthreads();                                              // every wave's dQ partials are in the accumulator
-  for (int i = tid; i < qpad_b * 16; i += blockDim.x) {         // 16 lanes = one 256-byte dQ row
-    const int q = i >> 4, c = i & 15;
-    if (q >= Tq_b) continue;
-    float v[8];
+  __syncthreads();                                              // every key tile's dS^T tiles and K image are in LDS
+  // dQ, output-stationary: wave w owns the 32-wide slice dt = w & 3 of query tile w >> 2 and walks ALL key tiles -- K^T operand
+  // from that tile's K image, dS^T from its tile, both already in LDS.  (The first version added each wave's partial dQ into an
+  // fp32 LDS accumulator in wave order and converted it in a last cooperative pass: 16 hand-overs, a barrier and 33 KiB more.)
+  {
+    const int qt = wave >> 2, dt = wave & 3;
+    if (32 * qt < Tq_b) {                                       // (wave-uniform)
+      const int nkt = (Tk_b + 31) >> 5;
+      f32x16 dqa[1] = {f32x16{}};
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = acc[q * AS + 8 * c + j] * p.scale;
-    *reinterpret_cast<u32x4*>(p.dq + (qbase + q) * p.lddq + head * D + 8 * c) =
-        u32x4{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+      for (int kt = 0; kt < 8; ++kt) {
+        if (kt < nkt) {
+#pragma unroll
+          for (int ss = 0; ss < 2; ++ss) {
+            const bf16x8 dstf = read_tr_tile64s(scr + (kt * NQT + qt) * 2048, 16 * ss, lane);
+            const bf16x8 ktf = read_tr_frag<D>(kimgs + kt * (32 * 2 * D), 16 * ss, 32 * dt, lane);
+            dqa[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dstf, dqa[0], 0, 0, 0);
+          }
+        }
+      }
+      // lane (q = r, h) holds d = 32 dt + 8 g + 4 h + {0..3} in registers 4 g .. 4 g + 3
+      const int q = 32 * qt + r;
+      const bool ok = q < Tq_b;
+      store_acc_row<32>(p.dq + (qbase + (ok ? q : 0)) * p.lddq + head * D + 32 * dt, dqa, p.scale, h, ok);
+    }
   }
 }
 
@@ -1364,8 +1345,8 @@ int launch_bwd_fused(const AttnBwdParams& p, hipStream_t s) {
 
 inline int launch_bwd_fewq128(const AttnBwdParams& p, hipStream_t s) {
   constexpr int D = 128, NQT = 2, QPAD = NQT * 32;
-  const size_t lds = (size_t)2 * QPAD * 2 * D + 2 * QPAD * sizeof(float) + (size_t)8 * QPAD * sizeof(uint32_t) + 8 * 2048 +
-                     (size_t)8 * 32 * 2 * D + (size_t)QPAD * (D + 4) * sizeof(float) + NQT * sizeof(int);
+  const size_t lds = (size_t)2 * QPAD * 2 * D + 2 * QPAD * sizeof(float) + (size_t)8 * QPAD * sizeof(uint32_t) + 8 * NQT * 2048 +
+                     (size_t)8 * 32 * 2 * D;
   auto kern = attn_bwd_fewq128_kernel<NQT>;
   if (set_lds(kern, lds) != UNIMM_OK) return UNIMM_E_HIP;
   AttnBwdParams q = p;
