@@ -253,8 +253,10 @@ int unimm_plan_lengths(const uint32_t* text_words, int32_t t_q_stride, int32_t t
  * NULL = the argument is exact).  unimm_plan_build writes those words: dims_i = {valid text rows, decoded rows, regions in
  * the masked-region loss}, dims_f = {1 / decoded rows, 1 / regions (inf when none, as the reference's division)}; it also
  * fills rows[real .. rows_cap) and the lm_* lists [real .. lm_cap) with safe values (index 0, label -1, weight 0) so that
- * row-independent kernels (GEMM, LayerNorm forward, gathers) may run over the whole capacity.  dims_i / dims_f both or
- * neither; capacities 0 = lists are exact. */
+ * row-independent kernels (GEMM, LayerNorm forward, gathers) may run over the whole capacity.  dims_i (>= 4 words) / dims_f
+ * (>= 2) both or neither; capacities 0 = lists are exact.  A batch whose real counts EXCEED a capacity (a replayed step sized
+ * from a stale header) never writes past the lists: indices and the counts in dims_i are clamped to the capacities,
+ * dims_i[3] = 1 and both dims_f words are NaN (the step's losses come out NaN instead of memory being corrupted). */
 int unimm_plan_build(const int32_t* header, const int32_t* labels, const int32_t* weights, int32_t B, int32_t T,
                      int32_t* off, int32_t* lens, int64_t* rows, int64_t* inv, int32_t* lm_pos, int32_t* lm_idx,
                      int32_t* lm_label, int32_t* lm_weight, int32_t rows_cap, int32_t lm_cap, int32_t* dims_i, float* dims_f,

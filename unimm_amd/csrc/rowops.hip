@@ -198,10 +198,17 @@ __global__ __launch_bounds__(256) void plan_build_kernel(const int32_t* __restri
     const int mv = tot[0][0] + tot[0][1] + tot[0][2] + tot[0][3];
     const int nlm = tot[1][0] + tot[1][1] + tot[1][2] + tot[1][3];
     const int nimg = tot[2][0] + tot[2][1] + tot[2][2] + tot[2][3];
+    // The lists are sized by the CALLER's counts (launch arguments; under graph replay: the header the capture was sized
+    // with); the counts above come from the batch itself.  A batch that does not fit -- a stale `plan_header` handed to a
+    // replayed step -- must not write past the lists: every index below is bounded by its capacity, the row counts the other
+    // kernels read are clamped to it, and the step is marked (dims_i[3] = 1, NaN loss denominators: the losses come out NaN).
+    const bool over = (rows != nullptr && mv > rows_cap) || (lm_pos != nullptr && nlm > lm_cap);
     if (t == 0 && dims_i != nullptr) {
-      dims_i[0] = mv; dims_i[1] = lm_pos != nullptr ? nlm : 0; dims_i[2] = nimg;
-      dims_f[0] = 1.0f / (float)max(nlm, 1);
-      dims_f[1] = nimg > 0 ? 1.0f / (float)nimg : __builtin_inff();      // the reference divides by max(n, 0) (:1574)
+      dims_i[0] = rows != nullptr ? min(mv, rows_cap) : mv;
+      dims_i[1] = lm_pos != nullptr ? min(nlm, lm_cap) : 0; dims_i[2] = nimg;
+      dims_i[3] = over ? 1 : 0;
+      dims_f[0] = over ? __builtin_nanf("") : 1.0f / (float)max(nlm, 1);
+      dims_f[1] = over ? __builtin_nanf("") : (nimg > 0 ? 1.0f / (float)nimg : __builtin_inff());   // the reference divides by max(n, 0) (:1574)
     }
     if (rows != nullptr) for (int i = mv + t; i < rows_cap; i += 256) rows[i] = 0;
     if (lm_pos != nullptr)
@@ -225,7 +232,11 @@ __global__ __launch_bounds__(256) void plan_build_kernel(const int32_t* __restri
   __syncthreads();
   if (t == 0) { s_off = pa[0] + pa[1] + pa[2] + pa[3]; s_lmoff = pc[0] + pc[1] + pc[2] + pc[3]; }
   __syncthreads();
-  const int len = header[b], o0 = s_off;
+  int len = header[b], o0 = s_off;
+  if (rows != nullptr && o0 + len > rows_cap) {     // does not fit the packed layout (see `over` above): stay inside it
+    o0 = min(o0, rows_cap - 1);
+    len = max(1, min(len, rows_cap - o0));
+  }
   if (t == 0) { off[b] = o0; lens[b] = len; }
   if (t < T) {
     const bool in = t < len;
@@ -244,10 +255,12 @@ __global__ __launch_bounds__(256) void plan_build_kernel(const int32_t* __restri
     int r = __popcll(bal & ((1ull << lane) - 1ull));
     for (int w = 0; w < wv; ++w) r += wave_cnt[w];
     const int dst = s_lmoff + r;                    // row order: by sequence, then by position (what torch.nonzero gave)
-    lm_pos[dst] = b * T + t;
-    lm_idx[dst] = o0 + t;                           // a decoded row is valid by construction (t < len)
-    lm_lab[dst] = lab;
-    lm_w[dst] = weights != nullptr ? wt : 1;
+    if (dst < lm_cap) {
+      lm_pos[dst] = b * T + t;
+      lm_idx[dst] = rows != nullptr ? min(o0 + t, rows_cap - 1) : o0 + t;   // a decoded row is valid by construction (t < len)
+      lm_lab[dst] = lab;
+      lm_w[dst] = weights != nullptr ? wt : 1;
+    }
   }
 }
 

@@ -124,6 +124,7 @@ class Engine:
         self.image_tile = 0              # tile code of the image side's GEMMs in the large-batch regime (0 = the library's choice; see _tile)
         self.wgrad_overwrite = True      # weight gradients with a single contributor are WRITTEN into a freshly zeroed arena (no atomics)
         self._bwd_fresh = False
+        self.debug_fresh = False         # check (one device scan + sync per backward) that a `fresh` arena really is zero
         self.tile_table = {}             # {("t" | "i", N, K): tile code}: per-shape choices of the small-batch regime (see _tile)
         self.small_rows = 12000          # text rows per step below which the encoder GEMMs take the small-batch tile rule (_tile)
         self._step_rows = None           # text rows of the running step (set by _forward)
@@ -138,6 +139,13 @@ class Engine:
         self._pending = []               # gradient buckets whose weight gradients are still queued: (group, #text, #image queued)
         self._nq = [0, 0]                # weight-gradient problems ever queued (text side, image side) ...
         self._nf = [0, 0]                # ... and launched
+
+    def schedule_key(self):
+        """Every schedule attribute that is frozen into a captured launch sequence (unimm_amd/graphs.py keys its entries on
+        it: changing one after a capture re-captures instead of replaying the old schedule beside an eager new one)."""
+        return (self.dual_stream, self.unpad, self.lazy_ln, self.gemm_tile, self.wgrad_group_rounds, self.wgrad_stream, self.splitk,
+                self.attn_longest_first, self.wgrad_overwrite, tuple(sorted(self.tile_table.items())), self.image_tile,
+                self.small_rows, self.image_head_side, self.skinny_dx_rows, self.wgrad_ws_bytes, self.text_priority)
 
     def register_arena_user(self, obj):
         import weakref
@@ -1330,6 +1338,10 @@ class Engine:
         seq_t, seq_v = out["seq_out_t"], out["seq_out_v"]
         self.arena.attach_grads()
         self._bwd_fresh = bool(self.arena.fresh)   # gradients known to be zero: sole contributors may write instead of add (_wgrad)
+        if self._bwd_fresh and self.debug_fresh and bool(self.arena.grad_flat.any()):
+            raise RuntimeError("the gradient arena is marked fresh (zeroed since the last backward) but holds non-zero values: "
+                               "something wrote into .grad / grad_flat between zero_grad() and backward() without clearing "
+                               "`model.engine.arena.fresh` (INTEGRATION.md, 'Gradient arena')")
         self._step_rows = out["Mt"]              # the tile rule follows THIS step's rows (another forward may have run since)
 
         def gvec(g):

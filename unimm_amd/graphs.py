@@ -111,6 +111,23 @@ def _give_pool(index, sig, side, pool, stream):
     _FREE_POOLS.setdefault(index, []).append((sig, side, pool, stream))
 
 
+def release_all():
+    """Opt-in, for a process that will NEVER launch a captured step again (e.g. before an evaluation phase that needs the
+    memory): drop every graph exec and every recycled pool this module holds, so that the caching allocator can return the
+    private pools (the activations of dead entries: 14-19 GB under churn).  Live executors must be dropped by their owners
+    first (`engine.enable_graphs(False)`); destroying execs is exactly what the keep-alive list above exists to avoid (the
+    runtime fault it documents needs a LATER graph launch to fire), hence: only when no graph will be launched afterwards.
+    -> number of execs released."""
+    n = len(_KEPT)
+    _KEPT.clear()
+    _FREE_POOLS.clear()
+    gc.collect()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+    return n
+
+
 @contextlib.contextmanager
 def _quiet_collector():
     """No cyclic garbage collection while a stream is capturing.  The collector runs wherever an allocation count trips it;
@@ -217,15 +234,24 @@ class StepGraphs:
         (`outputs(entry)`) after it has enqueued the backward (BertForMultiModalPreTraining.forward_backward)."""
         eng = self.eng
         eng.refresh_weights()
-        hh = inp.get("_plan_header")                           # a prefetcher may have read the step's header already (count_rows_async)
+        hh = inp.get("_plan_header")                           # a prefetcher may have read the step's header already (Engine.count_rows)
+        B, T = inp["input_ids"].shape
         if hh is None:
             hh = eng.count_rows(inp)                           # the step's one host sync
-        B, T = inp["input_ids"].shape
+        else:
+            # A caller-supplied header alone sizes the capacities of the replayed launches.  What the host can check, it checks
+            # (shape and value ranges); that the header belongs to THIS batch only the device can know: the replayed plan kernel
+            # recomputes the counts, stays inside the capacities whatever they are and turns the losses into NaN when the batch
+            # does not fit (csrc/rowops.hip: plan_build_kernel).
+            hh = [int(x) for x in hh]
+            if len(hh) != 3 * B + 2:
+                raise ValueError(f"plan_header has {len(hh)} entries, expected 3 * B + 2 = {3 * B + 2} (Engine.count_rows of this batch)")
+            if any(not 1 <= x <= T for x in hh[:B]) or any(not 0 <= x <= T for x in hh[B:2 * B]):
+                raise ValueError(f"plan_header: valid lengths must lie in [1, {T}] and decoded-row counts in [0, {T}]")
         Mv, n_lm = sum(hh[:B]), sum(hh[B:2 * B])
         Mcap = min(_rup(Mv, self.row_bucket), B * T)
         ncap = _rup(n_lm, self.lm_bucket) if n_lm > 0 else 0
-        sig = self._key0(inp, opts) + (Mcap, ncap, eng.dual_stream, eng.unpad, eng.lazy_ln, eng.gemm_tile, eng.wgrad_group_rounds,
-                                         eng.grad_bucket_hook is not None, eng.wgrad_stream, eng.splitk)   # with a hook the backward is a chain of graphs
+        sig = self._key0(inp, opts) + (Mcap, ncap, eng.grad_bucket_hook is not None) + eng.schedule_key()   # with a hook the backward is a chain of graphs
         ent = self.entries.get(sig)
         if ent is not None and ent.inflight is not None and ent.inflight() is not None:
             # the previous forward of this signature has not been back-propagated yet (two losses summed before .backward(),

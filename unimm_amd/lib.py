@@ -507,8 +507,9 @@ def plan_lengths(text_mask, co_mask, R, labels, weights, nsp_weight, B, T, image
 
 def plan_build(header, labels, weights, B, T, Mv, n_lm, want_rows=True, dims=None):
     """-> dict(off, lens, rows, inv, lm_pos, lm_idx, lm_label, lm_weight) built on the device from the header.
-    Mv / n_lm are CAPACITIES (>= the header's totals): the lists' unused tails get safe values.  dims = (int32 [>=3],
-    fp32 [>=2]) device tensors that receive the step's real counts and loss denominators (unimm_hip.h)."""
+    Mv / n_lm are CAPACITIES (>= the header's totals): the lists' unused tails get safe values.  dims = (int32 [>=4],
+    fp32 [>=2]) device tensors that receive the step's real counts and loss denominators (unimm_hip.h; int32 needs >= 4
+    words: [3] = 1 when the batch did not fit the capacities)."""
     dev = header.device
     i32 = lambda n: torch.empty(max(n, 1), dtype=torch.int32, device=dev)
     off, lens = i32(B), i32(B)
