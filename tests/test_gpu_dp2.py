@@ -148,3 +148,41 @@ def test_two_engine_ranks_of_the_fp32_accuracy_engine(tmp_path, golden_dir):
         acc_err = float((out["acc"] - (out["grad"] + one["grads"][r])).abs().max())
         assert acc_err <= 2e-5 * scale, (r, acc_err)
         assert out["stats"]["buckets"] == out["stats"]["n_buckets_expected"]
+
+
+@pytest.mark.parametrize("rounds", [2, 4])
+def test_exchange_plan_matches_the_engine(rounds):
+    """`unimm_amd.bucket_plan` (host arithmetic; tests/test_bucket_plan_cpu.py checks the N = 8 plan with it) against the
+    hand-overs a REAL backward produces at the full config on the 8-GPU share of the headline batch: the same buckets in the
+    same order with the same `more` flags, for both grouping depths."""
+    from unimm_amd import BertConfig, BertForMultiModalPreTraining, bucket_plan as BP, synth
+    cfg = BertConfig.from_json_file(os.path.join(ROOT, "unimm_amd", "config", "bert_base_6layer_6conect.json"))
+    torch.manual_seed(0)
+    model = BertForMultiModalPreTraining(cfg).cuda().train()
+    eng = model.engine
+    eng.ensure(torch.device("cuda", 0))
+    eng.wgrad_group_rounds = rounds
+    calls = []
+    eng.grad_bucket_hook = lambda group, more=False: calls.append((group, bool(more)))
+    b = synth.make_batch(n_seq=30, T=256, R=37, cfg=cfg, seed=3, device="cuda")
+    kw = dict(token_type_ids=b["token_type_ids"], position_ids=b["token_position_ids"], attention_mask=b["attention_mask"],
+              image_attention_mask=b["image_attention_mask"], co_attention_mask=b["co_attention_mask"],
+              masked_lm_labels=b["masked_lm_labels"], image_label=b["image_label"], image_target=b["image_target"],
+              next_sentence_label=b["next_sentence_label"], nsp_weight=b["nsp_weight"], lm_weight=b["lm_weight"])
+    hdr = eng.count_rows({**kw, "input_ids": b["input_ids"], "image_feat": b["image_feat"]})
+    B = 30
+    lm, img, nsp_l, _, _, _ = model(b["input_ids"], b["image_feat"], b["image_loc"], _want_lm_scores=False, **kw)
+    (lm + img + nsp_l).sum().backward()
+    torch.cuda.synchronize()
+    want, launches = BP.hand_overs(cfg, B, sum(hdr[:B]), sum(hdr[B:2 * B]), wgrad_group_rounds=rounds)
+    assert calls == want, (calls, want)
+    assert sorted(g for g, _ in calls) == sorted(g for g, _, _ in eng.arena.buckets)
+    assert BP.arena_ranges(cfg) == list(eng.arena.buckets)
+    # one stream: the image side's problems join the text queue; the plan follows
+    calls.clear()
+    eng.dual_stream = False
+    lm, img, nsp_l, _, _, _ = model(b["input_ids"], b["image_feat"], b["image_loc"], _want_lm_scores=False, **kw)
+    (lm + img + nsp_l).sum().backward()
+    torch.cuda.synchronize()
+    want1, _ = BP.hand_overs(cfg, B, sum(hdr[:B]), sum(hdr[B:2 * B]), wgrad_group_rounds=rounds, dual_stream=False)
+    assert calls == want1, (calls, want1)

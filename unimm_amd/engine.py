@@ -21,6 +21,7 @@ from typing import Dict, List, Optional
 
 import torch
 
+from . import bucket_plan as BP
 from . import dropout as DR
 from . import lib as L
 from . import params as PM
@@ -463,8 +464,7 @@ class Engine:
             M = dy.shape[0] if M is None else M
             N = dy.shape[1] if N is None else N
             K = x.shape[1] if K is None else K
-            if N >= 256 and K >= 256 and M >= 1024:
-                t += ((N + 255) // 256) * ((K + 255) // 256)
+            t += BP.big_tiles_of(M, N, K)
         return t
 
     def _flush_due(self, queue):
@@ -474,16 +474,8 @@ class Engine:
         118 us of main loop; 8x the algorithmic write traffic).  Nothing waits for a weight gradient, so the queue
         simply keeps growing until its tiles fill whole rounds WITHOUT a split: each tile is then reduced by one
         workgroup over all rows and written once (round 3: 484 -> 394 us per text block at 7 blocks per launch).
-        Due = the tile count sits just below a multiple of 256 (<= 12.5 % of the last round idle) and covers at least half
-        of `wgrad_group_rounds`, or exceeds it, or the launch's descriptor table (48 problems) is nearly full."""
-        if len(queue) >= 40:
-            return True
-        t = self._big_tiles(queue)
-        slots = 256
-        if t >= self.wgrad_group_rounds * slots:
-            return True
-        waste = (-t) % slots
-        return t >= max(2, self.wgrad_group_rounds // 2) * slots - 32 and waste <= slots // 8
+        The rule itself is host arithmetic shared with the exchange planner: `bucket_plan.flush_due`."""
+        return BP.flush_due(len(queue), self._big_tiles(queue), self.wgrad_group_rounds)
 
     def _ws(self, which):
         """Zero-initialised workspace of the weight-gradient launches of one stream (0 bytes = fp32-atomic path)."""
@@ -494,10 +486,10 @@ class Engine:
             t = self._wgrad_ws[which] = torch.zeros(self.wgrad_ws_bytes, dtype=torch.uint8, device=self.arena.flat.device)
         return t
 
-    def _flush_wgrad(self, force=False):
-        """Launch the queues that are due (all of them with force=True)."""
+    def _flush_wgrad(self, force=False, force_img=False):
+        """Launch the queues that are due (all of them with force=True; force_img: the image side's whatever its size)."""
         shared = self._dual()                     # the launches of this backward share the chip with the other stream's
-        if (self._wq_img or self._fq_img) and (force or self._flush_due(self._wq_img)):
+        if (self._wq_img or self._fq_img) and (force or force_img or self._flush_due(self._wq_img)):
             with self._img():                     # image-side problems: operands were produced on that stream
                 L.gemm_tn_grouped(self._wq_img, shared=shared, ws=self._ws("img"))
                 L.colpartials_finish_grouped(self._fq_img)
@@ -1412,8 +1404,34 @@ class Engine:
         entries = list(reversed(bw["tape"]))
         if not self.image_head_side:
             self._to_img(gv)                     # the heads' gradient of the image stream was produced on the main stream
+        self._backward_encoder(bw, entries, gt, gv)
+        self._to_txt()                                       # everything joined before the caller continues
+        self._bucket_done("text_embeddings")
+        self.arena.fresh = False                             # the arena holds this pass's gradients now
+        self._bwd_fresh = False
+
+    def _backward_encoder(self, bw, entries, gt, gv):
+        """The encoder blocks of the tape in reverse (`entries`), then the two embedding backward passes; every block's bucket
+        is reported as it completes (`_bucket_done`).  Shared by the bf16 and the fp32x3 engine."""
         pos = 0
+        embv_done = False
+
+        def image_tail():
+            # The image stream's last work -- the image embedding's backward -- is enqueued as soon as no image or connection
+            # layer is left on the tape (the full config: after c0, with text layers 5..0 still to come), and the image side's
+            # queued weight gradients are launched with it: under data parallelism the image-side buckets (v0, c0's image half,
+            # the image embedding) then travel while the remaining text layers run, instead of after the end of backward behind
+            # everything else (bucket_plan.py: the last collective of an 8-rank step shrinks from 392 MB to 181 MB).
+            nonlocal embv_done
+            if embv_done or any(e[0] in ("c", "v") for e in entries[pos:]):
+                return
+            embv_done = True
+            with self._img():
+                bw["embv"](gv)
+                self._bucket_done("image_embeddings", force_img=True)
+
         while pos < len(entries):
+            image_tail()
             seg = []
             while pos < len(entries) and entries[pos][0] != "c":
                 seg.append(entries[pos])
@@ -1433,37 +1451,27 @@ class Engine:
                 with self._conn_tag():
                     gv, gt = fn(gv, gt)                      # exchanges between the streams happen inside
                 self._bucket_done(key)
-        with self._img():
-            bw["embv"](gv)
-            self._bucket_done("image_embeddings")
+        image_tail()
         bw["embt"](gt)
-        self._to_txt()                                       # everything joined before the caller continues
-        self._bucket_done("text_embeddings")
-        self.arena.fresh = False                             # the arena holds this pass's gradients now
-        self._bwd_fresh = False
 
-    def _bucket_done(self, group):
+    def _bucket_done(self, group, force_img=False):
         """A block's backward is enqueued.  Its weight gradients may stay queued for a later grouped launch (`_flush_due`);
-        the data-parallel hook of a bucket fires once the launches that cover it are enqueued, in bucket order."""
+        the data-parallel hook of a bucket fires once the launches that cover it are enqueued.  Buckets are handed over as
+        they complete, not in the order they were finished: a bucket whose launches are out is not held back by an older one
+        that still waits for the other stream's queue (bucket_plan.py restates this rule on the host)."""
         last = group == "text_embeddings"
         force = last or group == "heads"          # the decoder's gradient has its own row count: a launch of its own
         if self.grad_bucket_hook is not None:
             self._pending.append((group, self._nq[0], self._nq[1]))
-        self._flush_wgrad(force=force)
+        self._flush_wgrad(force=force, force_img=force_img)
         if self.grad_bucket_hook is not None:
-            fired = False
-            while self._pending and not self._on_side:
-                g, nt, ni = self._pending[0]
-                if self._nf[0] < nt or self._nf[1] < ni:
-                    break
-                if not fired:
-                    self._join_wgrad()            # the exchange reads them
-                    self._to_txt()                # ... including the ones the image side produced for these buckets
-                    fired = True
-                self._pending.pop(0)
-                nxt = self._pending[0] if self._pending else None
-                more = nxt is not None and self._nf[0] >= nxt[1] and self._nf[1] >= nxt[2]
-                self.grad_bucket_hook(g, more)    # more: the next bucket follows at once (adjacent slices can travel together)
+            ready = [] if self._on_side else [p for p in self._pending if self._nf[0] >= p[1] and self._nf[1] >= p[2]]
+            if ready:
+                self._join_wgrad()                # the exchange reads them
+                self._to_txt()                    # ... including the ones the image side produced for these buckets
+                self._pending = [p for p in self._pending if p not in ready]
+                for j, (g, _, _) in enumerate(ready):
+                    self.grad_bucket_hook(g, j + 1 < len(ready))    # more: the next bucket follows at once (adjacent slices travel together)
             assert not (last and self._pending), self._pending
         elif last:                                # last bucket: everything joined before the caller continues
             self._join_wgrad()

@@ -565,30 +565,6 @@ class EngineX3(Engine):
         # ---- encoder blocks in reverse --------------------------------------------------------------------------------
         gt, gv = dseq_t, dseq_v
         entries = list(reversed(bw["tape"]))
-        pos = 0
-        while pos < len(entries):                    # the base engine's bucket order: a segment's image layers, then its text layers
-            seg = []
-            while pos < len(entries) and entries[pos][0] != "c":
-                seg.append(entries[pos])
-                pos += 1
-            for kind, key, fn in seg:
-                if kind == "v":
-                    with self._img():
-                        gv = fn(gv)
-                        self._bucket_done(key)
-            for kind, key, fn in seg:
-                if kind == "t":
-                    gt = fn(gt)
-                    self._bucket_done(key)
-            if pos < len(entries):
-                _, key, fn = entries[pos]
-                pos += 1
-                with self._conn_tag():
-                    gv, gt = fn(gv, gt)
-                self._bucket_done(key)
-        with self._img():
-            bw["embv"](gv)
-            self._bucket_done("image_embeddings")
-        bw["embt"](gt)
+        self._backward_encoder(bw, entries, gt, gv)      # the base engine's block loop and bucket order
         self._to_txt()                                       # everything joined before the caller continues
         self._bucket_done("text_embeddings")
