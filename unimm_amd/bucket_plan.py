@@ -65,7 +65,7 @@ def backward_events(cfg, n_seq: int, text_rows: int, lm_rows: int, regions: int 
     H, Hv, Hb = cfg.hidden_size, cfg.v_hidden_size, cfg.bi_hidden_size
     I, Iv = cfg.intermediate_size, cfg.v_intermediate_size
     Mt, Mi = text_rows, n_seq * regions
-    img = 1 if dual_stream else 0
+    img = 1            # the image side keeps its own queue on one stream as on two (Engine._img)
     ev = []
     hs = img if image_head_side else 0
     ev.append(("w", hs, Mi, cfg.v_target_size, Hv))              # image head decoder, transform

@@ -428,6 +428,15 @@ __device__ __forceinline__ void tn_pp_stage(const TnPpStage& st, const u32x4& sr
   }
 }
 
+#ifdef UNIMM_TN_TRACE
+// tools/exp/tn_drift.py (variant build only): wall-clock stamps of every workgroup at reduction steps 0, 32, 64, ... --
+// how far apart the workgroups that share operand panels through one XCD's L2 drift over a launch.
+__device__ unsigned long long* g_tn_trace = nullptr;
+extern "C" int unimm_debug_tn_trace(void* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_tn_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
+}
+#endif
+
 __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmTnGroup grp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NW = 8, NT = 8, TNB = 256, TKB = 256;
@@ -545,7 +554,19 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmTnGroup grp) {
     else { accb[JH] = dot_ones(fa[0][3], accb[JH]); accb[JH] = dot_ones(fa[1][3], accb[JH]); }                  \
   }
 
+#ifdef UNIMM_TN_TRACE
+  unsigned long long* const tn_trace = g_tn_trace;
+#endif
   for (int t = 0; t < nk; ++t) {
+#ifdef UNIMM_TN_TRACE
+    if (tn_trace != nullptr && tid == 0 && (t & 31) == 0 && (t >> 5) < 30) {
+      tn_trace[(size_t)blockIdx.x * 32 + (t >> 5)] = wall_clock64();
+      if (t == 0) {
+        tn_trace[(size_t)blockIdx.x * 32 + 30] = (unsigned long long)__builtin_amdgcn_s_getreg(6164);   // HW_REG_XCC_ID[3:0]
+        tn_trace[(size_t)blockIdx.x * 32 + 31] = ((unsigned long long)gi << 32) | (unsigned)(tn * 4096 + tk);
+      }
+    }
+#endif
     const bool bias_now = do_bias && t == tb;                       // wave-uniform
     if (t == tb) tb += nbk;
     const uint32_t off = (uint32_t)((t & 1) * 65536);
@@ -771,6 +792,21 @@ int launch_tn_group(const unimm_gemm_tn_args* const* a, int count, bool big, boo
   const int tb = big ? 256 : 128;
   int tiles = 0, max_m = 0;
   double flops = 0.0;
+  // Longest reduction first.  Workgroups are dispatched in grid order as CUs free up (greedy list scheduling), so with the
+  // problems sorted by descending row count the short tiles (the image side's 8.9k rows, the decoder's ~5k beside the text
+  // side's ~31k: a one-stream step queues them all into one launch) fill the tail of the launch instead of sitting in front of
+  // long tiles that then start late.  Stable: problems of one row count keep the caller's order.
+  const unimm_gemm_tn_args* sorted[TN_MAXG];
+  for (int i = 0; i < count; ++i) sorted[i] = a[i];
+#ifndef UNIMM_TN_NOSORT
+  for (int i = 1; i < count; ++i) {
+    const unimm_gemm_tn_args* x = sorted[i];
+    int j = i - 1;
+    while (j >= 0 && sorted[j]->M < x->M) { sorted[j + 1] = sorted[j]; --j; }
+    sorted[j + 1] = x;
+  }
+#endif
+  a = sorted;
   for (int i = 0; i < count; ++i) {
     GemmTnParams& p = g.pr[i];
     p.dy = (const bf16_t*)a[i]->dy; p.x = (const bf16_t*)a[i]->x; p.dw = a[i]->dw; p.dbias = a[i]->dbias;

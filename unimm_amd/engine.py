@@ -625,7 +625,14 @@ class Engine:
         """Launches inside the block go to the image-side stream, in that stream's order (no waits: use
         `_to_img` / `_to_txt` where the two streams exchange data).  No-op when the dual-stream schedule is off."""
         if not self._dual():
-            yield
+            # one stream: the same schedule serialised -- the block's launches still COUNT as image-side ones (their own
+            # weight-gradient queue, i.e. the same grouped launches as the two-stream step, and the image side's tile rule),
+            # so that `dual_stream = False` measures the production kernels with the chip to themselves
+            was, self._on_side = self._on_side, True
+            try:
+                yield
+            finally:
+                self._on_side = was
             return
         side = self._side_stream()
         was, self._on_side = self._on_side, True
