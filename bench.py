@@ -77,6 +77,9 @@ def parse():
     ap.add_argument("--compact-inputs", action="store_true",
                     help="feed mask descriptors + per-image tensors + image_index (SURVEY 8 row F3) instead of the "
                          "reference-shaped dense masks and per-sequence image copies")
+    ap.add_argument("--host-staging", choices=["on", "off"], default="on",
+                    help="with --host-inputs direct: the engine's own pinned staging ring + copy stream for CPU tensors handed to "
+                         "forward() (Engine.stage_host_inputs; default) or the plain .to(device) path (A/B)")
     ap.add_argument("--host-inputs", choices=["off", "direct", "prefetch"], default="off",
                     help="off (default, the contract's metric): the step's inputs are resident in HBM.  direct: every step takes a "
                          "fresh batch of CPU tensors handed straight to forward(), the reference's calling convention "
@@ -563,6 +566,8 @@ def main():
             model.engine.tile_table[(side, int(n_), int(k_))] = int(code)
     if args.no_splitk:
         model.engine.splitk = False
+    if args.host_staging == "off":
+        model.engine.host_staging = False
     if args.single_stream:
         model.engine.dual_stream = False
     if args.wgrad_stream:
@@ -656,6 +661,11 @@ def main():
     lib.prof_enable(False)
     loss_val = float(loss.detach())
     log(f"timed region: {dt / args.steps * 1e3:.2f} ms/step")
+    if getattr(model.engine, "_stager", None) is not None:
+        st_ = model.engine._stager.stats
+        log(f"host staging: {st_['steps']} steps, {st_.get('host_ms', 0.0) / max(1, st_['steps']):.2f} ms of host time per step, "
+            f"{st_['bytes_h2d'] / max(1, st_['steps']) / 1e6:.1f} MB per step over PCIe, pinned {model.engine._stager.pinned_bytes() / 1e6:.0f} MB; "
+            + ", ".join(f"{k} {st_.get(k, 0.0) / max(1, st_['steps']):.2f}" for k in ("wait_ms", "pack_ms", "copy_ms")))
     # Outside the timed region (N=1 only): the same kernel with the chip to itself.  In the production schedule the image
     # side runs on its own stream, so a weight-gradient launch shares CUs with image-layer kernels and its in-situ
     # duration (the `achieved` / `frac` above) is not an exclusive one; two single-stream steps give that figure.
@@ -824,7 +834,7 @@ def main():
                   ("; compact inputs (mask descriptors, per-image tensors)" if args.compact_inputs else "") +
                   ("" if args.host_inputs == "off" else
                    f"; inputs start in HOST memory every step ({args.host_inputs}: "
-                   + ("CPU tensors handed to forward()" if args.host_inputs == "direct" else "pinned + copied one step ahead by DevicePrefetcher")
+                   + ("CPU tensors handed to forward()" + ("" if args.host_staging == "on" else ", plain .to(device) path") if args.host_inputs == "direct" else "pinned + copied one step ahead by DevicePrefetcher")
                    + f", {h2d_bytes / 1e6:.0f} MB per step, 3 batches cycled) -- NOT the contract's resident-input metric"))
         out = {
             "metric": metric,

@@ -223,6 +223,14 @@ enum { UNIMM_DT_U8 = 0, UNIMM_DT_I32 = 1, UNIMM_DT_I64 = 2, UNIMM_DT_F32 = 3 };
  * ceil(t/32) words per row.  Replaces the fp32 (1-m)*-10000 mask tensors of
  * models/vilbert_dialog.py:1415-1431 (the -10000 is applied inside the attention kernels). */
 int unimm_mask_pack(const void* mask, int dtype, uint32_t* out, int64_t rows, int32_t t, void* stream);
+/* The same words computed on the HOST (ABI 18; no device work, no stream): `mask` and `out` are host pointers.  The reference's
+ * callers pass CPU tensors to forward() (train.py:113-129; utils/data_parallel.py:123-124 scatters them) -- int64 [B, 256, 256]
+ * masks, 512 KiB per sequence; packed on the host side of the copy, 8 KiB per sequence cross PCIe.  threads: 0 = up to 16. */
+int unimm_host_mask_pack(const void* mask, int dtype, uint32_t* out, int64_t rows, int32_t t, int32_t threads);
+/* memcpy between two HOST buffers on `threads` threads (0 = up to 8): the caller's pageable tensors -> the pinned staging ring the
+ * asynchronous host->device copies read (one thread moves the 130 MB of region features / targets of a 240-sequence batch in
+ * ~25 ms: most of a step).  ABI 18. */
+int unimm_host_memcpy(void* dst, const void* src, int64_t bytes, int32_t threads);
 /* The same words without the dense mask: the text mask [B, T, ceil(T/32)] and the
  * co-attention key mask [B, ceil(T/32)] (one row per sequence, mask_q_stride = 0) of B sequences from three
  * int32 device arrays: mode (0 = discriminative, utils/data_utils.py:391-396; 1 = generative, :199-210),

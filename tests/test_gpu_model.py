@@ -645,3 +645,75 @@ def test_weight_gradients_written_into_a_fresh_arena_equal_the_atomic_path(golde
         scale = float(a.abs().max())
         assert float((a - c).abs().max()) <= 1e-5 * scale and float((a - d).abs().max()) <= 1e-5 * scale
     assert float((got[1] - got[0]).abs().max()) > 0.1 * float(got[0].abs().max())      # the second pass really accumulated
+
+
+def test_host_tensors_handed_to_forward_equal_resident_inputs(golden_dir):
+    """The reference's calling convention -- CPU tensors straight into forward() (train.py:113-161, utils/data_parallel.py:123-124)
+    -- goes through the engine's own pinned staging ring and copy stream (inputs.HostStager; dense masks are bit-packed on the
+    host side of the copy by unimm_host_mask_pack): same losses / NSP logits bit for bit and the same gradients as the step on
+    resident inputs, over several different batches from REUSED, mutated host buffers (a real loader), for int64 [B,T,T] masks
+    (the reference's), bool masks and a [B,T] key-padding mask; pinned memory stays bounded by the ring; the plain .to(device)
+    path (`host_staging = False`) agrees too; host words == device words."""
+    from unimm_amd import lib as L
+    from unimm_amd import synth
+    from unimm_amd.inputs import PackedMask
+    model, _, _ = build_small(golden_dir)
+    model.train()
+    model.set_dropout_seed(17)
+    ref, _, _ = build_small(golden_dir)
+    ref.train()
+    ref.set_dropout_seed(17)
+    cfg = model.config
+
+    def kw(b):
+        return dict(token_type_ids=b["token_type_ids"], position_ids=b["token_position_ids"], attention_mask=b["attention_mask"],
+                    image_attention_mask=b["image_attention_mask"], co_attention_mask=b["co_attention_mask"],
+                    masked_lm_labels=b["masked_lm_labels"], image_label=b["image_label"], image_target=b["image_target"],
+                    next_sentence_label=b["next_sentence_label"], nsp_weight=b["nsp_weight"], lm_weight=b["lm_weight"], _want_lm_scores=False)
+
+    def step(m, b):
+        m.engine.arena.zero_grads() if m.engine.arena is not None else None
+        r = m(b["input_ids"], b["image_feat"], b["image_loc"], **kw(b))
+        (r[0] + r[1] + r[2]).sum().backward()
+        torch.cuda.synchronize()
+        return [float(x.detach()) for x in r[:3]], r[5].detach().clone(), m.engine.arena.grad_flat.clone()
+
+    host = None
+    pinned = []
+    for it, seed in enumerate((5, 6, 7, 5, 8, 6)):
+        hb = synth.make_batch(n_seq=12, T=64, R=37, cfg=cfg, seed=seed, device="cpu", mask_dtype=torch.int64 if it % 2 == 0 else torch.bool)
+        if it == 4:                                            # a [B, T] key-padding mask and no co-attention mask
+            hb["attention_mask"] = (hb["attention_mask"].sum(1) > 0).to(torch.int64)
+            hb["co_attention_mask"] = None
+        if host is None:
+            host = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in hb.items()}
+        else:                                                  # the loader REUSES its buffers where the shapes allow
+            for k, v in hb.items():
+                if torch.is_tensor(v) and torch.is_tensor(host.get(k)) and host[k].shape == v.shape and host[k].dtype == v.dtype:
+                    host[k].copy_(v)
+                else:
+                    host[k] = v
+        dev = {k: (v.cuda() if torch.is_tensor(v) and k != "nsp_weight" else v) for k, v in host.items()}
+        want = step(ref, dev)
+        got = step(model, host)
+        assert want[0] == got[0] and torch.equal(want[1], got[1]), (it, want[0], got[0])
+        assert (want[2] - got[2]).abs().max() <= 1e-5 * want[2].abs().max(), it
+        pinned.append(model.engine._stager.pinned_bytes())
+    st = model.engine._stager
+    assert st.stats["steps"] == 6
+    one_batch = 12 * (64 * 64 // 8 + 64 * 8 * 6 + 37 * (64 + 5 * 4 + 1601 * 4 + 2048 * 4 + 8 + 8) + 64)   # packed masks, token fields, region fields
+    assert max(pinned) <= 3 * 1.2 * one_batch and pinned[2] == pinned[3], (pinned, one_batch)      # bounded by ring x one batch
+    # the staging ring is reused: after the shapes have been seen, further steps allocate nothing
+    step(model, host); step(model, host); step(model, host)      # every slot of the ring has now seen the current shapes
+    n0 = st.stats["realloc"]
+    step(model, host); step(model, host); step(model, host)
+    assert st.stats["realloc"] == n0
+    # plain path
+    model.engine.host_staging = False
+    ref.set_dropout_seed(3); model.set_dropout_seed(3)
+    dev = {k: (v.cuda() if torch.is_tensor(v) and k != "nsp_weight" else v) for k, v in host.items()}
+    want, got = step(ref, dev), step(model, host)
+    assert want[0] == got[0] and torch.equal(want[1], got[1])
+    # host words == device words
+    m = (torch.rand((5, 64, 64)) < 0.3).to(torch.int64)
+    assert torch.equal(L.host_mask_pack(m), L.mask_pack(m.cuda()).cpu())

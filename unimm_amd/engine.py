@@ -26,7 +26,7 @@ from . import dropout as DR
 from . import lib as L
 from . import params as PM
 from .arena import FlatArena
-from .inputs import DialogMaskSpec
+from .inputs import DialogMaskSpec, HostStager, PackedMask
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -38,6 +38,11 @@ def _site(name: str) -> int:
 
 def _rup(x, m):
     return (x + m - 1) // m * m
+
+
+# inputs that `stage_host_inputs` moves to the device (nsp_weight stays on the host: it is read there)
+_STAGED_KEYS = ("input_ids", "token_type_ids", "position_ids", "masked_lm_labels", "lm_weight", "next_sentence_label", "image_label",
+                "image_attention_mask", "attention_mask", "co_attention_mask", "image_loc", "image_feat", "image_target", "image_index")
 
 
 class _LazyLN:
@@ -140,6 +145,8 @@ class Engine:
         self._pending = []               # gradient buckets whose weight gradients are still queued: (group, #text, #image queued)
         self._nq = [0, 0]                # weight-gradient problems ever queued (text side, image side) ...
         self._nf = [0, 0]                # ... and launched
+        self.host_staging = True         # CPU tensors handed to forward() go through a pinned staging ring + copy stream (stage_host_inputs)
+        self._stager = None
 
     def schedule_key(self):
         """Every schedule attribute that is frozen into a captured launch sequence (unimm_amd/graphs.py keys its entries on
@@ -844,8 +851,31 @@ class Engine:
     def _i32(x, device):
         return x.to(device=device, dtype=torch.int32, non_blocking=True).contiguous()
 
+    def stage_host_inputs(self, inp: dict):
+        """CPU tensors among the step's inputs -> device tensors through the engine's pinned staging ring and copy stream
+        (inputs.HostStager; dense masks arrive bit-packed), in place.  Called by the model's forward entry points, so that the
+        reference's calling convention -- host tensors handed to forward(), train.py:113-161 -- runs at the speed of resident
+        inputs.  `host_staging = False` restores the plain `.to(device)` path."""
+        if not self.host_staging or not self.arena.flat.is_cuda:
+            return False
+        if not any(torch.is_tensor(inp.get(k)) and not inp[k].is_cuda for k in _STAGED_KEYS):
+            return False
+        if self._stager is None:
+            self._stager = HostStager(self.arena.flat.device)
+        staged = self._stager.stage(inp, _STAGED_KEYS)
+        if staged and self._dual():
+            side = self._side_stream()
+            for k in ("image_feat", "image_loc", "image_attention_mask", "image_target", "image_label"):
+                v = inp.get(k)
+                self._touch(v.words if isinstance(v, PackedMask) else v, side)
+        return staged
+
     def _pack_mask(self, m, device, rows_expected):
         """-> (words, q_stride, b_stride).  m: [B, Tk] (key padding) or [B, Tq, Tk]."""
+        if isinstance(m, PackedMask):              # packed on the host side of the copy (inputs.HostStager)
+            words = m.words
+            nw = words.shape[-1]
+            return (words, 0, nw) if m.dim() == 2 else (words, nw, m.shape[1] * nw)
         if m.dtype not in (torch.bool, torch.uint8, torch.int32, torch.int64, torch.float32):
             m = m.float()
         if not m.is_cuda and m.dtype == torch.int64:

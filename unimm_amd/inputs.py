@@ -149,3 +149,111 @@ class DevicePrefetcher:
                 v.record_stream(cur)              # allocated on the copy stream, consumed on the compute stream
         self._next = self._issue()
         return db
+
+
+class PackedMask:
+    """A 0/1 mask that exists only as bit-packed words on the device: `words` int32 [..., ceil(T/32)] (the layout of
+    unimm_mask_pack) standing for a dense mask of `shape` [..., T].  What `HostStager` hands the engine instead of the
+    caller's dense CPU mask."""
+    __slots__ = ("words", "shape")
+
+    def __init__(self, words, shape):
+        self.words, self.shape = words, tuple(shape)
+
+    def dim(self):
+        return len(self.shape)
+
+
+class HostStager:
+    """CPU tensors handed straight to `forward()` -> device tensors, without the caller adopting anything.
+
+    The reference's scripts call `model.forward` with HOST tensors (train.py:113-161; the .to(device) lines are commented out
+    and `DataParallelImbalance` scatters them, utils/data_parallel.py:123-124).  Taken literally -- `.to(device)` of pageable
+    memory on the compute stream, int64 masks converted on one host thread -- that call ran 44 % slower than the step on
+    resident inputs (3,398 against 5,927 sequences/s, profiles/r5z_bench_host_direct_dense.json).  This is the same staging
+    `DevicePrefetcher` does, but INSIDE the call: every CPU tensor of the step is copied into a reusable PINNED staging set
+    (a ring of `ring` sets, re-allocated only when a shape or dtype changes: pinned memory stays bounded by ring x one batch)
+    and sent from there with asynchronous copies on a copy stream of the engine's own; dense attention masks are bit-packed on
+    the host side of the copy (unimm_host_mask_pack: 8 KiB instead of 512 KiB per sequence on the wire) and reach the engine
+    as `PackedMask`.  The compute stream waits for the copies through an event, never the host.  Why this is enough without a
+    one-step-ahead prefetch: the host runs AHEAD of the GPU (it enqueues a 240-sequence step in ~15 of the step's 40 ms), so
+    when forward(k) is called the GPU still has most of step k-1's backward in front of it; the host-side staging and the
+    PCIe copies of step k happen under that backward, and the step's own host sync (the plan header) comes after them."""
+
+    MASK_KEYS = ("attention_mask", "co_attention_mask", "image_attention_mask")
+
+    def __init__(self, device, ring=3, pack_threads=0):
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self._ring = [dict(bufs={}, ev=None) for _ in range(max(2, int(ring)))]
+        self._turn = 0
+        self.pack_threads = pack_threads
+        self.stats = dict(steps=0, bytes_h2d=0, realloc=0)
+
+    def pinned_bytes(self):
+        return sum(b.numel() * b.element_size() for s in self._ring for b in s["bufs"].values())
+
+    def _buf(self, slot, key, shape, dtype):
+        buf = slot["bufs"].get(key)
+        if buf is None or buf.shape != tuple(shape) or buf.dtype != dtype:
+            buf = slot["bufs"][key] = torch.empty(tuple(shape), dtype=dtype, pin_memory=True)
+            self.stats["realloc"] += 1
+        return buf
+
+    def stage(self, inp, keys):
+        """Replaces, in place, every CPU tensor among inp[k] for k in keys by its device copy (dense masks: PackedMask).
+        Returns True when something was staged."""
+        from . import lib as L
+        todo = [k for k in keys if torch.is_tensor(inp.get(k)) and not inp[k].is_cuda]
+        if not todo:
+            return False
+        import time
+        t0 = time.perf_counter()
+        slot = self._ring[self._turn % len(self._ring)]
+        self._turn += 1
+        if slot["ev"] is not None:
+            slot["ev"].synchronize()               # the copies that last read this staging set (ring - 1 steps ago) are done
+        t1 = time.perf_counter()
+        self.stats["wait_ms"] = self.stats.get("wait_ms", 0.0) + (t1 - t0) * 1e3
+        cur = torch.cuda.current_stream(self.device)
+        # NO wait on the compute stream here: the copies of step k+1 must run while step k still computes (a
+        # `stream.wait_stream(cur)` would queue them behind the whole backward pass: +5 ms per 240-sequence step).  The device
+        # tensors come from the caching allocator on the copy stream and are handed to the consumers with record_stream(), so a
+        # block the consumer has freed is only handed out again after the consumer's work on it has completed.
+        staged = {}
+        # small tensors and masks first (the text stream's first kernels need them), the region features and targets last
+        todo.sort(key=lambda k: inp[k].numel() * inp[k].element_size() if k not in self.MASK_KEYS else 0)
+        with torch.cuda.stream(self.stream):
+            for k in todo:
+                v = inp[k]
+                if k in self.MASK_KEYS and v.dim() in (2, 3):
+                    if v.dtype not in (torch.bool, torch.uint8, torch.int32, torch.int64, torch.float32):
+                        v = v.float()
+                    nw = (v.shape[-1] + 31) // 32
+                    words = self._buf(slot, k, v.shape[:-1] + (nw,), torch.int32)
+                    tp = time.perf_counter()
+                    L.host_mask_pack(v, out=words, threads=self.pack_threads)
+                    self.stats["pack_ms"] = self.stats.get("pack_ms", 0.0) + (time.perf_counter() - tp) * 1e3
+                    staged[k] = PackedMask(words.to(self.device, non_blocking=True), v.shape)
+                    self.stats["bytes_h2d"] += words.numel() * 4
+                    continue
+                if v.is_pinned():
+                    src = v
+                else:
+                    src = self._buf(slot, k, v.shape, v.dtype)
+                    tp = time.perf_counter()
+                    L.host_copy(src, v)            # pageable -> pinned staging (threaded memcpy: torch's copy_ is one thread)
+                    self.stats["copy_ms"] = self.stats.get("copy_ms", 0.0) + (time.perf_counter() - tp) * 1e3
+                staged[k] = src.to(self.device, non_blocking=True)
+                self.stats["bytes_h2d"] += v.numel() * v.element_size()
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        slot["ev"] = ev
+        cur.wait_event(ev)
+        for k, v in staged.items():
+            t = v.words if isinstance(v, PackedMask) else v
+            t.record_stream(cur)                  # allocated on the copy stream, consumed on the compute stream(s)
+            inp[k] = v
+        self.stats["steps"] += 1
+        self.stats["host_ms"] = self.stats.get("host_ms", 0.0) + (time.perf_counter() - t0) * 1e3
+        return True

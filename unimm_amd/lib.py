@@ -13,7 +13,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libunimm_hip.so")
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROP_RESID, EPI_BIAS_RELU, EPI_DGELU, EPI_ADD, EPI_MUL, EPI_BIAS_GELU_DG = range(8)
 
@@ -96,7 +96,7 @@ SYMBOLS = ["unimm_version", "unimm_arch", "unimm_gemm_nt", "unimm_gemm_tn", "uni
            # the fp32-accuracy mode (csrc/x3ops.hip)
            "unimm_x3_split", "unimm_x3_split_wt", "unimm_x3_layernorm_bwd_partials", "unimm_embed_bwd_f32", "unimm_x3_lm_loss_bwd",
            "unimm_x3_kl_loss_bwd", "unimm_x3_rows_add", "unimm_x3_attn_fwd", "unimm_x3_attn_bwd", "unimm_x3_attn_set_impl", "unimm_x3_layernorm_fwd", "unimm_prof_tag", "unimm_prof_tagged",
-           "unimm_sum_dropout", "unimm_sum_dropout_bwd", "unimm_mse_loss_fwd", "unimm_mse_loss_bwd"]
+           "unimm_sum_dropout", "unimm_sum_dropout_bwd", "unimm_mse_loss_fwd", "unimm_mse_loss_bwd", "unimm_host_mask_pack", "unimm_host_memcpy"]
 
 
 def _check(rc, what):
@@ -374,6 +374,38 @@ def mask_pack(mask, out=None):
     _check(lib().unimm_mask_pack(_ptr(mask), _DT[mask.dtype], _ptr(out), C.c_int64(rows), C.c_int32(t), _stream()),
            "unimm_mask_pack")
     return out
+
+
+def host_mask_pack(mask, out=None, threads=0):
+    """The words of `mask_pack` for a mask in HOST memory, computed on the host (unimm_host_mask_pack): 0/1 mask [..., T] ->
+    int32 words [..., ceil(T/32)] in `out` (e.g. a pinned staging buffer) or a new CPU tensor."""
+    if mask.is_cuda:
+        raise UnimmHipError("host_mask_pack takes a CPU tensor (device masks: mask_pack)")
+    if mask.dtype not in _DT:
+        raise UnimmHipError(f"mask dtype {mask.dtype} not supported (bool, uint8, int32, int64, float32)")
+    mask = mask.contiguous()
+    t = mask.shape[-1]
+    rows = mask.numel() // t
+    nw = (t + 31) // 32
+    if out is None:
+        out = torch.empty(mask.shape[:-1] + (nw,), dtype=torch.int32)
+    if out.is_cuda or out.dtype != torch.int32 or out.numel() != rows * nw or not out.is_contiguous():
+        raise UnimmHipError("host_mask_pack: out must be a contiguous int32 CPU tensor of rows x ceil(T/32) words")
+    _check(lib().unimm_host_mask_pack(C.c_void_p(mask.data_ptr()), _DT[mask.dtype], C.c_void_p(out.data_ptr()), C.c_int64(rows),
+                                      C.c_int32(t), C.c_int32(threads)), "unimm_host_mask_pack")
+    return out
+
+
+def host_copy(dst, src, threads=0):
+    """dst.copy_(src) for two CPU tensors of one shape and dtype, both contiguous, on several threads (unimm_host_memcpy);
+    anything else falls back to torch's copy_."""
+    if (dst.is_cuda or src.is_cuda or dst.dtype != src.dtype or dst.shape != src.shape or not dst.is_contiguous()
+            or not src.is_contiguous() or src.numel() * src.element_size() < (8 << 20)):
+        dst.copy_(src)
+        return dst
+    _check(lib().unimm_host_memcpy(C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), C.c_int64(src.numel() * src.element_size()),
+                                   C.c_int32(threads)), "unimm_host_memcpy")
+    return dst
 
 
 def colpartials_bytes(H):

@@ -201,6 +201,7 @@ class BertForMultiModalPreTraining(nn.Module):
                    co_attention_mask=co_attention_mask, masked_lm_labels=masked_lm_labels, image_label=image_label,
                    image_target=image_target, next_sentence_label=next_sentence_label, nsp_weight=nsp_weight,
                    lm_weight=lm_weight, image_index=image_index)
+        eng.stage_host_inputs(inp)             # the reference's callers pass CPU tensors (train.py:113-161): pinned ring + copy stream
         B, T = input_ids.shape
         H, V = self.config.hidden_size, self.config.vocab_size
         train_branch = masked_lm_labels is not None and next_sentence_label is not None and image_target is not None
@@ -256,6 +257,7 @@ class BertForMultiModalPreTraining(nn.Module):
                    co_attention_mask=co_attention_mask, masked_lm_labels=masked_lm_labels, image_label=image_label,
                    image_target=image_target, next_sentence_label=next_sentence_label, nsp_weight=nsp_weight,
                    lm_weight=lm_weight, image_index=image_index)
+        eng.stage_host_inputs(inp)
         if plan_header is not None:
             inp["_plan_header"] = plan_header
         if self.training:
