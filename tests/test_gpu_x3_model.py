@@ -303,7 +303,7 @@ def test_full_config_b6_backward_matches_reference_golden_fp32(golden_dir, full5
         if l2 > worst_l2:
             worst_name = n
         worst_l2, worst_max = max(worst_l2, l2), max(worst_max, r)
-        assert l2 <= 2e-3 and r <= 2e-3, (n, l2, r)
+        assert l2 <= 1e-3 and r <= 1e-3, (n, l2, r)          # <= 1e-3 of the tensor's scale, poolers and the top connection block included
         nslices += 1
     assert nslices > 100
     print(f"\nfp32x3 full-config backward vs the reference: worst norm error {worst_n:.2e}; sampled slices: worst L2 {worst_l2:.2e} "
