@@ -642,5 +642,21 @@ def test_generative_scoring_shared_context_full_config():
     keep = torch.ones(n, dtype=torch.bool, device=bad.device)
     keep[137] = False
     assert float((bad[keep] - got[keep]).abs().max()) <= 1e-4
+    # ... and so is a dense mask that is not the generative one in its context block, a deviating co-attention mask, or a member
+    # that carries another image / image location than its group (these were assumed, not read)
+    def only_nan_at(scores, i):
+        return bool(torch.isnan(scores[i])) and int(torch.isnan(scores).sum()) == 1
+    am_bad = kw["attention_mask"].clone()
+    am_bad[41, 3, 2] = 0                                              # a context row that does not attend a context column
+    assert only_nan_at(model.sequence_log_likelihood(*args, shared_context=grp, **{**kw, "attention_mask": am_bad})[0], 41)
+    am_bad = kw["attention_mask"].clone()
+    am_bad[42, 2, 0] = 1                                              # a context row that attends column 0
+    assert only_nan_at(model.sequence_log_likelihood(*args, shared_context=grp, **{**kw, "attention_mask": am_bad})[0], 42)
+    co_bad = kw["co_attention_mask"].clone()
+    co_bad[43, 5, 1] = 0
+    assert only_nan_at(model.sequence_log_likelihood(*args, shared_context=grp, **{**kw, "co_attention_mask": co_bad})[0], 43)
+    loc_bad = args[2].clone()
+    loc_bad[44, 7, 2] += 0.25
+    assert only_nan_at(model.sequence_log_likelihood(args[0], args[1], loc_bad, *args[3:], shared_context=grp, **kw)[0], 44)
     with pytest.raises(ValueError):                                   # groups of different context lengths are refused up front
         model.sequence_log_likelihood(*args, shared_context=torch.zeros(n, dtype=torch.int64), **kw)

@@ -188,6 +188,17 @@ def _forward_shared(eng, inp, groups, want_nsp):
     n_d = _i64(plan.n, dev)[:, None]
     copy_cols = (col >= len_d - n_d) & (col < len_d)
     same &= ((lab_d != -1) == copy_cols).all(1)                    # the labelled rows are exactly the copy rows
+    if spec is None:
+        # The S rows run with an all-ones mask bounded by their length and the regions attend them the same way: that IS the
+        # generative mask's context block (utils/data_utils.py:199-210: rows and columns [1, c) fully connected, nothing else
+        # visible to a context row; co-attention keys [1, c)) -- checked here instead of assumed: a dense mask that deviates in
+        # the context block, or a non-generative row, gives NaN instead of a silently different score.
+        colw = torch.arange(nw * 32, device=dev).view(1, nw, 32)
+        bits = ((colw >= 1) & (colw < c_d[:, :, None])).to(torch.int64)                        # [B, nw, 32]
+        expw = (bits << torch.arange(32, device=dev)).sum(-1)
+        expw = torch.where(expw >= 2 ** 31, expw - 2 ** 32, expw).to(torch.int32)                 # the packed words of columns [1, c)
+        same &= ((twords.view(B, T, nw) == expw[:, None, :]).all(-1) | ~ctx_cols).all(1)
+        same &= (comask[0].view(B, -1, nw) == expw[:, None, :]).all(-1).all(1)
     img_idx = inp.get("image_index")
     if img_idx is not None:
         img_idx = img_idx.to(dev, dtype=torch.int64, non_blocking=True).reshape(-1)
@@ -206,8 +217,8 @@ def _forward_shared(eng, inp, groups, want_nsp):
     feat_d = feat.to(dev, non_blocking=True)
     loc_d = inp["image_loc"].to(dev, non_blocking=True)
     if img_idx is None:                                            # per-sequence copies (val_lm.py:78-91 expands them): every member
-        fv = feat_d.reshape(B, -1)[:, ::61]                        # must carry its group's image -- sampled comparison on the device
-        same &= (fv == fv[rep[gid]]).all(1)
+        fv, lv = feat_d.reshape(B, -1), loc_d.reshape(B, -1)       # must carry its group's image -- compared in full on the device
+        same &= (fv == fv[rep[gid]]).all(1) & (lv == lv[rep[gid]]).all(1)
     eng._to_img()
     with eng._img():
         featd = feat_d.index_select(0, img_rows).to(F32).contiguous().view(G * R, F)
@@ -220,6 +231,8 @@ def _forward_shared(eng, inp, groups, want_nsp):
     if im is None:
         im = torch.ones((B, R), dtype=torch.uint8, device=dev)
     imd = im.to(dev, non_blocking=True)
+    if imd.dim() == 2:
+        same &= (imd == imd[rep[gid]]).all(1)                      # ... and its group's image key mask
     eng._dev_masks = []
     vmask = eng._pack_mask(imd.index_select(0, rep), dev, R)       # [G] image key masks
     eng._dev_masks = []
