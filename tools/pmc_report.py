@@ -42,6 +42,7 @@ if len(sys.argv) > 4:
                "fetch_kb_raw_per_launch": dom["fetch_kb_raw"], "write_kb_per_launch": dom["write_kb"],
                "bytes_per_launch_corrected": dom["bytes_per_launch"], "mfma_busy_fraction": dom["mfma_util"],
                "launches_profiled": dom["launches"],
+               "commit": os.environ.get("UNIMM_COMMIT") or None,      # the commit the passes ran at (tools/profile_round.sh <tag> <commit>)
                # bench.py nulls `roofline.traffic` when the kernel source no longer hashes to this
                "gemm_hip_sha256": hashlib.sha256(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "unimm_amd",
                                                                    "csrc", "gemm.hip"), "rb").read()).hexdigest()},

@@ -1,6 +1,7 @@
 # All the judged measurement artefacts of one state of the tree, in ONE gpurun call:  bash tools/profile_round.sh <tag>
 # -> gpurun_out/<tag>/...; copy what is to be kept into profiles/ (see profiles/README.md).
 tag=$1
+export UNIMM_COMMIT=$2      # (the GPU box has no .git: pass $(git rev-parse --short HEAD) from the build container)
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -35,6 +36,7 @@ python tools/exp/splitk_time.py 3900 > $out/small_batch_gemm_microbench.txt 2>&1
 python tools/exp/splitk_time.py 1110 >> $out/small_batch_gemm_microbench.txt 2>&1
 python tools/exp/splitk_time.py 7800 >> $out/small_batch_gemm_microbench.txt 2>&1
 python tools/exp/tn_sharing.py > $out/tn_panel_sharing_experiment.txt 2>&1
+python tools/vendor_gemm_yardstick.py > $out/vendor_gemm_yardstick.txt 2> $out/vendor_gemm_yardstick.err
 python bench.py --workload scoring --no-cpu-baseline > $out/bench_scoring.json 2> $out/bench_scoring.err
 python bench.py --workload scoring --no-cpu-baseline --compact-inputs > $out/bench_scoring_compact.json 2> $out/bench_scoring_compact.err
 python bench.py --workload scoring --no-cpu-baseline --scoring-chunk 1000 > $out/bench_scoring_chunk1000.json 2> $out/bench_scoring_chunk1000.err

@@ -956,6 +956,14 @@ template <class C, int EPI, bool OUT_F32>
 __global__ __launch_bounds__(C::THREADS, C::MIN_WAVES) void gemm_ntp_kernel(GemmNtParams p, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if constexpr (EPI == UNIMM_EPI_BIAS_DROP_RESID) drop_resolve(p.drop);
+#ifdef UNIMM_STAGGER_US
+  // tools/exp/desync_steady_state.py (variant build only): half of every XCD's workgroups start UNIMM_STAGGER_US late, so that
+  // their tile boundaries (epilogue bursts) fall between the other half's for the rest of the launch
+  if ((blockIdx.x >> 3) & 1) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < (long long)(UNIMM_STAGGER_US) * 100) __builtin_amdgcn_s_sleep(32);
+  }
+#endif
   for (int lt = blockIdx.x; lt < ntiles; lt += gridDim.x) {
     if (lt != (int)blockIdx.x) __builtin_amdgcn_s_barrier();   // every wave has left its epilogue slab (it aliases the ring)
     nt_tile<C, EPI, OUT_F32>(p, smem, xcd_remap(lt, ntiles));
