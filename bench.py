@@ -379,6 +379,12 @@ def main():
                          "or run `python bench.py --gpus N` without a launcher")
     if args.rank_probe:
         return rank_probe(world, rank, args.batch)
+    # Host thread pools sized for the CPU share this process really has (affinity capped by the cgroup quota: 16 of the box's
+    # 256 hardware threads per GPU).  torch's default is one intra-op thread per hardware thread (128 here): one parallel CPU op
+    # then burns the cgroup's quota for the scheduling period and EVERY thread of the process stalls until the next one
+    # (cpu.stat: seconds of throttled time per run) -- seen as 20 ms host copies in host-fed steps.
+    if "OMP_NUM_THREADS" not in os.environ:
+        torch.set_num_threads(max(1, min(host_cores() // max(1, world), 16)))
     # Rehearsal of the N > 1 path on a one-GPU box: UNIMM_BENCH_REHEARSAL=1 puts every rank on device 0 and
     # exchanges gradients over gloo (RCCL refuses two ranks on one device).  Never set by the driver.
     rehearsal = os.environ.get("UNIMM_BENCH_REHEARSAL", "0") == "1"

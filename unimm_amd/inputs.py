@@ -181,6 +181,9 @@ class HostStager:
     PCIe copies of step k happen under that backward, and the step's own host sync (the plan header) comes after them."""
 
     MASK_KEYS = ("attention_mask", "co_attention_mask", "image_attention_mask")
+    # (Host-side cost of a 240-sequence batch in the reference's layout, 16-CPU share of the GPU box: 1.3 ms for the masks,
+    # 2.5 ms for the copies into pinned memory; a process whose torch intra-op pool is larger than its cgroup CPU quota can
+    # see these stall for a whole scheduling period when some parallel CPU op exhausts the quota: torch.set_num_threads().)
 
     def __init__(self, device, ring=3, pack_threads=0):
         self.device = torch.device(device)
