@@ -189,6 +189,36 @@ def gen_switches(vd):
     save("small_sumfeat.npz", **{("in::" + k): v for k, v in b.items()}, **out)
 
 
+def gen_frozen(vd):
+    """Encoder options that are off in bert_base_6layer_6conect.json (and set by none of the reference's scripts) but honoured by
+    BertEncoder.forward: fixed_t_layer (the first text layers run under torch.no_grad(): no gradient below them,
+    models/vilbert_dialog.py:864-869) and with_coattention=False (:901: the connection layers are skipped).  Small config, eval
+    mode: losses, NSP scores, gradient norms of every tensor (-1 = the reference leaves .grad None) and a few gradients."""
+    for tag, extra in (("frozen", dict(fixed_t_layer=2)), ("nocoatt", dict(with_coattention=False))):
+        cfgd = dict(SMALL_CFG, **extra)
+        cfg = R.make_config(cfgd)
+        sd = R.init_state_dict(cfg, seed=11)
+        model = build_reference_model(vd, cfgd, sd)
+        modes, negs = ["gen", "dis", "gen", "dis"], [0, 1, 1, 0]
+        rng = np.random.Generator(np.random.PCG64(300))
+        b = make_batch(rng, cfgd, len(modes), 64, 37, modes, negs, share_image=False)
+        model.zero_grad()
+        lm, img, nsp_l, seq_t, pred_t, nsp = run_reference(model, b, train=True)
+        (lm + img + nsp_l).sum().backward()
+        names = [n for n, _ in model.named_parameters()]
+        out = dict(lm_loss=lm, img_loss=img, nsp_loss=nsp_l, nsp=nsp, seq_out_t=seq_t, grad_names=np.array(names),
+                   grad_norms=np.array([float(p.grad.norm()) if p.grad is not None else -1.0 for _, p in model.named_parameters()],
+                                       dtype=np.float64))
+        for n, p in model.named_parameters():
+            if p.grad is not None and any(k in n for k in ("layer.2.attention.self.query.weight", "layer.3.output.dense.bias",
+                                                           "v_layer.1.output.dense.weight", "v_layer.0.intermediate.dense.bias",
+                                                           "c_layer.1.biOutput.dense2.weight", "cls.bi_seq_relationship",
+                                                           "image_location_embeddings.weight", "cls.predictions.bias")):
+                out["grad::" + n] = p.grad
+        out["grad_rows::word_embeddings"] = model.bert.embeddings.word_embeddings.weight.grad[:64]
+        save(f"small_{tag}.npz", **{("in::" + k): v for k, v in b.items()}, **out)
+
+
 def gen_blocks(vd):
     """G3: full-size single blocks with seeded inputs (weights from the seeded generator)."""
     cfg = R.make_config(FULL_CFG)
@@ -449,7 +479,7 @@ def gen_rankloss(vm):
 
 
 if __name__ == "__main__":
-    groups = sys.argv[1:] or ["masks", "ranks", "small", "blocks", "losses", "full", "sched", "rankloss", "fullgrad", "attn", "switches"]
+    groups = sys.argv[1:] or ["masks", "ranks", "small", "blocks", "losses", "full", "sched", "rankloss", "fullgrad", "attn", "switches", "frozen"]
     vd, du, vm = import_reference()
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -457,4 +487,4 @@ if __name__ == "__main__":
         {"masks": lambda: gen_masks(du), "ranks": lambda: gen_ranks(vm), "small": lambda: gen_small(vd),
          "blocks": lambda: gen_blocks(vd), "losses": lambda: gen_losses(vd), "full": lambda: gen_full(vd),
          "sched": gen_sched, "rankloss": lambda: gen_rankloss(vm), "fullgrad": lambda: gen_fullgrad(vd),
-         "attn": lambda: gen_attn(vd), "switches": lambda: gen_switches(vd)}[g]()
+         "attn": lambda: gen_attn(vd), "switches": lambda: gen_switches(vd), "frozen": lambda: gen_frozen(vd)}[g]()

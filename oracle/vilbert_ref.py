@@ -327,8 +327,18 @@ def trunk(sd, cfg, input_ids, image_feat, image_loc, token_type_ids=None, positi
 
     v_start = t_start = 0
     for count, (v_end, t_end) in enumerate(zip(cfg.v_biattention_id, cfg.t_biattention_id)):
+        assert cfg.fixed_t_layer <= t_end                              # :847-848
+        assert cfg.fixed_v_layer <= v_end
+        for i in range(v_start, cfg.fixed_v_layer):                    # frozen lower layers run without a graph (:850-857)
+            with torch.no_grad():
+                xv = image_layer(sd, cfg, i, xv, v_add, drop)
+            v_start = cfg.fixed_v_layer
         for i in range(v_start, v_end):
             xv = image_layer(sd, cfg, i, xv, v_add, drop)
+        for i in range(t_start, cfg.fixed_t_layer):                    # (:864-869)
+            with torch.no_grad():
+                xt = text_layer(sd, cfg, i, xt, t_add, drop)
+            t_start = cfg.fixed_t_layer
         for i in range(t_start, t_end):
             xt = text_layer(sd, cfg, i, xt, t_add, drop)
         if cfg.with_coattention:

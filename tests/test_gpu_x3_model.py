@@ -422,3 +422,72 @@ def test_two_streams_equal_one_stream_fp32(golden_dir, small):
         assert torch.equal(x[0], y[0]) and torch.equal(x[1], y[1])
         d = float((x[2] - y[2]).abs().max() / x[2].abs().max())
         assert d <= 2e-6, d
+
+
+@pytest.mark.parametrize("tag,extra", [("frozen", dict(fixed_t_layer=2)), ("nocoatt", dict(with_coattention=False))])
+def test_encoder_options_frozen_text_layers_and_no_coattention(golden_dir, tag, extra):
+    """fixed_t_layer (the first text layers run under no_grad: models/vilbert_dialog.py:864-869) and with_coattention=False (:901)
+    on the bf16 engine against the REFERENCE's output on the small config (tests/golden/small_frozen.npz / small_nocoatt.npz):
+    losses, NSP scores, hidden states, gradient norms of every tensor, sampled gradients -- and exactly the reference's set of
+    parameters whose .grad stays None (an optimizer must not touch them, not even with weight decay).  Under a data-parallel
+    hook every bucket is still reported once; the graph executor replays the same step; the fp32x3 engine refuses the options."""
+    from oracle import vilbert_ref as R
+    from unimm_amd import BertConfig, BertForMultiModalPreTraining
+    cfgd = dict(json.load(open(os.path.join(golden_dir, "small_config.json"))), **extra)
+    model = BertForMultiModalPreTraining(BertConfig.from_dict(cfgd))
+    model.load_state_dict(R.init_state_dict(R.make_config(cfgd), seed=11), strict=True)
+    model = model.cuda().eval()
+    g = np.load(os.path.join(golden_dir, f"small_{tag}.npz"))
+    args, kw = kwargs_from(g)
+    model.engine.ensure(torch.device("cuda", 0))
+    calls = []
+    model.engine.grad_bucket_hook = lambda group, more=False: calls.append(group)
+    model.zero_grad(set_to_none=True)
+    lm, img, nsp_l, _, _, nsp = model(*args, **kw, _want_lm_scores=False)
+    (lm + img + nsp_l).sum().backward()
+    torch.cuda.synchronize()
+    model.engine.grad_bucket_hook = None
+    print()
+    tol = 1e-2
+    close(lm, g["lm_loss"], tol=tol, what="lm_loss"); close(img, g["img_loss"], tol=tol, what="img_loss")
+    close(nsp_l, g["nsp_loss"], tol=tol, what="nsp_loss"); close(nsp, g["nsp"], tol=tol, what="nsp")
+    assert sorted(calls) == sorted(gname for gname, _, _ in model.engine.arena.buckets) and calls[-1] == "text_embeddings"
+    params = dict(model.named_parameters())
+    n_none = 0
+    for n, want in zip([str(x) for x in g["grad_names"]], g["grad_norms"]):
+        if want < 0:
+            assert params[n].grad is None, n
+            n_none += 1
+            continue
+        assert params[n].grad is not None, n
+        got = float(params[n].grad.double().norm())
+        assert abs(got - want) <= 4e-2 * max(want, 1e-4), (n, got, want)
+    assert n_none == (46 if tag == "frozen" else 73)
+    for k in g.files:
+        if k.startswith("grad::"):
+            want = g[k]
+            err = np.abs(params[k[6:]].grad.cpu().numpy() - want).max() / max(np.abs(want).max(), 1e-6)
+            assert err <= 4e-2, (k, err)
+    werr = np.abs(params["bert.embeddings.word_embeddings.weight"].grad[:64].cpu().numpy() - g["grad_rows::word_embeddings"]).max()
+    assert werr <= 4e-2 * np.abs(g["grad_rows::word_embeddings"]).max()          # the tied decoder still trains the word table
+    with torch.no_grad():
+        seq = model(*args, **kw)[3]
+    am = g["in::attention_mask"]
+    valid = torch.from_numpy((am.reshape(am.shape[0], am.shape[1], -1) != 0).any(-1))      # (padding rows: zeros here, garbage there)
+    close(seq.cpu()[valid], g["seq_out_t"][valid.numpy()], tol=tol, what="seq_out_t (valid rows)")
+    # the step executor replays the same step
+    model.engine.enable_graphs(row_bucket=16, lm_bucket=8, capture_after=0)
+    dargs = [a.cuda() if torch.is_tensor(a) else a for a in args]
+    dkw = {k: (v.cuda() if torch.is_tensor(v) and k != "nsp_weight" else v) for k, v in kw.items()}
+    want_g = model.engine.arena.grad_flat.clone()
+    for _ in range(2):
+        model.engine.arena.zero_grads()
+        lm2, img2, nsp_l2, _, _, _ = model(*dargs, **dkw, _want_lm_scores=False)
+        (lm2 + img2 + nsp_l2).sum().backward()
+        torch.cuda.synchronize()
+    assert model.engine.graphs.stats["replays"] >= 1
+    assert abs(float(lm2) - float(lm)) <= 2e-6 * max(1.0, abs(float(lm)))
+    assert float((model.engine.arena.grad_flat - want_g).abs().max()) <= 2e-5 * float(want_g.abs().max())
+    with pytest.raises(NotImplementedError):
+        m3 = BertForMultiModalPreTraining(BertConfig.from_dict(cfgd), compute_dtype="fp32x3").cuda().eval()
+        m3(*args, **kw, _want_lm_scores=False)

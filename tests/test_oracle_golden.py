@@ -254,3 +254,35 @@ def test_config_switches_sum_fusion_and_predict_feature(golden_dir):
         inf = R.forward(sd, cfg, *args, **kw)
     close(inf["pred_v"], g["inf_pred_v"], what="pred_v")
     close(inf["nsp"], g["inf_nsp"], what="inf nsp")
+
+
+@pytest.mark.parametrize("tag,extra", [("frozen", dict(fixed_t_layer=2)), ("nocoatt", dict(with_coattention=False))])
+def test_encoder_options_frozen_text_layers_and_no_coattention(golden_dir, tag, extra):
+    """fixed_t_layer (the first text layers run under no_grad, models/vilbert_dialog.py:864-869) and with_coattention=False
+    (:901): the oracle's branches against the reference's own losses, scores, hidden states and gradients
+    (tests/golden/small_frozen.npz / small_nocoatt.npz, oracle/make_goldens.py::gen_frozen) -- including WHICH parameters the
+    reference leaves without a gradient (norm -1)."""
+    cfgd = dict(json.load(open(os.path.join(golden_dir, "small_config.json"))), **extra)
+    cfg = R.make_config(cfgd)
+    sd = R.init_state_dict(cfg, seed=11)
+    g = np.load(os.path.join(golden_dir, f"small_{tag}.npz"))
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != R.TIED[0]}
+    leaves[R.TIED[0]] = leaves[R.TIED[1]]
+    args, kw = oracle_kwargs(g)
+    out = R.forward(leaves, cfg, *args, **kw)
+    for k in ("lm_loss", "img_loss", "nsp_loss", "nsp"):
+        close(out[k], g[k], what=k)
+    (out["lm_loss"] + out["img_loss"] + out["nsp_loss"]).sum().backward()
+    n_none = 0
+    for n, want in zip([str(x) for x in g["grad_names"]], g["grad_norms"]):
+        if want < 0:
+            assert leaves[n].grad is None or float(leaves[n].grad.abs().max()) == 0.0, n
+            n_none += 1
+            continue
+        got = float(leaves[n].grad.norm())
+        assert abs(got - want) <= 2e-4 * max(want, 1e-3), (n, got, want)
+    assert n_none > (30 if tag == "frozen" else 50)               # two frozen text layers + the text embeddings / both connection layers
+    for k in g.files:
+        if k.startswith("grad::"):
+            close(leaves[k[6:]].grad, g[k], tol=2e-4, what=k)
+    close(leaves[R.TIED[1]].grad[:64], g["grad_rows::word_embeddings"], tol=2e-4, what="word embedding rows")

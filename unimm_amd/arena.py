@@ -19,8 +19,10 @@ ALIGN = 64  # elements: keeps every parameter 256-byte aligned (16-B vector load
 
 
 class FlatArena:
-    def __init__(self, named_params: Dict[str, torch.nn.Parameter], groups, device=None):
-        """named_params: state_dict name -> Parameter (tied alias excluded).  groups: arena_groups(cfg)."""
+    def __init__(self, named_params: Dict[str, torch.nn.Parameter], groups, device=None, no_grad=()):
+        """named_params: state_dict name -> Parameter (tied alias excluded).  groups: arena_groups(cfg).  no_grad: names whose
+        .grad stays None as in the reference (params.no_grad_names: frozen layers, skipped connection layers)."""
+        self.no_grad = frozenset(no_grad)
         self.offsets: Dict[str, Tuple[int, tuple]] = {}
         self.buckets: List[Tuple[str, int, int]] = []   # (group, lo, hi) element ranges
         off = 0
@@ -88,7 +90,7 @@ class FlatArena:
         dropped, e.g. by optimizer.zero_grad(set_to_none=True))."""
         probe = None
         for name, p in self.params.items():
-            if not P.is_unused(name):
+            if not P.is_unused(name) and name not in self.no_grad:
                 probe = (name, p)
                 break
         name, p = probe
@@ -99,7 +101,7 @@ class FlatArena:
         self.grad_flat.zero_()
         self.fresh = True
         for name, p in self.params.items():
-            p.grad = None if P.is_unused(name) else self.grad(name)
+            p.grad = None if (P.is_unused(name) or name in self.no_grad) else self.grad(name)
         self._grads_attached = True
 
     def zero_grads(self):

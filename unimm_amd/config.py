@@ -88,4 +88,6 @@ class BertConfig(object):
         need(self.fusion_method in ("mul", "sum"), "fusion_method must be 'mul' or 'sum' (models/vilbert_dialog.py:1062-1067 asserts on anything else)")
         need(not (self.fast_mode or self.in_batch_pairs), "fast_mode / in_batch_pairs (every text paired with every image of the batch, "
              "models/vilbert_dialog.py:876-899) are not built: off in bert_base_6layer_6conect.json and unused by the reference's scripts")
-        need(self.fixed_t_layer == 0 and self.fixed_v_layer == 0 and self.with_coattention, "fixed layers / with_coattention=False unsupported")
+        for v_end, t_end in zip(self.v_biattention_id, self.t_biattention_id):       # the reference's own asserts (:847-848)
+            assert self.fixed_t_layer <= t_end
+            assert self.fixed_v_layer <= v_end

@@ -145,6 +145,7 @@ class Engine:
         self._pending = []               # gradient buckets whose weight gradients are still queued: (group, #text, #image queued)
         self._nq = [0, 0]                # weight-gradient problems ever queued (text side, image side) ...
         self._nf = [0, 0]                # ... and launched
+        self._reported = set()
         self.host_staging = True         # CPU tensors handed to forward() go through a pinned staging ring + copy stream (stage_host_inputs)
         self._stager = None
 
@@ -179,7 +180,7 @@ class Engine:
                     "data-parallel wrapper after the model has reached its final device")
         self.cfg.validate_for_hip()
         named = {n: p for n, p in self.model.named_parameters()}   # tied decoder alias is deduplicated
-        self.arena = FlatArena(named, PM.arena_groups(self.cfg), device=device)
+        self.arena = FlatArena(named, PM.arena_groups(self.cfg), device=device, no_grad=PM.no_grad_names(self.cfg))
         A = self.arena
         self.w16 = torch.zeros(A.numel, dtype=BF16, device=device)
         self._anchor = torch.zeros(1, device=device, requires_grad=True)
@@ -1174,33 +1175,40 @@ class Engine:
         # co-attention needs the other side's K/V) and meet again before the heads.  Within a segment the image
         # layers are enqueued first so that both queues are fed; the tape keeps each stream's order for backward.
         sched = PM.encoder_schedule(cfg)
+        st_frozen = dict(train=train, tape=None)
         pos = 0
         while pos < len(sched):
             seg = []
             while pos < len(sched) and sched[pos][0] != "c":
                 seg.append(sched[pos])
                 pos += 1
+            # fixed_t_layer / fixed_v_layer (models/vilbert_dialog.py:850-869): the first layers of a stream run under no_grad in
+            # the reference -- here: nothing of them is saved and no backward step is taped, so no gradient reaches them or the
+            # stream's embeddings.  with_coattention = False (:901): the connection layers are skipped.
             for kind, i in seg:
                 if kind == "v":
+                    fz = i < cfg.fixed_v_layer
                     with self._img():
                         xv32, xv = self._self_block(f"v{i}", xv32, xv, vmask, B, R, cfg.v_num_attention_heads,
                                                     f"bert.encoder.v_layer.{i}.", cfg.v_attention_probs_dropout_prob,
-                                                    cfg.v_hidden_dropout_prob, st)
-                    if save:
+                                                    cfg.v_hidden_dropout_prob, st_frozen if fz else st)
+                    if save and not fz:
                         tape[-1] = ("v", tape[-1][0], tape[-1][1])
             for kind, i in seg:
                 if kind == "t":
+                    fz = i < cfg.fixed_t_layer
                     xt32, xt = self._self_block(f"t{i}", xt32, xt, tmask, B, T, cfg.num_attention_heads, f"bert.encoder.layer.{i}.",
-                                                cfg.attention_probs_dropout_prob, cfg.hidden_dropout_prob, st, var=var)
-                    if save:
+                                                cfg.attention_probs_dropout_prob, cfg.hidden_dropout_prob, st_frozen if fz else st, var=var)
+                    if save and not fz:
                         tape[-1] = ("t", tape[-1][0], tape[-1][1])
             if pos < len(sched):
                 i = sched[pos][1]
                 pos += 1
-                with self._conn_tag():
-                    xv32, xv, xt32, xt = self._conn_block(f"c{i}", i, xv32, xv, xt32, xt, B, R, T, vmask, comask, st, var=var)
-                if save:
-                    tape[-1] = ("c", tape[-1][0], tape[-1][1])
+                if cfg.with_coattention:
+                    with self._conn_tag():
+                        xv32, xv, xt32, xt = self._conn_block(f"c{i}", i, xv32, xv, xt32, xt, B, R, T, vmask, comask, st, var=var)
+                    if save:
+                        tape[-1] = ("c", tape[-1][0], tape[-1][1])
         # ---- image head (:1001-1005, :1085-1088; its masked KL :1569-1574 is in _losses): on the image stream, beside the
         # text side's last layers and the MLM head
         img = None
@@ -1367,6 +1375,7 @@ class Engine:
         seq_t, seq_v = out["seq_out_t"], out["seq_out_v"]
         self.arena.attach_grads()
         self._bwd_fresh = bool(self.arena.fresh)   # gradients known to be zero: sole contributors may write instead of add (_wgrad)
+        self._reported = set()                     # gradient buckets reported done in this pass (_bucket_done)
         if self._bwd_fresh and self.debug_fresh and bool(self.arena.grad_flat.any()):
             raise RuntimeError("the gradient arena is marked fresh (zeroed since the last backward) but holds non-zero values: "
                                "something wrote into .grad / grad_flat between zero_grad() and backward() without clearing "
@@ -1464,7 +1473,8 @@ class Engine:
                 return
             embv_done = True
             with self._img():
-                bw["embv"](gv)
+                if self.cfg.fixed_v_layer == 0:              # (frozen lower image layers: no gradient reaches the image embedding)
+                    bw["embv"](gv)
                 self._bucket_done("image_embeddings", force_img=True)
 
         while pos < len(entries):
@@ -1489,7 +1499,13 @@ class Engine:
                     gv, gt = fn(gv, gt)                      # exchanges between the streams happen inside
                 self._bucket_done(key)
         image_tail()
-        bw["embt"](gt)
+        if self.cfg.fixed_t_layer == 0:
+            bw["embt"](gt)
+        # blocks without a backward step (frozen layers, connection layers under with_coattention = False) still own a gradient
+        # bucket: report them, so that a data-parallel wrapper sees every bucket once per step (their gradients are zero / None)
+        for g, _, _ in self.arena.buckets:
+            if g not in self._reported and g != "text_embeddings":
+                self._bucket_done(g)
 
     def _bucket_done(self, group, force_img=False):
         """A block's backward is enqueued.  Its weight gradients may stay queued for a later grouped launch (`_flush_due`);
@@ -1498,6 +1514,7 @@ class Engine:
         that still waits for the other stream's queue (bucket_plan.py restates this rule on the host)."""
         last = group == "text_embeddings"
         force = last or group == "heads"          # the decoder's gradient has its own row count: a launch of its own
+        self._reported.add(group)
         if self.grad_bucket_hook is not None:
             self._pending.append((group, self._nq[0], self._nq[1]))
         self._flush_wgrad(force=force, force_img=force_img)

@@ -341,6 +341,8 @@ class EngineX3(Engine):
     # ------------------------------------------------------------------------------------------
     def _forward(self, inp: dict, train: bool, save: bool, lm_rows: str, want_pred_v: bool):
         cfg = self.cfg
+        if cfg.fixed_t_layer or cfg.fixed_v_layer or not cfg.with_coattention:
+            raise NotImplementedError("fixed_t_layer / fixed_v_layer / with_coattention=False run on the bf16 engine only")
         dev = self.arena.device
         self.refresh_weights()
         ids = inp["input_ids"]

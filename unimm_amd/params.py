@@ -129,3 +129,21 @@ def state_dict_names(cfg) -> Dict[str, tuple]:
 
 def is_unused(name: str) -> bool:
     return name.endswith(UNUSED_SUFFIXES)
+
+
+def no_grad_names(cfg):
+    """Parameters that take part in forward but never receive a gradient under the encoder options of
+    models/vilbert_dialog.py:842-929 -- the reference leaves their .grad None, so an optimizer never touches them (not even with
+    weight decay): the first `fixed_t_layer` text layers and everything of the text embedding except the word table (which the
+    tied decoder still trains), the same for `fixed_v_layer` on the image side, and every connection layer when
+    `with_coattention` is off."""
+    out = set()
+    ft, fv = getattr(cfg, "fixed_t_layer", 0), getattr(cfg, "fixed_v_layer", 0)
+    for gname, items in arena_groups(cfg):
+        frozen = (gname.startswith("t") and gname[1:].isdigit() and int(gname[1:]) < ft) or \
+                 (gname.startswith("v") and gname[1:].isdigit() and int(gname[1:]) < fv) or \
+                 (gname.startswith("c") and gname[1:].isdigit() and not getattr(cfg, "with_coattention", True)) or \
+                 (gname == "text_embeddings" and ft > 0) or (gname == "image_embeddings" and fv > 0)
+        if frozen:
+            out.update(n for n, _ in items if n != WORD_EMB)
+    return out

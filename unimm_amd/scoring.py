@@ -121,6 +121,8 @@ def _forward_shared(eng, inp, groups, want_nsp):
     dev = eng.arena.device
     if getattr(eng, "compute_dtype", "bf16") != "bf16":
         raise NotImplementedError("shared-context scoring runs on the bf16 engine")
+    if not cfg.with_coattention:
+        raise NotImplementedError("shared-context scoring needs the connection layers (with_coattention)")
     eng.refresh_weights()
     ids = inp["input_ids"]
     B, T = ids.shape
