@@ -10,23 +10,41 @@ step in the predicted number of collectives, and that the step time and the expo
 within 25 % (+ an absolute slack for sub-millisecond figures) of DESIGN.md 6's table.  Exit code 1 on any deviation, with
 one line per finding -- a deviation is a finding about the model of section 6, not necessarily a bug.
 
-Expected values ("Expected at N x (240 / N) sequences"; 1-GPU figures measured in round 5, strong scaling of
-the global batch of 240):
+Expected values (DESIGN.md 6; 1-GPU figures measured in round 6 (profiles/r6z_*), strong scaling of the global batch of 240;
+the number of collectives is computed from unimm_amd/bucket_plan.py, the rule the engine itself uses):
   N  per-GPU  step without exchange   collectives/step   exposed exchange (fp32 wire)
-  1    240        40.8 ms                   0                  0
-  2    120        22.6 ms (eager)           11                 <= 1.0 ms  (the last grouped launch's buckets)
-  4     60        13.7 ms (graph replay)    11                 <= 1.2 ms
-  8     30         9.1 ms (graph replay)    11                 ~0.9 ms (1.6 ms with 4-round grouping)
-(1-GPU figures of profiles/r5p_*: 42.88 / 23.48 / 14.17 / 9.14 ms, + 2 % for the 2-round weight-gradient grouping under N > 1)
+  1    240        40.7 ms                   0                  0
+  2    120        22.7 ms (eager)           14                 <= 4.5 ms: ONE xGMI link pair carries the 1.0 GB (~18 ms at ~55 GB/s per direction:
+                                                                 more than backward can hide); the tail alone (181 MB) is 3.3 ms.  `--wire bf16` halves both
+  4     60        13.8 ms (graph replay)    14                 <= 1.8 ms (three links per GPU, ~150 GB/s bus bandwidth; tail 181 MB)
+  8     30         9.1 ms (graph replay)    14                 ~1.0 ms (181 MB x 1.75 at ~320 GB/s; 2.1 ms with the 392 MB tail of rounds 3-5)
+(step = the 1-GPU step of that share + 2 % for the 2-round weight-gradient grouping under N > 1)
 """
 import json
+import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def _collectives():
+    """Collectives per step of the N-rank step, from the exchange planner (host arithmetic, no torch)."""
+    try:
+        from unimm_amd import bucket_plan as BP
+        from unimm_amd.config import BertConfig
+        cfg = BertConfig.from_json_file(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "unimm_amd", "config",
+                                                     "bert_base_6layer_6conect.json"))
+        return {n: len(BP.exchange_plan(cfg, 240 // n, 31162 // n, 5016 // n, wgrad_group_rounds=2)["collectives"]) for n in (2, 4, 8)}
+    except Exception:
+        return {2: 14, 4: 14, 8: 14}
+
+
+_C = _collectives()
 EXPECT = {   # n_gpus: (step_ms_without_exchange, collectives_per_step, exposed_exchange_ms)
-    1: (40.8, 0, 0.0),
-    2: (22.6, 11, 1.0),
-    4: (13.7, 11, 1.2),
-    8: (9.1, 11, 0.9),
+    1: (40.7, 0, 0.0),
+    2: (22.7, _C[2], 4.5),
+    4: (13.8, _C[4], 1.8),
+    8: (9.1, _C[8], 1.0),
 }
 REL = 0.25
 ABS_MS = 0.6          # slack for the sub-millisecond exposed-exchange figures
