@@ -8,6 +8,9 @@ This module restates that function without a device: `Engine` takes its flush ru
 `tests/test_bucket_plan_cpu.py` checks the N = 8 plan of the full config on the CPU, and `tests/test_gpu_dp2.py` holds the
 plan against the hand-overs a real backward produces.
 
+Covers the default encoder options (every layer trained, connection layers on: what bert_base_6layer_6conect.json and every script of
+the reference use); under `fixed_t_layer` / `with_coattention=False` the engine reports the buckets of skipped blocks at the end of backward.
+
 Nothing here touches torch."""
 from __future__ import annotations
 
