@@ -673,3 +673,50 @@ def test_device_prefetcher_reads_fresh_host_buffers_and_keeps_pinned_memory_boun
     pf2 = DevicePrefetcher(itertools.islice(itertools.cycle(hb), 8), "cuda", cache_pinned=True)
     vals = [float(b["x"][0]) for b in pf2]
     assert vals == [0.0, 1.0] * 4 and len(pf2._pinned) == 2
+
+
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+def test_attention_few_queries_forward_packed_keys_match_padded(p_drop):
+    """attn_fwd_fewq128_kernel (round 6: the regions-attend-text forward with the KEYS dealt to the waves, D = 128, 37 queries x up
+    to 256 keys): packed (variable-length) keys with per-sequence offsets and lengths == the padded layout bit for bit, with and
+    without dropout, with a per-query co-attention mask and with a key-padding mask; both agree with the fp32 reference."""
+    from unimm_amd import lib
+    from unimm_amd import dropout as DR
+    B, H, Tq, T, D = 4, 2, 37, 256, 128
+    HD = H * D
+    g = torch.Generator(device=DEV).manual_seed(23)
+    lens = [256, 37, 130, 1]
+    q = bf(torch.randn((B * Tq, HD), generator=g, device=DEV))
+    kv = bf(torch.randn((B * T, 2 * HD), generator=g, device=DEV))
+    scale = D ** -0.5
+    drop = DR.drop_arg(p_drop, DR.make_key(5, 2, 99)) if p_drop > 0 else lib.NO_DROP
+    for dense in (True, False):
+        m = torch.zeros((B, Tq if dense else 1, T), dtype=torch.bool, device=DEV)
+        for b, l in enumerate(lens):
+            m[b, :, :l] = torch.rand((m.shape[1], l), generator=g, device=DEV) < 0.7
+            m[b, :, 0] = True
+        packed = lib.mask_pack(m)
+        nw = T // 32
+        mq, mb = (nw, Tq * nw) if dense else (0, nw)
+        out_p = torch.zeros((B * Tq, HD), device=DEV, dtype=torch.bfloat16)
+        lse_p = torch.zeros((B, H, Tq), device=DEV)
+        lib.attn_fwd(q, kv[:, :HD], kv[:, HD:], out_p, lse_p, packed, B, H, Tq, T, D, scale, mq, mb, drop)
+        rows = torch.cat([torch.arange(b * T, b * T + l, device=DEV) for b, l in enumerate(lens)])
+        off = torch.tensor(np.concatenate([[0], np.cumsum(lens)[:-1]]), dtype=torch.int32, device=DEV)
+        ln = torch.tensor(lens, dtype=torch.int32, device=DEV)
+        kv_v = kv[rows].contiguous()
+        out_v = torch.zeros_like(out_p)
+        lse_v = torch.zeros_like(lse_p)
+        lib.attn_fwd(q, kv_v[:, :HD], kv_v[:, HD:], out_v, lse_v, packed, B, H, Tq, T, D, scale, mq, mb, drop, kvar=(off, ln))
+        torch.cuda.synchronize()
+        assert torch.equal(out_v, out_p) and torch.equal(lse_v, lse_p), (dense, p_drop)
+        qf = q.float().reshape(B, Tq, H, D).permute(0, 2, 1, 3)
+        kf = kv[:, :HD].float().reshape(B, T, H, D).permute(0, 2, 1, 3)
+        vf = kv[:, HD:].float().reshape(B, T, H, D).permute(0, 2, 1, 3)
+        s = qf @ kf.transpose(-1, -2) * scale + ((1.0 - m.float()) * -10000.0)[:, None]
+        pr = torch.softmax(s, -1)
+        if p_drop > 0:
+            pr = pr * torch.from_numpy(DR.keep_mask_nd(drop[0], drop[1], (B, H, Tq, T))).to(DEV) * drop[2]
+        ref = (pr @ vf).permute(0, 2, 1, 3).reshape(B * Tq, HD)
+        assert relerr(out_p, ref) < 2 ** -6, relerr(out_p, ref)
+        assert (lse_p - torch.logsumexp(s, -1)).abs().max().item() < 2e-2

@@ -782,6 +782,173 @@ __device__ __forceinline__ bf16x8 read_tr_tile64s(const char* tile, int rowbase,
   return __builtin_bit_cast(bf16x8, v);
 }
 
+// ------------------------------------------------------------------------------------------------
+// forward for FEW queries (the co-attention direction whose queries are the 37 regions: D = 128, <= 64 queries x <= 256 keys,
+// models/vilbert_dialog.py:701-721).  In attn_fwd_kernel a wave owns a 32-query tile, so two of the eight waves of an item
+// compute (64 + 64 MFMAs and 128 scores per lane each) while six only help staging 128 KiB of K / V, one workgroup per CU:
+// 6 x 85 us per step.  Here the KEYS are dealt to the waves, as the backward forms do:
+//   phase 1   wave w = key tile w.  Its K rows come straight from HBM as MFMA operands (never staged), S^T = K Q^T for both
+//             query tiles (query on the lane, the wave's 32 keys in 16 + 16 registers of the lane pair), the tile's row maximum
+//             goes to LDS [wave][query]; after a barrier every wave takes the maximum over the eight, forms p = 2^(v - max),
+//             leaves its partial row sum in LDS and its P tile (dropped, bf16, [query][32 keys]) for phase 2;
+//   phase 2   OUTPUT-stationary: wave (d slice of 32, query tile) = 4 x 2 reads every key tile's P and V^T fragments and owns
+//             O^T[32 d][32 q] over all keys -- no accumulator is shared between waves; row sums are added in wave order.
+// Same scores, masks (-10000, reference :1418), dropout words and lse as attn_fwd_kernel; sums associate differently (per key
+// tile), i.e. results agree to fp32 rounding, and a packed (variable-length) run equals the padded one bit for bit as there.
+// LDS: V image 64 KiB + Q image 16 KiB + P tiles 32 KiB + row statistics 4 KiB = 116 KiB.
+// ------------------------------------------------------------------------------------------------
+#ifndef UNIMM_ATTN_FEWQ_FWD
+#define UNIMM_ATTN_FEWQ_FWD 1      // (A/B builds: 0 = attn_fwd_kernel<128, 8> for this shape, as rounds 1-5)
+#endif
+__global__ __launch_bounds__(512, 1) void attn_fwd_fewq128_kernel(AttnParams p) {
+  constexpr int D = 128, KPAD = 256, QPAD = 64, NW = 8;
+  drop_resolve(p.drop);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* vimg = smem;
+  char* qimg = smem + KPAD * 2 * D;
+  char* pt = qimg + QPAD * 2 * D;                                  // [key tile][query tile][32 q][32 keys] bf16
+  float* mx_w = reinterpret_cast<float*>(pt + NW * 2 * 2048);       // [wave][QPAD]
+  float* sm_w = mx_w + NW * QPAD;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int item = blockIdx.x;
+  const int b = p.order != nullptr ? p.order[item / p.H] : item / p.H, head = item % p.H;
+  const int r = lane & 31, h = lane >> 5;
+  int Tk_b = p.k_len ? p.k_len[b] : p.Tk;
+  Tk_b = Tk_b < KPAD ? Tk_b : KPAD;
+  int Tq_b = p.q_len ? p.q_len[b] : p.Tq;
+  Tq_b = Tq_b < QPAD ? Tq_b : QPAD;
+  const size_t qbase = p.q_off ? (size_t)p.q_off[b] : (size_t)b * p.Tq;
+  const size_t kbase = p.k_off ? (size_t)p.k_off[b] : (size_t)b * p.Tk;
+  const int kpad_b = (Tk_b + 31) & ~31, qpad_b = (Tq_b + 31) & ~31;
+  const int nqt = qpad_b >> 5;
+  stage_head<D>(p.v + kbase * p.ldv + head * D, p.ldv, Tk_b, kpad_b, vimg, tid, blockDim.x);
+  stage_head<D>(p.q + qbase * p.ldq + head * D, p.ldq, Tq_b, qpad_b, qimg, tid, blockDim.x);
+
+  // ---- phase 1a: this wave's key tile
+  const int wt = wave;
+  const bool wave_on = wt * 32 < Tk_b;
+  int krow = wt * 32 + r;
+  if (krow >= Tk_b) krow = Tk_b - 1;
+  const bf16_t* kg = p.k + (kbase + krow) * p.ldk + head * D;
+  bf16x8 kf[D / 16];
+#pragma unroll
+  for (int ks = 0; ks < D / 16; ++ks) kf[ks] = *reinterpret_cast<const bf16x8*>(kg + 16 * ks + 8 * h);
+  uint32_t mw[2];
+  int qrow[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    int q = 32 * qt + r;
+    q = q < Tq_b ? q : Tq_b - 1;
+    qrow[qt] = q;
+    mw[qt] = p.mask[(size_t)b * p.mask_b_stride + (size_t)q * p.mask_q_stride + wt];
+  }
+  stage_wait();
+  __syncthreads();
+
+  const float c1 = p.scale * LOG2E;
+  constexpr float MOFF = -10000.0f * LOG2E;
+  f32x16 s[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    float mxl = -INFINITY;
+    s[qt] = f32x16{};
+    if (wave_on && qt < nqt) {
+      f32x16 acc = {};
+#pragma unroll
+      for (int ks = 0; ks < D / 16; ++ks) {
+        const bf16x8 qf = read_row_frag<D>(qimg, 32 * qt + r, 2 * ks + h);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf, acc, 0, 0, 0);
+      }
+      const uint32_t wn = ~(mw[qt] >> (4 * h));               // bit kk set = key kk (+ 4h folded in) of this tile is masked
+      const bool partial = 32 * (wt + 1) > Tk_b;               // (wave-uniform) the sequence's last, partial key tile
+#pragma unroll
+      for (int e = 0; e < 16; e += 2) {
+        const int kk = (e & 3) + 8 * (e >> 2);
+        f32x2v madd;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const uint32_t mb = (uint32_t)__builtin_amdgcn_sbfe((int)wn, kk + u, 1) & __builtin_bit_cast(uint32_t, MOFF);
+          madd[u] = __uint_as_float(mb);
+          if (partial) madd[u] = (32 * wt + kk + u + 4 * h) < Tk_b ? madd[u] : -INFINITY;   // padded keys do not exist
+        }
+        const f32x2v v = f32x2v{acc[e], acc[e + 1]} * c1 + madd;
+        acc[e] = v.x; acc[e + 1] = v.y;
+        mxl = fmaxf(mxl, fmaxf(v.x, v.y));
+      }
+      s[qt] = acc;
+      mxl = fmaxf(mxl, __shfl_xor(mxl, 32, 64));
+    }
+    if (h == 0) mx_w[wave * QPAD + 32 * qt + r] = mxl;
+  }
+  __syncthreads();
+
+  // ---- phase 1b: the row maximum over all key tiles, p = 2^(v - max), partial row sums, the wave's P tiles
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    float suml = 0.f;
+    if (wave_on && qt < nqt) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) mx = fmaxf(mx, mx_w[w * QPAD + 32 * qt + r]);
+      f32x2v sum2 = {0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 16; e += 2) {
+        const f32x2v a = f32x2v{s[qt][e], s[qt][e + 1]} - mx;
+        const float p0 = __builtin_amdgcn_exp2f(a.x), p1 = __builtin_amdgcn_exp2f(a.y);
+        s[qt][e] = p0; s[qt][e + 1] = p1;
+        sum2 += f32x2v{p0, p1};
+      }
+      suml = sum2.x + sum2.y;
+      suml += __shfl_xor(suml, 32, 64);
+      if (p.drop.thr != 0u) {          // the dropout words of attn_fwd_kernel: one hash per two neighbouring keys
+        const uint32_t wl = drop_lin(p.drop, drop_wbase(((uint32_t)b * p.H + head) * p.Tq + (uint32_t)qrow[qt], (uint32_t)p.Tk, 0u) + 2u * (uint32_t)h);
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+          const uint32_t w = drop_fin(p.drop, wl + (uint32_t)((32 * wt + key_of_reg(e, 0)) >> 1) * DROP_M1);
+          s[qt][e] = drop_keep(p.drop, w, 0u) ? s[qt][e] : 0.0f;
+          s[qt][e + 1] = drop_keep(p.drop, w, 1u) ? s[qt][e + 1] : 0.0f;
+        }
+      }
+      char* tile = pt + (wt * 2 + qt) * 2048;                 // [32 q][32 keys] bf16, 64-byte rows, 8-byte chunks swizzled by the row
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4)
+        *reinterpret_cast<u32x2*>(tile + r * 64 + (((2 * g4 + h) ^ tile64_swz(r)) << 3)) =
+            u32x2{pack2bf(s[qt][4 * g4], s[qt][4 * g4 + 1]), pack2bf(s[qt][4 * g4 + 2], s[qt][4 * g4 + 3])};
+    }
+    if (h == 0) sm_w[wave * QPAD + 32 * qt + r] = suml;
+  }
+  __syncthreads();
+
+  // ---- phase 2: wave (dt, qt) owns O^T[32 dt .. 32 dt + 31][query tile qt] over every key tile
+  const int dt = wave & 3, qt2 = wave >> 2;
+  if (qt2 < nqt) {
+    f32x16 o1[1] = {f32x16{}};
+    for (int t = 0; t < NW; ++t) {
+      if (32 * t >= Tk_b) break;
+      const char* tile = pt + (t * 2 + qt2) * 2048;
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        const u32x2 lo = *reinterpret_cast<const u32x2*>(tile + r * 64 + (((4 * ss + h) ^ tile64_swz(r)) << 3));
+        const u32x2 hi = *reinterpret_cast<const u32x2*>(tile + r * 64 + (((4 * ss + 2 + h) ^ tile64_swz(r)) << 3));
+        const bf16x8 pf = __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi[0], hi[1]});
+        const bf16x8 vf = read_tr_frag<D>(vimg, 32 * t + 16 * ss, 32 * dt, lane);
+        o1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o1[0], 0, 0, 0);
+      }
+    }
+    float mx = -INFINITY, sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      mx = fmaxf(mx, mx_w[w * QPAD + 32 * qt2 + r]);
+      sum += sm_w[w * QPAD + 32 * qt2 + r];
+    }
+    const float inv = (p.drop.thr != 0u ? p.drop.scale : 1.0f) / sum;
+    const int q = 32 * qt2 + r;
+    const bool qvalid = q < Tq_b;
+    store_acc_row<32>(p.o + (qbase + (qvalid ? q : 0)) * p.ldo + head * D + 32 * dt, o1, inv, h, qvalid);
+    if (dt == 0 && qvalid && h == 0 && p.lse != nullptr) p.lse[((size_t)b * p.H + head) * p.Tq + q] = (mx + __log2f(sum)) * LN2;
+  }
+}
+
 template <int NQT>
 __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(AttnBwdParams p) {
   constexpr int D = 64;
@@ -1369,6 +1536,17 @@ inline int launch_bwd_fewk128(const AttnBwdParams& p, hipStream_t s) {
   return UNIMM_OK;
 }
 
+inline int launch_fwd_fewq128(const AttnParams& p, hipStream_t s) {
+  const size_t lds = (size_t)256 * 2 * 128 + (size_t)64 * 2 * 128 + 8 * 2 * 2048 + 2 * 8 * 64 * sizeof(float);
+  auto kern = attn_fwd_fewq128_kernel;
+  if (set_lds(kern, lds) != UNIMM_OK) return UNIMM_E_HIP;
+  AttnParams q = p;
+  q.parts = 1;
+  hipLaunchKernelGGL(kern, dim3(p.B * p.H), dim3(512), lds, s, q);
+  UNIMM_CHECK_LAUNCH();
+  return UNIMM_OK;
+}
+
 template <int D, int NKT>
 int launch_fwd(const AttnParams& p, hipStream_t s) {
   const int waves = (p.Tq + 31) / 32;
@@ -1478,6 +1656,7 @@ extern "C" int unimm_attn_fwd(const unimm_attn_args* a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const bool small_k = a->Tk <= 64;
   if (a->D == 64) return small_k ? launch_fwd<64, 2>(p, s) : launch_fwd<64, 8>(p, s);
+  if (UNIMM_ATTN_FEWQ_FWD && !small_k && a->Tq <= 64 && p.ks_off == nullptr) return launch_fwd_fewq128(p, s);   // few queries, many keys
   return small_k ? launch_fwd<128, 2>(p, s) : launch_fwd<128, 8>(p, s);
 }
 
