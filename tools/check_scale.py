@@ -13,11 +13,11 @@ one line per finding -- a deviation is a finding about the model of section 6, n
 Expected values (DESIGN.md 6; 1-GPU figures measured in round 6 (profiles/r6z_*), strong scaling of the global batch of 240;
 the number of collectives is computed from unimm_amd/bucket_plan.py, the rule the engine itself uses):
   N  per-GPU  step without exchange   collectives/step   exposed exchange (fp32 wire)
-  1    240        40.7 ms                   0                  0
-  2    120        22.7 ms (eager)           14                 <= 4.5 ms: ONE xGMI link pair carries the 1.0 GB (~18 ms at ~55 GB/s per direction:
+  1    240        40.0 ms                   0                  0
+  2    120        22.3 ms (eager)           14                 <= 4.5 ms: ONE xGMI link pair carries the 1.0 GB (~18 ms at ~55 GB/s per direction:
                                                                  more than backward can hide); the tail alone (181 MB) is 3.3 ms.  `--wire bf16` halves both
-  4     60        13.8 ms (graph replay)    14                 <= 1.8 ms (three links per GPU, ~150 GB/s bus bandwidth; tail 181 MB)
-  8     30         9.1 ms (graph replay)    14                 ~1.0 ms (181 MB x 1.75 at ~320 GB/s; 2.1 ms with the 392 MB tail of rounds 3-5)
+  4     60        13.5 ms (graph replay)    14                 <= 1.8 ms (three links per GPU, ~150 GB/s bus bandwidth; tail 181 MB)
+  8     30         9.0 ms (graph replay)    14                 ~1.0 ms (181 MB x 1.75 at ~320 GB/s; 2.1 ms with the 392 MB tail of rounds 3-5)
 (step = the 1-GPU step of that share + 2 % for the 2-round weight-gradient grouping under N > 1)
 """
 import json
@@ -41,10 +41,10 @@ def _collectives():
 
 _C = _collectives()
 EXPECT = {   # n_gpus: (step_ms_without_exchange, collectives_per_step, exposed_exchange_ms)
-    1: (40.7, 0, 0.0),
-    2: (22.7, _C[2], 4.5),
-    4: (13.8, _C[4], 1.8),
-    8: (9.1, _C[8], 1.0),
+    1: (40.0, 0, 0.0),
+    2: (22.3, _C[2], 4.5),
+    4: (13.5, _C[4], 1.8),
+    8: (9.0, _C[8], 1.0),
 }
 REL = 0.25
 ABS_MS = 0.6          # slack for the sub-millisecond exposed-exchange figures
