@@ -9,13 +9,17 @@ opt = FusedAdamW(reference_param_groups(enc, 2e-5, 2e-5, default_language_weight
 sch = WarmupLinearScheduleNonZero(opt, 100, 1000)
 losses = []
 t0 = time.time()
-# python tools/soak.py [steps=40] [sequences=240] [graphs: 0 | 1] [bf16 | fp32x3]
+# python tools/soak.py [steps=40] [sequences=240] [graphs: 0 | 1] [bf16 | fp32x3] [host]
 STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 NSEQ = int(sys.argv[2]) if len(sys.argv) > 2 else 240
 if len(sys.argv) > 3 and sys.argv[3] == "1":
     enc.bert_pretrained.engine.ensure(dev)
     enc.bert_pretrained.engine.enable_graphs()
-batches = [synth.make_batch(n_seq=NSEQ, cfg=enc.bert_pretrained.config, seed=s, device=dev) for s in range(4)]
+HOST = len(sys.argv) > 5 and sys.argv[5] == "host"           # fifth argument "host": the batches stay in host memory (CPU tensors into forward())
+if HOST:
+    torch.set_num_threads(8)
+batches = [synth.make_batch(n_seq=NSEQ, cfg=enc.bert_pretrained.config, seed=s, device="cpu" if HOST else dev,
+                            **(dict(mask_dtype=torch.int64) if HOST else {})) for s in range(4)]
 for it in range(STEPS):
     b = dict(batches[it % 4])                                                                  # 4 batches cycled: loss must fall
     nw = b.pop("nsp_weight")
