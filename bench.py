@@ -217,8 +217,13 @@ def scoring(args, world, rank, dev, enc, lib, synth, dist):
     model = enc.bert_pretrained
     enc.eval()
     cfg = model.config
-    img = synth.make_scoring_batch(rounds=10, options=100, cfg=cfg, seed=4321 + 16 * rank, device=dev)
+    host = args.host_inputs == "direct"       # the chunks stay in HOST memory, in the reference's layout (int64 masks), and are handed to
+    #                                           sequence_log_likelihood as val_lm.py:86-121 hands them over: staged inside the call
+    img = synth.make_scoring_batch(rounds=10, options=100, cfg=cfg, seed=4321 + 16 * rank, device="cpu" if host else dev,
+                                   **(dict(mask_dtype=torch.int64) if host else {}))
     spec = img.pop("mask_spec")
+    if host and args.host_staging == "off":
+        model.engine.host_staging = False
     ck = args.scoring_chunk
     if 1000 % ck:
         raise SystemExit("--scoring-chunk must divide 1000")
@@ -230,7 +235,7 @@ def scoring(args, world, rank, dev, enc, lib, synth, dist):
             b["attention_mask"] = DialogMaskSpec(spec.mode[sl], spec.length[sl], spec.answer[sl])
             b["co_attention_mask"] = None
             b["image_feat"], b["image_loc"] = b["image_feat"][:1].contiguous(), b["image_loc"][:1].contiguous()
-            b["image_index"] = torch.zeros(ck, dtype=torch.int64, device=dev)
+            b["image_index"] = torch.zeros(ck, dtype=torch.int64, device="cpu" if host else dev)
     n_rows = int((img["masked_lm_labels"] != -1).sum())
     shared = args.shared_context == "on" and args.compute == "bf16"
 
@@ -246,7 +251,7 @@ def scoring(args, world, rank, dev, enc, lib, synth, dist):
         return harness.scores_to_ranks(torch.cat(sc).view(1, 10, 100))
 
     log(f"scoring: {len(chunks)} chunks x {ck} sequences ready on {dev}, {n_rows} decoded rows per image, shared context {'on' if shared else 'off'}")
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 2) if host else args.warmup):
         step()
 
     def fence():
@@ -297,7 +302,8 @@ def scoring(args, world, rank, dev, enc, lib, synth, dist):
                           "per_candidate_value": round(per_cand, 2) if per_cand is not None else None,
                           "ranks_equal_to_per_candidate_schedule": round(rank_agree, 4) if per_cand is not None else None,
                           "global_batch": 1000 * world, "per_gpu_batch": 1000, "chunk": args.scoring_chunk,
-                          "inputs": "mask descriptors + one image entry + image_index (row F3)" if args.compact_inputs else "reference layout (dense masks, per-sequence image copies)",
+                          "inputs": ("mask descriptors + one image entry + image_index (row F3)" if args.compact_inputs else "reference layout (dense masks, per-sequence image copies)")
+                                    + ("; chunks start in HOST memory every call (CPU tensors handed to sequence_log_likelihood) -- NOT the contract's resident-input metric" if host else ""),
                           "seq_len": 256, "regions": 37,
                           "parallelism": f"dp{world}", "lm_rows_decoded_per_seq": round(n_rows / 1000, 2),
                           "gflop_per_seq_fwd_padded_equivalent": round(f_fwd, 3),
@@ -456,7 +462,7 @@ def main():
     h2d_bytes = None
     if args.host_inputs != "off":
         if args.workload != "train":
-            raise SystemExit("--host-inputs is measured on the train workload")
+            raise SystemExit("--host-inputs prefetch is measured on the train workload")
         import itertools
         hbs = []
         for j in range(3):                          # three different host batches, cycled (other lengths, other row counts)

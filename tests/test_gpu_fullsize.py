@@ -642,6 +642,15 @@ def test_generative_scoring_shared_context_full_config():
     keep = torch.ones(n, dtype=torch.bool, device=bad.device)
     keep[137] = False
     assert float((bad[keep] - got[keep]).abs().max()) <= 1e-4
+    # CPU tensors handed over as val_lm.py does (val_lm.py:86-121): staged inside the call, the same scores on both paths (up to
+    # the order of the per-sequence sums, as between two runs on device tensors)
+    cargs = tuple(a.cpu() for a in args)
+    ckw = {k: v.cpu() for k, v in kw.items()}
+    got_h, nsp_h = model.sequence_log_likelihood(*cargs, shared_context=grp.cpu(), **ckw)
+    base_h, _ = model.sequence_log_likelihood(*cargs, **ckw)
+    torch.cuda.synchronize()
+    assert float((got_h - got).abs().max()) <= 1e-4 and float((base_h - base).abs().max()) <= 1e-4
+    assert float((nsp_h - nsp1).abs().max()) <= 1e-5
     # ... and so is a dense mask that is not the generative one in its context block, a deviating co-attention mask, or a member
     # that carries another image / image location than its group (these were assumed, not read)
     def only_nan_at(scores, i):

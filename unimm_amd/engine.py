@@ -852,7 +852,7 @@ class Engine:
     def _i32(x, device):
         return x.to(device=device, dtype=torch.int32, non_blocking=True).contiguous()
 
-    def stage_host_inputs(self, inp: dict):
+    def stage_host_inputs(self, inp: dict, pack=None):
         """CPU tensors among the step's inputs -> device tensors through the engine's pinned staging ring and copy stream
         (inputs.HostStager; dense masks arrive bit-packed), in place.  Called by the model's forward entry points, so that the
         reference's calling convention -- host tensors handed to forward(), train.py:113-161 -- runs at the speed of resident
@@ -863,7 +863,7 @@ class Engine:
             return False
         if self._stager is None:
             self._stager = HostStager(self.arena.flat.device)
-        staged = self._stager.stage(inp, _STAGED_KEYS)
+        staged = self._stager.stage(inp, _STAGED_KEYS, pack=pack)
         if staged and self._dual():
             side = self._side_stream()
             for k in ("image_feat", "image_loc", "image_attention_mask", "image_target", "image_label"):

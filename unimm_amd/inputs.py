@@ -203,9 +203,10 @@ class HostStager:
             self.stats["realloc"] += 1
         return buf
 
-    def stage(self, inp, keys):
-        """Replaces, in place, every CPU tensor among inp[k] for k in keys by its device copy (dense masks: PackedMask).
-        Returns True when something was staged."""
+    def stage(self, inp, keys, pack=None):
+        """Replaces, in place, every CPU tensor among inp[k] for k in keys by its device copy (dense masks among `pack`,
+        default MASK_KEYS: PackedMask).  Returns True when something was staged."""
+        pack = self.MASK_KEYS if pack is None else pack
         from . import lib as L
         todo = [k for k in keys if torch.is_tensor(inp.get(k)) and not inp[k].is_cuda]
         if not todo:
@@ -225,11 +226,11 @@ class HostStager:
         # block the consumer has freed is only handed out again after the consumer's work on it has completed.
         staged = {}
         # small tensors and masks first (the text stream's first kernels need them), the region features and targets last
-        todo.sort(key=lambda k: inp[k].numel() * inp[k].element_size() if k not in self.MASK_KEYS else 0)
+        todo.sort(key=lambda k: inp[k].numel() * inp[k].element_size() if k not in pack else 0)
         with torch.cuda.stream(self.stream):
             for k in todo:
                 v = inp[k]
-                if k in self.MASK_KEYS and v.dim() in (2, 3):
+                if k in pack and v.dim() in (2, 3):
                     if v.dtype not in (torch.bool, torch.uint8, torch.int32, torch.int64, torch.float32):
                         v = v.float()
                     nw = (v.shape[-1] + 31) // 32

@@ -312,7 +312,9 @@ class BertForMultiModalPreTraining(nn.Module):
         eng.ensure(self._device())
         inp = dict(input_ids=input_ids, image_feat=image_feat, image_loc=image_loc, masked_lm_labels=masked_lm_labels,
                    lm_weight=None, **kw)
+        eng.stage_host_inputs(inp)                 # val_lm.py hands CPU tensors over chunk by chunk (val_lm.py:86-121)
         out = eng.forward(inp, train=False, save=False, lm_rows="labelled", want_pred_v=False)
+        input_ids = inp["input_ids"]
         B, T = input_ids.shape
         scores = torch.zeros(B, dtype=torch.float32, device=eng.arena.device)
         lm = out.get("lm")

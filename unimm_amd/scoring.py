@@ -358,6 +358,9 @@ def sequence_log_likelihood_shared(model, input_ids, image_feat, image_loc, mask
     eng = model._engine
     eng.ensure(model._device())
     inp = dict(input_ids=input_ids, image_feat=image_feat, image_loc=image_loc, masked_lm_labels=masked_lm_labels, **kw)
+    # CPU tensors (val_lm.py:86-121 passes them chunk by chunk) through the engine's staging ring; the text masks packed on the host,
+    # the [B, R] image key mask as a tensor (this path indexes it by group)
+    eng.stage_host_inputs(inp, pack=("attention_mask", "co_attention_mask"))
     out = forward_shared(eng, inp, shared_context)
     B = input_ids.shape[0]
     scores = torch.zeros(B, dtype=torch.float32, device=eng.arena.device)
