@@ -229,7 +229,7 @@ int unimm_mask_pack(const void* mask, int dtype, uint32_t* out, int64_t rows, in
 int unimm_host_mask_pack(const void* mask, int dtype, uint32_t* out, int64_t rows, int32_t t, int32_t threads);
 /* memcpy between two HOST buffers on `threads` threads (0 = up to 8): the caller's pageable tensors -> the pinned staging ring the
  * asynchronous host->device copies read (one thread moves the 130 MB of region features / targets of a 240-sequence batch in
- * ~25 ms: most of a step).  ABI 18. */
+ * ~25 ms: most of a step; torch's copy_ depends on the size of torch's intra-op pool).  ABI 18. */
 int unimm_host_memcpy(void* dst, const void* src, int64_t bytes, int32_t threads);
 /* The same words without the dense mask: the text mask [B, T, ceil(T/32)] and the
  * co-attention key mask [B, ceil(T/32)] (one row per sequence, mask_q_stride = 0) of B sequences from three

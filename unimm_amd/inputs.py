@@ -246,7 +246,7 @@ class HostStager:
                 else:
                     src = self._buf(slot, k, v.shape, v.dtype)
                     tp = time.perf_counter()
-                    L.host_copy(src, v)            # pageable -> pinned staging (threaded memcpy: torch's copy_ is one thread)
+                    L.host_copy(src, v)            # pageable -> pinned staging (a threaded memcpy of its own: independent of torch's pool size)
                     self.stats["copy_ms"] = self.stats.get("copy_ms", 0.0) + (time.perf_counter() - tp) * 1e3
                 staged[k] = src.to(self.device, non_blocking=True)
                 self.stats["bytes_h2d"] += v.numel() * v.element_size()
