@@ -64,7 +64,9 @@ def backward_events(cfg, n_seq: int, text_rows: int, lm_rows: int, regions: int 
                     image_head_side: bool = True):
     """The backward pass as the engine enqueues it (Engine._backward): a list of
     ("w", side, M, N, K) weight gradients queued (side 0 = text queue, 1 = image queue) and
-    ("b", group, on_side, force, force_img) bucket-done marks, in order."""
+    ("b", group, on_side, force, force_img) bucket-done marks, in order.  `dual_stream` does not change the plan: on one stream the
+    image side keeps its own queue (Engine._img), so the same launches and hand-overs happen, one after the other."""
+    del dual_stream
     H, Hv, Hb = cfg.hidden_size, cfg.v_hidden_size, cfg.bi_hidden_size
     I, Iv = cfg.intermediate_size, cfg.v_intermediate_size
     Mt, Mi = text_rows, n_seq * regions
