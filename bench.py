@@ -625,7 +625,7 @@ def main():
         torch.cuda.synchronize()
 
     use_graphs = (args.graphs == "on" or (args.graphs == "auto" and per_gpu <= GRAPHS_AUTO_MAX_SEQ)) and args.workload in ("train", "dense") \
-        and not args.compact_inputs and not args.host_profile and args.host_inputs == "off"
+        and not args.compact_inputs and not args.host_profile and (args.host_inputs == "off" or (args.host_inputs == "direct" and args.host_staging == "on"))
     gx = None
     fused_step[0] = args.workload == "train" and not args.compact_inputs and \
         args.fused_step == "on"
@@ -633,7 +633,8 @@ def main():
         gx = model.engine.enable_graphs(True)
         done = 0
         try:
-            for _ in range(3):                  # eager once more, capture, first replay
+            n_pre = 9 if feed is not None else 3    # eager once more, capture, first replay -- of EVERY signature (three host batches are cycled)
+            for _ in range(n_pre):
                 step()
                 done += 1
             torch.cuda.synchronize()
@@ -641,7 +642,7 @@ def main():
             log(f"graph executor unavailable ({type(e).__name__}: {e}); continuing with eager launches")
             model.engine.enable_graphs(False)
             use_graphs, gx = False, None
-            for _ in range(3 - done):           # the other ranks' collectives of these steps still need their partners
+            for _ in range(n_pre - done):       # the other ranks' collectives of these steps still need their partners
                 step()
             torch.cuda.synchronize()
     if world > 1:                               # every rank runs the same executor (their collectives pair up either way)

@@ -63,15 +63,40 @@ def test_graph_replay_equals_eager_steps(golden_dir, train, compute):
 
 
 def test_graph_executor_falls_back_when_not_eligible(golden_dir):
-    """Host inputs (and dense LM scores) keep the eager path (and still work)."""
+    """Inputs left on the host (`host_staging = False`) keep the eager path (and still work)."""
     from unimm_amd import synth
     m = _build(golden_dir)
     m.train(False)
     m.engine.ensure(torch.device("cuda", 0))
+    m.engine.host_staging = False
     graphs = m.engine.enable_graphs(capture_after=0)
     b = synth.make_batch(n_seq=6, T=64, R=37, cfg=m.config, seed=3, device="cpu")
     _step(m, b)
     assert graphs.stats["replays"] == 0 and graphs.stats["captures"] == 0
+
+
+def test_host_tensors_are_replayed_too(golden_dir):
+    """CPU tensors handed to forward() (the reference's calling convention) reach the executor as device tensors -- their masks as
+    bit-packed words (inputs.HostStager / PackedMask) -- and are replayed like resident inputs: same losses, NSP logits and
+    gradients as the eager step on device tensors, over different batches, dropout on."""
+    from unimm_amd import synth
+    ref, gm = _build(golden_dir), _build(golden_dir)
+    for m in (ref, gm):
+        m.train(True)
+        m.set_dropout_seed(55)
+    cfg = ref.config
+    seeds = [5, 6, 5, 7, 5]
+    host = {s: synth.make_batch(n_seq=12, T=64, R=37, cfg=cfg, seed=s, device="cpu", mask_dtype=torch.int64) for s in set(seeds)}
+    dev = {s: {k: (v.cuda() if torch.is_tensor(v) and k != "nsp_weight" else v) for k, v in b.items()} for s, b in host.items()}
+    want = [_step(ref, dev[s]) for s in seeds]
+    gm.engine.ensure(torch.device("cuda", 0))
+    graphs = gm.engine.enable_graphs(row_bucket=64, lm_bucket=16, capture_after=0, max_entries=8)
+    got = [_step(gm, host[s]) for s in seeds]
+    assert graphs.stats["replays"] >= 3 and graphs.stats["eager"] == 0, graphs.stats
+    for i, (w, h) in enumerate(zip(want, got)):
+        assert (w[0] - h[0]).abs().max() <= 2e-6 * max(1.0, float(w[0].abs().max())), (i, w[0], h[0])
+        assert (w[1] - h[1]).abs().max() <= 2e-6, i
+        assert float((w[2] - h[2]).abs().max() / w[2].abs().max()) <= 2e-5, i
 
 
 def test_graph_entries_are_evicted_and_recaptured(golden_dir):

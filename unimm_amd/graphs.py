@@ -25,8 +25,9 @@ ordinary eager calls of whatever backend the wrapper uses.  At a cut both stream
 there too: the exchange reads what the image side produced) and the image stream is forked back in at the start of the
 next segment.
 
-Not covered (falls back to the eager path): inputs on the host, mask descriptors (`DialogMaskSpec`), dense LM scores
-(`output_lm_scores=True`)."""
+Not covered (falls back to the eager path): mask descriptors (`DialogMaskSpec`), dense LM scores (`output_lm_scores=True`), inputs
+left on the host (`engine.host_staging = False`; with the default staging ring, CPU tensors handed to `forward()` are device
+tensors -- their masks bit-packed words -- by the time the executor sees them)."""
 from __future__ import annotations
 
 import contextlib
@@ -38,6 +39,7 @@ import torch
 
 from . import dropout as DR
 from . import lib as L
+from .inputs import PackedMask
 
 _TENSOR_KEYS = ("input_ids", "image_feat", "image_loc", "token_type_ids", "position_ids", "attention_mask",
                 "image_attention_mask", "co_attention_mask", "masked_lm_labels", "image_label", "image_target",
@@ -196,6 +198,8 @@ class StepGraphs:
             v = inp.get(k)
             if v is None:
                 continue
+            if isinstance(v, PackedMask):          # a mask bit-packed on the host side of the copy (inputs.HostStager): its words are the input
+                v = v.words
             if not torch.is_tensor(v) or not v.is_cuda:
                 return False
         for k in ("attention_mask", "co_attention_mask", "masked_lm_labels", "image_target", "next_sentence_label"):
@@ -209,7 +213,7 @@ class StepGraphs:
         parts = [bool(opts["train"])]
         for k in _TENSOR_KEYS:
             v = inp.get(k)
-            parts.append(None if v is None else (tuple(v.shape), v.dtype))
+            parts.append(None if v is None else (("packed",) + tuple(v.shape) if isinstance(v, PackedMask) else (tuple(v.shape), v.dtype)))
         nw = inp.get("nsp_weight")
         parts.append(None if nw is None else tuple(float(x) for x in nw.reshape(-1).tolist()))
         return tuple(parts)
@@ -269,7 +273,9 @@ class StepGraphs:
         else:
             self.entries.move_to_end(sig)
             for k, t in ent.sin.items():
-                if torch.is_tensor(t) and t is not inp[k]:     # (a caller that feeds the entry's own static inputs back skips the copy)
+                if isinstance(t, PackedMask):
+                    t.words.copy_(inp[k].words, non_blocking=True)
+                elif torch.is_tensor(t) and t is not inp[k]:   # (a caller that feeds the entry's own static inputs back skips the copy)
                     t.copy_(inp[k], non_blocking=True)
         ent.salt_val = self._set_salt()
         self._replay(ent.gF)
@@ -296,7 +302,8 @@ class StepGraphs:
         side = int(eng._side_stream().cuda_stream) if eng._dual() else 0
         ent.pool, ent.stream = _take_pool(dev, sig, side)
         weakref.finalize(ent, _give_pool, _dev_index(dev), sig, side, ent.pool, ent.stream)   # with its tensors gone the pool is free for the next entry
-        ent.sin = {k: (v.clone() if torch.is_tensor(v) and v.is_cuda else v) for k, v in inp.items()}
+        ent.sin = {k: (v.clone() if torch.is_tensor(v) and v.is_cuda else
+                       (PackedMask(v.words.clone(), v.shape) if isinstance(v, PackedMask) else v)) for k, v in inp.items()}
         ent.gB, ent.gin, ent.gkey = None, None, None
         ent.inflight, ent.salt_val = None, None
         was = (eng.row_bucket, eng.lm_bucket, eng.salt_word, eng._inject_header)
